@@ -1,0 +1,149 @@
+/*
+ * nextou_hip.h — C-ABI of libnextou_hip.so, the MI355X (gfx950) implementation of the
+ * NexToU graph hot path.
+ *
+ * The reference (PengchengShi1220/NexToU) is pure Python/PyTorch and has no FFI of its own;
+ * every entry point below replaces a *sequence of ATen ops* in the reference and cites the
+ * reference file:line it stands in for.  INTEGRATION.md shows the ctypes stub a maintainer of
+ * the reference would add to call them.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers (HBM) unless the name ends in `_host`;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing here
+ *    synchronises the device, allocates device memory or blocks the host, so every call is
+ *    hipGraph-capturable;
+ *  - tensors are dense row-major in the reference's own layouts:
+ *        features  (B, C, N)        "channel-major", N contiguous   [reference (B,C,N,1)]
+ *        nn_idx    (B, N, K)  int32 neighbour ids in [0, M)
+ *        relpos    (N, M)     float, shared by every batch element [reference (1,N,M)]
+ *  - return value: 0 on success, a positive hipError_t on a HIP failure, a negative
+ *    NEXTOU_E* code on an argument error; nextou_last_error() returns a message.
+ */
+#ifndef NEXTOU_HIP_H
+#define NEXTOU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEXTOU_ABI_VERSION 1
+
+#define NEXTOU_EINVAL   (-1)  /* bad argument (null pointer, non-positive size, k > M ...) */
+#define NEXTOU_ENOSPACE (-2)  /* workspace too small */
+#define NEXTOU_ENOTSUP  (-3)  /* shape not supported by the requested algorithm */
+
+/* algorithm selector of nextou_knn_graph */
+#define NEXTOU_KNN_AUTO   0   /* fused MFMA kernel when k <= 32, else the naive pair */
+#define NEXTOU_KNN_FUSED  1   /* fused normalised-distance (f32 MFMA) + streaming top-k */
+#define NEXTOU_KNN_NAIVE  2   /* materialise (B,N,M) distances, then one wave per row */
+
+typedef void* nextou_stream_t;
+
+int nextou_abi_version(void);
+const char* nextou_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  dense kNN graph.
+ * Replaces DenseDilatedKnnGraph.forward + {dense,xy_dense}_knn_matrix + *_pairwise_distance
+ *   (reference network_architecture/torch_edge.py:151-163, 58-110, 12-55): F.normalize over
+ *   channels, dist = (|x|^2 + (-2 x.y)) + |y|^2 (+ relative_pos), topk(-dist, K).
+ * Canonical arithmetic (bit-exact contract with oracle/knn_canonical.c):
+ *   den  = max(sqrtf(fma-chain_c x^2), 1e-12);  xn = x / den          (IEEE division)
+ *   xs   = fma-chain_c xn^2 ;  inner = fma-chain_c xn*yn  (c ascending, one rounding per step)
+ *   dist = ((xs + (-2*inner)) + ys) [+ relpos]
+ *   neighbours = K smallest by (dist, index) lexicographic, emitted in that order.
+ * y == NULL selects the self graph (M must equal N).  K here is k*dilation of the reference.
+ * normalize = 1: the F.normalize step is part of the call (DenseDilatedKnnGraph.forward);
+ * normalize = 0: inputs are taken as they are (dense_knn_matrix / xy_dense_knn_matrix called
+ *   directly, torch_edge.py:58-110).
+ * workspace: nextou_knn_workspace_bytes() bytes of device scratch (normalised copies, norms,
+ *   and for the NAIVE algorithm the (B,N,M) distance matrix).
+ * ---------------------------------------------------------------------------------------- */
+size_t nextou_knn_workspace_bytes(int B, int C, int N, int M, int K, int has_y, int algo);
+
+int nextou_knn_graph(const float* x, const float* y, const float* relpos,
+                     int32_t* nn_idx,
+                     void* workspace, size_t workspace_bytes,
+                     int B, int C, int N, int M, int K, int algo, int normalize,
+                     nextou_stream_t stream);
+
+/* Materialised squared-distance matrix WITHOUT normalisation or bias — the reference's public
+ * helpers pairwise_distance / part_pairwise_distance / xy_pairwise_distance
+ * (torch_edge.py:12-23, 26-39, 42-55):  dist[b, n-row_start, m] = (|x_n|^2 + (-2 x_n.y_m)) + |y_m|^2
+ * for rows n in [row_start, row_end).  y == NULL: y = x.  Same canonical fma-chain arithmetic. */
+size_t nextou_pairwise_workspace_bytes(int B, int N, int M, int has_y);
+int nextou_pairwise_distance(const float* x, const float* y, float* dist,
+                             void* workspace, size_t workspace_bytes,
+                             int B, int C, int N, int M, int row_start, int row_end,
+                             nextou_stream_t stream);
+
+/* Expands nn_idx (B,N,K_total) int32 into the reference's edge_index (2,B,N,K_total/dilation)
+ * int64: [0] = nn_idx[..., ::dilation], [1] = centre ids (arange(N) broadcast).
+ * Replaces torch_edge.py:89-90,109-110 (arange/repeat/transpose/stack) and :126-136 (::d). */
+int nextou_edge_index_i64(const int32_t* nn_idx, int64_t* edge_index,
+                          int B, int N, int K_total, int dilation,
+                          nextou_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  max-relative aggregation (the gather / sub / max / interleave part of MRConv.forward,
+ *   reference network_architecture/NexToU_Encoder_Decoder.py:401-409 and the two
+ *   batched_index_select calls, torch_nn.py:94-115).
+ *     out[b, 2c,   n] = x[b, c, n]
+ *     out[b, 2c+1, n] = max_j ( src[b, c, nn_idx[b,n,j*idx_step]] - x[b, c, ctr] ),  j < K
+ *   src = y if y != NULL (M points) else x;  ctr = center_idx[b,n,j*idx_step] if
+ *   center_idx != NULL else n.  idx rows have idx_stride int32 entries.
+ * Backward (autograd of the above): gout (B,2C,N) -> dx (B,C,N), dy (B,C,M) (dy NULL iff y
+ *   NULL).  The arg-max is recomputed; ties go to the first j (neighbour order).
+ *   dx and dy are fully overwritten.
+ * ---------------------------------------------------------------------------------------- */
+int nextou_mr_aggregate_fwd(const float* x, const float* y,
+                            const int32_t* nn_idx, const int32_t* center_idx,
+                            float* out,
+                            int B, int C, int N, int M, int K, int idx_stride, int idx_step,
+                            nextou_stream_t stream);
+
+int nextou_mr_aggregate_bwd(const float* gout, const float* x, const float* y,
+                            const int32_t* nn_idx, const int32_t* center_idx,
+                            float* dx, float* dy,
+                            int B, int C, int N, int M, int K, int idx_stride, int idx_step,
+                            nextou_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * batched_index_select (reference torch_nn.py:94-115):
+ *     out[b, c, n, j] = src[b, c, idx[b, n, j]]        src (B,C,M), idx (B,N,K) -> (B,C,N,K)
+ * backward: dsrc[b, c, m] = sum_{(n,j): idx[b,n,j]==m} gout[b,c,n,j]   (dsrc overwritten)
+ * ---------------------------------------------------------------------------------------- */
+int nextou_gather_fwd(const float* src, const int32_t* idx, float* out,
+                      int B, int C, int M, int N, int K, nextou_stream_t stream);
+int nextou_gather_bwd(const float* gout, const int32_t* idx, float* dsrc,
+                      int B, int C, int M, int N, int K, nextou_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5  BTI critical-voxel map (reference loss/bti_loss.py:76-117 and :132-134).
+ *   nextou_argmax_labels: labels[b,v] = first arg-max over the L class planes of
+ *     logits (B,L,V) (softmax is monotone, so this is argmax(softmax(x),1), :132-134).
+ *   nextou_bti_critical_map: labels (B,D,H,W) uint8 (D = 1 for 2-D) ->
+ *     critical (B,D,H,W) uint8 in {0,1}.  lut_a[l] / lut_c[l] hold one bit per interaction:
+ *     bit i of lut_a[l] = (l in A_i); bit i of lut_c[l] = (l in C_i) for an exclusion pair,
+ *     (l not in A_i and not in C_i) for an inclusion pair (:90-98).  A voxel is critical iff
+ *     (OR_nbhd(c) & a) | (OR_nbhd(a) & c) != 0 with zero padding (:101-115); the
+ *     neighbourhood is the (2*min_thick+1)^dim box for connectivity 26 / 8 and the 6 / 4
+ *     cross otherwise (:52-73).  Up to 32 interactions per call.
+ * ---------------------------------------------------------------------------------------- */
+int nextou_argmax_labels(const float* logits, uint8_t* labels,
+                         int B, int L, int64_t V, nextou_stream_t stream);
+
+int nextou_bti_critical_map(const uint8_t* labels,
+                            const uint32_t* lut_a, const uint32_t* lut_c, int n_labels,
+                            uint8_t* critical,
+                            int B, int D, int H, int W,
+                            int connectivity, int min_thick,
+                            nextou_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEXTOU_HIP_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libnextou_hip.so (the C-ABI declared in include/nextou_hip.h).
+
+The library is the product; there is no Python/CPU fallback.  ``lib()`` raises
+``RuntimeError`` with the build command when the shared object is missing, and every wrapper
+turns a non-zero return code into a ``RuntimeError`` carrying ``nextou_last_error()``.
+
+torch is imported first on purpose: PyTorch-ROCm bundles its own ``libamdhip64.so.7``; loading
+it before ``dlopen`` makes the dynamic loader reuse that one runtime (same SONAME) so device
+pointers and streams are shared between torch and this library.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_int64, c_size_t, c_void_p
+
+import torch  # noqa: F401  (must precede the dlopen, see module docstring)
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libnextou_hip.so")
+
+KNN_AUTO, KNN_FUSED, KNN_NAIVE = 0, 1, 2
+ABI_VERSION = 1
+
+# name -> (restype, argtypes); mirrors include/nextou_hip.h one to one
+_SIGNATURES = {
+    "nextou_abi_version": (c_int, []),
+    "nextou_last_error": (c_char_p, []),
+    "nextou_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "nextou_knn_graph": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "nextou_pairwise_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "nextou_pairwise_distance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                         c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "nextou_edge_index_i64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "nextou_mr_aggregate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "nextou_mr_aggregate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_void_p]),
+    "nextou_gather_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                  c_void_p]),
+    "nextou_gather_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                  c_void_p]),
+    "nextou_argmax_labels": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "nextou_bti_critical_map": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                        c_int, c_int, c_int, c_int, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the HIP library; fail loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "nextou_amd: %s is missing — the HIP extension is the only implementation of the graph "
+            "hot path (there is no CPU/PyTorch fallback). Build it with `python -m nextou_amd.build` "
+            "(hipcc --offload-arch=gfx950)." % LIB_PATH)
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if the .so does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = handle.nextou_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError("nextou_amd: libnextou_hip.so ABI %d != expected %d; rebuild" % (got, ABI_VERSION))
+    _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().nextou_last_error()
+        raise RuntimeError("nextou_amd.%s failed (code %d): %s" % (what, code, (msg or b"").decode()))

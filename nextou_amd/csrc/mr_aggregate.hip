@@ -1,0 +1,355 @@
+// K2 — max-relative aggregation (MRConv's gather / sub / max / interleave) and the plain
+// neighbour gather, for gfx950.
+//
+// Reference op sequence replaced (network_architecture/NexToU_Encoder_Decoder.py:401-409,
+// torch_nn.py:94-115): two batched_index_select calls that materialise (B,C,N,K) tensors,
+// a subtraction, a max over K and a cat/reshape channel interleave.  Here a workgroup stages a
+// chunk of source channel rows in LDS once and every lane gathers its K neighbours from LDS;
+// the (B,C,N,K) tensors never exist.  HBM traffic is the algorithmic minimum:
+//   fwd  4*B*C*(N+M_y) + 4*B*N*K(idx) + 4*B*2C*N        bwd  fwd + 4*B*C*(N+M_y)
+//
+// Layout: features (B,C,N) channel-major, idx (B,N,idx_stride) int32, out (B,2C,N) with
+// channels interleaved [x_0, mr_0, x_1, mr_1, ...] (reference :409).
+#include "common.h"
+#include <cmath>
+
+namespace nextou {
+
+// linear copy of `count` floats (HBM -> LDS staging of consecutive channel rows, or LDS -> HBM)
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ src,
+                                           int count) {
+    const bool vec = (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) &&
+                     ((count & 3) == 0);
+    if (vec) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int e = threadIdx.x; e < (count >> 2); e += blockDim.x) d4[e] = s4[e];
+    } else {
+        for (int e = threadIdx.x; e < count; e += blockDim.x) dst[e] = src[e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward.  grid = (n_tiles, c_chunks, B); LDS = chunk * M floats.
+// ---------------------------------------------------------------------------------------------
+template <int KB>
+__global__ __launch_bounds__(256) void mr_fwd_lds_kernel(
+    const float* __restrict__ x, const float* __restrict__ src, const int32_t* __restrict__ idx,
+    float* __restrict__ out, int C, int N, int M, int K, int idx_stride, int idx_step, int chunk,
+    int n_per_block) {
+    extern __shared__ float lds[];
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * chunk;
+    const int nc = (C - c0 < chunk) ? (C - c0) : chunk;
+    stage_rows(lds, src + ((size_t)b * C + c0) * M, nc * M);
+    __syncthreads();
+    const int n_begin = blockIdx.x * n_per_block;
+    int n_end = n_begin + n_per_block;
+    if (n_end > N) n_end = N;
+    for (int n = n_begin + threadIdx.x; n < n_end; n += blockDim.x) {
+        int id[KB];
+        const int32_t* irow = idx + ((size_t)b * N + n) * idx_stride;
+#pragma unroll
+        for (int j = 0; j < KB; ++j) id[j] = irow[(j < K ? j : 0) * idx_step];
+        for (int c = 0; c < nc; ++c) {
+            const float* row = lds + c * M;
+            float mx = row[id[0]];
+#pragma unroll
+            for (int j = 1; j < KB; ++j) mx = fmaxf(mx, row[id[j]]);
+            const float xv = x[((size_t)b * C + c0 + c) * N + n];
+            float* o = out + ((size_t)b * 2 * C + 2 * (c0 + c)) * N + n;
+            o[0] = xv;
+            o[N] = mx - xv;
+        }
+    }
+}
+
+// generic forward: arbitrary centre ids and/or source rows too long for LDS; gathers from
+// global memory (L2-resident rows).  One thread per (b, c, n).
+__global__ __launch_bounds__(256) void mr_fwd_global_kernel(
+    const float* __restrict__ x, const float* __restrict__ src, const int32_t* __restrict__ idx,
+    const int32_t* __restrict__ ctr, float* __restrict__ out, int C, int N, int M, int K,
+    int idx_stride, int idx_step) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    const int b = blockIdx.z;
+    if (n >= N) return;
+    const float* xrow = x + ((size_t)b * C + c) * N;
+    const float* srow = src + ((size_t)b * C + c) * M;
+    const size_t ioff = ((size_t)b * N + n) * idx_stride;
+    float mx = -INFINITY;
+    for (int j = 0; j < K; ++j) {
+        const float xc = ctr ? xrow[ctr[ioff + (size_t)j * idx_step]] : xrow[n];
+        const float v = srow[idx[ioff + (size_t)j * idx_step]] - xc;
+        mx = (j == 0) ? v : fmaxf(mx, v);
+    }
+    float* o = out + ((size_t)b * 2 * C + 2 * c) * N + n;
+    o[0] = xrow[n];
+    o[N] = mx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, LDS accumulate.  grid = (n_tiles, c_chunks, B); LDS = 2 * chunk * M floats
+// (source rows + gradient accumulators).
+//   SELF  (src == x, n_tiles == 1): accumulators start at g_x - g_mr, receive the scattered g_mr
+//         and are stored to dx — one pass, no atomics outside LDS.
+//   !SELF (src == y): dx = g_x - g_mr is written directly; the accumulators are flushed into the
+//         pre-zeroed dy with one global atomic per touched (c, m).
+// ---------------------------------------------------------------------------------------------
+template <int KB, bool SELF>
+__global__ __launch_bounds__(256) void mr_bwd_lds_kernel(
+    const float* __restrict__ gout, const float* __restrict__ x, const float* __restrict__ src,
+    const int32_t* __restrict__ idx, float* __restrict__ dx, float* __restrict__ dsrc, int C, int N,
+    int M, int K, int idx_stride, int idx_step, int chunk, int n_per_block) {
+    extern __shared__ float lds[];
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * chunk;
+    const int nc = (C - c0 < chunk) ? (C - c0) : chunk;
+    float* vals = lds;               // [nc][M] source values
+    float* accg = lds + chunk * M;   // [nc][M] gradient accumulators
+    stage_rows(vals, src + ((size_t)b * C + c0) * M, nc * M);
+    if (SELF) {
+        for (int e = threadIdx.x; e < nc * M; e += blockDim.x) {
+            const int c = e / M, m = e - c * M;
+            const float* g = gout + ((size_t)b * 2 * C + 2 * (c0 + c)) * N + m;
+            accg[e] = g[0] - g[N];
+        }
+    } else {
+        for (int e = threadIdx.x; e < nc * M; e += blockDim.x) accg[e] = 0.f;
+    }
+    __syncthreads();
+    const int n_begin = blockIdx.x * n_per_block;
+    int n_end = n_begin + n_per_block;
+    if (n_end > N) n_end = N;
+    for (int n = n_begin + threadIdx.x; n < n_end; n += blockDim.x) {
+        int id[KB];
+        const int32_t* irow = idx + ((size_t)b * N + n) * idx_stride;
+#pragma unroll
+        for (int j = 0; j < KB; ++j) id[j] = irow[(j < K ? j : 0) * idx_step];
+        for (int c = 0; c < nc; ++c) {
+            const float* row = vals + c * M;
+            const float xv = SELF ? row[n] : x[((size_t)b * C + c0 + c) * N + n];
+            float mx = row[id[0]] - xv;
+            int am = id[0];
+#pragma unroll
+            for (int j = 1; j < KB; ++j) {
+                const float v = row[id[j]] - xv;  // the rounded difference autograd's max saw
+                if (v > mx) { mx = v; am = id[j]; }  // strict: first max wins
+            }
+            const float* g = gout + ((size_t)b * 2 * C + 2 * (c0 + c)) * N + n;
+            const float gm = g[N];
+            atomicAdd(&accg[c * M + am], gm);
+            if (!SELF) dx[((size_t)b * C + c0 + c) * N + n] = g[0] - gm;
+        }
+    }
+    __syncthreads();
+    if (SELF) {
+        stage_rows(dx + ((size_t)b * C + c0) * N, accg, nc * M);  // LDS -> HBM, same linear copy
+    } else {
+        float* drow = dsrc + ((size_t)b * C + c0) * M;
+        for (int e = threadIdx.x; e < nc * M; e += blockDim.x) {
+            const float v = accg[e];
+            if (v != 0.f) atomicAdd(&drow[e], v);
+        }
+    }
+}
+
+// generic backward: global atomics, arbitrary centre ids.  dx / dsrc pre-zeroed by the host.
+__global__ __launch_bounds__(256) void mr_bwd_global_kernel(
+    const float* __restrict__ gout, const float* __restrict__ x, const float* __restrict__ src,
+    const int32_t* __restrict__ idx, const int32_t* __restrict__ ctr, float* __restrict__ dx,
+    float* __restrict__ dsrc, int C, int N, int M, int K, int idx_stride, int idx_step) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    const int b = blockIdx.z;
+    if (n >= N) return;
+    const float* xrow = x + ((size_t)b * C + c) * N;
+    const float* srow = src + ((size_t)b * C + c) * M;
+    const size_t ioff = ((size_t)b * N + n) * idx_stride;
+    float mx = 0.f;
+    int am = 0, ac = n;
+    for (int j = 0; j < K; ++j) {
+        const int cj = ctr ? ctr[ioff + (size_t)j * idx_step] : n;
+        const int sj = idx[ioff + (size_t)j * idx_step];
+        const float v = srow[sj] - xrow[cj];
+        if (j == 0 || v > mx) { mx = v; am = sj; ac = cj; }
+    }
+    const float* g = gout + ((size_t)b * 2 * C + 2 * c) * N + n;
+    const float gm = g[N];
+    atomicAdd(&dx[((size_t)b * C + c) * N + n], g[0]);
+    atomicAdd(&dx[((size_t)b * C + c) * N + ac], -gm);
+    atomicAdd(&dsrc[((size_t)b * C + c) * M + am], gm);
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched_index_select forward / backward
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_fwd_kernel(const float* __restrict__ src,
+                                                         const int32_t* __restrict__ idx,
+                                                         float* __restrict__ out, int C, int M,
+                                                         long long NK) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over N*K
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (e >= NK) return;
+    out[((size_t)b * C + c) * NK + e] = src[((size_t)b * C + c) * M + idx[(size_t)b * NK + e]];
+}
+
+__global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict__ gout,
+                                                         const int32_t* __restrict__ idx,
+                                                         float* __restrict__ dsrc, int C, int M,
+                                                         long long NK) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (e >= NK) return;
+    atomicAdd(&dsrc[((size_t)b * C + c) * M + idx[(size_t)b * NK + e]],
+              gout[((size_t)b * C + c) * NK + e]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct MrPlan {
+    int chunk, c_chunks, n_tiles, n_per_block, threads;
+    size_t lds;
+};
+
+// rows_per_channel: LDS floats needed per channel (M forward, 2M backward)
+static bool plan_lds(int B, int C, int N, int M, int floats_per_channel, bool tile_n, MrPlan* p) {
+    const int budget = kGatherLdsBytes / (int)sizeof(float);
+    int max_chunk = budget / floats_per_channel;
+    if (max_chunk < 1) return false;
+    if (max_chunk > C) max_chunk = C;
+    int threads = ((N < 256 ? N : 256) + 63) / 64 * 64;
+    int n_per_block = N, n_tiles = 1;
+    if (tile_n && N > 1024) {
+        n_per_block = 1024;
+        n_tiles = cdiv(N, n_per_block);
+    }
+    // shrink the channel chunk until the grid has >= 512 workgroups; keep >= 4 channels per
+    // workgroup when N is tiled so the idx registers are reused across channels
+    int chunk = max_chunk;
+    while (chunk > 4 && (long long)cdiv(C, chunk) * n_tiles * B < 512) chunk = (chunk + 1) / 2;
+    if (!tile_n) {
+        while (chunk > 1 && (long long)cdiv(C, chunk) * n_tiles * B < 512) chunk = (chunk + 1) / 2;
+    }
+    chunk = cdiv(C, cdiv(C, chunk));  // balance the last chunk
+    p->chunk = chunk;
+    p->c_chunks = cdiv(C, chunk);
+    p->n_tiles = n_tiles;
+    p->n_per_block = n_per_block;
+    p->threads = threads;
+    p->lds = (size_t)chunk * floats_per_channel * sizeof(float);
+    return p->c_chunks <= 65535 && B <= 65535;
+}
+
+static int check_mr_args(const char* who, const void* a, const void* b, const void* c, int B, int C,
+                         int N, int M, int K, int idx_stride, int idx_step) {
+    NEXTOU_REQUIRE(a && b && c, "%s: null pointer", who);
+    NEXTOU_REQUIRE(B > 0 && C > 0 && N > 0 && M > 0 && K > 0, "%s: non-positive size B=%d C=%d N=%d M=%d K=%d",
+                   who, B, C, N, M, K);
+    NEXTOU_REQUIRE(idx_step > 0 && idx_stride >= (K - 1) * idx_step + 1,
+                   "%s: idx_stride=%d too small for K=%d step=%d", who, idx_stride, K, idx_step);
+    NEXTOU_REQUIRE(B <= 65535 && C <= 65535, "%s: B=%d / C=%d exceed the grid limit 65535", who, B, C);
+    return 0;
+}
+
+}  // namespace nextou
+
+using namespace nextou;
+
+extern "C" int nextou_mr_aggregate_fwd(const float* x, const float* y, const int32_t* nn_idx,
+                                       const int32_t* center_idx, float* out, int B, int C, int N,
+                                       int M, int K, int idx_stride, int idx_step,
+                                       nextou_stream_t stream) {
+    if (int e = check_mr_args("mr_aggregate_fwd", x, nn_idx, out, B, C, N, M, K, idx_stride, idx_step)) return e;
+    NEXTOU_REQUIRE(y != nullptr || M == N, "mr_aggregate_fwd: y == NULL needs M == N (N=%d M=%d)", N, M);
+    hipStream_t s = (hipStream_t)stream;
+    const float* src = y ? y : x;
+    MrPlan p;
+    if (center_idx == nullptr && K <= 32 && plan_lds(B, C, N, M, M, true, &p)) {
+        dim3 grid(p.n_tiles, p.c_chunks, B), block(p.threads);
+#define NEXTOU_MR_FWD(KB)                                                                          \
+    hipLaunchKernelGGL((mr_fwd_lds_kernel<KB>), grid, block, p.lds, s, x, src, nn_idx, out, C, N, M, \
+                       K, idx_stride, idx_step, p.chunk, p.n_per_block)
+        if (K <= 8) NEXTOU_MR_FWD(8);
+        else if (K <= 16) NEXTOU_MR_FWD(16);
+        else NEXTOU_MR_FWD(32);
+#undef NEXTOU_MR_FWD
+        return check_launch("mr_fwd_lds_kernel");
+    }
+    hipLaunchKernelGGL(mr_fwd_global_kernel, dim3(cdiv(N, 256), C, B), dim3(256), 0, s, x, src, nn_idx,
+                       center_idx, out, C, N, M, K, idx_stride, idx_step);
+    return check_launch("mr_fwd_global_kernel");
+}
+
+extern "C" int nextou_mr_aggregate_bwd(const float* gout, const float* x, const float* y,
+                                       const int32_t* nn_idx, const int32_t* center_idx, float* dx,
+                                       float* dy, int B, int C, int N, int M, int K, int idx_stride,
+                                       int idx_step, nextou_stream_t stream) {
+    if (int e = check_mr_args("mr_aggregate_bwd", gout, nn_idx, dx, B, C, N, M, K, idx_stride, idx_step)) return e;
+    NEXTOU_REQUIRE(x != nullptr, "mr_aggregate_bwd: x is null");
+    NEXTOU_REQUIRE((y == nullptr) == (dy == nullptr), "mr_aggregate_bwd: dy must be given iff y is");
+    NEXTOU_REQUIRE(y != nullptr || M == N, "mr_aggregate_bwd: y == NULL needs M == N (N=%d M=%d)", N, M);
+    hipStream_t s = (hipStream_t)stream;
+    const bool self = (y == nullptr);
+    const float* src = self ? x : y;
+    MrPlan p;
+    if (center_idx == nullptr && K <= 32 && plan_lds(B, C, N, M, 2 * M, !self, &p)) {
+        dim3 grid(p.n_tiles, p.c_chunks, B), block(p.threads);
+        if (!self) {
+            hipError_t e = hipMemsetAsync(dy, 0, (size_t)B * C * M * sizeof(float), s);
+            if (e != hipSuccess) return fail((int)e, "mr_aggregate_bwd: memset dy: %s", hipGetErrorString(e));
+        }
+#define NEXTOU_MR_BWD(KB)                                                                            \
+    do {                                                                                             \
+        if (self)                                                                                    \
+            hipLaunchKernelGGL((mr_bwd_lds_kernel<KB, true>), grid, block, p.lds, s, gout, x, src,   \
+                               nn_idx, dx, dx, C, N, M, K, idx_stride, idx_step, p.chunk,            \
+                               p.n_per_block);                                                       \
+        else                                                                                         \
+            hipLaunchKernelGGL((mr_bwd_lds_kernel<KB, false>), grid, block, p.lds, s, gout, x, src,  \
+                               nn_idx, dx, dy, C, N, M, K, idx_stride, idx_step, p.chunk,            \
+                               p.n_per_block);                                                       \
+    } while (0)
+        if (K <= 8) NEXTOU_MR_BWD(8);
+        else if (K <= 16) NEXTOU_MR_BWD(16);
+        else NEXTOU_MR_BWD(32);
+#undef NEXTOU_MR_BWD
+        return check_launch("mr_bwd_lds_kernel");
+    }
+    // generic path: everything through global atomics
+    hipError_t e = hipMemsetAsync(dx, 0, (size_t)B * C * N * sizeof(float), s);
+    if (e != hipSuccess) return fail((int)e, "mr_aggregate_bwd: memset dx: %s", hipGetErrorString(e));
+    if (!self) {
+        e = hipMemsetAsync(dy, 0, (size_t)B * C * M * sizeof(float), s);
+        if (e != hipSuccess) return fail((int)e, "mr_aggregate_bwd: memset dy: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(mr_bwd_global_kernel, dim3(cdiv(N, 256), C, B), dim3(256), 0, s, gout, x, src,
+                       nn_idx, center_idx, dx, self ? dx : dy, C, N, M, K, idx_stride, idx_step);
+    return check_launch("mr_bwd_global_kernel");
+}
+
+extern "C" int nextou_gather_fwd(const float* src, const int32_t* idx, float* out, int B, int C,
+                                 int M, int N, int K, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(src && idx && out, "gather_fwd: null pointer");
+    NEXTOU_REQUIRE(B > 0 && C > 0 && M > 0 && N > 0 && K > 0 && B <= 65535 && C <= 65535,
+                   "gather_fwd: bad size B=%d C=%d M=%d N=%d K=%d", B, C, M, N, K);
+    const long long NK = (long long)N * K;
+    hipLaunchKernelGGL(gather_fwd_kernel, dim3((unsigned)cdiv64(NK, 256), C, B), dim3(256), 0,
+                       (hipStream_t)stream, src, idx, out, C, M, NK);
+    return check_launch("gather_fwd_kernel");
+}
+
+extern "C" int nextou_gather_bwd(const float* gout, const int32_t* idx, float* dsrc, int B, int C,
+                                 int M, int N, int K, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(gout && idx && dsrc, "gather_bwd: null pointer");
+    NEXTOU_REQUIRE(B > 0 && C > 0 && M > 0 && N > 0 && K > 0 && B <= 65535 && C <= 65535,
+                   "gather_bwd: bad size B=%d C=%d M=%d N=%d K=%d", B, C, M, N, K);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dsrc, 0, (size_t)B * C * M * sizeof(float), s);
+    if (e != hipSuccess) return fail((int)e, "gather_bwd: memset: %s", hipGetErrorString(e));
+    const long long NK = (long long)N * K;
+    hipLaunchKernelGGL(gather_bwd_kernel, dim3((unsigned)cdiv64(NK, 256), C, B), dim3(256), 0, s, gout,
+                       idx, dsrc, C, M, NK);
+    return check_launch("gather_bwd_kernel");
+}

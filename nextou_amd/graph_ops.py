@@ -1,0 +1,369 @@
+"""Host-side operators of the NexToU graph hot path, backed by libnextou_hip.so.
+
+Each operator is the fused replacement of a run of ATen ops in the reference:
+
+=====================  =====================================================================
+``knn_graph``          F.normalize -> bmm -> add -> add -> (+relative_pos) -> neg -> topk
+                       (reference network_architecture/torch_edge.py:151-163, 58-110, 12-55)
+``mr_aggregate``       2x batched_index_select -> sub -> max -> cat/reshape interleave
+                       (reference NexToU_Encoder_Decoder.py:401-409, torch_nn.py:94-115)
+``gather_neighbors``   batched_index_select (reference torch_nn.py:94-115)
+``bti_critical_map``   softmax/argmax + per-interaction isin/conv3d/where loop
+                       (reference loss/bti_loss.py:132-134, 76-117)
+=====================  =====================================================================
+
+Device tensors go to the HIP kernels through the C-ABI (plain pointers + the current HIP stream).
+There is no CPU implementation in the product: a CPU tensor raises ``RuntimeError`` unless test
+infrastructure has installed a checker with :func:`install_cpu_checker` (tests/ and bench.py's
+``cpu_baseline`` leg install the oracle there; nothing in this package imports ``oracle``).
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Callable, List, Optional
+
+import torch
+
+from . import _lib
+
+__all__ = [
+    "knn_graph", "pairwise_sq_distance", "edge_index_from_nn_idx", "mr_aggregate", "gather_neighbors",
+    "argmax_labels", "bti_critical_map", "install_cpu_checker", "IndexTape", "index_tape",
+]
+
+
+# ----------------------------------------------------------------------------------------------
+# backend selection
+# ----------------------------------------------------------------------------------------------
+_cpu_checker = None
+
+
+def install_cpu_checker(backend) -> None:
+    """TEST / BASELINE INFRASTRUCTURE ONLY: route CPU tensors to ``backend`` (the oracle).
+
+    ``backend`` must offer the same methods as :class:`_HipBackend`.  Pass ``None`` to remove.
+    """
+    global _cpu_checker
+    _cpu_checker = backend
+
+
+def _backend_for(t: torch.Tensor):
+    if t.device.type == "cuda":
+        return _HIP
+    if _cpu_checker is not None:
+        return _cpu_checker
+    raise RuntimeError(
+        "nextou_amd: the graph hot path only runs on an MI355X through libnextou_hip.so; got a %s "
+        "tensor and there is no CPU fallback." % t.device.type)
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    """contiguous float32 view/copy (autocast-safe: K1/K2 always run in fp32)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class _HipBackend:
+    """Thin marshalling layer: shapes -> ints, tensors -> device pointers."""
+
+    name = "hip"
+
+    @staticmethod
+    def knn_graph(x, y, relpos, k_total, algo=_lib.KNN_AUTO, normalize=True):
+        L = _lib.lib()
+        B, C, N = x.shape
+        M = N if y is None else y.shape[2]
+        out = torch.empty((B, N, k_total), dtype=torch.int32, device=x.device)
+        nbytes = L.nextou_knn_workspace_bytes(B, C, N, M, k_total, int(y is not None), algo)
+        ws = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L.nextou_knn_graph(x.data_ptr(), _ptr(y), _ptr(relpos), out.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), B, C, N, M, k_total, algo, int(normalize),
+                                    _stream_ptr(x.device))
+        _lib.check(rc, "knn_graph")
+        return out
+
+    @staticmethod
+    def pairwise_distance(x, y, row_start, row_end):
+        L = _lib.lib()
+        B, C, N = x.shape
+        M = N if y is None else y.shape[2]
+        out = torch.empty((B, row_end - row_start, M), dtype=torch.float32, device=x.device)
+        nbytes = L.nextou_pairwise_workspace_bytes(B, N, M, int(y is not None))
+        ws = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L.nextou_pairwise_distance(x.data_ptr(), _ptr(y), out.data_ptr(), ws.data_ptr(),
+                                            ws.numel(), B, C, N, M, row_start, row_end,
+                                            _stream_ptr(x.device))
+        _lib.check(rc, "pairwise_distance")
+        return out
+
+    @staticmethod
+    def edge_index(nn_idx, dilation):
+        L = _lib.lib()
+        B, N, K = nn_idx.shape
+        k_out = len(range(0, K, dilation))
+        out = torch.empty((2, B, N, k_out), dtype=torch.int64, device=nn_idx.device)
+        with torch.cuda.device(nn_idx.device):
+            rc = L.nextou_edge_index_i64(nn_idx.data_ptr(), out.data_ptr(), B, N, K, dilation,
+                                         _stream_ptr(nn_idx.device))
+        _lib.check(rc, "edge_index_i64")
+        return out
+
+    @staticmethod
+    def mr_fwd(x, y, nn_idx, center, K, idx_step):
+        L = _lib.lib()
+        B, C, N = x.shape
+        M = N if y is None else y.shape[2]
+        out = torch.empty((B, 2 * C, N), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L.nextou_mr_aggregate_fwd(x.data_ptr(), _ptr(y), nn_idx.data_ptr(), _ptr(center),
+                                           out.data_ptr(), B, C, N, M, K, nn_idx.shape[2], idx_step,
+                                           _stream_ptr(x.device))
+        _lib.check(rc, "mr_aggregate_fwd")
+        return out
+
+    @staticmethod
+    def mr_bwd(gout, x, y, nn_idx, center, K, idx_step):
+        L = _lib.lib()
+        B, C, N = x.shape
+        M = N if y is None else y.shape[2]
+        dx = torch.empty_like(x)
+        dy = None if y is None else torch.empty_like(y)
+        with torch.cuda.device(x.device):
+            rc = L.nextou_mr_aggregate_bwd(gout.data_ptr(), x.data_ptr(), _ptr(y), nn_idx.data_ptr(),
+                                           _ptr(center), dx.data_ptr(), _ptr(dy), B, C, N, M, K,
+                                           nn_idx.shape[2], idx_step, _stream_ptr(x.device))
+        _lib.check(rc, "mr_aggregate_bwd")
+        return dx, dy
+
+    @staticmethod
+    def gather_fwd(src, idx):
+        L = _lib.lib()
+        B, C, M = src.shape
+        _, N, K = idx.shape
+        out = torch.empty((B, C, N, K), dtype=torch.float32, device=src.device)
+        with torch.cuda.device(src.device):
+            rc = L.nextou_gather_fwd(src.data_ptr(), idx.data_ptr(), out.data_ptr(), B, C, M, N, K,
+                                     _stream_ptr(src.device))
+        _lib.check(rc, "gather_fwd")
+        return out
+
+    @staticmethod
+    def gather_bwd(gout, idx, M):
+        L = _lib.lib()
+        B, C, N, K = gout.shape
+        dsrc = torch.empty((B, C, M), dtype=torch.float32, device=gout.device)
+        with torch.cuda.device(gout.device):
+            rc = L.nextou_gather_bwd(gout.data_ptr(), idx.data_ptr(), dsrc.data_ptr(), B, C, M, N, K,
+                                     _stream_ptr(gout.device))
+        _lib.check(rc, "gather_bwd")
+        return dsrc
+
+    @staticmethod
+    def argmax_labels(logits):
+        L = _lib.lib()
+        B, nl = logits.shape[:2]
+        V = logits[0, 0].numel()
+        out = torch.empty((B,) + tuple(logits.shape[2:]), dtype=torch.uint8, device=logits.device)
+        with torch.cuda.device(logits.device):
+            rc = L.nextou_argmax_labels(logits.data_ptr(), out.data_ptr(), B, nl, V,
+                                        _stream_ptr(logits.device))
+        _lib.check(rc, "argmax_labels")
+        return out
+
+    @staticmethod
+    def bti_critical(labels, lut_a, lut_c, connectivity, min_thick):
+        L = _lib.lib()
+        if labels.dim() == 3:
+            B, H, W = labels.shape
+            D = 1
+        else:
+            B, D, H, W = labels.shape
+        out = torch.empty_like(labels)
+        with torch.cuda.device(labels.device):
+            rc = L.nextou_bti_critical_map(labels.data_ptr(), lut_a.data_ptr(), lut_c.data_ptr(),
+                                           lut_a.numel(), out.data_ptr(), B, D, H, W, connectivity,
+                                           min_thick, _stream_ptr(labels.device))
+        _lib.check(rc, "bti_critical_map")
+        return out
+
+
+_HIP = _HipBackend()
+
+
+# ----------------------------------------------------------------------------------------------
+# index tape: record / replay of the discrete decisions (kNN ids, max-pool arg-max locations).
+# The model is discontinuous in those (SURVEY.md §7 hard part 0), so whole-model parity is
+# measured teacher-forced (protocol P-B): record on one implementation, replay on the other.
+# ----------------------------------------------------------------------------------------------
+class IndexTape:
+    def __init__(self, entries: Optional[List[torch.Tensor]] = None):
+        self.entries: List[torch.Tensor] = list(entries or [])
+        self.cursor = 0
+        self.replay = entries is not None
+
+    def take(self, compute: Callable[[], torch.Tensor], device) -> torch.Tensor:
+        if self.replay:
+            if self.cursor >= len(self.entries):
+                raise RuntimeError("IndexTape exhausted after %d entries" % self.cursor)
+            t = self.entries[self.cursor].to(device)
+            self.cursor += 1
+            return t
+        t = compute()
+        self.entries.append(t.detach().cpu())
+        return t
+
+
+_tape: Optional[IndexTape] = None
+
+
+@contextlib.contextmanager
+def index_tape(tape: IndexTape):
+    """Test hook: while active, ``knn_graph`` and the pooled stage's arg-max go through ``tape``."""
+    global _tape
+    prev, _tape = _tape, tape
+    try:
+        yield tape
+    finally:
+        _tape = prev
+
+
+def taped(compute: Callable[[], torch.Tensor], device) -> torch.Tensor:
+    return compute() if _tape is None else _tape.take(compute, device)
+
+
+# ----------------------------------------------------------------------------------------------
+# public operators
+# ----------------------------------------------------------------------------------------------
+_ALGOS = {"auto": _lib.KNN_AUTO, "fused": _lib.KNN_FUSED, "naive": _lib.KNN_NAIVE}
+
+
+@torch.no_grad()
+def knn_graph(x: torch.Tensor, y: Optional[torch.Tensor] = None,
+              relative_pos: Optional[torch.Tensor] = None, k: int = 9, algo: str = "auto",
+              normalize: bool = True) -> torch.Tensor:
+    """Indices of the ``k`` nearest candidates of every point, ascending by (distance, index).
+
+    x: (B,C,N[,1]) queries; y: (B,C,M[,1]) candidates or None (self graph); relative_pos:
+    (1,N,M) or (N,M) additive bias.  Returns int32 (B,N,k).  With ``normalize`` (default) the
+    L2 normalisation over channels is part of the op, as in the reference's
+    DenseDilatedKnnGraph.forward; ``normalize=False`` is ``dense_knn_matrix`` called directly.
+    """
+    x3 = _f32c(x.detach().reshape(x.shape[0], x.shape[1], -1))
+    y3 = None if y is None else _f32c(y.detach().reshape(y.shape[0], y.shape[1], -1))
+    B, C, N = x3.shape
+    M = N if y3 is None else y3.shape[2]
+    if y3 is not None and (y3.shape[0] != B or y3.shape[1] != C):
+        raise ValueError("knn_graph: x %s and y %s disagree in batch/channels" % (tuple(x3.shape), tuple(y3.shape)))
+    rp = None
+    if relative_pos is not None:
+        rp = _f32c(relative_pos.detach()).reshape(-1, relative_pos.shape[-1])
+        if tuple(rp.shape) != (N, M):
+            raise ValueError("knn_graph: relative_pos %s does not match (N=%d, M=%d)" % (tuple(relative_pos.shape), N, M))
+    if k > M:
+        raise RuntimeError("knn_graph: k=%d out of range for %d candidates" % (k, M))
+    be = _backend_for(x3)
+    return taped(lambda: be.knn_graph(x3, y3, rp, int(k), _ALGOS[algo], bool(normalize)), x3.device)
+
+
+@torch.no_grad()
+def pairwise_sq_distance(x: torch.Tensor, y: Optional[torch.Tensor] = None, row_start: int = 0,
+                         row_end: Optional[int] = None) -> torch.Tensor:
+    """``(|x|^2 + (-2 x.y^T)) + |y|^2^T`` for x (B,C,N), y (B,C,M) or None -> (B,rows,M) float32."""
+    x3 = _f32c(x.detach())
+    y3 = None if y is None else _f32c(y.detach())
+    row_end = x3.shape[2] if row_end is None else row_end
+    return _backend_for(x3).pairwise_distance(x3, y3, int(row_start), int(row_end))
+
+
+def edge_index_from_nn_idx(nn_idx: torch.Tensor, dilation: int = 1) -> torch.Tensor:
+    """(B,N,K) int32 -> the reference's (2,B,N,K/d) int64 ``edge_index`` (torch_edge.py:89-90,126-136)."""
+    return _backend_for(nn_idx).edge_index(nn_idx.contiguous(), int(dilation))
+
+
+class _MRAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, nn_idx, center, K, idx_step):
+        be = _backend_for(x)
+        out = be.mr_fwd(x, y, nn_idx, center, K, idx_step)
+        ctx.save_for_backward(x, y if y is not None else x.new_empty(0), nn_idx,
+                              center if center is not None else nn_idx.new_empty(0))
+        ctx.has_y, ctx.has_center = y is not None, center is not None
+        ctx.K, ctx.idx_step = K, idx_step
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, y, nn_idx, center = ctx.saved_tensors
+        y = y if ctx.has_y else None
+        center = center if ctx.has_center else None
+        be = _backend_for(x)
+        dx, dy = be.mr_bwd(_f32c(gout), x, y, nn_idx, center, ctx.K, ctx.idx_step)
+        return dx, dy, None, None, None, None
+
+
+def mr_aggregate(x: torch.Tensor, nn_idx: torch.Tensor, y: Optional[torch.Tensor] = None,
+                 center_idx: Optional[torch.Tensor] = None, k: Optional[int] = None,
+                 idx_step: int = 1) -> torch.Tensor:
+    """Max-relative aggregation with interleaved output channels.
+
+    x: (B,C,N) float; y: (B,C,M) or None; nn_idx: (B,N,K_total) int32 ids into y (or x);
+    uses neighbours ``nn_idx[..., ::idx_step][..., :k]``.  Returns (B,2C,N):
+    ``out[:,2c] = x[:,c]``, ``out[:,2c+1] = max_j(src[:,c,nn_idx_j] - x[:,c,centre_j])``.
+    """
+    if k is None:
+        k = len(range(0, nn_idx.shape[2], idx_step))
+    x = _f32c(x)
+    y = None if y is None else _f32c(y)
+    nn_idx = nn_idx.contiguous()
+    if nn_idx.dtype != torch.int32:
+        nn_idx = nn_idx.to(torch.int32)
+    if center_idx is not None:
+        center_idx = center_idx.contiguous().to(torch.int32)
+    return _MRAggregate.apply(x, y, nn_idx, center_idx, int(k), int(idx_step))
+
+
+class _Gather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, idx):
+        ctx.save_for_backward(idx)
+        ctx.M = src.shape[2]
+        return _backend_for(src).gather_fwd(src, idx)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (idx,) = ctx.saved_tensors
+        return _backend_for(gout).gather_bwd(_f32c(gout), idx, ctx.M), None
+
+
+def gather_neighbors(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """``out[b,c,n,j] = x[b,c,idx[b,n,j]]`` — x (B,C,M), idx (B,N,K) -> (B,C,N,K)."""
+    return _Gather.apply(_f32c(x), idx.contiguous().to(torch.int32))
+
+
+@torch.no_grad()
+def argmax_labels(logits: torch.Tensor) -> torch.Tensor:
+    """uint8 arg-max over dim 1 (first index on ties) of (B,L,*spatial) float32 logits."""
+    logits = _f32c(logits.detach())
+    return _backend_for(logits).argmax_labels(logits)
+
+
+@torch.no_grad()
+def bti_critical_map(labels: torch.Tensor, lut_a: torch.Tensor, lut_c: torch.Tensor,
+                     connectivity: int, min_thick: int = 1) -> torch.Tensor:
+    """uint8 critical-voxel map of a uint8 label volume (B,[D,]H,W); LUTs are uint32-as-int32."""
+    labels = labels.contiguous()
+    if labels.dtype != torch.uint8:
+        raise TypeError("bti_critical_map: labels must be uint8, got %s" % labels.dtype)
+    return _backend_for(labels).bti_critical(labels, lut_a.contiguous(), lut_c.contiguous(),
+                                             int(connectivity), int(min_thick))

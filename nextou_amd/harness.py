@@ -1,0 +1,196 @@
+"""Standalone stand-ins for the parts of nnU-Net v2 that call the NexToU plug-in surface.
+
+nnU-Net v2.0 (CLI, dataloading, augmentation, planning, checkpointing, logging …) is external to
+the reference and out of scope.  This module reproduces only the *calls* a trainer
+makes on the plug-ins — build the network from plans, build the loss, run forward / loss / backward
+/ SGD — so that the path can be driven, tested and benchmarked without an nnU-Net installation.
+With nnU-Net installed the trainer classes in ``nextou_amd.nnUNetTrainer`` derive from the real
+``nnUNetTrainer`` instead and nothing here is used.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class SimpleConfigurationManager:
+    """The plans fields ``nnUNetTrainer_NexToU.build_network_architecture`` reads
+    (reference nnUNetTrainer_NexToU.py:24-27,76-82)."""
+    patch_size: Sequence[int]
+    conv_kernel_sizes: Sequence[Sequence[int]]
+    pool_op_kernel_sizes: Sequence[Sequence[int]]
+    UNet_base_num_features: int = 32
+    unet_max_num_features: int = 320
+    n_conv_per_stage_encoder: Sequence[int] = ()
+    n_conv_per_stage_decoder: Sequence[int] = ()
+    batch_size: int = 2
+    batch_dice: bool = False
+
+    def __post_init__(self):
+        n = len(self.conv_kernel_sizes)
+        if not self.n_conv_per_stage_encoder:
+            self.n_conv_per_stage_encoder = [2] * n
+        if not self.n_conv_per_stage_decoder:
+            self.n_conv_per_stage_decoder = [2] * (n - 1)
+
+
+@dataclass
+class SimpleLabelManager:
+    num_segmentation_heads: int
+    ignore_label: Optional[int] = None
+    has_regions: bool = False
+
+
+@dataclass
+class SimplePlansManager:
+    label_manager: SimpleLabelManager
+
+    def get_label_manager(self, dataset_json):
+        return self.label_manager
+
+
+# topology of the reference's example plans (nnUNetPlans.json:338-401 "3d_fullres", :26-154 "2d")
+KERNELS_3D = [[1, 3, 3]] + [[3, 3, 3]] * 5
+STRIDES_3D = [[1, 1, 1], [1, 2, 2]] + [[2, 2, 2]] * 4
+
+
+def config_3d_fullres_nextou(patch_size=(64, 224, 192), base=33, max_features=324, batch_size=2):
+    """BASELINE.json configs[1] / nnUNetPlans.json:426-435 ('3d_fullres_nextou')."""
+    return SimpleConfigurationManager(patch_size=list(patch_size), conv_kernel_sizes=KERNELS_3D,
+                                      pool_op_kernel_sizes=STRIDES_3D, UNet_base_num_features=base,
+                                      unet_max_num_features=max_features, batch_size=batch_size)
+
+
+def config_2d_nextou(patch_size=(512, 512), base=32, max_features=512, n_stages=7, batch_size=1):
+    """BASELINE.json configs[0] (2-D, 7 stages, SURVEY.md §8d cfg 1)."""
+    return SimpleConfigurationManager(patch_size=list(patch_size), conv_kernel_sizes=[[3, 3]] * n_stages,
+                                      pool_op_kernel_sizes=[[1, 1]] + [[2, 2]] * (n_stages - 1),
+                                      UNet_base_num_features=base, unet_max_num_features=max_features,
+                                      batch_size=batch_size)
+
+
+class StandaloneTrainerBase:
+    """The slice of ``nnunetv2.training.nnUNetTrainer.nnUNetTrainer`` the plug-ins touch
+    (SURVEY.md §8b 'trainer API')."""
+
+    initial_lr, weight_decay, momentum = 1e-2, 3e-5, 0.99
+
+    def __init__(self, configuration_manager: SimpleConfigurationManager, num_classes: int,
+                 num_input_channels: int = 1, device: torch.device = torch.device("cpu"),
+                 ignore_label: Optional[int] = None, is_ddp: bool = False, enable_deep_supervision: bool = True,
+                 log=print):
+        self.configuration_manager = configuration_manager
+        self.label_manager = SimpleLabelManager(num_classes, ignore_label)
+        self.plans_manager = SimplePlansManager(self.label_manager)
+        self.dataset_json = {}
+        self.num_input_channels = num_input_channels
+        self.device = device
+        self.is_ddp = is_ddp
+        self.enable_deep_supervision = enable_deep_supervision
+        self._log = log
+        self.network = self.loss = self.optimizer = None
+
+    # -- hooks the plug-ins use -----------------------------------------------------------------
+    def print_to_log_file(self, *args, **kwargs):
+        if self._log is not None:
+            self._log(*args)
+
+    def _get_deep_supervision_scales(self):
+        pools = np.vstack(self.configuration_manager.pool_op_kernel_sizes)
+        return list(list(i) for i in 1 / np.cumprod(pools, axis=0))[:-1]
+
+    def _build_loss(self):
+        """nnU-Net's default: Dice + CE under the deep-supervision wrapper."""
+        from .loss.nnunet_losses import DeepSupervisionWrapper, MemoryEfficientSoftDiceLoss, \
+            RobustCrossEntropyLoss, softmax_helper_dim1
+        from torch import nn
+
+        class _DCandCE(nn.Module):
+            def __init__(self, batch_dice, ddp):
+                super().__init__()
+                self.ce = RobustCrossEntropyLoss()
+                self.dc = MemoryEfficientSoftDiceLoss(apply_nonlin=softmax_helper_dim1, batch_dice=batch_dice,
+                                                      do_bg=False, smooth=1e-5, ddp=ddp)
+
+            def forward(self, out, target):
+                return self.ce(out, target[:, 0].long()) + self.dc(out, target)
+
+        loss = _DCandCE(self.configuration_manager.batch_dice, self.is_ddp)
+        return DeepSupervisionWrapper(loss, deep_supervision_weights(len(self._get_deep_supervision_scales())))
+
+    # -- lifecycle ------------------------------------------------------------------------------
+    def initialize(self):
+        self.network = self.build_network_architecture(self.plans_manager, self.dataset_json,
+                                                       self.configuration_manager, self.num_input_channels,
+                                                       self.enable_deep_supervision).to(self.device)
+        self.loss = self._build_loss()
+        self.optimizer = torch.optim.SGD(self.network.parameters(), self.initial_lr, weight_decay=self.weight_decay,
+                                         momentum=self.momentum, nesterov=True)
+        return self
+
+    def train_step(self, data: torch.Tensor, target: List[torch.Tensor]) -> torch.Tensor:
+        """forward -> deep-supervision loss -> backward -> clip -> SGD, like nnU-Net's train_step."""
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.loss(self.network(data), target)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
+        self.optimizer.step()
+        return loss.detach()
+
+
+def deep_supervision_weights(n_scales: int) -> np.ndarray:
+    """1/2^i, last scale 0, normalised (reference nnUNetTrainer_NexToU_BTI_Synapse.py:23-27)."""
+    w = np.array([1 / (2 ** i) for i in range(n_scales)])
+    w[-1] = 0
+    return w / w.sum()
+
+
+def downsample_targets(target: torch.Tensor, outputs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """Nearest-neighbour label pyramids matching the deep-supervision heads (what nnU-Net's
+    DownsampleSegForDSTransform2 hands the loss)."""
+    out = []
+    for o in outputs:
+        if tuple(o.shape[2:]) == tuple(target.shape[2:]):
+            out.append(target)
+        else:
+            out.append(F.interpolate(target.float(), size=o.shape[2:], mode="nearest").to(target.dtype))
+    return out
+
+
+def synthetic_batch(configuration_manager, num_input_channels, num_classes, batch_size, device, seed=1234,
+                    blob_labels=False):
+    """i.i.d. N(0,1) images (nnU-Net z-scores its inputs) and integer label maps, generated on the
+    device (SURVEY.md §8d 'synthetic inputs')."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    shape = [batch_size, num_input_channels] + list(configuration_manager.patch_size)
+    data = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
+    lab_shape = [batch_size, 1] + list(configuration_manager.patch_size)
+    if blob_labels:
+        target = _blob_label_volume(lab_shape, num_classes, device, g)
+    else:
+        target = torch.randint(0, num_classes, lab_shape, generator=g, device=device).float()
+    return data, target
+
+
+def _blob_label_volume(shape, num_classes, device, g, n_seeds=40):
+    """Nearest-seed Voronoi label blobs (BTCV-style, SURVEY.md §8d cfg 4): i.i.d. labels would make
+    ~93 % of the voxels critical, which is unrepresentative for the BTI loss."""
+    b, spatial = shape[0], shape[2:]
+    dim = len(spatial)
+    out = torch.zeros(shape, device=device)
+    axes = [torch.arange(s, device=device, dtype=torch.float32) / s for s in spatial]
+    grid = torch.stack(torch.meshgrid(*axes, indexing="ij"), -1).reshape(-1, dim)
+    for i in range(b):
+        pts = torch.rand((n_seeds, dim), generator=g, device=device)
+        cls = torch.randint(1, num_classes, (n_seeds,), generator=g, device=device).float()
+        nearest = torch.cdist(grid, pts).argmin(1)
+        lab = cls[nearest]
+        lab[((grid - 0.5).abs().max(1).values > 0.45)] = 0
+        out[i, 0] = lab.reshape(spatial)
+    return out

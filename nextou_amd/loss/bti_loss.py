@@ -1,0 +1,116 @@
+"""Binary topological interaction (BTI) loss on the MI355X critical-voxel kernel.
+
+Interface mirror of the reference's ``loss/bti_loss.py:8-145`` (``BTI_Loss(dim, connectivity,
+inclusion, exclusion, min_thick).forward(x, y) -> 0-dim float64``), and — because a scalar label is a
+one-element set — of ``loss/ti_loss.py`` as well (``TI_Loss`` below).
+
+The reference computes the critical-voxel map with, per interaction, two ``isin`` masks, two
+float64 ``conv3d`` used as binary dilations and three ``where`` thresholds (:83-117).  That loop is
+pure bit logic: give every interaction one bit, look the two bit masks of a voxel's label up in a
+table, OR them over the neighbourhood and test ``(OR_c & a) | (OR_a & c)``.  Here the label map
+comes from ``graph_ops.argmax_labels`` and the map from ``graph_ops.bti_critical_map`` (one HIP pass
+over the uint8 volume); only the float64 cross-entropy of :141-143, through which all gradient
+flows, stays on PyTorch.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import graph_ops
+
+_BITS = 32  # interactions per kernel pass (one uint32 bit each)
+
+
+def _label_set(spec) -> List[int]:
+    """labels of one side of an interaction: 0-dim / 1-D tensor, int, or list of ints."""
+    if isinstance(spec, torch.Tensor):
+        return [int(v) for v in spec.detach().reshape(-1).tolist()]
+    if isinstance(spec, (list, tuple, np.ndarray)):
+        return [int(v) for v in np.asarray(spec).reshape(-1).tolist()]
+    return [int(spec)]
+
+
+class BTI_Loss(torch.nn.Module):
+    def __init__(self, dim=3, connectivity=26, inclusion=[], exclusion=[], min_thick=1):
+        """
+        :param dim: 2 or 3
+        :param connectivity: 4 or 8 in 2-D; 6 or 26 in 3-D
+        :param inclusion: list of [A, B] label sets, A completely surrounded by B
+        :param exclusion: list of [A, C] label sets that must not touch
+        :param min_thick: minimum separation; only used for connectivity 8 / 26
+        """
+        super().__init__()
+        if dim not in (2, 3):
+            raise ValueError("dim must be 2 or 3, got %r" % (dim,))
+        allowed = (4, 8) if dim == 2 else (6, 26)
+        if connectivity not in allowed:
+            raise ValueError("connectivity %r is not valid for dim=%d (use one of %s)" % (connectivity, dim, allowed))
+        self.dim, self.connectivity, self.min_thick = dim, connectivity, min_thick
+        self.sum_dim_list = [1, 2, 3] if dim == 2 else [1, 2, 3, 4]
+        # same bookkeeping as the reference (:38-49): [is_inclusion, A, C]
+        self.interaction_list = [[True, inc[0], inc[1]] for inc in inclusion] + \
+                                [[False, exc[0], exc[1]] for exc in exclusion]
+        self._luts = self._build_luts(self.interaction_list)
+        self._device_luts = {}
+
+    @staticmethod
+    def _build_luts(interactions: Sequence) -> List[np.ndarray]:
+        """One (lut_a, lut_c) uint32[256] pair per group of 32 interactions (reference :90-98)."""
+        groups = []
+        for g0 in range(0, len(interactions), _BITS):
+            lut_a = np.zeros(256, dtype=np.uint32)
+            lut_c = np.zeros(256, dtype=np.uint32)
+            for bit, (is_inclusion, spec_a, spec_c) in enumerate(interactions[g0:g0 + _BITS]):
+                set_a = [l for l in _label_set(spec_a) if 0 <= l < 256]
+                set_c = [l for l in _label_set(spec_c) if 0 <= l < 256]
+                lut_a[set_a] |= np.uint32(1 << bit)
+                if is_inclusion:  # C := not (C or A)
+                    member = np.zeros(256, dtype=bool)
+                    member[set_a] = True
+                    member[set_c] = True
+                    lut_c[~member] |= np.uint32(1 << bit)
+                else:
+                    lut_c[set_c] |= np.uint32(1 << bit)
+            groups.append((lut_a, lut_c))
+        return groups
+
+    def _luts_on(self, device):
+        key = str(device)
+        if key not in self._device_luts:
+            self._device_luts[key] = [
+                (torch.from_numpy(a.view(np.int32).copy()).to(device), torch.from_numpy(c.view(np.int32).copy()).to(device))
+                for a, c in self._luts]
+        return self._device_luts[key]
+
+    @torch.no_grad()
+    def critical_voxels_from_labels(self, labels: torch.Tensor) -> torch.Tensor:
+        """uint8 label map (B,*spatial) -> uint8 critical map of the same shape."""
+        critical = None
+        for lut_a, lut_c in self._luts_on(labels.device):
+            part = graph_ops.bti_critical_map(labels, lut_a, lut_c, self.connectivity, self.min_thick)
+            critical = part if critical is None else critical | part
+        if critical is None:  # no interactions: the reference would fail on an unbound name (:117)
+            raise UnboundLocalError("BTI_Loss needs at least one inclusion or exclusion interaction")
+        return critical
+
+    def binary_topological_interaction_module(self, P):
+        """Reference signature (:76-117): float label map (B,1,*spatial) -> float64 {0,1} map."""
+        labels = P.squeeze(1).to(torch.uint8).contiguous()
+        return self.critical_voxels_from_labels(labels).unsqueeze(1).double()
+
+    def forward(self, x, y):
+        """x: logits (B,L,*spatial); y: labels (B,1,*spatial) in [0,L) -> 0-dim float64 loss."""
+        labels = graph_ops.argmax_labels(x)                      # argmax(softmax(x,1),1), :132-134
+        critical = self.critical_voxels_from_labels(labels)
+        ce = F.cross_entropy(x.double(), y[:, 0].long(), reduction='none')   # :141
+        ce = ce * critical.to(ce.dtype)                                        # :142
+        return ce.sum(dim=self.sum_dim_list[:-1]).mean()                      # :143
+
+
+class TI_Loss(BTI_Loss):
+    """All-pairs topological interaction loss (reference loss/ti_loss.py:8-145): the same module with
+    scalar labels; more than 32 interactions run as several kernel passes OR-ed together."""

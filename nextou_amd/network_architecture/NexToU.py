@@ -1,0 +1,68 @@
+"""``NexToU`` — the nn.Module nnU-Net instantiates (drop-in boundary b of SURVEY.md §8).
+
+Constructor signature, attributes (``encoder``, ``decoder``, ``decoder.deep_supervision``), forward
+results and ``state_dict`` keys follow the reference's ``network_architecture/NexToU.py:11-63``.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple, Type, Union
+
+import torch
+from torch import nn
+from torch.nn.modules.conv import _ConvNd
+from torch.nn.modules.dropout import _DropoutNd
+
+from .NexToU_Encoder_Decoder import NexToU_Decoder, NexToU_Encoder
+from .conv_blocks import convert_conv_op_to_dim
+
+
+class NexToU(nn.Module):
+    def __init__(self,
+                 input_channels: int,
+                 patch_size: List[int],
+                 n_stages: int,
+                 features_per_stage: Union[int, List[int], Tuple[int, ...]],
+                 conv_op: Type[_ConvNd],
+                 kernel_sizes: Union[int, List[int], Tuple[int, ...]],
+                 strides: Union[int, List[int], Tuple[int, ...]],
+                 n_conv_per_stage: Union[int, List[int], Tuple[int, ...]],
+                 num_classes: int,
+                 n_conv_per_stage_decoder: Union[int, Tuple[int, ...], List[int]],
+                 conv_bias: bool = False,
+                 norm_op: Union[None, Type[nn.Module]] = None,
+                 norm_op_kwargs: dict = None,
+                 dropout_op: Union[None, Type[_DropoutNd]] = None,
+                 dropout_op_kwargs: dict = None,
+                 nonlin: Union[None, Type[torch.nn.Module]] = None,
+                 nonlin_kwargs: dict = None,
+                 deep_supervision: bool = False,
+                 nonlin_first: bool = False):
+        """nonlin_first: conv -> nonlin -> norm instead of conv -> norm -> nonlin."""
+        super().__init__()
+        if isinstance(n_conv_per_stage, int):
+            n_conv_per_stage = [n_conv_per_stage] * n_stages
+        if isinstance(n_conv_per_stage_decoder, int):
+            n_conv_per_stage_decoder = [n_conv_per_stage_decoder] * (n_stages - 1)
+        assert len(n_conv_per_stage) == n_stages, \
+            f"n_conv_per_stage must have as many entries as we have resolution stages. here: {n_stages}. " \
+            f"n_conv_per_stage: {n_conv_per_stage}"
+        assert len(n_conv_per_stage_decoder) == (n_stages - 1), \
+            f"n_conv_per_stage_decoder must have one less entries as we have resolution stages. here: " \
+            f"{n_stages} stages, so it should have {n_stages - 1} entries. " \
+            f"n_conv_per_stage_decoder: {n_conv_per_stage_decoder}"
+        self.encoder = NexToU_Encoder(input_channels, patch_size, n_stages, features_per_stage, conv_op,
+                                      kernel_sizes, strides, n_conv_per_stage, conv_bias, norm_op,
+                                      norm_op_kwargs, dropout_op, dropout_op_kwargs, nonlin, nonlin_kwargs,
+                                      return_skips=True, nonlin_first=nonlin_first)
+        self.decoder = NexToU_Decoder(self.encoder, patch_size, strides, num_classes, n_conv_per_stage_decoder,
+                                      deep_supervision, nonlin_first=nonlin_first)
+
+    def forward(self, x):
+        return self.decoder(self.encoder(x))
+
+    def compute_conv_feature_map_size(self, input_size):
+        assert len(input_size) == convert_conv_op_to_dim(self.encoder.conv_op), \
+            "just give the image size without color/feature channels or batch channel. Do not give " \
+            "input_size=(b, c, x, y(, z)). Give input_size=(x, y(, z))!"
+        return self.encoder.compute_conv_feature_map_size(input_size) + \
+            self.decoder.compute_conv_feature_map_size(input_size)

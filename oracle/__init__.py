@@ -1,0 +1,141 @@
+"""CPU oracle of the NexToU graph hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package; nothing under ``nextou_amd/`` does (tests/test_layout.py enforces it).
+
+Two checkers, both speaking the backend protocol of ``nextou_amd.graph_ops``:
+
+* :class:`CanonicalBackend` — ``liboracle.so`` (``nextou_oracle.c``): plain-C restatement with the
+  canonical arithmetic (fma chains, (dist, index) tie order).  The HIP kernels must match it bit for
+  bit on kNN indices and to fp32 rounding elsewhere.
+* :class:`TorchRefBackend` (``ref_ops.py``) — the reference's own op sequence in PyTorch-CPU
+  (normalize -> matmul -> topk -> gather -> sub -> max -> interleave); validated against golden
+  vectors generated from the reference itself; used as the timed CPU baseline ("port").
+
+Parity pin: ``tests/golden/*.npz`` were produced by importing ``/root/reference`` in the build
+container (``tests/golden/make_golden.py``); ``tests/test_oracle_golden.py`` holds both checkers to
+them.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_int, c_int64, c_void_p
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            from . import build as _build
+            _build.build(verbose=False)
+        h = ctypes.CDLL(LIB_PATH)
+        h.oracle_knn_graph.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6
+        h.oracle_pairwise_distance.argtypes = [c_void_p, c_void_p, c_void_p] + [c_int] * 6
+        h.oracle_mr_fwd.argtypes = [c_void_p] * 5 + [c_int] * 7
+        h.oracle_mr_bwd.argtypes = [c_void_p] * 7 + [c_int] * 7
+        h.oracle_argmax_labels.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int64]
+        h.oracle_bti_critical.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 6
+        for f in ("oracle_knn_graph", "oracle_pairwise_distance", "oracle_mr_fwd", "oracle_mr_bwd",
+                  "oracle_argmax_labels", "oracle_bti_critical"):
+            getattr(h, f).restype = c_int
+        _lib = h
+    return _lib
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ok(rc, what):
+    if rc != 0:
+        raise RuntimeError("oracle.%s rejected its arguments (rc=%d)" % (what, rc))
+
+
+class CanonicalBackend:
+    """Backend protocol of nextou_amd.graph_ops on CPU tensors, via liboracle.so."""
+
+    name = "oracle-canonical"
+
+    @staticmethod
+    def knn_graph(x, y, relpos, k_total, algo=0, normalize=True):
+        B, C, N = x.shape
+        M = N if y is None else y.shape[2]
+        out = torch.empty((B, N, k_total), dtype=torch.int32)
+        _ok(lib().oracle_knn_graph(_p(x), _p(y), _p(relpos), _p(out), B, C, N, M, k_total, int(normalize)),
+            "knn_graph")
+        return out
+
+    @staticmethod
+    def pairwise_distance(x, y, row_start, row_end):
+        B, C, N = x.shape
+        M = N if y is None else y.shape[2]
+        out = torch.empty((B, row_end - row_start, M), dtype=torch.float32)
+        _ok(lib().oracle_pairwise_distance(_p(x), _p(y), _p(out), B, C, N, M, row_start, row_end),
+            "pairwise_distance")
+        return out
+
+    @staticmethod
+    def edge_index(nn_idx, dilation):
+        B, N, K = nn_idx.shape
+        nn = nn_idx[:, :, ::dilation].to(torch.int64)
+        center = torch.arange(N, dtype=torch.int64).view(1, N, 1).expand_as(nn)
+        return torch.stack((nn, center), dim=0).contiguous()
+
+    @staticmethod
+    def mr_fwd(x, y, nn_idx, center, K, idx_step):
+        B, C, N = x.shape
+        M = N if y is None else y.shape[2]
+        out = torch.empty((B, 2 * C, N), dtype=torch.float32)
+        _ok(lib().oracle_mr_fwd(_p(x), _p(y), _p(nn_idx), _p(center), _p(out), B, C, N, M, K,
+                                nn_idx.shape[2], idx_step), "mr_fwd")
+        return out
+
+    @staticmethod
+    def mr_bwd(gout, x, y, nn_idx, center, K, idx_step):
+        B, C, N = x.shape
+        M = N if y is None else y.shape[2]
+        dx = torch.empty_like(x)
+        dy = None if y is None else torch.empty_like(y)
+        _ok(lib().oracle_mr_bwd(_p(gout), _p(x), _p(y), _p(nn_idx), _p(center), _p(dx), _p(dy), B, C, N, M,
+                                K, nn_idx.shape[2], idx_step), "mr_bwd")
+        return dx, dy
+
+    @staticmethod
+    def gather_fwd(src, idx):
+        B, C, M = src.shape
+        _, N, K = idx.shape
+        flat = idx.to(torch.int64).reshape(B, 1, N * K).expand(B, C, N * K)
+        return src.gather(2, flat).reshape(B, C, N, K)
+
+    @staticmethod
+    def gather_bwd(gout, idx, M):
+        B, C, N, K = gout.shape
+        flat = idx.to(torch.int64).reshape(B, 1, N * K).expand(B, C, N * K)
+        return torch.zeros((B, C, M), dtype=gout.dtype).scatter_add_(2, flat, gout.reshape(B, C, N * K))
+
+    @staticmethod
+    def argmax_labels(logits):
+        B, L = logits.shape[:2]
+        V = logits[0, 0].numel()
+        out = torch.empty((B,) + tuple(logits.shape[2:]), dtype=torch.uint8)
+        _ok(lib().oracle_argmax_labels(_p(logits), _p(out), B, L, V), "argmax_labels")
+        return out
+
+    @staticmethod
+    def bti_critical(labels, lut_a, lut_c, connectivity, min_thick):
+        if labels.dim() == 3:
+            (B, H, W), D = labels.shape, 1
+        else:
+            B, D, H, W = labels.shape
+        out = torch.empty_like(labels)
+        _ok(lib().oracle_bti_critical(_p(labels), _p(lut_a), _p(lut_c), lut_a.numel(), _p(out), B, D, H, W,
+                                      connectivity, min_thick), "bti_critical")
+        return out

@@ -1,0 +1,263 @@
+/*
+ * nextou_oracle.c — CPU restatement of the NexToU graph hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * nothing under nextou_amd/ does.  It restates, in plain C, the algorithm of the reference files
+ * cited at each function and fixes the arithmetic the reference leaves to BLAS / ATen
+ * (accumulation order, tie order) to the canonical form of SURVEY.md §7 hard parts 1-2:
+ *
+ *   den   = max(sqrtf(chain_c x^2), 1e-12f);   xn = x / den            [F.normalize, eps 1e-12]
+ *   xs    = chain_c xn^2;   inner = chain_c xn*yn      chain: acc = fmaf(a_c, b_c, acc), c ascending
+ *   dist  = ((xs + (-2*inner)) + ys) [+ relpos]        same association as torch_edge.py:23,55,79
+ *   kNN   = K smallest by (dist, index), ascending
+ *
+ * Parity pin: tests/test_oracle_golden.py checks every function here against golden vectors
+ * produced by importing the reference itself (tests/golden/make_golden.py).
+ *
+ * Build: gcc -O2 -fPIC -shared -ffp-contract=off -fopenmp (oracle/build.py); -ffp-contract=off
+ * keeps every rounding where it is written.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NORM_EPS 1e-12f
+
+/* ---- normalisation: reference torch_edge.py:154-155,160 (F.normalize(x, p=2, dim=1)) ---------- */
+/* x (B,C,N) -> xn (B,C,N) (if normalize) and sq (B,N) = chain of (normalised) squares */
+static void prep(const float* x, float* xn, float* sq, int B, int C, int N, int normalize) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n) {
+            const float* xb = x + (size_t)b * C * N + n;
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) s = fmaf(xb[(size_t)c * N], xb[(size_t)c * N], s);
+            if (!normalize) {
+                sq[(size_t)b * N + n] = s;
+                continue;
+            }
+            float den = sqrtf(s);
+            if (!(den > NORM_EPS)) den = NORM_EPS;
+            float q = 0.f;
+            float* xo = xn + (size_t)b * C * N + n;
+            for (int c = 0; c < C; ++c) {
+                const float v = xb[(size_t)c * N] / den;
+                xo[(size_t)c * N] = v;
+                q = fmaf(v, v, q);
+            }
+            sq[(size_t)b * N + n] = q;
+        }
+}
+
+static inline uint64_t knn_key(float d, int m) {
+    uint32_t u;
+    memcpy(&u, &d, 4);
+    if (u == 0x80000000u) u = 0u; /* -0 == +0 */
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((uint64_t)u << 32) | (uint32_t)m;
+}
+
+/* one row of distances: reference torch_edge.py:12-23 / 26-39 / 42-55 (+ :79,86,107 bias) */
+static void dist_row(const float* xn, const float* yn, const float* xs, const float* ys,
+                     const float* relpos, float* drow, int b, int n, int C, int N, int M) {
+    const float* xb = xn + (size_t)b * C * N + n;
+    const float xsv = xs[(size_t)b * N + n];
+    for (int m = 0; m < M; ++m) drow[m] = 0.f;
+    for (int c = 0; c < C; ++c) { /* c outer keeps the per-(n,m) chain order and streams y rows */
+        const float xv = xb[(size_t)c * N];
+        const float* yr = yn + ((size_t)b * C + c) * M;
+        for (int m = 0; m < M; ++m) drow[m] = fmaf(yr[m], xv, drow[m]);
+    }
+    for (int m = 0; m < M; ++m) {
+        float d = (xsv + (-2.0f * drow[m])) + ys[(size_t)b * M + m];
+        if (relpos) d = d + relpos[(size_t)n * M + m];
+        drow[m] = d;
+    }
+}
+
+static int cmp_u64(const void* a, const void* b) {
+    const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return (x > y) - (x < y);
+}
+
+/* kNN graph: reference torch_edge.py:151-163 (normalize), :58-110 (distance + topk).
+ * x (B,C,N), y (B,C,M) or NULL, relpos (N,M) or NULL -> nn_idx (B,N,K) int32.  returns 0 / -1 */
+int oracle_knn_graph(const float* x, const float* y, const float* relpos, int32_t* nn_idx, int B, int C,
+                     int N, int M, int K, int normalize) {
+    if (!x || !nn_idx || B <= 0 || C <= 0 || N <= 0 || M <= 0 || K <= 0 || K > M) return -1;
+    if (!y && M != N) return -1;
+    float* xn = normalize ? (float*)malloc((size_t)B * C * N * sizeof(float)) : (float*)x;
+    float* xs = (float*)malloc((size_t)B * N * sizeof(float));
+    float *yn = xn, *ys = xs;
+    prep(x, xn, xs, B, C, N, normalize);
+    if (y) {
+        yn = normalize ? (float*)malloc((size_t)B * C * M * sizeof(float)) : (float*)y;
+        ys = (float*)malloc((size_t)B * M * sizeof(float));
+        prep(y, yn, ys, B, C, M, normalize);
+    }
+#pragma omp parallel
+    {
+        float* drow = (float*)malloc((size_t)M * sizeof(float));
+        uint64_t* keys = (uint64_t*)malloc((size_t)M * sizeof(uint64_t));
+#pragma omp for collapse(2) schedule(dynamic, 16)
+        for (int b = 0; b < B; ++b)
+            for (int n = 0; n < N; ++n) {
+                dist_row(xn, yn, xs, ys, relpos, drow, b, n, C, N, M);
+                for (int m = 0; m < M; ++m) keys[m] = knn_key(drow[m], m);
+                /* K smallest keys, ascending: selection for small K, full sort otherwise */
+                int32_t* o = nn_idx + ((size_t)b * N + n) * K;
+                if ((long)K * 8 < M) {
+                    uint64_t prev = 0;
+                    for (int j = 0; j < K; ++j) {
+                        uint64_t best = ~(uint64_t)0;
+                        for (int m = 0; m < M; ++m)
+                            if ((j == 0 || keys[m] > prev) && keys[m] < best) best = keys[m];
+                        o[j] = (int32_t)(best & 0xffffffffu);
+                        prev = best;
+                    }
+                } else {
+                    qsort(keys, (size_t)M, sizeof(uint64_t), cmp_u64);
+                    for (int j = 0; j < K; ++j) o[j] = (int32_t)(keys[j] & 0xffffffffu);
+                }
+            }
+        free(drow);
+        free(keys);
+    }
+    if (normalize) free(xn);
+    free(xs);
+    if (y) {
+        if (normalize) free(yn);
+        free(ys);
+    }
+    return 0;
+}
+
+/* materialised distances, no normalisation, no bias: reference torch_edge.py:12-55.
+ * dist (B, row_end-row_start, M) */
+int oracle_pairwise_distance(const float* x, const float* y, float* dist, int B, int C, int N, int M,
+                             int row_start, int row_end) {
+    if (!x || !dist || row_start < 0 || row_end > N || row_start >= row_end) return -1;
+    if (!y && M != N) return -1;
+    float* xs = (float*)malloc((size_t)B * N * sizeof(float));
+    float* ys = xs;
+    prep(x, NULL, xs, B, C, N, 0);
+    if (y) {
+        ys = (float*)malloc((size_t)B * M * sizeof(float));
+        prep(y, NULL, ys, B, C, M, 0);
+    }
+    const int rows = row_end - row_start;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int r = 0; r < rows; ++r)
+            dist_row(x, y ? y : x, xs, ys, NULL, dist + ((size_t)b * rows + r) * M, b, row_start + r, C, N, M);
+    free(xs);
+    if (y) free(ys);
+    return 0;
+}
+
+/* max-relative aggregation forward: reference NexToU_Encoder_Decoder.py:401-409 with
+ * batched_index_select torch_nn.py:94-115.  out (B,2C,N) interleaved [x_c, mr_c]. */
+int oracle_mr_fwd(const float* x, const float* y, const int32_t* nn_idx, const int32_t* center,
+                  float* out, int B, int C, int N, int M, int K, int idx_stride, int idx_step) {
+    const float* src = y ? y : x;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const float* xr = x + ((size_t)b * C + c) * N;
+            const float* sr = src + ((size_t)b * C + c) * M;
+            float* o = out + ((size_t)b * 2 * C + 2 * c) * N;
+            for (int n = 0; n < N; ++n) {
+                const size_t io = ((size_t)b * N + n) * idx_stride;
+                float mx = 0.f;
+                for (int j = 0; j < K; ++j) {
+                    const float xc = center ? xr[center[io + (size_t)j * idx_step]] : xr[n];
+                    const float v = sr[nn_idx[io + (size_t)j * idx_step]] - xc;
+                    if (j == 0 || v > mx) mx = v;
+                }
+                o[n] = xr[n];
+                o[N + n] = mx;
+            }
+        }
+    return 0;
+}
+
+/* backward of the above (autograd: max -> first arg-max, sub, index_put accumulate).
+ * Accumulation in n-ascending order per (b,c): deterministic. dx (B,C,N), dy (B,C,M) or NULL. */
+int oracle_mr_bwd(const float* gout, const float* x, const float* y, const int32_t* nn_idx,
+                  const int32_t* center, float* dx, float* dy, int B, int C, int N, int M, int K,
+                  int idx_stride, int idx_step) {
+    const float* src = y ? y : x;
+    memset(dx, 0, (size_t)B * C * N * sizeof(float));
+    if (dy) memset(dy, 0, (size_t)B * C * M * sizeof(float));
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const float* xr = x + ((size_t)b * C + c) * N;
+            const float* sr = src + ((size_t)b * C + c) * M;
+            const float* g = gout + ((size_t)b * 2 * C + 2 * c) * N;
+            float* dxr = dx + ((size_t)b * C + c) * N;
+            float* dsr = dy ? dy + ((size_t)b * C + c) * M : dxr;
+            for (int n = 0; n < N; ++n) {
+                const size_t io = ((size_t)b * N + n) * idx_stride;
+                float mx = 0.f;
+                int am = 0, ac = n;
+                for (int j = 0; j < K; ++j) {
+                    const int cj = center ? center[io + (size_t)j * idx_step] : n;
+                    const int sj = nn_idx[io + (size_t)j * idx_step];
+                    const float v = sr[sj] - xr[cj];
+                    if (j == 0 || v > mx) { mx = v; am = sj; ac = cj; }
+                }
+                dxr[n] += g[n];
+                dxr[ac] -= g[N + n];
+                dsr[am] += g[N + n];
+            }
+        }
+    return 0;
+}
+
+/* first arg-max over the class planes: reference bti_loss.py:132-134 (argmax of softmax) */
+int oracle_argmax_labels(const float* logits, uint8_t* labels, int B, int L, int64_t V) {
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int64_t v = 0; v < V; ++v) {
+            const float* p = logits + (size_t)b * L * V + v;
+            float best = p[0];
+            uint8_t arg = 0;
+            for (int l = 1; l < L; ++l)
+                if (p[(size_t)l * V] > best) { best = p[(size_t)l * V]; arg = (uint8_t)l; }
+            labels[(size_t)b * V + v] = arg;
+        }
+    return 0;
+}
+
+/* critical-voxel map as bit logic: reference bti_loss.py:76-117 (kernel :52-73).
+ * labels (B,D,H,W) uint8; bit i of lut_a[l] / lut_c[l] = membership of l in A_i / C_i. */
+int oracle_bti_critical(const uint8_t* labels, const uint32_t* lut_a, const uint32_t* lut_c, int n_labels,
+                        uint8_t* critical, int B, int D, int H, int W, int connectivity, int min_thick) {
+    const int full = (connectivity == 26 || connectivity == 8);
+    if (!full && connectivity != 6 && connectivity != 4) return -1;
+    const int rad = full ? min_thick : 1;
+    const int64_t HW = (int64_t)H * W, V = HW * D;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int d = 0; d < D; ++d)
+            for (int h = 0; h < H; ++h)
+                for (int w = 0; w < W; ++w) {
+                    const uint8_t* lb = labels + (size_t)b * V;
+                    const uint8_t self = lb[d * HW + (int64_t)h * W + w];
+                    const uint32_t a = self < n_labels ? lut_a[self] : 0, c = self < n_labels ? lut_c[self] : 0;
+                    uint32_t na = 0, nc = 0;
+                    for (int dz = -rad; dz <= rad; ++dz)
+                        for (int dy = -rad; dy <= rad; ++dy)
+                            for (int dx = -rad; dx <= rad; ++dx) {
+                                if (!full && (abs(dz) + abs(dy) + abs(dx) > 1)) continue;
+                                const int z = d + dz, yy = h + dy, xx = w + dx;
+                                if (z < 0 || z >= D || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                                const uint8_t l = lb[z * HW + (int64_t)yy * W + xx];
+                                if (l < n_labels) { na |= lut_a[l]; nc |= lut_c[l]; }
+                            }
+                    critical[(size_t)b * V + d * HW + (int64_t)h * W + w] = ((nc & a) | (na & c)) ? 1 : 0;
+                }
+    return 0;
+}

@@ -1,0 +1,152 @@
+"""The reference's op sequence for the graph hot path, restated in PyTorch-CPU.  TEST
+INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Where ``nextou_oracle.c`` fixes the arithmetic to a canonical form, this file keeps the *ops* the
+reference executes, in its order, so that (a) it can be compared value-for-value with golden
+vectors made from the reference itself and (b) timing it on the host is a fair stand-in for the
+reference's CPU path (bench.py ``cpu_baseline.kind = "port"``; the reference's Python cannot
+travel to the GPU box).  Each function cites the reference lines it follows.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def knn_graph_ref(x, y=None, relpos=None, k=9, normalize=True):
+    """torch_edge.py:151-163 (normalize) + :58-110 (distance, += relative_pos, topk(-dist)).
+    x (B,C,N), y (B,C,M)|None, relpos (N,M)|None -> int64 (B,N,k) in torch.topk's order."""
+    with torch.no_grad():
+        if normalize:
+            x = F.normalize(x, p=2.0, dim=1)
+            y = None if y is None else F.normalize(y, p=2.0, dim=1)
+        xt = x.transpose(2, 1)                                    # (B,N,C)            :66 / :103
+        yt = xt if y is None else y.transpose(2, 1)
+        inner = -2 * torch.matmul(xt, yt.transpose(2, 1))         # :20 / :52
+        x_sq = torch.sum(torch.mul(xt, xt), dim=-1, keepdim=True)  # :21 / :53
+        y_sq = torch.sum(torch.mul(yt, yt), dim=-1, keepdim=True)
+        dist = x_sq + inner + y_sq.transpose(2, 1)                # :22 / :55
+        if relpos is not None:
+            dist += relpos.unsqueeze(0)                           # :79 / :86 / :107
+        _, nn_idx = torch.topk(-dist, k=k)                        # :87 / :108
+    return nn_idx
+
+
+def pairwise_ref(x, y=None, row_start=0, row_end=None):
+    """torch_edge.py:12-23 / :26-39 / :42-55 on channel-major inputs."""
+    xt = x.transpose(2, 1)
+    yt = xt if y is None else y.transpose(2, 1)
+    row_end = xt.shape[1] if row_end is None else row_end
+    xp = xt[:, row_start:row_end]
+    inner = -2 * torch.matmul(xp, yt.transpose(2, 1))
+    return (xp * xp).sum(-1, keepdim=True) + inner + (yt * yt).sum(-1, keepdim=True).transpose(2, 1)
+
+
+def batched_index_select_ref(x, idx):
+    """torch_nn.py:94-115 — x (B,C,M), idx (B,N,k) int64 -> (B,C,N,k) via the flat (B*M, C) gather."""
+    B, C, M = x.shape
+    _, N, k = idx.shape
+    base = torch.arange(0, B, device=idx.device).view(-1, 1, 1) * M
+    flat = (idx + base).contiguous().view(-1)
+    feat = x.transpose(2, 1).contiguous().view(B * M, -1)[flat, :]
+    return feat.view(B, N, k, C).permute(0, 3, 1, 2).contiguous()
+
+
+def mr_aggregate_ref(x, nn_idx, y=None, center_idx=None):
+    """NexToU_Encoder_Decoder.py:401-409 — x (B,C,N), nn_idx (B,N,k) -> (B,2C,N), differentiable."""
+    B, C, N = x.shape
+    nn_idx = nn_idx.to(torch.int64)
+    if center_idx is None:
+        center_idx = torch.arange(N, device=x.device).view(1, N, 1).expand_as(nn_idx)
+    x_i = batched_index_select_ref(x, center_idx.to(torch.int64))
+    x_j = batched_index_select_ref(x if y is None else y, nn_idx)
+    x_j, _ = torch.max(x_j - x_i, -1, keepdim=True)               # :407
+    out = torch.cat([x.unsqueeze(2).unsqueeze(-1), x_j.unsqueeze(2)], dim=2)  # :409
+    return out.reshape(B, 2 * C, N)
+
+
+def bti_critical_ref(P, interactions, dim, connectivity, min_thick=1):
+    """loss/bti_loss.py:76-117 with the kernel of :52-73 — the float64 conv formulation.
+    P: float64 label map (B,1,*sp); interactions: list of (is_inclusion, A tensor, C tensor)."""
+    import numpy as np
+    k = 2 * min_thick + 1
+    if dim == 2:
+        kern = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]]) if connectivity == 4 else np.ones((k, k))
+        conv = F.conv2d
+    else:
+        if connectivity == 6:
+            kern = np.zeros((3, 3, 3))
+            kern[1, 1, :] = 1
+            kern[1, :, 1] = 1
+            kern[:, 1, 1] = 1
+        else:
+            kern = np.ones((k, k, k))
+        conv = F.conv3d
+    kernel = torch.from_numpy(kern[None, None]).double()
+    critical = None
+    for inclusion, lab_a, lab_c in interactions:
+        mask_a = torch.isin(P, lab_a).double()
+        mask_c = torch.isin(P, lab_c).double()
+        if inclusion:
+            mask_c = torch.logical_not(torch.logical_or(mask_c, mask_a)).double()
+        nb_c = (conv(mask_c, kernel, padding='same') >= 1.0).double()
+        nb_a = (conv(mask_a, kernel, padding='same') >= 1.0).double()
+        viol = ((nb_c * mask_a + nb_a * mask_c) >= 1.0).double()
+        critical = viol if critical is None else torch.logical_or(critical, viol).double()
+    return critical
+
+
+class TorchRefBackend:
+    """Backend protocol of nextou_amd.graph_ops with the reference's op sequence (CPU baseline)."""
+
+    name = "oracle-torch-ref"
+
+    @staticmethod
+    def knn_graph(x, y, relpos, k_total, algo=0, normalize=True):
+        return knn_graph_ref(x, y, relpos, k_total, normalize).to(torch.int32)
+
+    @staticmethod
+    def pairwise_distance(x, y, row_start, row_end):
+        return pairwise_ref(x, y, row_start, row_end)
+
+    @staticmethod
+    def edge_index(nn_idx, dilation):
+        from . import CanonicalBackend
+        return CanonicalBackend.edge_index(nn_idx, dilation)
+
+    # mr_fwd / mr_bwd as a pair through autograd of the reference op sequence
+    @staticmethod
+    def mr_fwd(x, y, nn_idx, center, K, idx_step):
+        idx = nn_idx[:, :, ::idx_step][:, :, :K]
+        ctr = None if center is None else center[:, :, ::idx_step][:, :, :K]
+        with torch.no_grad():
+            return mr_aggregate_ref(x, idx, y, ctr)
+
+    @staticmethod
+    def mr_bwd(gout, x, y, nn_idx, center, K, idx_step):
+        idx = nn_idx[:, :, ::idx_step][:, :, :K]
+        ctr = None if center is None else center[:, :, ::idx_step][:, :, :K]
+        with torch.enable_grad():
+            xg = x.detach().requires_grad_(True)
+            yg = None if y is None else y.detach().requires_grad_(True)
+            out = mr_aggregate_ref(xg, idx, yg, ctr)
+            grads = torch.autograd.grad(out, [xg] if yg is None else [xg, yg], gout)
+        return grads[0], (None if yg is None else grads[1])
+
+    @staticmethod
+    def gather_fwd(src, idx):
+        return batched_index_select_ref(src, idx.to(torch.int64))
+
+    @staticmethod
+    def gather_bwd(gout, idx, M):
+        from . import CanonicalBackend
+        return CanonicalBackend.gather_bwd(gout, idx, M)
+
+    @staticmethod
+    def argmax_labels(logits):
+        return torch.argmax(F.softmax(logits, 1), dim=1).to(torch.uint8)   # bti_loss.py:132-133
+
+    @staticmethod
+    def bti_critical(labels, lut_a, lut_c, connectivity, min_thick):
+        from . import CanonicalBackend
+        return CanonicalBackend.bti_critical(labels, lut_a, lut_c, connectivity, min_thick)

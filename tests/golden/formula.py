@@ -1,0 +1,70 @@
+"""Deterministic, formula-generated tensors shared by the golden generator and the tests.
+
+Weights and inputs of the fixtures are *recomputed* from (name, shape, seed) on both sides instead
+of being stored: ``torch.manual_seed`` streams are not a contract, numpy's PCG64 bit stream is.
+"""
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+import torch
+
+
+def _rng(tag: str, seed: int) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64([zlib.crc32(tag.encode()), seed]))
+
+
+def gaussian(tag: str, shape, seed: int = 0, scale: float = 1.0) -> torch.Tensor:
+    return torch.from_numpy((_rng(tag, seed).standard_normal(tuple(shape)) * scale).astype(np.float32))
+
+
+def fill_module_(module: torch.nn.Module, seed: int = 0) -> None:
+    """He-style formula weights keyed by the ``state_dict`` name (identical key grammar on the
+    reference and on nextou_amd).  ``relative_pos`` tables are left as built."""
+    seen = {}
+    with torch.no_grad():
+        for name, p in list(module.named_parameters(remove_duplicate=False)) + \
+                list(module.named_buffers(remove_duplicate=False)):
+            if name.endswith("relative_pos") or name.endswith("num_batches_tracked"):
+                continue
+            if id(p) in seen:  # aliases (decoder.encoder.*, all_modules.*) share storage
+                continue
+            seen[id(p)] = name
+            leaf = name.rsplit(".", 1)[-1]
+            if leaf == "weight" and p.dim() >= 3:          # conv / transposed conv
+                fan_in = int(np.prod(p.shape[1:]))
+                v = gaussian(name, p.shape, seed, scale=float(np.sqrt(2.0 / fan_in)))
+            elif leaf == "weight":                          # norm scale
+                v = 1.0 + gaussian(name, p.shape, seed, scale=0.1)
+            elif leaf == "bias":
+                v = gaussian(name, p.shape, seed, scale=0.05)
+            elif leaf == "running_mean":
+                v = gaussian(name, p.shape, seed, scale=0.1)
+            elif leaf == "running_var":
+                v = 1.0 + gaussian(name, p.shape, seed, scale=0.1).abs()
+            else:
+                raise KeyError("no formula for %s" % name)
+            p.copy_(v)
+
+
+def blob_labels(shape, n_classes: int, n_seeds: int = 40, seed: int = 4321) -> np.ndarray:
+    """BTCV-style synthetic label volume: nearest-seed Voronoi cells with a background shell
+    (SURVEY.md §8d cfg 4) — i.i.d. labels would make ~93 % of the voxels critical."""
+    rng = _rng("blob_labels", seed)
+    dim = len(shape)
+    pts = rng.random((n_seeds, dim)) * np.asarray(shape)
+    cls = rng.integers(1, n_classes, size=n_seeds)
+    grids = np.meshgrid(*[np.arange(s, dtype=np.float32) for s in shape], indexing="ij")
+    coords = np.stack(grids, -1).reshape(-1, dim)
+    best = np.full(coords.shape[0], np.inf, dtype=np.float32)
+    lab = np.zeros(coords.shape[0], dtype=np.int64)
+    for p, c in zip(pts, cls):
+        d = ((coords - p.astype(np.float32)) ** 2).sum(1)
+        take = d < best
+        best[take] = d[take]
+        lab[take] = c
+    centre = (np.asarray(shape, dtype=np.float32) - 1) / 2
+    r = np.sqrt((((coords - centre) / (np.asarray(shape, dtype=np.float32) / 2)) ** 2).sum(1))
+    lab[r > 0.9] = 0
+    return lab.reshape(shape)
