@@ -1,0 +1,268 @@
+#!/usr/bin/env python
+"""bench.py — voxels/sec of the NexToU train step (fwd + loss + bwd [+ grad all-reduce] + SGD) on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]            # N = 1: plain process
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W  # one rank per GPU over RCCL
+
+Workload (BASELINE.json configs[1], SURVEY.md §8d cfg 2): 3-D NexToU, patch 64x224x192, base 33 /
+max 324 features, 6 stages, 14 classes, batch 2 per GPU, fp32, BatchNorm in train mode,
+deep-supervision-weighted cross-entropy; synthetic N(0,1) volumes and random-init (He) weights.
+One step = zero_grad -> forward (5 heads) -> loss -> backward -> (N > 1: bucketed RCCL gradient
+average, overlapped with backward) -> clip_grad_norm_(12) -> SGD(nesterov).  `value` = all ranks'
+voxels / max-over-ranks time of exactly K steps between barrier + synchronize pairs.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     — the dominant own HIP kernel of the timed region: algorithmic flops or bytes per launch
+                 / its mean launch duration (HIP events on the launch stream, recorded inside
+                 libnextou_hip.so), against the MI355X peak it is bound by;
+  cpu_baseline — the oracle's PyTorch-CPU port of the reference op sequence (oracle/ref_ops.py) timed on
+                 this box's host cores on a bounded sample (N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from nextou_amd import _lib, graph_ops  # noqa: E402
+from nextou_amd.ddp import BucketedGradientAverager, init_process_group_from_env  # noqa: E402
+from nextou_amd.harness import (config_3d_fullres_nextou, deep_supervision_weights, downsample_targets,  # noqa: E402
+                                synthetic_batch)
+from nextou_amd.loss.nnunet_losses import DeepSupervisionWrapper, RobustCrossEntropyLoss  # noqa: E402
+from nextou_amd.nnUNetTrainer.nnUNetTrainer_NexToU import nnUNetTrainer_NexToU  # noqa: E402
+from nextou_amd.nnUNetTrainer.nnUNetTrainer_NexToU_BTI_Synapse import nnUNetTrainer_NexToU_BTI_Synapse  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA = f32 vector peak
+
+WORKLOADS = {
+    # name: (patch, base, max_features, batch/GPU, classes)
+    "cfg2": ((64, 224, 192), 33, 324, 2, 14),
+    "cfg4": ((64, 224, 192), 33, 324, 2, 14),      # cfg2 + Dice + CE + BTI loss, blob labels
+    "tiny": ((32, 128, 128), 6, 48, 2, 14),        # plumbing check only — never a reported number
+}
+
+
+class _CETrainer(nnUNetTrainer_NexToU):
+    """cfg 2: deep-supervision-weighted cross-entropy."""
+
+    def _build_loss(self):
+        return DeepSupervisionWrapper(RobustCrossEntropyLoss(),
+                                      deep_supervision_weights(len(self._get_deep_supervision_scales())))
+
+
+def build_trainer(workload, device, is_ddp, seed=0):
+    patch, base, max_f, batch, classes = WORKLOADS[workload]
+    cfg = config_3d_fullres_nextou(patch_size=patch, base=base, max_features=max_f, batch_size=batch)
+    cls = nnUNetTrainer_NexToU_BTI_Synapse if workload == "cfg4" else _CETrainer
+    torch.manual_seed(seed)
+    trainer = cls(cfg, classes, num_input_channels=1, device=torch.device("cpu"), is_ddp=is_ddp, log=None)
+    trainer.initialize()              # built on the host (position tables), moved below
+    trainer.device = device
+    return trainer, cfg, batch, classes
+
+
+def move_to(trainer, device):
+    trainer.network.to(device)
+    trainer.device = device
+    trainer.optimizer = torch.optim.SGD(trainer.network.parameters(), trainer.initial_lr,
+                                        weight_decay=trainer.weight_decay, momentum=trainer.momentum, nesterov=True)
+    if hasattr(trainer.loss, "loss") and hasattr(trainer.loss.loss, "ti"):
+        trainer.loss = trainer._build_loss()      # interaction tensors follow the device
+
+
+def make_step(trainer, data, targets, averager):
+    params = [p for p in trainer.network.parameters() if p.requires_grad]
+
+    def step():
+        trainer.optimizer.zero_grad(set_to_none=True)
+        loss = trainer.loss(trainer.network(data), targets)
+        loss.backward()
+        if averager is not None:
+            averager.finalize()
+        torch.nn.utils.clip_grad_norm_(params, 12)
+        trainer.optimizer.step()
+        return loss
+    return step
+
+
+def profile_report():
+    buf = ctypes.create_string_buffer(1 << 20)
+    n = _lib.lib().nextou_profile_report(buf, len(buf))
+    return json.loads(buf.value.decode()) if n else []
+
+
+def roofline_from(report):
+    """Dominant own kernel (largest summed time in the timed region)."""
+    if not report:
+        return None
+    top = max(report, key=lambda r: r["ms"])
+    per_launch_work = top["work"] / top["launches"]
+    per_launch_s = top["ms"] / top["launches"] / 1e3
+    if top["bound"] == "mfma":
+        achieved, peak, unit = per_launch_work / per_launch_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+    else:
+        achieved, peak, unit = per_launch_work / per_launch_s / 1e9, HBM_PEAK_GBS, "GB/s"
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):   # HBM bytes per launch from a committed rocprofv3 --pmc run
+        traffic = json.load(open(tpath)).get(top["kernel"].split("[")[0])
+    return {"bound": top["bound"], "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+            "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": top["kernel"],
+            "launches": top["launches"], "avg_us": round(per_launch_s * 1e6, 2),
+            "own_kernels_ms_per_step": None}
+
+
+def cpu_baseline(workload, seconds_budget=90.0):
+    """oracle/ref_ops.py (the reference's op sequence, PyTorch-CPU fp32) on this host's cores:
+    one full train step of the same network at batch 1 — a bounded sample of the same workload."""
+    from oracle.ref_ops import TorchRefBackend   # checker / baseline only — never the product path
+    import oracle  # noqa: F401
+    patch, base, max_f, _, classes = WORKLOADS[workload]
+    threads = torch.get_num_threads()
+    graph_ops.install_cpu_checker(TorchRefBackend)
+    try:
+        trainer, cfg, _, _ = build_trainer(workload, torch.device("cpu"), False)
+        data, target = synthetic_batch(cfg, 1, classes, 1, torch.device("cpu"), blob_labels=(workload == "cfg4"))
+        with torch.no_grad():
+            shapes = [tuple(o.shape[2:]) for o in _head_shapes(cfg)]
+        targets = [target if s == tuple(target.shape[2:]) else
+                   torch.nn.functional.interpolate(target, size=s, mode="nearest") for s in shapes]
+        step = make_step(trainer, data, targets, None)
+        t0 = time.perf_counter()
+        step()
+        dt = time.perf_counter() - t0
+    finally:
+        graph_ops.install_cpu_checker(None)
+    voxels = int(np.prod(patch))
+    return {"value": round(voxels / dt, 1), "unit": "voxels/s", "cores": threads, "kind": "port",
+            "sample": "1 train step (fwd+loss+bwd+SGD), batch 1 of the %s patch, fp32, %.1f s" % ("x".join(map(str, patch)), dt),
+            "cpu": _cpu_model()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip() + " (%d logical)" % os.cpu_count()
+    except OSError:
+        pass
+    return "unknown"
+
+
+class _Shape:
+    def __init__(self, shape):
+        self.shape = shape
+
+
+def _head_shapes(cfg):
+    """(B, L, *spatial) of the deep-supervision heads, highest resolution first (all but the
+    bottleneck resolution)."""
+    shape = list(cfg.patch_size)
+    out = []
+    for pool in cfg.pool_op_kernel_sizes[:-1]:
+        shape = [s // p for s, p in zip(shape, pool)]
+        out.append(_Shape((1, 1, *shape)))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-miopen-find", action="store_true", help="disable MIOpen's find/benchmark mode")
+    ap.add_argument("--bucket-mb", type=int, default=32)
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    _lib.lib()  # fail loudly if the HIP extension is missing
+    rank, local_rank, world = init_process_group_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    torch.backends.cudnn.benchmark = not args.no_miopen_find
+
+    trainer, cfg, batch, classes = build_trainer(args.workload, device, world > 1)
+    cpu_copy_ok = (rank == 0 and world == 1 and not args.no_cpu_baseline)
+    move_to(trainer, device)
+    averager = BucketedGradientAverager(trainer.network, bucket_bytes=args.bucket_mb << 20) if world > 1 else None
+    data, target = synthetic_batch(cfg, 1, classes, batch, device, seed=1234 + rank,
+                                   blob_labels=(args.workload == "cfg4"))
+    targets = downsample_targets(target, _head_shapes(cfg))
+    step = make_step(trainer, data, targets, averager)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _lib.lib().nextou_profile_enable(64 * max(args.steps, 1) * 8)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    report = profile_report()
+    _lib.lib().nextou_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        voxels_per_step = world * batch * int(np.prod(cfg.patch_size))
+        ms = elapsed / args.steps * 1e3
+        roof = roofline_from(report)
+        if roof is not None:
+            roof["own_kernels_ms_per_step"] = round(sum(r["ms"] for r in report) / args.steps, 3)
+        line = {
+            "metric": "voxels/sec fwd+bwd, 3D 64x224x192 patch batch=2",
+            "value": round(voxels_per_step / (elapsed / args.steps), 1),
+            "unit": "voxels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: 3D NexToU %s, base %d / max %d features, batch %d per GPU, "
+                                   "%d classes, fp32, train-mode BN, %s; step = fwd+loss+bwd%s+clip+SGD"
+                                   % ("x".join(map(str, cfg.patch_size)), cfg.UNet_base_num_features,
+                                      cfg.unet_max_num_features, batch, classes,
+                                      "Dice+CE+BTI(Synapse) loss" if args.workload == "cfg4" else "deep-supervision CE loss",
+                                      "+RCCL grad all-reduce" if world > 1 else ""),
+                       "name": args.workload, "global_batch": world * batch,
+                       "parallelism": "dp%d" % world, "final_loss": float(loss)},
+            "roofline": roof,
+        }
+        if cpu_copy_ok:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.workload)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                line["cpu_baseline"] = {"value": None, "unit": "voxels/s", "cores": torch.get_num_threads(),
+                                        "kind": "port", "sample": "failed: %r" % (e,)}
+        elif world == 1:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

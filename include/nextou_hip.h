@@ -45,6 +45,16 @@ typedef void* nextou_stream_t;
 int nextou_abi_version(void);
 const char* nextou_last_error(void);
 
+/* Optional launch profiler (measurement only, used by bench.py's `roofline` object): while enabled,
+ * every kernel launch of this library is bracketed by HIP events on its own stream.
+ * nextou_profile_enable(n): n > 0 (re)starts recording with room for n launches, n == 0 stops.
+ * nextou_profile_report(): after a device synchronise, writes a JSON array aggregated per launch
+ *   label — {"kernel", "bound": "hbm"|"mfma", "launches", "ms", "work"} where work is the summed
+ *   ALGORITHMIC bytes (hbm) or flops (mfma) — and returns its length (0 = buffer too small).
+ * Do not enable while capturing a hipGraph. */
+int nextou_profile_enable(int max_records);
+size_t nextou_profile_report(char* buf, size_t cap);
+
 /* ------------------------------------------------------------------------------------------
  * K1  dense kNN graph.
  * Replaces DenseDilatedKnnGraph.forward + {dense,xy_dense}_knn_matrix + *_pairwise_distance

@@ -26,6 +26,8 @@ ABI_VERSION = 1
 _SIGNATURES = {
     "nextou_abi_version": (c_int, []),
     "nextou_last_error": (c_char_p, []),
+    "nextou_profile_enable": (c_int, [c_int]),
+    "nextou_profile_report": (c_size_t, [c_char_p, c_size_t]),
     "nextou_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "nextou_knn_graph": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

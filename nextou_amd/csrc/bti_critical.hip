@@ -121,6 +121,7 @@ extern "C" int nextou_argmax_labels(const float* logits, uint8_t* labels, int B,
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15u) == 0) &&
                      ((reinterpret_cast<uintptr_t>(labels) & 3u) == 0);
+    ProfScope prof(s, kBoundHbm, (4.0 * L + 1.0) * B * (double)V, "argmax_labels_kernel[B%d L%d V%lld]", B, L, (long long)V);
     const long long items = vec ? V / 4 : V;
     long long blocks = cdiv64(items, 256);
     if (blocks > 8192) blocks = 8192;  // grid-stride the rest
@@ -149,6 +150,8 @@ extern "C" int nextou_bti_critical_map(const uint8_t* labels, const uint32_t* lu
     NEXTOU_REQUIRE(!((connectivity == 8 || connectivity == 4) && D != 1),
                    "bti_critical_map: 2-D connectivity %d needs D == 1 (got %d)", connectivity, D);
     const long long V = (long long)D * H * W;
+    ProfScope prof((hipStream_t)stream, kBoundHbm, 2.0 * B * (double)V, "bti_critical_kernel[B%d %dx%dx%d c%d]", B, D, H, W,
+                   connectivity);
     hipLaunchKernelGGL(bti_critical_kernel, dim3((unsigned)cdiv64(V, 256), 1, B), dim3(256), 0,
                        (hipStream_t)stream, labels, lut_a, lut_c, n_labels, critical, D, H, W, full_box,
                        full_box ? min_thick : 1);

@@ -21,6 +21,17 @@ inline int check_launch(const char* what) {
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Optional per-launch timing with HIP events on the launch stream (bench.py's roofline object).
+// Disabled by default: a disabled scope costs one branch and records nothing, so captured
+// hipGraphs never see an event record.
+enum ProfBound { kBoundHbm = 0, kBoundMfma = 1 };
+struct ProfScope {
+    ProfScope(hipStream_t s, int bound, double work, const char* fmt, ...);
+    ~ProfScope();
+    int slot;
+    hipStream_t stream;
+};
+
 // LDS budget one workgroup of the gather kernels may claim (keeps >= 2 workgroups per CU).
 constexpr int kGatherLdsBytes = 64 * 1024;
 

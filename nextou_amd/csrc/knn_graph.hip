@@ -315,6 +315,9 @@ static KnnWorkspace knn_layout(int B, int C, int N, int M, int has_y, int algo) 
 
 static int launch_prep(const float* x, float* xn, float* sq, int B, int C, int N, bool normalize,
                        hipStream_t s) {
+    // reads x twice (second pass L2-hot: counted once), writes xn and the norms
+    ProfScope prof(s, kBoundHbm, 4.0 * B * (double)N * ((normalize ? 2.0 : 1.0) * C + 1), "knn_prep_kernel[B%d C%d N%d]",
+                   B, C, N);
     if (normalize)
         hipLaunchKernelGGL(knn_prep_kernel<true>, dim3(cdiv(N, 256), B), dim3(256), 0, s, x, xn, sq, C, N);
     else
@@ -329,6 +332,9 @@ static int launch_fused(const float* xn, const float* yn, const float* xs, const
     const int QW = 32 * nw;
     const size_t lds = (size_t)32 * (32 * TILES + QW) * sizeof(float);
     dim3 grid(cdiv(N, QW), B);
+    // algorithmic work of the distance contraction: 2*B*N*M*C flops
+    ProfScope prof(s, kBoundMfma, 2.0 * B * (double)N * M * C, "knn_fused_kernel<%d,%d>[B%d C%d N%d M%d K%d]",
+                   KB, TILES, B, C, N, M, K);
     hipLaunchKernelGGL((knn_fused_kernel<KB, TILES>), grid, dim3(64 * nw), lds, s, xn, yn, xs, ys,
                        relpos, out, C, N, M, K);
     return check_launch("knn_fused_kernel");

@@ -266,8 +266,12 @@ extern "C" int nextou_mr_aggregate_fwd(const float* x, const float* y, const int
     hipStream_t s = (hipStream_t)stream;
     const float* src = y ? y : x;
     MrPlan p;
+    // algorithmic HBM bytes: read x (+y), read idx (int32), write the 2C-channel output
+    const double fwd_bytes = 4.0 * B * C * ((double)N + (y ? M : 0)) + 4.0 * B * (double)N * K + 8.0 * B * C * (double)N;
     if (center_idx == nullptr && K <= 32 && plan_lds(B, C, N, M, M, true, &p)) {
         dim3 grid(p.n_tiles, p.c_chunks, B), block(p.threads);
+        ProfScope prof(s, kBoundHbm, fwd_bytes, "mr_fwd_lds_kernel<%d>[B%d C%d N%d M%d K%d]", K <= 8 ? 8 : (K <= 16 ? 16 : 32),
+                       B, C, N, M, K);
 #define NEXTOU_MR_FWD(KB)                                                                          \
     hipLaunchKernelGGL((mr_fwd_lds_kernel<KB>), grid, block, p.lds, s, x, src, nn_idx, out, C, N, M, \
                        K, idx_stride, idx_step, p.chunk, p.n_per_block)
@@ -294,8 +298,13 @@ extern "C" int nextou_mr_aggregate_bwd(const float* gout, const float* x, const 
     const bool self = (y == nullptr);
     const float* src = self ? x : y;
     MrPlan p;
+    // algorithmic HBM bytes: read gout (2C), x (+y), idx; write dx (+dy)
+    const double bwd_bytes = 8.0 * B * C * (double)N + 4.0 * B * C * ((double)N + (y ? M : 0)) + 4.0 * B * (double)N * K +
+                             4.0 * B * C * ((double)N + (y ? M : 0));
     if (center_idx == nullptr && K <= 32 && plan_lds(B, C, N, M, 2 * M, !self, &p)) {
         dim3 grid(p.n_tiles, p.c_chunks, B), block(p.threads);
+        ProfScope prof(s, kBoundHbm, bwd_bytes, "mr_bwd_lds_kernel<%d,%s>[B%d C%d N%d M%d K%d]", K <= 8 ? 8 : (K <= 16 ? 16 : 32),
+                       self ? "self" : "xy", B, C, N, M, K);
         if (!self) {
             hipError_t e = hipMemsetAsync(dy, 0, (size_t)B * C * M * sizeof(float), s);
             if (e != hipSuccess) return fail((int)e, "mr_aggregate_bwd: memset dy: %s", hipGetErrorString(e));

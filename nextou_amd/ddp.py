@@ -1,0 +1,153 @@
+"""Data-parallel gradient exchange for the NexToU hot path: one process per GPU, RCCL over xGMI.
+
+The reference has no distributed code of its own; nnU-Net wraps the network in
+torch's DistributedDataParallel.  Patches are independent samples, so the path shards with exactly
+one exchange step: the average of the 30.7 M trainable fp32 gradients (122.7 MB for cfg 2).  The
+frozen ``relative_pos`` tables (145 MB) are ``requires_grad=False`` and never enter a bucket.
+
+Design for xGMI (7 point-to-point links x ~153 GB/s per GPU): the whole gradient is
+~1.4 ms of ring time, far below the backward pass, so the job is *overlap*, not bandwidth —
+few, large, flat buckets (default 32 MiB -> 4 collectives per step instead of DDP's ~5 x 25 MiB +
+first-bucket 1 MiB), filled in reverse parameter order (the order backward produces gradients) from
+``post_accumulate_grad`` hooks, each all-reduced asynchronously on RCCL's own HIP stream the moment
+its last gradient lands; ``finalize()`` joins the streams once, after backward.  BatchNorm
+statistics stay per replica (no SyncBN), as in nnU-Net.
+
+``backend='nccl'`` is RCCL on ROCm; the same code runs on ``gloo`` (CPU) for the world-size-2 tests.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    __slots__ = ("flat", "params", "offsets", "pending", "filled", "work")
+
+    def __init__(self, params: List[torch.nn.Parameter]):
+        self.params = params
+        self.offsets, total = [], 0
+        for p in params:
+            self.offsets.append(total)
+            total += p.numel()
+        self.flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
+        self.pending = len(params)
+        self.filled = [False] * len(params)
+        self.work = None
+
+
+class BucketedGradientAverager:
+    """Overlapped, bucketed all-reduce (mean) of ``module``'s gradients.
+
+    usage per step::
+
+        loss.backward()          # hooks launch one async all-reduce per completed bucket
+        averager.finalize()      # wait, scale by 1/world, point p.grad at the reduced views
+        optimizer.step()
+    """
+
+    def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20,
+                 process_group: Optional[dist.ProcessGroup] = None, broadcast_from_rank0: bool = True):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed must be initialised before building the averager")
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.module = module
+        params = [p for p in module.parameters() if p.requires_grad]
+        params.reverse()  # gradients become ready roughly in reverse registration order
+        self.buckets: List[_Bucket] = []
+        current, size = [], 0
+        for p in params:
+            nbytes = p.numel() * p.element_size()
+            if current and (size + nbytes > bucket_bytes or p.dtype != current[0].dtype):
+                self.buckets.append(_Bucket(current))
+                current, size = [], 0
+            current.append(p)
+            size += nbytes
+        if current:
+            self.buckets.append(_Bucket(current))
+        self._slot = {}
+        self._hooks = []
+        for bi, b in enumerate(self.buckets):
+            for pi, p in enumerate(b.params):
+                self._slot[p] = (bi, pi)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+        if broadcast_from_rank0:
+            self.broadcast_state()
+
+    # ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def broadcast_state(self) -> None:
+        """One-time sync of parameters (incl. the frozen position tables) and buffers from rank 0."""
+        tensors = [p.data for p in self.module.parameters()] + [b.data for b in self.module.buffers()]
+        by_dtype = {}
+        for t in tensors:
+            by_dtype.setdefault(t.dtype, []).append(t)
+        for group in by_dtype.values():
+            flat = torch.cat([t.reshape(-1) for t in group])
+            dist.broadcast(flat, src=0, group=self.group)
+            off = 0
+            for t in group:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+
+    @torch.no_grad()
+    def _on_grad_ready(self, p: torch.nn.Parameter) -> None:
+        bi, pi = self._slot[p]
+        b = self.buckets[bi]
+        off = b.offsets[pi]
+        b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        if not b.filled[pi]:
+            b.filled[pi] = True
+            b.pending -= 1
+        if b.pending == 0 and b.work is None:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    @torch.no_grad()
+    def finalize(self) -> None:
+        """Join the collectives; parameters that received no gradient this step (e.g. the
+        zero-weighted lowest deep-supervision head) contribute zeros."""
+        for b in self.buckets:
+            if b.work is None:
+                for pi, p in enumerate(b.params):
+                    if not b.filled[pi]:
+                        b.flat[b.offsets[pi]:b.offsets[pi] + p.numel()].zero_()
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        inv = 1.0 / self.world
+        for b in self.buckets:
+            b.work.wait()
+            b.flat.mul_(inv)
+            for pi, p in enumerate(b.params):
+                p.grad = b.flat[b.offsets[pi]:b.offsets[pi] + p.numel()].view_as(p)
+            b.work = None
+            b.pending = len(b.params)
+            b.filled = [False] * len(b.params)
+
+    def remove_hooks(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    @property
+    def bytes_per_step(self) -> int:
+        return sum(b.flat.numel() * b.flat.element_size() for b in self.buckets)
+
+
+def init_process_group_from_env(backend: Optional[str] = None):
+    """(rank, local_rank, world) from torchrun's environment; initialises the default group when
+    WORLD_SIZE > 1.  ``backend`` defaults to nccl (= RCCL) with a GPU, gloo without."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world

@@ -1,0 +1,74 @@
+"""Shared builders for the module / model parity tests (CPU via the oracle checker, GPU via HIP)."""
+import numpy as np
+import torch
+from torch import nn
+
+import formula
+from conftest import load_golden
+from nextou_amd import graph_ops
+from nextou_amd.network_architecture import NexToU_Encoder_Decoder as encdec
+from nextou_amd.network_architecture.NexToU import NexToU
+
+KW3 = dict(conv_op=nn.Conv3d, norm_op=nn.BatchNorm3d, norm_op_kwargs={'eps': 1e-5, 'affine': True}, dropout_op=None)
+
+BLOCKS = {
+    "pool_pooled": (lambda: encdec.PoolGrapher(12, (8, 16, 32), 4, 1, 'mr', 'leakyrelu', 'instance', True, True, 0.2,
+                                               2, n=4096, relative_pos=True, img_min_shape=(2, 4, 4), **KW3),
+                    (2, 12, 8, 16, 32)),
+    "pool_plain": (lambda: encdec.PoolGrapher(12, (4, 8, 8), 6, 1, 'mr', 'leakyrelu', 'instance', True, True, 0.2, 1,
+                                              n=256, relative_pos=True, img_min_shape=(2, 4, 4), **KW3),
+                   (2, 12, 4, 8, 8)),
+    "swin": (lambda: encdec.SwinGrapher(12, (4, 8, 8), 4, 1, 'mr', 'leakyrelu', 'instance', True, True, 0.2, 1, n=32,
+                                        relative_pos=True, window_size=(2, 4, 4), shift_size=[1, 2, 2], **KW3),
+             (2, 12, 4, 8, 8)),
+}
+
+TINY_2D = dict(in_ch=1, patch=[64, 64], features=[8, 16, 32, 64, 64], conv_op=nn.Conv2d, norm_op=nn.BatchNorm2d,
+               kernels=[[3, 3]] * 5, strides=[[1, 1]] + [[2, 2]] * 4, classes=3)
+TINY_3D = dict(in_ch=1, patch=[32, 128, 128], features=[6, 12, 24, 48, 48, 48], conv_op=nn.Conv3d,
+               norm_op=nn.BatchNorm3d, kernels=[[1, 3, 3]] + [[3, 3, 3]] * 5,
+               strides=[[1, 1, 1], [1, 2, 2]] + [[2, 2, 2]] * 4, classes=4)
+
+
+def build_model(cfg, deep_supervision=True):
+    return NexToU(input_channels=cfg["in_ch"], patch_size=cfg["patch"], n_stages=len(cfg["kernels"]),
+                  features_per_stage=cfg["features"], conv_op=cfg["conv_op"], kernel_sizes=cfg["kernels"],
+                  strides=cfg["strides"], n_conv_per_stage=2, num_classes=cfg["classes"],
+                  n_conv_per_stage_decoder=2, conv_bias=True, norm_op=cfg["norm_op"],
+                  norm_op_kwargs={'eps': 1e-5, 'affine': True}, dropout_op=None, dropout_op_kwargs=None,
+                  nonlin=nn.LeakyReLU, nonlin_kwargs={'inplace': True}, deep_supervision=deep_supervision)
+
+
+def run_block(name, mode, device, teacher_forced):
+    """-> (out, dx, golden_out, golden_dx, n_tape_used) for one G5 block fixture."""
+    g = load_golden("g5_blocks")
+    make, shape = BLOCKS[name]
+    blk = make()
+    formula.fill_module_(blk, seed=5)
+    blk = blk.to(device).train(mode == "train")
+    x = formula.gaussian("g5.%s.x" % name, shape).to(device).requires_grad_(True)
+    entries = []
+    i = 0
+    while "%s_%s_tape%d" % (name, mode, i) in g.files:
+        entries.append(torch.from_numpy(g["%s_%s_tape%d" % (name, mode, i)]))
+        i += 1
+    tape = graph_ops.IndexTape(entries if teacher_forced else None)
+    with graph_ops.index_tape(tape):
+        y = blk(x)
+    gout = formula.gaussian("g5.%s.g" % name, y.shape).to(device)
+    (dx,) = torch.autograd.grad(y, x, gout)
+    return y.detach().cpu(), dx.cpu(), torch.from_numpy(g["%s_%s_out" % (name, mode)]), \
+        torch.from_numpy(g["%s_%s_dx" % (name, mode)]), tape, entries
+
+
+def run_model(name, cfg, batch, device, teacher_forced):
+    g = load_golden(name)
+    model = build_model(cfg)
+    formula.fill_module_(model, seed=1)
+    model = model.to(device).train()
+    x = formula.gaussian(name + ".x", [batch, cfg["in_ch"]] + cfg["patch"]).to(device)
+    entries = [torch.from_numpy(g["tape%d" % i]) for i in range(int(g["n_tape"]))]
+    tape = graph_ops.IndexTape(entries if teacher_forced else None)
+    with torch.no_grad(), graph_ops.index_tape(tape):
+        outs = model(x)
+    return [o.cpu() for o in outs], g, tape, entries, model

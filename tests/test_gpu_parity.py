@@ -1,0 +1,379 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same inputs.
+
+Bars (BASELINE.json north_star): kNN neighbour indices bit-exact vs the canonical oracle; integer /
+bit work (labels, critical map, gather, MR-aggregate forward, which is exact max/sub arithmetic)
+bit-exact; float accumulations (MR-aggregate backward, whose scatter order is not fixed) within a
+stated fp32 tolerance; block / model outputs vs reference goldens within the tolerances of
+test_modules_golden.py.  Full cfg-2 sizes are covered through size-independent properties plus
+oracle checks on row subsets.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import formula
+import model_cases as mc
+from conftest import knn_rows_equal_as_sets, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nextou_amd import _lib, graph_ops
+    _lib.lib()  # fails loudly if the .so is missing
+    maps = open("/proc/self/maps").read()
+    assert "libnextou_hip.so" in maps, "HIP extension not loaded into this process"
+    return graph_ops
+
+
+@pytest.fixture(scope="module")
+def ora():
+    import oracle
+    oracle.lib()
+    return oracle.CanonicalBackend
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _knn_case(ops, ora, B, C, N, M, k, relpos, seed, algos=("fused", "naive"), normalize=True):
+    x = _rand((B, C, N), seed)
+    y = None if M is None else _rand((B, C, M), seed + 1)
+    rp = _rand((N, M or N), seed + 2, 0.05) if relpos else None
+    want = ora.knn_graph(x, y, rp, k, normalize=normalize).numpy()
+    for algo in algos:
+        if algo == "fused" and k > 32:
+            continue
+        got = ops.knn_graph(x.to(DEV), None if y is None else y.to(DEV), None if rp is None else rp.to(DEV), k,
+                            algo=algo, normalize=normalize).cpu().numpy()
+        bad = (got != want).any(-1)
+        assert not bad.any(), "%s kNN differs from the oracle in %d of %d rows (first: row %s got %s want %s)" % (
+            algo, bad.sum(), bad.size, np.argwhere(bad)[0], got[bad][0], want[bad][0])
+
+
+# ---------------------------------------------------------------------------------------------
+# K1
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g1_self_a", "g1_self_a_rp", "g1_self_dil", "g1_self_dil_rp", "g1_window",
+                                  "g2_xy", "g2_xy_norp", "g3_chunked"])
+def test_knn_golden_fixtures(ops, ora, name):
+    """HIP == oracle bit for bit, and == the reference's sets wherever the k-th gap is > 1e-5."""
+    g = load_golden(name)
+    x = torch.from_numpy(g["x"]).squeeze(-1).contiguous()
+    y = torch.from_numpy(g["y"]).squeeze(-1).contiguous() if g["y"].size else None
+    rp = torch.from_numpy(g["relpos"]).squeeze(0).contiguous() if g["relpos"].size else None
+    kt = int(g["k"]) * int(g["dilation"])
+    want = ora.knn_graph(x, y, rp, kt).numpy()
+    for algo in ("fused", "naive"):
+        got = ops.knn_graph(x.to(DEV), None if y is None else y.to(DEV), None if rp is None else rp.to(DEV), kt,
+                            algo=algo).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+        same = knn_rows_equal_as_sets(got, g["nn_full"])
+        assert same[g["kth_gap"] > 1e-5].all() and same.mean() >= 0.999
+
+
+@pytest.mark.parametrize("B,C,N,M,k,relpos", [
+    (2, 12, 64, None, 9, False),      # one partial tile
+    (3, 7, 50, None, 1, True),        # odd channel count, k = 1, ragged N
+    (2, 6, 33, 17, 5, True),          # tiny ragged xy
+    (1, 24, 300, 100, 16, True),      # several query tiles, ragged candidates
+    (2, 36, 200, 200, 32, False),     # k = 32 (largest fused list)
+    (2, 36, 257, 129, 28, True),      # k = 28 bucketed into 32
+    (4, 132, 168, None, 7, True),     # cfg-2 Swin window shape
+    (2, 264, 512, 1344, 28, True),    # cfg-2 Pool s3 shape, fewer queries
+    (1, 324, 1344, None, 32, True),   # cfg-2 Pool s4 self graph
+    (2, 12, 40, None, 40, False),     # k == M (everything selected), naive only above 32
+    (1, 8, 70, 70, 33, True),         # k > 32 -> naive algorithm
+    (1, 4, 9, None, 3, False),        # smaller than one wave
+])
+def test_knn_shape_sweep_bit_exact(ops, ora, B, C, N, M, k, relpos):
+    _knn_case(ops, ora, B, C, N, M, k, relpos, seed=1000 + N + (M or 0) + k)
+
+
+def test_knn_auto_selects_and_rejects(ops):
+    x = _rand((1, 8, 40), 3).to(DEV)
+    assert ops.knn_graph(x, k=33).shape == (1, 40, 33)           # auto -> naive
+    with pytest.raises(RuntimeError, match="K <= 32"):
+        ops.knn_graph(x, k=33, algo="fused")
+    with pytest.raises(RuntimeError, match="out of range"):
+        ops.knn_graph(x, k=41)
+
+
+def test_knn_exact_ties_break_by_index(ops, ora):
+    """Duplicated candidates (exact distance ties) and all-equal rows."""
+    x = _rand((2, 16, 96), 5)
+    y = torch.cat([x[:, :, :48], x[:, :, :48]], 2).contiguous()      # every candidate twice
+    for k in (4, 16):
+        want = ora.knn_graph(x, y, None, k).numpy()
+        for algo in ("fused", "naive"):
+            got = ops.knn_graph(x.to(DEV), y.to(DEV), None, k, algo=algo).cpu().numpy()
+            np.testing.assert_array_equal(got, want)
+    const = torch.ones(1, 6, 40)
+    got = ops.knn_graph(const.to(DEV), None, None, 8).cpu().numpy()
+    np.testing.assert_array_equal(got, np.broadcast_to(np.arange(8), (1, 40, 8)))
+
+
+def test_knn_unnormalised_and_pairwise(ops, ora):
+    _knn_case(ops, ora, 2, 10, 70, 30, 6, False, seed=77, normalize=False)
+    _knn_case(ops, ora, 2, 10, 70, None, 6, True, seed=78, normalize=False)
+    x, y = _rand((2, 10, 70), 9), _rand((2, 10, 30), 10)
+    for yy, (r0, r1) in ((None, (0, 70)), (None, (13, 41)), (y, (0, 70))):
+        want = ora.pairwise_distance(x, yy, r0, r1)
+        got = ops.pairwise_sq_distance(x.to(DEV), None if yy is None else yy.to(DEV), r0, r1).cpu()
+        assert torch.equal(got, want)
+    g = load_golden("g_distance")
+    from nextou_amd.network_architecture import torch_edge
+    xr, yr = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    np.testing.assert_allclose(torch_edge.pairwise_distance(xr).cpu().numpy(), g["pairwise"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(torch_edge.part_pairwise_distance(xr, 7, 19).cpu().numpy(), g["part"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(torch_edge.xy_pairwise_distance(xr, yr).cpu().numpy(), g["xy"], rtol=1e-5, atol=1e-5)
+
+
+def test_knn_full_size_cfg2(ops, ora):
+    """cfg-2 sizes: fused == naive on the GPU for every row; oracle on row subsets; properties."""
+    # Swin s2: 1024 windows x 168 points, C = 132, k = 7
+    x = _rand((1024, 132, 168), 21)
+    rp = _rand((168, 168), 22, 0.05)
+    fused = ops.knn_graph(x.to(DEV), None, rp.to(DEV), 7, algo="fused")
+    naive = ops.knn_graph(x.to(DEV), None, rp.to(DEV), 7, algo="naive")
+    assert torch.equal(fused, naive)
+    sub = [0, 1, 511, 1023]
+    want = ora.knn_graph(x[sub].contiguous(), None, rp, 7)
+    assert torch.equal(fused[sub].cpu(), want)
+    f = fused.cpu().numpy()
+    assert f.min() >= 0 and f.max() < 168
+    assert (np.sort(f, -1)[..., 1:] != np.sort(f, -1)[..., :-1]).all()      # distinct per row
+    # Pool s3: N = 10752 queries, M = 1344 pooled candidates, C = 264, k = 28
+    xq, yc, rp = _rand((2, 264, 10752), 23), _rand((2, 264, 1344), 24), _rand((10752, 1344), 25, 0.05)
+    fused = ops.knn_graph(xq.to(DEV), yc.to(DEV), rp.to(DEV), 28, algo="fused")
+    naive = ops.knn_graph(xq.to(DEV), yc.to(DEV), rp.to(DEV), 28, algo="naive")
+    assert torch.equal(fused, naive)
+    rows = torch.arange(0, 10752, 41)
+    want = ora.knn_graph(xq[:, :, rows].contiguous(), yc, rp[rows].contiguous(), 28)
+    assert torch.equal(fused[:, rows].cpu(), want)
+    # ascending distance along k (recomputed in fp64 on the GPU)
+    xn, yn = F.normalize(xq.to(DEV).double(), dim=1), F.normalize(yc.to(DEV).double(), dim=1)
+    d = (xn * xn).sum(1).unsqueeze(2) - 2 * torch.einsum("bcn,bcm->bnm", xn, yn) + (yn * yn).sum(1).unsqueeze(1)
+    d = d + rp.to(DEV).double()
+    picked = d.gather(2, fused.long())
+    assert (picked[:, :, 1:] - picked[:, :, :-1]).min() > -1e-5
+    kth = torch.kthvalue(d, 28, dim=2).values
+    assert (picked[:, :, -1] - kth).abs().max() < 1e-5                     # really the 28 smallest
+
+
+# ---------------------------------------------------------------------------------------------
+# K2 + gather
+# ---------------------------------------------------------------------------------------------
+def _idx(B, N, M, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.stack([torch.stack([torch.randperm(M, generator=g)[:K] for _ in range(N)]) for _ in range(B)]).to(torch.int32)
+
+
+@pytest.mark.parametrize("B,C,N,M,K,stride_extra,step", [
+    (2, 12, 48, None, 5, 0, 1),
+    (3, 6, 200, 64, 8, 0, 1),
+    (2, 33, 168, None, 7, 0, 1),         # window shape, K < bucket
+    (2, 24, 3000, 300, 14, 0, 1),        # N tiled over several workgroups, atomics flush
+    (1, 10, 1500, None, 28, 0, 1),       # self graph, K bucket 32
+    (2, 8, 100, 40, 4, 4, 2),            # dilated view: every 2nd of 8 stored neighbours
+    (1, 4, 20000, None, 6, 0, 1),        # self rows too long for LDS -> global-atomic fallback
+    (1, 3, 64, 20000, 9, 0, 1),          # source rows too long for LDS (forward fallback)
+    (2, 5, 70, 70, 33, 0, 1),            # K > 32 -> generic kernels
+])
+def test_mr_aggregate_vs_oracle(ops, ora, B, C, N, M, K, stride_extra, step):
+    x = _rand((B, C, N), 31)
+    y = None if M is None else _rand((B, C, M), 32)
+    idx = _idx(B, N, M or N, K * step + stride_extra, 33)
+    want = ora.mr_fwd(x, y, idx, None, K, step)
+    xd = x.to(DEV).requires_grad_(True)
+    yd = None if y is None else y.to(DEV).requires_grad_(True)
+    out = ops.mr_aggregate(xd, idx.to(DEV), yd, k=K, idx_step=step)
+    assert torch.equal(out.detach().cpu(), want), "forward must be bit-exact (pure max / sub arithmetic)"
+    gout = _rand(out.shape, 34)
+    grads = torch.autograd.grad(out, [xd] if yd is None else [xd, yd], gout.to(DEV))
+    dx, dy = ora.mr_bwd(gout, x, y, idx, None, K, step)
+    # scatter-add order differs (LDS / L2 atomics): fp32 tolerance relative to the accumulated magnitude
+    tol = 1e-5 * max(1.0, float(dx.abs().max()))
+    assert float((grads[0].cpu() - dx).abs().max()) <= tol
+    if yd is not None:
+        tol = 1e-5 * max(1.0, float(dy.abs().max()))
+        assert float((grads[1].cpu() - dy).abs().max()) <= tol
+
+
+def test_mr_aggregate_center_index_and_golden(ops, ora):
+    x = _rand((2, 7, 60), 41)
+    idx, ctr = _idx(2, 60, 60, 5, 42), _idx(2, 60, 60, 5, 43)
+    want = ora.mr_fwd(x, None, idx, ctr, 5, 1)
+    xd = x.to(DEV).requires_grad_(True)
+    out = ops.mr_aggregate(xd, idx.to(DEV), None, center_idx=ctr.to(DEV))
+    assert torch.equal(out.detach().cpu(), want)
+    gout = _rand(out.shape, 44)
+    (dx,) = torch.autograd.grad(out, xd, gout.to(DEV))
+    want_dx, _ = ora.mr_bwd(gout, x, None, idx, ctr, 5, 1)
+    assert float((dx.cpu() - want_dx).abs().max()) <= 1e-5 * max(1.0, float(want_dx.abs().max()))
+    g = load_golden("g4_mrconv")   # the reference's own numbers
+    for tag in ("self", "xy"):
+        xg = torch.from_numpy(g[tag + "_x"]).squeeze(-1).to(DEV).requires_grad_(True)
+        yg = torch.from_numpy(g[tag + "_y"]).squeeze(-1).to(DEV).requires_grad_(True) if tag == "xy" else None
+        ig = torch.from_numpy(g[tag + "_idx"]).to(DEV)
+        pre = ops.mr_aggregate(xg, ig, yg)
+        np.testing.assert_array_equal(pre.detach().cpu().numpy(), g[tag + "_pre"].squeeze(-1))
+        gg = torch.from_numpy(g[tag + "_gout"]).squeeze(-1).to(DEV)
+        grads = torch.autograd.grad(pre, [xg] if yg is None else [xg, yg], gg)
+        np.testing.assert_allclose(grads[0].cpu().numpy(), g[tag + "_dx"].squeeze(-1), rtol=1e-5, atol=1e-6)
+        if yg is not None:
+            np.testing.assert_allclose(grads[1].cpu().numpy(), g[tag + "_dy"].squeeze(-1), rtol=1e-5, atol=1e-6)
+        gathered = ops.gather_neighbors(yg if yg is not None else xg, ig)
+        np.testing.assert_array_equal(gathered.detach().cpu().numpy(), g[tag + "_gather"])
+
+
+def test_gather_backward(ops, ora):
+    src = _rand((2, 9, 50), 51)
+    idx = _idx(2, 80, 50, 6, 52)
+    sd = src.to(DEV).requires_grad_(True)
+    out = ops.gather_neighbors(sd, idx.to(DEV))
+    assert torch.equal(out.detach().cpu(), ora.gather_fwd(src, idx))
+    gout = _rand(out.shape, 53)
+    (ds,) = torch.autograd.grad(out, sd, gout.to(DEV))
+    want = ora.gather_bwd(gout, idx, 50)
+    assert float((ds.cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_mr_aggregate_full_size_cfg2(ops):
+    """cfg-2 Swin s2 and Pool s3 sizes against the materialising torch formulation on the GPU."""
+    for (B, C, N, M, K) in ((1024, 132, 168, None, 7), (2, 264, 10752, 1344, 28)):
+        x = _rand((B, C, N), 61).to(DEV).requires_grad_(True)
+        y = None if M is None else _rand((B, C, M), 62).to(DEV).requires_grad_(True)
+        g = torch.Generator().manual_seed(63)
+        idx = torch.randint(0, M or N, (B, N, K), generator=g, dtype=torch.int32).to(DEV)
+        out = ops.mr_aggregate(x, idx, y)
+        src = x if y is None else y
+        gathered = torch.gather(src.unsqueeze(2).expand(B, C, N, M or N), 3,
+                                idx.long().unsqueeze(1).expand(B, C, N, K)) if B * C * N * (M or N) < 2 ** 31 else None
+        if gathered is None:   # expand-gather index space too large: flat formulation per batch
+            gathered = torch.stack([src[b][:, idx[b].long().reshape(-1)].reshape(C, N, K) for b in range(B)])
+        mr = (gathered - x.unsqueeze(-1)).max(-1).values
+        ref = torch.stack((x, mr), 2).reshape(B, 2 * C, N)
+        assert torch.equal(out, ref)
+        assert torch.equal(out[:, 0::2], x)                        # interleave: even channels are x
+        gout = _rand((B, 2 * C, N), 64).to(DEV)
+        got = torch.autograd.grad(out, [x] if y is None else [x, y], gout)
+        want = torch.autograd.grad(ref, [x] if y is None else [x, y], gout)
+        for a, b in zip(got, want):
+            assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+        # conservation: sum of dx (+ dy) equals the sum of the identity-branch gradient
+        total = sum(float(t.double().sum()) for t in got)
+        assert abs(total - float(gout[:, 0::2].double().sum())) <= 1e-2 * (1 + abs(total))
+
+
+# ---------------------------------------------------------------------------------------------
+# K5
+# ---------------------------------------------------------------------------------------------
+def test_bti_kernels_vs_oracle_and_reference(ops, ora):
+    from nextou_amd.loss.bti_loss import BTI_Loss
+    from test_oracle_golden import BTI_CASES, bti_luts
+    g = load_golden("g7_bti")
+    for name, dim, conn in BTI_CASES:
+        inc, exc = bti_luts(name)
+        loss = BTI_Loss(dim=dim, connectivity=conn, inclusion=inc, exclusion=exc, min_thick=1)
+        logits = torch.from_numpy(g[name + "_logits"]).to(DEV).requires_grad_(True)
+        target = torch.from_numpy(g[name + "_target"]).float().to(DEV)
+        labels = ops.argmax_labels(logits)
+        np.testing.assert_array_equal(labels.cpu().numpy(), g[name + "_labels"])
+        crit = loss.critical_voxels_from_labels(labels)
+        np.testing.assert_array_equal(crit.cpu().numpy(), g[name + "_critical"])
+        value = loss(logits, target)
+        np.testing.assert_allclose(value.item(), float(g[name + "_loss"]), rtol=1e-10)
+        (grad,) = torch.autograd.grad(value, logits)
+        np.testing.assert_allclose(grad.cpu().numpy(), g[name + "_grad"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape,conn,thick", [((2, 7, 9, 11), 26, 1), ((1, 5, 6, 7), 26, 2), ((2, 9, 10, 13), 6, 1),
+                                              ((3, 17, 19), 8, 1), ((3, 17, 19), 4, 1), ((1, 33, 21), 8, 2)])
+def test_bti_ragged_shapes(ops, ora, shape, conn, thick):
+    g = torch.Generator().manual_seed(sum(shape) + conn)
+    labels = torch.randint(0, 6, shape, generator=g, dtype=torch.uint8)
+    lut_a = torch.tensor([0, 1, 2, 4, 1, 0] + [0] * 250, dtype=torch.int32)
+    lut_c = torch.tensor([0, 2, 1, 0, 4, 7] + [0] * 250, dtype=torch.int32)
+    want = ora.bti_critical(labels, lut_a, lut_c, conn, thick)
+    got = ops.bti_critical_map(labels.to(DEV), lut_a.to(DEV), lut_c.to(DEV), conn, thick)
+    assert torch.equal(got.cpu(), want)
+    logits = torch.randn((2, 5) + shape[1:], generator=g)
+    logits[0, 3] = logits[0, 1]                                  # exact ties -> first index wins
+    assert torch.equal(ops.argmax_labels(logits.to(DEV)).cpu(), ora.argmax_labels(logits))
+
+
+def test_bti_full_size_cfg4(ops, ora):
+    """14 classes at 64x224x192, B = 2: label map and critical map bit-exact vs the oracle."""
+    from nextou_amd.harness import synthetic_batch, config_3d_fullres_nextou
+    from nextou_amd.loss.bti_loss import BTI_Loss
+    from nextou_amd.nnUNetTrainer.nnUNetTrainer_NexToU_BTI_Synapse import nnUNetTrainer_NexToU_BTI_Synapse as SYN
+    cfg = config_3d_fullres_nextou()
+    _, target = synthetic_batch(cfg, 1, 14, 2, DEV, blob_labels=True)
+    labels = target[:, 0].to(torch.uint8).contiguous()
+    loss = BTI_Loss(3, 26, [], SYN.exclusion_list, 1)
+    crit = loss.critical_voxels_from_labels(labels)
+    (lut_a, lut_c), = loss._luts_on(torch.device("cpu"))
+    want = ora.bti_critical(labels.cpu(), lut_a, lut_c, 26, 1)
+    assert torch.equal(crit.cpu(), want)
+    frac = float(crit.float().mean())
+    assert 0.0 < frac < 0.5       # blob labels: only interfaces between excluded organs are critical
+    # idempotence-style property: a volume with one label has no critical voxel
+    assert int(loss.critical_voxels_from_labels(torch.full_like(labels, 5)).sum()) == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# modules / models through the HIP path vs the reference's goldens
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(mc.BLOCKS))
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_blocks_on_gpu(ops, name, mode):
+    out, dx, g_out, g_dx, tape, entries = mc.run_block(name, mode, DEV, teacher_forced=True)
+    assert tape.cursor == len(entries)
+    assert float((out - g_out).abs().max()) <= 2e-5 * max(1.0, float(g_out.abs().max()))
+    assert float((dx - g_dx).abs().max()) <= 5e-5 * max(1.0, float(g_dx.abs().max()))
+    out2, dx2, _, _, tape2, _ = mc.run_block(name, mode, DEV, teacher_forced=False)
+    for mine, ref in zip(tape2.entries, entries):
+        if mine.dtype == torch.int32:
+            assert knn_rows_equal_as_sets(mine.numpy(), ref.numpy()).mean() >= 0.999
+        else:
+            assert (mine == ref).float().mean() >= 0.999
+
+
+@pytest.mark.parametrize("name,cfg,batch", [("g8_tiny2d", mc.TINY_2D, 2), ("g8_tiny3d", mc.TINY_3D, 1)])
+def test_tiny_models_on_gpu_teacher_forced(ops, name, cfg, batch):
+    """Protocol P-B on the MI355X: max |logit - logit_ref| <= 1e-3 with injected decisions."""
+    torch.backends.cudnn.benchmark = False
+    outs, g, tape, entries, _ = mc.run_model(name, cfg, batch, DEV, teacher_forced=True)
+    assert tape.cursor == len(entries)
+    worst = 0.0
+    for i, o in enumerate(outs):
+        if "logits%d" % i in g.files:
+            worst = max(worst, float((o - torch.from_numpy(g["logits%d" % i])).abs().max()))
+        else:
+            worst = max(worst, float((o.reshape(-1)[::97] - torch.from_numpy(g["logits%d_sample" % i])).abs().max()))
+    print("\n%s teacher-forced max |dlogit| = %.3e" % (name, worst))
+    assert worst <= 1e-3
+
+
+def test_train_step_runs_and_is_repeatable(ops):
+    """Harness train step on the GPU: forward is bit-identical across runs (no atomics in it)."""
+    from nextou_amd.harness import config_3d_fullres_nextou, downsample_targets, synthetic_batch
+    from nextou_amd.nnUNetTrainer.nnUNetTrainer_NexToU_BTI_Synapse import nnUNetTrainer_NexToU_BTI_Synapse
+    cfg = config_3d_fullres_nextou(patch_size=(32, 128, 128), base=6, max_features=48, batch_size=2)
+    torch.manual_seed(0)
+    tr = nnUNetTrainer_NexToU_BTI_Synapse(cfg, 14, device=DEV, log=None).initialize()
+    data, target = synthetic_batch(cfg, 1, 14, 2, DEV, blob_labels=True)
+    with torch.no_grad():
+        a = tr.network(data)
+        b = tr.network(data)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    tgt = downsample_targets(target, a)
+    l0 = float(tr.train_step(data, tgt))
+    l1 = float(tr.train_step(data, tgt))
+    assert np.isfinite(l0) and np.isfinite(l1)
