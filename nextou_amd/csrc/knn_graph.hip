@@ -77,29 +77,40 @@ struct TopK {
 #pragma unroll
         for (int j = 0; j < KB; ++j) { d[j] = INFINITY; i[j] = kSentinelIdx; }
     }
-    // insert (v, vi); caller guarantees vi is larger than every index already present.
+    // Both inserts are "find the slot, shift the tail down": slot j takes the new entry iff the
+    // entry sorts before old[j] but not before old[j-1].  The predicate is evaluated against the
+    // NEW entry for every slot (it is monotone over a sorted list), never against a displaced old
+    // entry — comparing displaced entries with `<` would reorder exact ties among the old ones.
+    //
+    // insert (v, vi); caller guarantees vi is larger than every index already present, so a strict
+    // `<` on the distance alone is the (dist, index) order.
     __device__ __forceinline__ void push_ascending(float v, int vi) {
+        bool before_hi = v < d[KB - 1];
 #pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            const bool c = v < d[j];
-            const float lo = c ? v : d[j];
-            const float hi = c ? d[j] : v;
-            const int li = c ? vi : i[j];
-            const int hi_i = c ? i[j] : vi;
-            d[j] = lo; i[j] = li; v = hi; vi = hi_i;
+        for (int j = KB - 1; j >= 1; --j) {
+            const bool before_lo = v < d[j - 1];
+            d[j] = before_lo ? d[j - 1] : (before_hi ? v : d[j]);
+            i[j] = before_lo ? i[j - 1] : (before_hi ? vi : i[j]);
+            before_hi = before_lo;
         }
+        d[0] = before_hi ? v : d[0];
+        i[0] = before_hi ? vi : i[0];
     }
     // general insert with the full (dist, index) comparison.
+    __device__ __forceinline__ bool sorts_before(float v, int vi, int j) const {
+        return (v < d[j]) || (v == d[j] && vi < i[j]);
+    }
     __device__ __forceinline__ void push_any(float v, int vi) {
+        bool before_hi = sorts_before(v, vi, KB - 1);
 #pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            const bool c = (v < d[j]) || (v == d[j] && vi < i[j]);
-            const float lo = c ? v : d[j];
-            const float hi = c ? d[j] : v;
-            const int li = c ? vi : i[j];
-            const int hi_i = c ? i[j] : vi;
-            d[j] = lo; i[j] = li; v = hi; vi = hi_i;
+        for (int j = KB - 1; j >= 1; --j) {
+            const bool before_lo = sorts_before(v, vi, j - 1);
+            d[j] = before_lo ? d[j - 1] : (before_hi ? v : d[j]);
+            i[j] = before_lo ? i[j - 1] : (before_hi ? vi : i[j]);
+            before_hi = before_lo;
         }
+        d[0] = before_hi ? v : d[0];
+        i[0] = before_hi ? vi : i[0];
     }
 };
 
@@ -345,8 +356,6 @@ static int launch_fused_tiles(int tiles, const float* xn, const float* yn, const
                               const float* ys, const float* relpos, int32_t* out, int B, int C,
                               int N, int M, int K, int nw, hipStream_t s) {
     if (tiles == 2) return launch_fused<KB, 2>(xn, yn, xs, ys, relpos, out, B, C, N, M, K, nw, s);
-    // the K <= 32 lists take 64 VGPRs: 4 accumulator tiles keep the kernel free of spills
-    if (KB > 16) return launch_fused<KB, 4>(xn, yn, xs, ys, relpos, out, B, C, N, M, K, nw, s);
     return launch_fused<KB, 6>(xn, yn, xs, ys, relpos, out, B, C, N, M, K, nw, s);
 }
 
@@ -359,10 +368,11 @@ static int pick_waves(int B, int N) {
     return nw;
 }
 
-// candidate tiles per chunk: wide (6 tiles = 192, or 4 = 128 for K > 16) unless a 64-wide chunk
-// wastes >10 % fewer MFMAs on padding.
+// candidate tiles per chunk: 6 tiles (192 wide) unless a 64-wide chunk wastes >10 % fewer MFMAs on
+// padding (M = 168, 384, 1344, 3072 of cfg 2 / cfg 5 are all multiples or near-multiples of 192).
 static int pick_tiles(int M, int K) {
-    const int wide = (K > 16) ? 128 : 192;
+    (void)K;
+    const int wide = 192;
     const long long ww = (long long)cdiv(M, wide) * wide, w2 = (long long)cdiv(M, 64) * 64;
     return (w2 * 10 < ww * 9) ? 2 : 6;
 }
