@@ -35,13 +35,22 @@ template <bool NORMALIZE>
 __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__ x,
                                                        float* __restrict__ xn,
                                                        float* __restrict__ sq, int C, int N) {
+    constexpr int U = 16;  // loads in flight per lane; the fma chain itself stays strictly c-ordered
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (n >= N) return;
     const float* xb = x + (size_t)b * C * N + n;
     float* xo = xn + (size_t)b * C * N + n;
     float s = 0.f;
-    for (int c = 0; c < C; ++c) {
+    int c = 0;
+    for (; c + U <= C; c += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = xb[(size_t)(c + u) * N];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s = fmaf(v[u], v[u], s);
+    }
+    for (; c < C; ++c) {
         const float v = xb[(size_t)c * N];
         s = fmaf(v, v, s);
     }
@@ -51,7 +60,18 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__
     }
     const float den = fmaxf(sqrtf(s), kNormEps);
     float q = 0.f;
-    for (int c = 0; c < C; ++c) {
+    for (c = 0; c + U <= C; c += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = xb[(size_t)(c + u) * N];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u] = v[u] / den;
+            xo[(size_t)(c + u) * N] = v[u];
+            q = fmaf(v[u], v[u], q);
+        }
+    }
+    for (; c < C; ++c) {
         const float v = xb[(size_t)c * N] / den;
         xo[(size_t)c * N] = v;
         q = fmaf(v, v, q);
@@ -84,16 +104,18 @@ struct TopK {
     //
     // insert (v, vi); caller guarantees vi is larger than every index already present, so a strict
     // `<` on the distance alone is the (dist, index) order.
+    // For a sorted list the shifted-in distance of slot j is the median of (v, d[j-1], d[j]):
+    // one v_med3_f32 instead of two selects.
     __device__ __forceinline__ void push_ascending(float v, int vi) {
         bool before_hi = v < d[KB - 1];
 #pragma unroll
         for (int j = KB - 1; j >= 1; --j) {
             const bool before_lo = v < d[j - 1];
-            d[j] = before_lo ? d[j - 1] : (before_hi ? v : d[j]);
+            d[j] = __builtin_amdgcn_fmed3f(v, d[j - 1], d[j]);
             i[j] = before_lo ? i[j - 1] : (before_hi ? vi : i[j]);
             before_hi = before_lo;
         }
-        d[0] = before_hi ? v : d[0];
+        d[0] = fminf(v, d[0]);
         i[0] = before_hi ? vi : i[0];
     }
     // general insert with the full (dist, index) comparison.
@@ -114,15 +136,52 @@ struct TopK {
     }
 };
 
+// stage ROWS x WIDTH floats of a (rows, ld) matrix into LDS, zero-filling out-of-range rows/cols.
+// `vec` (ld % 4 == 0, col0 % 4 == 0, 16-B aligned base): 16-B loads and ds_write_b128.
+template <int ROWS>
+__device__ __forceinline__ void stage_slab(float* __restrict__ dst, const float* __restrict__ src, int ld,
+                                           int row0, int rows_total, int col0, int cols_total, int width,
+                                           bool vec) {
+    if (vec) {
+        const int w4 = width >> 2;
+        for (int e = threadIdx.x; e < ROWS * w4; e += blockDim.x) {
+            const int r = e / w4, c4 = (e - r * w4) << 2;
+            const int row = row0 + r, col = col0 + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rows_total) {
+                const float* p = src + (size_t)row * ld + col;
+                if (col + 3 < cols_total) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (col < cols_total) v.x = p[0];
+                    if (col + 1 < cols_total) v.y = p[1];
+                    if (col + 2 < cols_total) v.z = p[2];
+                }
+            }
+            *reinterpret_cast<float4*>(dst + r * width + c4) = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < ROWS * width; e += blockDim.x) {
+            const int r = e / width, c = e - r * width;
+            const int row = row0 + r, col = col0 + c;
+            dst[e] = (row < rows_total && col < cols_total) ? src[(size_t)row * ld + col] : 0.f;
+        }
+    }
+}
+
+// grid = (query tiles, B, S): split s handles candidates [s*m_per_split, (s+1)*m_per_split).
+// S == 1: the final indices go to `out`; S > 1: every split writes its K best (dist, index) pairs
+// to part_d / part_i [(b*N + n)*S + s][K] and knn_merge_kernel picks the overall K best.
 template <int KB, int TILES>
 __global__ __launch_bounds__(512) void knn_fused_kernel(
     const float* __restrict__ xn, const float* __restrict__ yn,
     const float* __restrict__ xs, const float* __restrict__ ys,
     const float* __restrict__ relpos, int32_t* __restrict__ out,
-    int C, int N, int M, int K) {
+    float* __restrict__ part_d, int32_t* __restrict__ part_i,
+    int C, int N, int M, int K, int m_per_split, int vec_ok) {
     constexpr int KS = 32;          // channels per LDS slab
     constexpr int TM = 32 * TILES;  // candidates per chunk
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int nw = blockDim.x >> 6;
     const int QW = nw * 32;
     float* ldsA = lds;            // [KS][TM]  candidates
@@ -130,6 +189,7 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
+    const int split = blockIdx.z, n_splits = gridDim.z;
     const int n0 = blockIdx.x * QW;
     const int n = n0 + wave * 32 + lq;
     const bool nvalid = n < N;
@@ -138,11 +198,15 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
     const float* ysb = ys + (size_t)b * M;
     const float xsv = nvalid ? xs[(size_t)b * N + n] : 0.f;
     const float* rp_row = (relpos != nullptr && nvalid) ? relpos + (size_t)n * M : nullptr;
+    const int m_begin = split * m_per_split;
+    int m_end = m_begin + m_per_split;
+    if (m_end > M) m_end = M;
+    const bool vec = vec_ok != 0;
 
     TopK<KB> top;
     top.init();
 
-    for (int mc0 = 0; mc0 < M; mc0 += TM) {
+    for (int mc0 = m_begin; mc0 < m_end; mc0 += TM) {
         f32x16 acc[TILES];
 #pragma unroll
         for (int t = 0; t < TILES; ++t)
@@ -151,18 +215,8 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
 
         for (int c0 = 0; c0 < C; c0 += KS) {
             __syncthreads();  // previous slab fully consumed
-            for (int c = wave; c < KS; c += nw) {
-                const int cc = c0 + c;
-                const bool cvalid = cc < C;
-                for (int col = lane; col < TM; col += 64) {
-                    const int m = mc0 + col;
-                    ldsA[c * TM + col] = (cvalid && m < M) ? yb[(size_t)cc * M + m] : 0.f;
-                }
-                for (int col = lane; col < QW; col += 64) {
-                    const int q = n0 + col;
-                    ldsB[c * QW + col] = (cvalid && q < N) ? xb[(size_t)cc * N + q] : 0.f;
-                }
-            }
+            stage_slab<KS>(ldsA, yb, M, c0, C, mc0, m_end, TM, vec);
+            stage_slab<KS>(ldsB, xb, N, c0, C, n0, N, QW, vec);
             __syncthreads();
             int kmax = C - c0;
             if (kmax > KS) kmax = KS;
@@ -183,13 +237,29 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
             f32x16 v = acc[t];
             for (int g = 0; g < 4; ++g) {
                 const int mbase = mc0 + t * 32 + 8 * g + 4 * h;
+                float yv[4], rv[4];
+                if (vec && mbase + 3 < m_end) {  // 16-B aligned: M % 4 == 0 and mbase % 4 == 0
+                    const float4 y4 = *reinterpret_cast<const float4*>(ysb + mbase);
+                    yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
+                    if (rp_row != nullptr) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(rp_row + mbase);
+                        rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = mbase + r < m_end;
+                        yv[r] = ok ? ysb[mbase + r] : 0.f;
+                        rv[r] = (ok && rp_row != nullptr) ? rp_row[mbase + r] : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mbase + r;
                     float dist = INFINITY;
-                    if (nvalid && m < M) {
-                        dist = (xsv + (-2.0f * v[r])) + ysb[m];
-                        if (rp_row != nullptr) dist = dist + rp_row[m];
+                    if (nvalid && m < m_end) {
+                        dist = (xsv + (-2.0f * v[r])) + yv[r];
+                        if (rp_row != nullptr) dist = dist + rv[r];
                     }
                     if (__any(dist < top.d[KB - 1])) top.push_ascending(dist, m);
                 }
@@ -219,10 +289,44 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
         top.push_any(pd, pi);
     }
     if (nvalid && h == 0) {
-        int32_t* o = out + ((size_t)b * N + n) * K;
+        if (n_splits == 1) {
+            int32_t* o = out + ((size_t)b * N + n) * K;
 #pragma unroll
-        for (int j = 0; j < KB; ++j)
-            if (j < K) o[j] = top.i[j];
+            for (int j = 0; j < KB; ++j)
+                if (j < K) o[j] = top.i[j];
+        } else {
+            const size_t base = (((size_t)b * N + n) * n_splits + split) * K;
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+                if (j < K) { part_d[base + j] = top.d[j]; part_i[base + j] = top.i[j]; }
+        }
+    }
+}
+
+// S sorted partial lists per query -> the K best overall, by (dist, index).  One thread per query;
+// the lists are tiny (S*K <= 16*32 pairs) and this runs once per graph.
+constexpr int kMaxSplits = 16;
+__global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ part_d,
+                                                        const int32_t* __restrict__ part_i,
+                                                        int32_t* __restrict__ out, long long rows, int S,
+                                                        int K) {
+    const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const float* pd = part_d + (size_t)row * S * K;
+    const int32_t* pi = part_i + (size_t)row * S * K;
+    int head[kMaxSplits];
+    for (int s = 0; s < S; ++s) head[s] = 0;
+    for (int j = 0; j < K; ++j) {
+        float bd = INFINITY;
+        int bi = kSentinelIdx, bs = 0;
+        for (int s = 0; s < S; ++s) {
+            if (head[s] >= K) continue;
+            const float d = pd[s * K + head[s]];
+            const int i = pi[s * K + head[s]];
+            if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; bs = s; }
+        }
+        out[(size_t)row * K + j] = bi;
+        head[bs] += 1;
     }
 }
 
@@ -298,15 +402,47 @@ __global__ __launch_bounds__(256) void edge_index_i64_kernel(const int32_t* __re
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct KnnWorkspace {
-    size_t xn, xs, yn, ys, dist, total;
+    size_t xn, xs, yn, ys, dist, part_d, part_i, total;
 };
+
+struct FusedPlan {
+    int nw, tiles, splits, m_per_split;
+};
+
+// candidate tiles per chunk: 6 tiles (192 wide) unless a 64-wide chunk wastes >10 % fewer MFMAs on
+// padding (M = 168, 384, 1344, 3072 of cfg 2 / cfg 5 are all multiples or near-multiples of 192).
+static int pick_tiles(int M) {
+    const long long ww = (long long)cdiv(M, 192) * 192, w2 = (long long)cdiv(M, 64) * 64;
+    return (w2 * 10 < ww * 9) ? 2 : 6;
+}
+
+// Work decomposition of the fused kernel: 32 queries per wave, 4 waves per workgroup (6 when one
+// workgroup then covers a whole <= 192-point window), and the candidate range split over enough
+// workgroups to put >= 2 waves on every SIMD of the 256 CUs (1024 SIMDs).
+static FusedPlan plan_fused(int B, int N, int M) {
+    FusedPlan p;
+    const int need = cdiv(N, 32);
+    p.nw = need <= 6 ? (need < 1 ? 1 : need) : 4;
+    p.tiles = pick_tiles(M);
+    const int tm = 32 * p.tiles;
+    const int chunks = cdiv(M, tm);
+    const long long waves = (long long)B * cdiv(N, 32 * p.nw) * p.nw;
+    long long want = cdiv64(2048, waves);
+    if (want > chunks) want = chunks;
+    if (want > kMaxSplits) want = kMaxSplits;
+    if (want < 1) want = 1;
+    const int chunks_per_split = cdiv(chunks, (int)want);
+    p.splits = cdiv(chunks, chunks_per_split);
+    p.m_per_split = chunks_per_split * tm;
+    return p;
+}
 
 static int resolve_algo(int algo, int K) {
     if (algo == NEXTOU_KNN_AUTO) return K <= 32 ? NEXTOU_KNN_FUSED : NEXTOU_KNN_NAIVE;
     return algo;
 }
 
-static KnnWorkspace knn_layout(int B, int C, int N, int M, int has_y, int algo) {
+static KnnWorkspace knn_layout(int B, int C, int N, int M, int K, int has_y, int algo) {
     KnnWorkspace w{};
     size_t off = 0;
     w.xn = off; off += align256((size_t)B * C * N * sizeof(float));
@@ -319,6 +455,12 @@ static KnnWorkspace knn_layout(int B, int C, int N, int M, int has_y, int algo) 
     }
     if (algo == NEXTOU_KNN_NAIVE) {
         w.dist = off; off += align256((size_t)B * N * M * sizeof(float));
+    } else {
+        const FusedPlan p = plan_fused(B, N, M);
+        if (p.splits > 1) {
+            w.part_d = off; off += align256((size_t)B * N * p.splits * K * sizeof(float));
+            w.part_i = off; off += align256((size_t)B * N * p.splits * K * sizeof(int32_t));
+        }
     }
     w.total = off;
     return w;
@@ -336,45 +478,46 @@ static int launch_prep(const float* x, float* xn, float* sq, int B, int C, int N
     return check_launch("knn_prep_kernel");
 }
 
+struct FusedArgs {
+    const float *xn, *yn, *xs, *ys, *relpos;
+    int32_t* out;
+    float* part_d;
+    int32_t* part_i;
+    int B, C, N, M, K;
+};
+
 template <int KB, int TILES>
-static int launch_fused(const float* xn, const float* yn, const float* xs, const float* ys,
-                        const float* relpos, int32_t* out, int B, int C, int N, int M, int K,
-                        int nw, hipStream_t s) {
-    const int QW = 32 * nw;
+static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
+    const int QW = 32 * p.nw;
     const size_t lds = (size_t)32 * (32 * TILES + QW) * sizeof(float);
-    dim3 grid(cdiv(N, QW), B);
-    // algorithmic work of the distance contraction: 2*B*N*M*C flops
-    ProfScope prof(s, kBoundMfma, 2.0 * B * (double)N * M * C, "knn_fused_kernel<%d,%d>[B%d C%d N%d M%d K%d]",
-                   KB, TILES, B, C, N, M, K);
-    hipLaunchKernelGGL((knn_fused_kernel<KB, TILES>), grid, dim3(64 * nw), lds, s, xn, yn, xs, ys,
-                       relpos, out, C, N, M, K);
-    return check_launch("knn_fused_kernel");
+    dim3 grid(cdiv(a.N, QW), a.B, p.splits);
+    // 16-B staging needs row strides and bases that keep every 4-float piece aligned
+    const int vec_ok = (a.N % 4 == 0) && (a.M % 4 == 0) &&
+                       ((reinterpret_cast<uintptr_t>(a.xn) | reinterpret_cast<uintptr_t>(a.yn) |
+                         reinterpret_cast<uintptr_t>(a.ys) | reinterpret_cast<uintptr_t>(a.relpos)) & 15u) == 0;
+    {
+        // algorithmic work of the distance contraction: 2*B*N*M*C flops
+        ProfScope prof(s, kBoundMfma, 2.0 * a.B * (double)a.N * a.M * a.C,
+                       "knn_fused_kernel<%d,%d>[B%d C%d N%d M%d K%d]", KB, TILES, a.B, a.C, a.N, a.M, a.K);
+        hipLaunchKernelGGL((knn_fused_kernel<KB, TILES>), grid, dim3(64 * p.nw), lds, s, a.xn, a.yn, a.xs, a.ys,
+                           a.relpos, a.out, a.part_d, a.part_i, a.C, a.N, a.M, a.K, p.m_per_split, vec_ok);
+    }
+    if (int e = check_launch("knn_fused_kernel")) return e;
+    if (p.splits > 1) {
+        const long long rows = (long long)a.B * a.N;
+        ProfScope prof(s, kBoundHbm, 8.0 * rows * p.splits * a.K + 4.0 * rows * a.K, "knn_merge_kernel[B%d N%d S%d K%d]",
+                       a.B, a.N, p.splits, a.K);
+        hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)cdiv64(rows, 256)), dim3(256), 0, s, a.part_d, a.part_i,
+                           a.out, rows, p.splits, a.K);
+        return check_launch("knn_merge_kernel");
+    }
+    return 0;
 }
 
 template <int KB>
-static int launch_fused_tiles(int tiles, const float* xn, const float* yn, const float* xs,
-                              const float* ys, const float* relpos, int32_t* out, int B, int C,
-                              int N, int M, int K, int nw, hipStream_t s) {
-    if (tiles == 2) return launch_fused<KB, 2>(xn, yn, xs, ys, relpos, out, B, C, N, M, K, nw, s);
-    return launch_fused<KB, 6>(xn, yn, xs, ys, relpos, out, B, C, N, M, K, nw, s);
-}
-
-// waves per workgroup: cover N with 32-query waves, prefer >= 512 workgroups in the grid.
-static int pick_waves(int B, int N) {
-    const int need = cdiv(N, 32);
-    if (need <= 6) return need < 1 ? 1 : need;
-    int nw = 6;
-    while (nw > 2 && (long long)cdiv(N, 32 * nw) * B < 512) nw -= 2;
-    return nw;
-}
-
-// candidate tiles per chunk: 6 tiles (192 wide) unless a 64-wide chunk wastes >10 % fewer MFMAs on
-// padding (M = 168, 384, 1344, 3072 of cfg 2 / cfg 5 are all multiples or near-multiples of 192).
-static int pick_tiles(int M, int K) {
-    (void)K;
-    const int wide = 192;
-    const long long ww = (long long)cdiv(M, wide) * wide, w2 = (long long)cdiv(M, 64) * 64;
-    return (w2 * 10 < ww * 9) ? 2 : 6;
+static int launch_fused_tiles(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
+    if (p.tiles == 2) return launch_fused<KB, 2>(a, p, s);
+    return launch_fused<KB, 6>(a, p, s);
 }
 
 }  // namespace nextou
@@ -383,7 +526,7 @@ using namespace nextou;
 
 extern "C" size_t nextou_knn_workspace_bytes(int B, int C, int N, int M, int K, int has_y, int algo) {
     if (B <= 0 || C <= 0 || N <= 0 || M <= 0) return 0;
-    return knn_layout(B, C, N, M, has_y, resolve_algo(algo, K)).total;
+    return knn_layout(B, C, N, M, K, has_y, resolve_algo(algo, K)).total;
 }
 
 extern "C" int nextou_knn_graph(const float* x, const float* y, const float* relpos,
@@ -404,7 +547,7 @@ extern "C" int nextou_knn_graph(const float* x, const float* y, const float* rel
         return fail(NEXTOU_ENOTSUP, "knn_graph: fused kernel supports K <= 32, got %d", K);
     if (algo != NEXTOU_KNN_FUSED && algo != NEXTOU_KNN_NAIVE)
         return fail(NEXTOU_EINVAL, "knn_graph: unknown algo %d", algo);
-    const KnnWorkspace w = knn_layout(B, C, N, M, has_y, algo);
+    const KnnWorkspace w = knn_layout(B, C, N, M, K, has_y, algo);
     if (workspace_bytes < w.total)
         return fail(NEXTOU_ENOSPACE, "knn_graph: workspace %zu < required %zu", workspace_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
@@ -435,11 +578,11 @@ extern "C" int nextou_knn_graph(const float* x, const float* y, const float* rel
         return check_launch("knn_select_naive_kernel");
     }
 
-    const int nw = pick_waves(B, N);
-    const int tiles = pick_tiles(M, K);
-    if (K <= 8) return launch_fused_tiles<8>(tiles, xn, yn, xs, ys, relpos, nn_idx, B, C, N, M, K, nw, s);
-    if (K <= 16) return launch_fused_tiles<16>(tiles, xn, yn, xs, ys, relpos, nn_idx, B, C, N, M, K, nw, s);
-    return launch_fused_tiles<32>(tiles, xn, yn, xs, ys, relpos, nn_idx, B, C, N, M, K, nw, s);
+    const FusedPlan plan = plan_fused(B, N, M);
+    FusedArgs a{xn, yn, xs, ys, relpos, nn_idx, (float*)(base + w.part_d), (int32_t*)(base + w.part_i), B, C, N, M, K};
+    if (K <= 8) return launch_fused_tiles<8>(a, plan, s);
+    if (K <= 16) return launch_fused_tiles<16>(a, plan, s);
+    return launch_fused_tiles<32>(a, plan, s);
 }
 
 extern "C" int nextou_edge_index_i64(const int32_t* nn_idx, int64_t* edge_index, int B, int N,

@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Per-kernel roofline of libnextou_hip.so at the cfg-2 (or cfg-5) call shapes of SURVEY.md §A.2.
+
+    python tools/kernel_bench.py [--cfg 2|5] [--iters 10] [--json out.json]
+
+Every launch is timed with HIP events on its own stream by the library's launch profiler
+(nextou_profile_enable / nextou_profile_report); `achieved` = algorithmic flops or bytes per launch
+/ mean launch time, `frac` = achieved / MI355X peak (fp32 MFMA 157.3 TFLOP/s, HBM 8000 GB/s).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nextou_amd import _lib, graph_ops  # noqa: E402
+
+# (label, B', C, N, M (None = self), k)   — cfg 2, batch 2
+CFG2 = [("s2 Pool", 2, 132, 10752, 168, 14), ("s2 Swin", 1024, 132, 168, None, 7),
+        ("s3 Pool", 2, 264, 10752, 1344, 28), ("s3 Swin", 128, 264, 168, None, 14),
+        ("s4 Pool", 2, 324, 1344, None, 32), ("s4 Swin", 16, 324, 168, None, 14),
+        ("s5 Pool", 2, 324, 168, None, 32), ("s5 Swin", 2, 324, 168, None, 28)]
+# cfg 5: patch 96x256x256, min shape (6,8,8) = 384 points per window
+CFG5 = [("s2 Pool", 2, 132, 24576, 384, 32), ("s2 Swin", 1024, 132, 384, None, 16),
+        ("s3 Pool", 2, 264, 24576, 3072, 32), ("s3 Swin", 128, 264, 384, None, 32),
+        ("s4 Pool", 2, 324, 3072, None, 32), ("s4 Swin", 16, 324, 384, None, 32)]
+PEAK = {"mfma": 157.3e12, "hbm": 8000e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", type=int, default=2)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--only", default=None, help="substring filter on the call label")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    calls = CFG2 if args.cfg == 2 else CFG5
+    rows = []
+    for label, B, C, N, M, k in calls:
+        if args.only and args.only not in label:
+            continue
+        g = torch.Generator(device=dev).manual_seed(1)
+        x = torch.randn((B, C, N), generator=g, device=dev)
+        y = None if M is None else torch.randn((B, C, M), generator=g, device=dev)
+        rp = torch.randn((N, M or N), generator=g, device=dev) * 0.05
+        x.requires_grad_(True)
+        if y is not None:
+            y.requires_grad_(True)
+        gout = torch.randn((B, 2 * C, N), generator=g, device=dev)
+        for it in range(2 + args.iters):
+            if it == 2:
+                torch.cuda.synchronize()
+                L.nextou_profile_enable(64 * args.iters)
+            idx = graph_ops.knn_graph(x, y, rp, k)
+            out = graph_ops.mr_aggregate(x, idx, y)
+            torch.autograd.grad(out, [x] if y is None else [x, y], gout)
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 20)
+        L.nextou_profile_report(buf, len(buf))
+        L.nextou_profile_enable(0)
+        for r in json.loads(buf.value.decode()):
+            per_s = r["ms"] / r["launches"] / 1e3
+            ach = r["work"] / r["launches"] / per_s
+            rows.append({"call": label, "kernel": r["kernel"], "bound": r["bound"], "us": per_s * 1e6,
+                         "achieved": ach, "frac": ach / PEAK[r["bound"]]})
+    print("%-8s %-66s %5s %10s %14s %7s" % ("call", "kernel", "bound", "us/launch", "achieved", "frac"))
+    for r in rows:
+        unit = "TFLOP/s" if r["bound"] == "mfma" else "GB/s"
+        val = r["achieved"] / (1e12 if r["bound"] == "mfma" else 1e9)
+        print("%-8s %-66s %5s %10.1f %9.2f %-7s %6.1f%%" % (r["call"], r["kernel"][:66], r["bound"], r["us"], val, unit,
+                                                          100 * r["frac"]))
+    print("total own-kernel time for one fwd+bwd over these calls: %.3f ms" % (sum(r["us"] for r in rows) / 1e3))
+    if args.json:
+        json.dump(rows, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
