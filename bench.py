@@ -29,6 +29,13 @@ import os
 import sys
 import time
 
+# MIOpen's find step (torch.backends.cudnn.benchmark) also times its naive reference solvers, which
+# need ~0.1-0.4 s PER CALL on the 64x224x192 stages (measured: 317 s of a 350 s warm-up, profiles/).
+# They can never win, so they are excluded from the search; nothing else about MIOpen is changed.
+for _k in ("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD",
+           "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW"):
+    os.environ.setdefault(_k, "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist

@@ -215,6 +215,38 @@ class Recorder:
             h.remove()
 
 
+class Replayer:
+    """Teacher-forces a reference model: kNN results and real max-pool arg-max locations are
+    replaced, in call order, by the recorded entries (forward hooks may return a new output)."""
+
+    def __init__(self, model, ref, entries):
+        self.entries, self.cursor, self.handles = entries, 0, []
+
+        def knn_hook(mod, inp, out):
+            nn_idx = self.entries[self.cursor].to(torch.int64)
+            self.cursor += 1
+            return torch.stack((nn_idx, out[1]), 0)
+
+        def pool_hook(mod, inp, out):
+            idx = self.entries[self.cursor]
+            self.cursor += 1
+            x = inp[0]
+            vals = x.flatten(2).gather(2, idx.flatten(2)).reshape(idx.shape)
+            return vals, idx
+
+        for m in model.modules():
+            if isinstance(m, ref.torch_edge.DenseDilatedKnnGraph):
+                self.handles.append(m.register_forward_hook(knn_hook))
+            if isinstance(m, (nn.MaxPool2d, nn.MaxPool3d)) and m.return_indices:
+                ks = m.kernel_size if isinstance(m.kernel_size, (list, tuple)) else [m.kernel_size]
+                if any(int(k) != 1 for k in ks):
+                    self.handles.append(m.register_forward_hook(pool_hook))
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+
+
 def g_blocks(ref):
     """G5: PoolGrapher (pooled r=4 stage; un-pooled r=1 stage) and SwinGrapher, fwd + input grad,
     train and eval mode, with the recorded kNN / arg-max decisions for teacher forcing."""
@@ -328,9 +360,18 @@ def g_models(ref):
         with torch.no_grad():
             outs = model(x)
         rec.close()
-        # self-noise floor: the reference against itself under 1e-7 relative input noise, with the
-        # recorded decisions of the clean run (reported, not gating — SURVEY §7 hard part 0)
-        arrays = {"x": x.numpy(), "n_tape": len(rec.entries)}
+        # self-noise floor: the reference against ITSELF under 1e-7 relative input noise (below one
+        # fp32 ulp), teacher-forced with the decisions of the clean run (SURVEY §7 hard part 0):
+        # the smallest |dlogit| any other fp32 implementation of the dense stages can be held to.
+        rep = Replayer(model, ref, rec.entries)
+        with torch.no_grad():
+            noisy = model(x * (1 + 1e-7 * formula.gaussian(name + ".noise", x.shape)))
+        rep.close()
+        assert rep.cursor == len(rec.entries)
+        floor = max(float((a - b).abs().max()) for a, b in zip(outs, noisy))
+        absmax = max(float(o.abs().max()) for o in outs)
+        print("   %s: max|logit| %.2f, self-noise floor (1e-7 input noise, teacher-forced) %.3e" % (name, absmax, floor))
+        arrays = {"x": x.numpy(), "n_tape": len(rec.entries), "self_noise_floor": floor, "logit_absmax": absmax}
         for i, e in enumerate(rec.entries):
             arrays["tape%d" % i] = e.numpy()
         for i, o in enumerate(outs):
