@@ -17,7 +17,8 @@ from ctypes import c_char_p, c_int, c_int64, c_size_t, c_void_p
 import torch  # noqa: F401  (must precede the dlopen, see module docstring)
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libnextou_hip.so")
+# NEXTOU_HIP_LIB points experiments (tools/ablate_knn.sh) at a side build; the product never sets it.
+LIB_PATH = os.environ.get("NEXTOU_HIP_LIB") or os.path.join(_PKG_DIR, "libnextou_hip.so")
 
 KNN_AUTO, KNN_FUSED, KNN_NAIVE = 0, 1, 2
 ABI_VERSION = 1

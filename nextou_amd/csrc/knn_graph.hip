@@ -19,6 +19,13 @@
 #include "common.h"
 #include <cmath>
 
+// Experiment switch (tools/ablate_knn.sh builds side libraries with -DNEXTOU_ABLATE=n; the product
+// build leaves it 0):  1 = skip the top-K pushes, 2 = stage only the first slab of every chunk,
+// 4 = skip the MFMAs.  Results are wrong by construction with any bit set.
+#ifndef NEXTOU_ABLATE
+#define NEXTOU_ABLATE 0
+#endif
+
 namespace nextou {
 
 constexpr float kNormEps = 1e-12f;  // F.normalize eps (torch_edge.py:154-155,160)
@@ -138,10 +145,9 @@ struct TopK {
 
 // stage ROWS x WIDTH floats of a (rows, ld) matrix into LDS, zero-filling out-of-range rows/cols.
 // `vec` (ld % 4 == 0, col0 % 4 == 0, 16-B aligned base): 16-B loads and ds_write_b128.
-template <int ROWS>
 __device__ __forceinline__ void stage_slab(float* __restrict__ dst, const float* __restrict__ src, int ld,
                                            int row0, int rows_total, int col0, int cols_total, int width,
-                                           bool vec) {
+                                           bool vec, const int ROWS) {
     if (vec) {
         const int w4 = width >> 2;
         for (int e = threadIdx.x; e < ROWS * w4; e += blockDim.x) {
@@ -178,8 +184,8 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
     const float* __restrict__ xs, const float* __restrict__ ys,
     const float* __restrict__ relpos, int32_t* __restrict__ out,
     float* __restrict__ part_d, int32_t* __restrict__ part_i,
-    int C, int N, int M, int K, int m_per_split, int vec_ok) {
-    constexpr int KS = 32;          // channels per LDS slab
+    int C, int N, int M, int K, int m_per_split, int vec_ok, int KS) {
+    // KS = channels per LDS slab (even; 32 normally, 64 for latency-bound small grids)
     constexpr int TM = 32 * TILES;  // candidates per chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int nw = blockDim.x >> 6;
@@ -215,8 +221,10 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
 
         for (int c0 = 0; c0 < C; c0 += KS) {
             __syncthreads();  // previous slab fully consumed
-            stage_slab<KS>(ldsA, yb, M, c0, C, mc0, m_end, TM, vec);
-            stage_slab<KS>(ldsB, xb, N, c0, C, n0, N, QW, vec);
+            if (!(NEXTOU_ABLATE & 2) || c0 == 0) {
+                stage_slab(ldsA, yb, M, c0, C, mc0, m_end, TM, vec, KS);
+                stage_slab(ldsB, xb, N, c0, C, n0, N, QW, vec, KS);
+            }
             __syncthreads();
             int kmax = C - c0;
             if (kmax > KS) kmax = KS;
@@ -226,6 +234,10 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
                     const float a = ldsA[(kp + h) * TM + t * 32 + lq];
+                    if (NEXTOU_ABLATE & 4) {
+                        acc[t][0] += a * bq;  // keeps the LDS reads alive
+                        continue;
+                    }
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc[t], 0, 0, 0);
                 }
             }
@@ -260,6 +272,10 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
                     if (nvalid && m < m_end) {
                         dist = (xsv + (-2.0f * v[r])) + yv[r];
                         if (rp_row != nullptr) dist = dist + rv[r];
+                    }
+                    if (NEXTOU_ABLATE & 1) {
+                        top.d[0] = fminf(top.d[0], dist);  // keeps the distance alive
+                        continue;
                     }
                     if (__any(dist < top.d[KB - 1])) top.push_ascending(dist, m);
                 }
@@ -303,31 +319,37 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
     }
 }
 
-// S sorted partial lists per query -> the K best overall, by (dist, index).  One thread per query;
-// the lists are tiny (S*K <= 16*32 pairs) and this runs once per graph.
+// S sorted partial lists per query -> the K best overall, by (dist, index).  One thread per partial
+// entry: its final position is its own position plus the number of entries of the OTHER lists that
+// sort before it (binary search; every candidate lives in exactly one list, so ranks are unique).
 constexpr int kMaxSplits = 16;
 __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ part_d,
                                                         const int32_t* __restrict__ part_i,
                                                         int32_t* __restrict__ out, long long rows, int S,
                                                         int K) {
-    const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * S * K) return;
+    const long long row = e / ((long long)S * K);
+    const int rem = (int)(e - row * S * K);
+    const int sp = rem / K, j = rem - sp * K;
     const float* pd = part_d + (size_t)row * S * K;
     const int32_t* pi = part_i + (size_t)row * S * K;
-    int head[kMaxSplits];
-    for (int s = 0; s < S; ++s) head[s] = 0;
-    for (int j = 0; j < K; ++j) {
-        float bd = INFINITY;
-        int bi = kSentinelIdx, bs = 0;
-        for (int s = 0; s < S; ++s) {
-            if (head[s] >= K) continue;
-            const float d = pd[s * K + head[s]];
-            const int i = pi[s * K + head[s]];
-            if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; bs = s; }
+    const float d = pd[sp * K + j];
+    const int i = pi[sp * K + j];
+    if (i == kSentinelIdx) return;  // list shorter than K: not a candidate
+    int rank = j;
+    for (int o = 0; o < S && rank < K; ++o) {
+        if (o == sp) continue;
+        int lo = 0, hi = K;  // first position in list o that does NOT sort before (d, i)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const float dm = pd[o * K + mid];
+            const int im = pi[o * K + mid];
+            if (dm < d || (dm == d && im < i)) lo = mid + 1; else hi = mid;
         }
-        out[(size_t)row * K + j] = bi;
-        head[bs] += 1;
+        rank += lo;
     }
+    if (rank < K) out[(size_t)row * K + rank] = i;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -406,27 +428,25 @@ struct KnnWorkspace {
 };
 
 struct FusedPlan {
-    int nw, tiles, splits, m_per_split;
+    int nw, tiles, splits, m_per_split, ks;
 };
 
-// candidate tiles per chunk: 6 tiles (192 wide) unless a 64-wide chunk wastes >10 % fewer MFMAs on
-// padding (M = 168, 384, 1344, 3072 of cfg 2 / cfg 5 are all multiples or near-multiples of 192).
-static int pick_tiles(int M) {
-    const long long ww = (long long)cdiv(M, 192) * 192, w2 = (long long)cdiv(M, 64) * 64;
-    return (w2 * 10 < ww * 9) ? 2 : 6;
-}
-
-// Work decomposition of the fused kernel: 32 queries per wave, 4 waves per workgroup (6 when one
-// workgroup then covers a whole <= 192-point window), and the candidate range split over enough
-// workgroups to put >= 2 waves on every SIMD of the 256 CUs (1024 SIMDs).
+// Work decomposition of the fused kernel.  32 queries per wave; 4 waves per workgroup (up to 6 when
+// one workgroup then covers a whole <= 192-point window).  Candidates are processed in chunks of
+// 32*tiles; the chunk range is split over `splits` workgroups until ~2 waves sit on every SIMD of
+// the 256 CUs.  Large grids take 192-wide chunks (fewest staging passes per MFMA); grids that
+// cannot fill the chip even so take 64-wide chunks (more splits) and 64-channel slabs (half the
+// barrier / global-load round trips: these launches are latency-bound, LDS is plentiful).
 static FusedPlan plan_fused(int B, int N, int M) {
     FusedPlan p;
     const int need = cdiv(N, 32);
     p.nw = need <= 6 ? (need < 1 ? 1 : need) : 4;
-    p.tiles = pick_tiles(M);
+    const long long waves = (long long)B * cdiv(N, 32 * p.nw) * p.nw;
+    const bool small = waves < 1024;
+    const long long ww = (long long)cdiv(M, 192) * 192, w2 = (long long)cdiv(M, 64) * 64;
+    p.tiles = (small || w2 * 10 < ww * 9) ? 2 : 6;
     const int tm = 32 * p.tiles;
     const int chunks = cdiv(M, tm);
-    const long long waves = (long long)B * cdiv(N, 32 * p.nw) * p.nw;
     long long want = cdiv64(2048, waves);
     if (want > chunks) want = chunks;
     if (want > kMaxSplits) want = kMaxSplits;
@@ -434,6 +454,8 @@ static FusedPlan plan_fused(int B, int N, int M) {
     const int chunks_per_split = cdiv(chunks, (int)want);
     p.splits = cdiv(chunks, chunks_per_split);
     p.m_per_split = chunks_per_split * tm;
+    p.ks = (waves * p.splits < 2048) ? 64 : 32;
+    if ((size_t)p.ks * (tm + 32 * p.nw) * sizeof(float) > 64 * 1024) p.ks = 32;  // default dynamic-LDS limit
     return p;
 }
 
@@ -489,7 +511,7 @@ struct FusedArgs {
 template <int KB, int TILES>
 static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
     const int QW = 32 * p.nw;
-    const size_t lds = (size_t)32 * (32 * TILES + QW) * sizeof(float);
+    const size_t lds = (size_t)p.ks * (32 * TILES + QW) * sizeof(float);
     dim3 grid(cdiv(a.N, QW), a.B, p.splits);
     // 16-B staging needs row strides and bases that keep every 4-float piece aligned
     const int vec_ok = (a.N % 4 == 0) && (a.M % 4 == 0) &&
@@ -500,15 +522,15 @@ static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
         ProfScope prof(s, kBoundMfma, 2.0 * a.B * (double)a.N * a.M * a.C,
                        "knn_fused_kernel<%d,%d>[B%d C%d N%d M%d K%d]", KB, TILES, a.B, a.C, a.N, a.M, a.K);
         hipLaunchKernelGGL((knn_fused_kernel<KB, TILES>), grid, dim3(64 * p.nw), lds, s, a.xn, a.yn, a.xs, a.ys,
-                           a.relpos, a.out, a.part_d, a.part_i, a.C, a.N, a.M, a.K, p.m_per_split, vec_ok);
+                           a.relpos, a.out, a.part_d, a.part_i, a.C, a.N, a.M, a.K, p.m_per_split, vec_ok, p.ks);
     }
     if (int e = check_launch("knn_fused_kernel")) return e;
     if (p.splits > 1) {
         const long long rows = (long long)a.B * a.N;
         ProfScope prof(s, kBoundHbm, 8.0 * rows * p.splits * a.K + 4.0 * rows * a.K, "knn_merge_kernel[B%d N%d S%d K%d]",
                        a.B, a.N, p.splits, a.K);
-        hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)cdiv64(rows, 256)), dim3(256), 0, s, a.part_d, a.part_i,
-                           a.out, rows, p.splits, a.K);
+        hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)cdiv64(rows * p.splits * a.K, 256)), dim3(256), 0, s,
+                           a.part_d, a.part_i, a.out, rows, p.splits, a.K);
         return check_launch("knn_merge_kernel");
     }
     return 0;
