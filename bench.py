@@ -194,6 +194,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-miopen-find", action="store_true", help="disable MIOpen's find/benchmark mode")
     ap.add_argument("--bucket-mb", type=int, default=32)
+    ap.add_argument("--channels-last", action="store_true",
+                    help="experiment: run the dense stages in channels_last_3d (NDHWC) memory format")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -209,10 +211,14 @@ def main():
     trainer, cfg, batch, classes = build_trainer(args.workload, device, world > 1)
     cpu_copy_ok = (rank == 0 and world == 1 and not args.no_cpu_baseline)
     move_to(trainer, device)
+    if args.channels_last:
+        trainer.network.to(memory_format=torch.channels_last_3d)
     averager = BucketedGradientAverager(trainer.network, bucket_bytes=args.bucket_mb << 20) if world > 1 else None
     data, target = synthetic_batch(cfg, 1, classes, batch, device, seed=1234 + rank,
                                    blob_labels=(args.workload == "cfg4"))
     targets = downsample_targets(target, _head_shapes(cfg))
+    if args.channels_last:
+        data = data.contiguous(memory_format=torch.channels_last_3d)
     step = make_step(trainer, data, targets, averager)
 
     for _ in range(args.warmup):
