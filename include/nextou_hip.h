@@ -106,14 +106,25 @@ int nextou_edge_index_i64(const int32_t* nn_idx, int64_t* edge_index,
  *   src = y if y != NULL (M points) else x;  ctr = center_idx[b,n,j*idx_step] if
  *   center_idx != NULL else n.  idx rows have idx_stride int32 entries.
  * Backward (autograd of the above): gout (B,2C,N) -> dx (B,C,N), dy (B,C,M) (dy NULL iff y
- *   NULL).  The arg-max is recomputed; ties go to the first j (neighbour order).
- *   dx and dy are fully overwritten.
+ *   NULL).  nextou_mr_aggregate_bwd recomputes the arg-max (ties go to the first j, neighbour
+ *   order) and works for every shape; dx and dy are fully overwritten.
  * ---------------------------------------------------------------------------------------- */
 int nextou_mr_aggregate_fwd(const float* x, const float* y,
                             const int32_t* nn_idx, const int32_t* center_idx,
-                            float* out,
+                            float* out, uint16_t* arg_out,
                             int B, int C, int N, int M, int K, int idx_stride, int idx_step,
                             nextou_stream_t stream);
+
+/* Training fast path: when arg_out (B,C,N) uint16 is given (identity centres, K <= 32, M <= 65536 and
+ * source rows that fit the LDS staging — query with nextou_mr_aggregate_has_arg), the forward also
+ * records which source id won each max (first max over the rounded differences — the element
+ * autograd's max backward routes to).  nextou_mr_aggregate_bwd_arg is then a pure scatter-add:
+ *   dx[b,c,n] = g[b,2c,n] - g[b,2c+1,n] (+ scattered terms when dy == NULL, i.e. the self graph)
+ *   d{y|x}[b,c,arg[b,c,n]] += g[b,2c+1,n]
+ * with no gathers, no ids and no global atomics; x / y / nn_idx need not be kept for backward. */
+int nextou_mr_aggregate_has_arg(int B, int C, int N, int M, int K);
+int nextou_mr_aggregate_bwd_arg(const float* gout, const uint16_t* arg, float* dx, float* dy,
+                                int B, int C, int N, int M, nextou_stream_t stream);
 
 int nextou_mr_aggregate_bwd(const float* gout, const float* x, const float* y,
                             const int32_t* nn_idx, const int32_t* center_idx,

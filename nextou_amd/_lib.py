@@ -36,8 +36,11 @@ _SIGNATURES = {
     "nextou_pairwise_distance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                          c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "nextou_edge_index_i64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "nextou_mr_aggregate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "nextou_mr_aggregate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "nextou_mr_aggregate_has_arg": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "nextou_mr_aggregate_bwd_arg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                            c_void_p]),
     "nextou_mr_aggregate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p]),

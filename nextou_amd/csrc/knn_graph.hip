@@ -602,8 +602,13 @@ extern "C" int nextou_knn_graph(const float* x, const float* y, const float* rel
 
     const FusedPlan plan = plan_fused(B, N, M);
     FusedArgs a{xn, yn, xs, ys, relpos, nn_idx, (float*)(base + w.part_d), (int32_t*)(base + w.part_i), B, C, N, M, K};
+    // list-length buckets: every slot costs 4 VALU ops per candidate per lane, so the cfg-2 values
+    // 7 / 14 / 28 get their own instantiation instead of rounding up to 8 / 16 / 32
+    if (K <= 7) return launch_fused_tiles<7>(a, plan, s);
     if (K <= 8) return launch_fused_tiles<8>(a, plan, s);
+    if (K <= 14) return launch_fused_tiles<14>(a, plan, s);
     if (K <= 16) return launch_fused_tiles<16>(a, plan, s);
+    if (K <= 28) return launch_fused_tiles<28>(a, plan, s);
     return launch_fused_tiles<32>(a, plan, s);
 }
 

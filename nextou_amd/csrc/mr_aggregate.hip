@@ -32,12 +32,15 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
 // ---------------------------------------------------------------------------------------------
 // forward.  grid = (n_tiles, c_chunks, B); LDS = chunk * M floats.
 // ---------------------------------------------------------------------------------------------
-template <int KB>
+// WITH_ARG: also emit arg[b,c,n] = the source id that won the max (first max over the rounded
+// differences, the element autograd's max backward routes the gradient to), as uint16, so that the
+// backward pass is a pure scatter (mr_bwd_arg_kernel) instead of a second gather + arg-max.
+template <int KB, bool SELF, bool WITH_ARG>
 __global__ __launch_bounds__(256) void mr_fwd_lds_kernel(
     const float* __restrict__ x, const float* __restrict__ src, const int32_t* __restrict__ idx,
-    float* __restrict__ out, int C, int N, int M, int K, int idx_stride, int idx_step, int chunk,
-    int n_per_block) {
-    extern __shared__ float lds[];
+    float* __restrict__ out, uint16_t* __restrict__ arg, int C, int N, int M, int K, int idx_stride,
+    int idx_step, int chunk, int n_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.z;
     const int c0 = blockIdx.y * chunk;
     const int nc = (C - c0 < chunk) ? (C - c0) : chunk;
@@ -53,13 +56,26 @@ __global__ __launch_bounds__(256) void mr_fwd_lds_kernel(
         for (int j = 0; j < KB; ++j) id[j] = irow[(j < K ? j : 0) * idx_step];
         for (int c = 0; c < nc; ++c) {
             const float* row = lds + c * M;
-            float mx = row[id[0]];
-#pragma unroll
-            for (int j = 1; j < KB; ++j) mx = fmaxf(mx, row[id[j]]);
-            const float xv = x[((size_t)b * C + c0 + c) * N + n];
+            const float xv = SELF ? row[n] : x[((size_t)b * C + c0 + c) * N + n];
             float* o = out + ((size_t)b * 2 * C + 2 * (c0 + c)) * N + n;
-            o[0] = xv;
-            o[N] = mx - xv;
+            if (WITH_ARG) {
+                float mx = row[id[0]] - xv;
+                int am = id[0];
+#pragma unroll
+                for (int j = 1; j < KB; ++j) {
+                    const float v = row[id[j]] - xv;
+                    if (v > mx) { mx = v; am = id[j]; }  // strict: first max wins
+                }
+                o[0] = xv;
+                o[N] = mx;
+                arg[((size_t)b * C + c0 + c) * N + n] = (uint16_t)am;
+            } else {
+                float mx = row[id[0]];
+#pragma unroll
+                for (int j = 1; j < KB; ++j) mx = fmaxf(mx, row[id[j]]);
+                o[0] = xv;
+                o[N] = mx - xv;  // == max_j (src_j - x): rounding is monotone
+            }
         }
     }
 }
@@ -152,6 +168,43 @@ __global__ __launch_bounds__(256) void mr_bwd_lds_kernel(
             if (v != 0.f) atomicAdd(&drow[e], v);
         }
     }
+}
+
+// backward from the saved arg-max ids: a pure scatter-add, no gathers, no ids, no source rows.
+//   grid = (c_chunks, B); LDS = chunk * M accumulators.  The workgroup owns its channels for ALL
+//   points, so dx / dy rows are written exactly once with plain stores (no global atomics).
+//   SELF: acc starts at g_x - g_mr and is stored as dx.   !SELF: acc starts at 0 and is stored as dy;
+//   dx = g_x - g_mr is written on the way.
+template <bool SELF>
+__global__ __launch_bounds__(256) void mr_bwd_arg_kernel(const float* __restrict__ gout,
+                                                         const uint16_t* __restrict__ arg,
+                                                         float* __restrict__ dx, float* __restrict__ dy,
+                                                         int C, int N, int M, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * chunk;
+    const int nc = (C - c0 < chunk) ? (C - c0) : chunk;
+    if (SELF) {
+        for (int c = 0; c < nc; ++c) {
+            const float* g = gout + ((size_t)b * 2 * C + 2 * (c0 + c)) * N;
+            for (int n = threadIdx.x; n < N; n += blockDim.x) lds[c * M + n] = g[n] - g[N + n];
+        }
+    } else {
+        for (int e = threadIdx.x; e < nc * M; e += blockDim.x) lds[e] = 0.f;
+    }
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+        const float* g = gout + ((size_t)b * 2 * C + 2 * (c0 + c)) * N;
+        const uint16_t* a = arg + ((size_t)b * C + c0 + c) * N;
+        float* acc = lds + c * M;
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+            const float gm = g[N + n];
+            atomicAdd(&acc[a[n]], gm);
+            if (!SELF) dx[((size_t)b * C + c0 + c) * N + n] = g[n] - gm;
+        }
+    }
+    __syncthreads();
+    stage_rows((SELF ? dx : dy) + ((size_t)b * C + c0) * M, lds, nc * M);
 }
 
 // generic backward: global atomics, arbitrary centre ids.  dx / dsrc pre-zeroed by the host.
@@ -258,32 +311,79 @@ static int check_mr_args(const char* who, const void* a, const void* b, const vo
 using namespace nextou;
 
 extern "C" int nextou_mr_aggregate_fwd(const float* x, const float* y, const int32_t* nn_idx,
-                                       const int32_t* center_idx, float* out, int B, int C, int N,
-                                       int M, int K, int idx_stride, int idx_step,
+                                       const int32_t* center_idx, float* out, uint16_t* arg_out, int B,
+                                       int C, int N, int M, int K, int idx_stride, int idx_step,
                                        nextou_stream_t stream) {
     if (int e = check_mr_args("mr_aggregate_fwd", x, nn_idx, out, B, C, N, M, K, idx_stride, idx_step)) return e;
     NEXTOU_REQUIRE(y != nullptr || M == N, "mr_aggregate_fwd: y == NULL needs M == N (N=%d M=%d)", N, M);
+    NEXTOU_REQUIRE(arg_out == nullptr || (center_idx == nullptr && M <= 65536),
+                   "mr_aggregate_fwd: arg_out needs identity centres and M <= 65536 (M=%d)", M);
     hipStream_t s = (hipStream_t)stream;
     const float* src = y ? y : x;
+    const bool self = (y == nullptr);
+    // algorithmic HBM bytes: read x (+y), read idx (int32), write the 2C-channel output (+ arg)
+    const double fwd_bytes = 4.0 * B * C * ((double)N + (y ? M : 0)) + 4.0 * B * (double)N * K + 8.0 * B * C * (double)N +
+                             (arg_out ? 2.0 * B * C * (double)N : 0.0);
     MrPlan p;
-    // algorithmic HBM bytes: read x (+y), read idx (int32), write the 2C-channel output
-    const double fwd_bytes = 4.0 * B * C * ((double)N + (y ? M : 0)) + 4.0 * B * (double)N * K + 8.0 * B * C * (double)N;
     if (center_idx == nullptr && K <= 32 && plan_lds(B, C, N, M, M, true, &p)) {
         dim3 grid(p.n_tiles, p.c_chunks, B), block(p.threads);
-        ProfScope prof(s, kBoundHbm, fwd_bytes, "mr_fwd_lds_kernel<%d>[B%d C%d N%d M%d K%d]", K <= 8 ? 8 : (K <= 16 ? 16 : 32),
-                       B, C, N, M, K);
-#define NEXTOU_MR_FWD(KB)                                                                          \
-    hipLaunchKernelGGL((mr_fwd_lds_kernel<KB>), grid, block, p.lds, s, x, src, nn_idx, out, C, N, M, \
-                       K, idx_stride, idx_step, p.chunk, p.n_per_block)
-        if (K <= 8) NEXTOU_MR_FWD(8);
-        else if (K <= 16) NEXTOU_MR_FWD(16);
-        else NEXTOU_MR_FWD(32);
+        const int kb = K <= 8 ? 8 : (K <= 16 ? 16 : 32);
+        ProfScope prof(s, kBoundHbm, fwd_bytes, "mr_fwd_lds_kernel<%d,%s,%s>[B%d C%d N%d M%d K%d]", kb,
+                       self ? "self" : "xy", arg_out ? "arg" : "noarg", B, C, N, M, K);
+#define NEXTOU_MR_FWD(KB, SELF, ARG)                                                                      \
+    hipLaunchKernelGGL((mr_fwd_lds_kernel<KB, SELF, ARG>), grid, block, p.lds, s, x, src, nn_idx, out, arg_out, \
+                       C, N, M, K, idx_stride, idx_step, p.chunk, p.n_per_block)
+#define NEXTOU_MR_FWD_KB(KB)                                                     \
+    do {                                                                         \
+        if (self && arg_out) NEXTOU_MR_FWD(KB, true, true);                      \
+        else if (self) NEXTOU_MR_FWD(KB, true, false);                           \
+        else if (arg_out) NEXTOU_MR_FWD(KB, false, true);                        \
+        else NEXTOU_MR_FWD(KB, false, false);                                    \
+    } while (0)
+        if (kb == 8) NEXTOU_MR_FWD_KB(8);
+        else if (kb == 16) NEXTOU_MR_FWD_KB(16);
+        else NEXTOU_MR_FWD_KB(32);
+#undef NEXTOU_MR_FWD_KB
 #undef NEXTOU_MR_FWD
         return check_launch("mr_fwd_lds_kernel");
     }
+    if (arg_out != nullptr)
+        return fail(NEXTOU_ENOTSUP, "mr_aggregate_fwd: arg_out is only produced by the LDS kernel (K <= 32, rows <= %d floats)",
+                    kGatherLdsBytes / 4);
     hipLaunchKernelGGL(mr_fwd_global_kernel, dim3(cdiv(N, 256), C, B), dim3(256), 0, s, x, src, nn_idx,
                        center_idx, out, C, N, M, K, idx_stride, idx_step);
     return check_launch("mr_fwd_global_kernel");
+}
+
+// 1 if nextou_mr_aggregate_fwd can fill arg_out for this shape (lets the caller decide what to save)
+extern "C" int nextou_mr_aggregate_has_arg(int B, int C, int N, int M, int K) {
+    MrPlan p;
+    return (M <= 65536 && K <= 32 && B > 0 && C > 0 && N > 0 && M > 0 && plan_lds(B, C, N, M, M, true, &p)) ? 1 : 0;
+}
+
+extern "C" int nextou_mr_aggregate_bwd_arg(const float* gout, const uint16_t* arg, float* dx, float* dy, int B,
+                                           int C, int N, int M, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(gout && arg && dx, "mr_aggregate_bwd_arg: null pointer");
+    NEXTOU_REQUIRE(B > 0 && C > 0 && N > 0 && M > 0 && B <= 65535, "mr_aggregate_bwd_arg: bad size B=%d C=%d N=%d M=%d", B, C, N, M);
+    NEXTOU_REQUIRE(dy != nullptr || M == N, "mr_aggregate_bwd_arg: dy == NULL (self graph) needs M == N");
+    hipStream_t s = (hipStream_t)stream;
+    const bool self = (dy == nullptr);
+    const int budget = 32 * 1024 / (int)sizeof(float);  // <= 32 KB of accumulators per workgroup
+    int chunk = budget / M;
+    if (chunk < 1) return fail(NEXTOU_ENOTSUP, "mr_aggregate_bwd_arg: M=%d rows do not fit the LDS accumulators", M);
+    if (chunk > C) chunk = C;
+    while (chunk > 1 && (long long)cdiv(C, chunk) * B < 1024) chunk = (chunk + 1) / 2;
+    chunk = cdiv(C, cdiv(C, chunk));
+    const int threads = ((N < 256 ? N : 256) + 63) / 64 * 64;
+    const double bytes = 8.0 * B * C * (double)N + 2.0 * B * C * (double)N + 4.0 * B * C * ((double)N + (self ? 0 : M));
+    ProfScope prof(s, kBoundHbm, bytes, "mr_bwd_arg_kernel<%s>[B%d C%d N%d M%d]", self ? "self" : "xy", B, C, N, M);
+    dim3 grid(cdiv(C, chunk), B);
+    const size_t lds = (size_t)chunk * M * sizeof(float);
+    if (self)
+        hipLaunchKernelGGL(mr_bwd_arg_kernel<true>, grid, dim3(threads), lds, s, gout, arg, dx, dy, C, N, M, chunk);
+    else
+        hipLaunchKernelGGL(mr_bwd_arg_kernel<false>, grid, dim3(threads), lds, s, gout, arg, dx, dy, C, N, M, chunk);
+    return check_launch("mr_bwd_arg_kernel");
 }
 
 extern "C" int nextou_mr_aggregate_bwd(const float* gout, const float* x, const float* y,

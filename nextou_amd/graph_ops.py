@@ -120,17 +120,36 @@ class _HipBackend:
         return out
 
     @staticmethod
-    def mr_fwd(x, y, nn_idx, center, K, idx_step):
+    def mr_has_arg(B, C, N, M, K):
+        return bool(_lib.lib().nextou_mr_aggregate_has_arg(B, C, N, M, K))
+
+    @staticmethod
+    def mr_fwd(x, y, nn_idx, center, K, idx_step, want_arg=False):
         L = _lib.lib()
         B, C, N = x.shape
         M = N if y is None else y.shape[2]
         out = torch.empty((B, 2 * C, N), dtype=torch.float32, device=x.device)
+        arg = None
+        if want_arg and center is None and L.nextou_mr_aggregate_has_arg(B, C, N, M, K):
+            arg = torch.empty((B, C, N), dtype=torch.int16, device=x.device)   # uint16 payload
         with torch.cuda.device(x.device):
             rc = L.nextou_mr_aggregate_fwd(x.data_ptr(), _ptr(y), nn_idx.data_ptr(), _ptr(center),
-                                           out.data_ptr(), B, C, N, M, K, nn_idx.shape[2], idx_step,
+                                           out.data_ptr(), _ptr(arg), B, C, N, M, K, nn_idx.shape[2], idx_step,
                                            _stream_ptr(x.device))
         _lib.check(rc, "mr_aggregate_fwd")
-        return out
+        return out, arg
+
+    @staticmethod
+    def mr_bwd_arg(gout, arg, M, has_y):
+        L = _lib.lib()
+        B, C, N = arg.shape
+        dx = torch.empty((B, C, N), dtype=torch.float32, device=gout.device)
+        dy = torch.empty((B, C, M), dtype=torch.float32, device=gout.device) if has_y else None
+        with torch.cuda.device(gout.device):
+            rc = L.nextou_mr_aggregate_bwd_arg(gout.data_ptr(), arg.data_ptr(), dx.data_ptr(), _ptr(dy), B, C, N, M,
+                                               _stream_ptr(gout.device))
+        _lib.check(rc, "mr_aggregate_bwd_arg")
+        return dx, dy
 
     @staticmethod
     def mr_bwd(gout, x, y, nn_idx, center, K, idx_step):
@@ -292,23 +311,36 @@ def edge_index_from_nn_idx(nn_idx: torch.Tensor, dilation: int = 1) -> torch.Ten
 
 
 class _MRAggregate(torch.autograd.Function):
+    """Forward records which source id won every max (uint16) whenever a gradient will be needed and
+    the kernel supports it; backward is then a pure scatter-add and x / y / ids are not kept alive."""
+
     @staticmethod
     def forward(ctx, x, y, nn_idx, center, K, idx_step):
         be = _backend_for(x)
-        out = be.mr_fwd(x, y, nn_idx, center, K, idx_step)
-        ctx.save_for_backward(x, y if y is not None else x.new_empty(0), nn_idx,
-                              center if center is not None else nn_idx.new_empty(0))
+        needs_grad = x.requires_grad or (y is not None and y.requires_grad)
+        out, arg = be.mr_fwd(x, y, nn_idx, center, K, idx_step, want_arg=needs_grad)
         ctx.has_y, ctx.has_center = y is not None, center is not None
         ctx.K, ctx.idx_step = K, idx_step
+        ctx.M = x.shape[2] if y is None else y.shape[2]
+        ctx.use_arg = arg is not None
+        if ctx.use_arg:
+            ctx.save_for_backward(arg)
+        else:
+            ctx.save_for_backward(x, y if y is not None else x.new_empty(0), nn_idx,
+                                  center if center is not None else nn_idx.new_empty(0))
         return out
 
     @staticmethod
     def backward(ctx, gout):
+        gout = _f32c(gout)
+        if ctx.use_arg:
+            (arg,) = ctx.saved_tensors
+            dx, dy = _backend_for(gout).mr_bwd_arg(gout, arg, ctx.M, ctx.has_y)
+            return dx, dy, None, None, None, None
         x, y, nn_idx, center = ctx.saved_tensors
         y = y if ctx.has_y else None
         center = center if ctx.has_center else None
-        be = _backend_for(x)
-        dx, dy = be.mr_bwd(_f32c(gout), x, y, nn_idx, center, ctx.K, ctx.idx_step)
+        dx, dy = _backend_for(x).mr_bwd(gout, x, y, nn_idx, center, ctx.K, ctx.idx_step)
         return dx, dy, None, None, None, None
 
 

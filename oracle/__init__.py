@@ -39,11 +39,12 @@ def lib() -> ctypes.CDLL:
         h = ctypes.CDLL(LIB_PATH)
         h.oracle_knn_graph.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6
         h.oracle_pairwise_distance.argtypes = [c_void_p, c_void_p, c_void_p] + [c_int] * 6
-        h.oracle_mr_fwd.argtypes = [c_void_p] * 5 + [c_int] * 7
+        h.oracle_mr_fwd.argtypes = [c_void_p] * 6 + [c_int] * 7
+        h.oracle_mr_bwd_arg.argtypes = [c_void_p] * 4 + [c_int] * 4
         h.oracle_mr_bwd.argtypes = [c_void_p] * 7 + [c_int] * 7
         h.oracle_argmax_labels.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int64]
         h.oracle_bti_critical.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 6
-        for f in ("oracle_knn_graph", "oracle_pairwise_distance", "oracle_mr_fwd", "oracle_mr_bwd",
+        for f in ("oracle_knn_graph", "oracle_pairwise_distance", "oracle_mr_fwd", "oracle_mr_bwd", "oracle_mr_bwd_arg",
                   "oracle_argmax_labels", "oracle_bti_critical"):
             getattr(h, f).restype = c_int
         _lib = h
@@ -90,13 +91,26 @@ class CanonicalBackend:
         return torch.stack((nn, center), dim=0).contiguous()
 
     @staticmethod
-    def mr_fwd(x, y, nn_idx, center, K, idx_step):
+    def mr_has_arg(B, C, N, M, K):
+        return M <= 65536
+
+    @staticmethod
+    def mr_fwd(x, y, nn_idx, center, K, idx_step, want_arg=False):
         B, C, N = x.shape
         M = N if y is None else y.shape[2]
         out = torch.empty((B, 2 * C, N), dtype=torch.float32)
-        _ok(lib().oracle_mr_fwd(_p(x), _p(y), _p(nn_idx), _p(center), _p(out), B, C, N, M, K,
+        arg = torch.empty((B, C, N), dtype=torch.int16) if (want_arg and center is None and M <= 65536) else None
+        _ok(lib().oracle_mr_fwd(_p(x), _p(y), _p(nn_idx), _p(center), _p(out), _p(arg), B, C, N, M, K,
                                 nn_idx.shape[2], idx_step), "mr_fwd")
-        return out
+        return out, arg
+
+    @staticmethod
+    def mr_bwd_arg(gout, arg, M, has_y):
+        B, C, N = arg.shape
+        dx = torch.empty((B, C, N), dtype=torch.float32)
+        dy = torch.empty((B, C, M), dtype=torch.float32) if has_y else None
+        _ok(lib().oracle_mr_bwd_arg(_p(gout), _p(arg), _p(dx), _p(dy), B, C, N, M), "mr_bwd_arg")
+        return dx, dy
 
     @staticmethod
     def mr_bwd(gout, x, y, nn_idx, center, K, idx_step):

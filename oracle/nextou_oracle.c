@@ -159,7 +159,7 @@ int oracle_pairwise_distance(const float* x, const float* y, float* dist, int B,
 /* max-relative aggregation forward: reference NexToU_Encoder_Decoder.py:401-409 with
  * batched_index_select torch_nn.py:94-115.  out (B,2C,N) interleaved [x_c, mr_c]. */
 int oracle_mr_fwd(const float* x, const float* y, const int32_t* nn_idx, const int32_t* center,
-                  float* out, int B, int C, int N, int M, int K, int idx_stride, int idx_step) {
+                  float* out, uint16_t* arg, int B, int C, int N, int M, int K, int idx_stride, int idx_step) {
     const float* src = y ? y : x;
 #pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b)
@@ -170,13 +170,16 @@ int oracle_mr_fwd(const float* x, const float* y, const int32_t* nn_idx, const i
             for (int n = 0; n < N; ++n) {
                 const size_t io = ((size_t)b * N + n) * idx_stride;
                 float mx = 0.f;
+                int am = 0;
                 for (int j = 0; j < K; ++j) {
                     const float xc = center ? xr[center[io + (size_t)j * idx_step]] : xr[n];
-                    const float v = sr[nn_idx[io + (size_t)j * idx_step]] - xc;
-                    if (j == 0 || v > mx) mx = v;
+                    const int sj = nn_idx[io + (size_t)j * idx_step];
+                    const float v = sr[sj] - xc;
+                    if (j == 0 || v > mx) { mx = v; am = sj; } /* first max wins */
                 }
                 o[n] = xr[n];
                 o[N + n] = mx;
+                if (arg) arg[((size_t)b * C + c) * N + n] = (uint16_t)am;
             }
         }
     return 0;
@@ -212,6 +215,23 @@ int oracle_mr_bwd(const float* gout, const float* x, const float* y, const int32
                 dxr[ac] -= g[N + n];
                 dsr[am] += g[N + n];
             }
+        }
+    return 0;
+}
+
+/* backward from the recorded arg-max ids (the scatter formulation of the above).
+ * dy == NULL: self graph, everything accumulates into dx. */
+int oracle_mr_bwd_arg(const float* gout, const uint16_t* arg, float* dx, float* dy, int B, int C, int N, int M) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const float* g = gout + ((size_t)b * 2 * C + 2 * c) * N;
+            const uint16_t* a = arg + ((size_t)b * C + c) * N;
+            float* dxr = dx + ((size_t)b * C + c) * N;
+            float* dsr = dy ? dy + ((size_t)b * C + c) * M : dxr;
+            if (dy) memset(dsr, 0, (size_t)M * sizeof(float));
+            for (int n = 0; n < N; ++n) dxr[n] = g[n] - g[N + n];
+            for (int n = 0; n < N; ++n) dsr[a[n]] += g[N + n];
         }
     return 0;
 }

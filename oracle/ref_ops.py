@@ -116,11 +116,15 @@ class TorchRefBackend:
 
     # mr_fwd / mr_bwd as a pair through autograd of the reference op sequence
     @staticmethod
-    def mr_fwd(x, y, nn_idx, center, K, idx_step):
+    def mr_has_arg(B, C, N, M, K):
+        return False    # the reference has no such side output: backward re-runs its autograd
+
+    @staticmethod
+    def mr_fwd(x, y, nn_idx, center, K, idx_step, want_arg=False):
         idx = nn_idx[:, :, ::idx_step][:, :, :K]
         ctr = None if center is None else center[:, :, ::idx_step][:, :, :K]
         with torch.no_grad():
-            return mr_aggregate_ref(x, idx, y, ctr)
+            return mr_aggregate_ref(x, idx, y, ctr), None
 
     @staticmethod
     def mr_bwd(gout, x, y, nn_idx, center, K, idx_step):

@@ -189,7 +189,7 @@ def test_mr_aggregate_vs_oracle(ops, ora, B, C, N, M, K, stride_extra, step):
     x = _rand((B, C, N), 31)
     y = None if M is None else _rand((B, C, M), 32)
     idx = _idx(B, N, M or N, K * step + stride_extra, 33)
-    want = ora.mr_fwd(x, y, idx, None, K, step)
+    want, want_arg = ora.mr_fwd(x, y, idx, None, K, step, want_arg=True)
     xd = x.to(DEV).requires_grad_(True)
     yd = None if y is None else y.to(DEV).requires_grad_(True)
     out = ops.mr_aggregate(xd, idx.to(DEV), yd, k=K, idx_step=step)
@@ -197,6 +197,14 @@ def test_mr_aggregate_vs_oracle(ops, ora, B, C, N, M, K, stride_extra, step):
     gout = _rand(out.shape, 34)
     grads = torch.autograd.grad(out, [xd] if yd is None else [xd, yd], gout.to(DEV))
     dx, dy = ora.mr_bwd(gout, x, y, idx, None, K, step)
+    # both backward formulations of the library: recorded arg-max scatter and recompute
+    if ops._HIP.mr_has_arg(B, C, N, M or N, K):
+        _, arg = ops._HIP.mr_fwd(x.to(DEV), None if y is None else y.to(DEV), idx.to(DEV), None, K, step, want_arg=True)
+        assert torch.equal(arg.cpu(), want_arg), "recorded arg-max ids must equal the oracle's (first max wins)"
+    rdx, rdy = ops._HIP.mr_bwd(gout.to(DEV), x.to(DEV), None if y is None else y.to(DEV), idx.to(DEV), None, K, step)
+    assert float((rdx.cpu() - dx).abs().max()) <= 1e-5 * max(1.0, float(dx.abs().max()))
+    if rdy is not None:
+        assert float((rdy.cpu() - dy).abs().max()) <= 1e-5 * max(1.0, float(dy.abs().max()))
     # scatter-add order differs (LDS / L2 atomics): fp32 tolerance relative to the accumulated magnitude
     tol = 1e-5 * max(1.0, float(dx.abs().max()))
     assert float((grads[0].cpu() - dx).abs().max()) <= tol
@@ -208,7 +216,7 @@ def test_mr_aggregate_vs_oracle(ops, ora, B, C, N, M, K, stride_extra, step):
 def test_mr_aggregate_center_index_and_golden(ops, ora):
     x = _rand((2, 7, 60), 41)
     idx, ctr = _idx(2, 60, 60, 5, 42), _idx(2, 60, 60, 5, 43)
-    want = ora.mr_fwd(x, None, idx, ctr, 5, 1)
+    want, _ = ora.mr_fwd(x, None, idx, ctr, 5, 1)
     xd = x.to(DEV).requires_grad_(True)
     out = ops.mr_aggregate(xd, idx.to(DEV), None, center_idx=ctr.to(DEV))
     assert torch.equal(out.detach().cpu(), want)

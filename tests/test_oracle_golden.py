@@ -82,9 +82,14 @@ def test_mr_aggregate_and_gather(oracle_lib, backend):
         k = idx.shape[2]
         gathered = be.gather_fwd(x if y is None else y, idx)
         np.testing.assert_array_equal(gathered.numpy(), g[tag + "_gather"])
-        pre = be.mr_fwd(x, y, idx, None, k, 1)
+        pre, arg = be.mr_fwd(x, y, idx, None, k, 1, want_arg=True)
         np.testing.assert_array_equal(pre.numpy(), g[tag + "_pre"].squeeze(-1))
         gout = torch.from_numpy(g[tag + "_gout"]).squeeze(-1).contiguous()
+        if arg is not None:   # scatter formulation from the recorded arg-max ids
+            dx2, dy2 = be.mr_bwd_arg(gout, arg, (x if y is None else y).shape[2], y is not None)
+            np.testing.assert_allclose(dx2.numpy(), g[tag + "_dx"].squeeze(-1), rtol=1e-5, atol=1e-6)
+            if y is not None:
+                np.testing.assert_allclose(dy2.numpy(), g[tag + "_dy"].squeeze(-1), rtol=1e-5, atol=1e-6)
         dx, dy = be.mr_bwd(gout, x, y, idx, None, k, 1)
         np.testing.assert_allclose(dx.numpy(), g[tag + "_dx"].squeeze(-1), rtol=1e-5, atol=1e-6)
         if y is not None:

@@ -4,7 +4,8 @@
 # counters only with --kernel-trace.  Run on the GPU box from the repo root:  tools/pmc_traffic.sh "s3 Pool"
 set -e
 ONLY="${1:-s3 Pool}"
-OUT=$PWD/gpurun_out/pmc
+TAG=$(echo "$ONLY" | tr " " "_")
+OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
