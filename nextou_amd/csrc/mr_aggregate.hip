@@ -173,34 +173,49 @@ __global__ __launch_bounds__(256) void mr_bwd_lds_kernel(
 // backward from the saved arg-max ids: a pure scatter-add, no gathers, no ids, no source rows.
 //   grid = (c_chunks, B); LDS = chunk * M accumulators.  The workgroup owns its channels for ALL
 //   points, so dx / dy rows are written exactly once with plain stores (no global atomics).
-//   SELF: acc starts at g_x - g_mr and is stored as dx.   !SELF: acc starts at 0 and is stored as dy;
-//   dx = g_x - g_mr is written on the way.
+//   One pass over (c, n), 4 independent elements in flight per lane.  SELF: the identity-branch
+//   term g_x - g_mr is added to the accumulator too and the accumulator is stored as dx.
+//   !SELF: dx = g_x - g_mr is written on the way and the accumulator is stored as dy.
 template <bool SELF>
 __global__ __launch_bounds__(256) void mr_bwd_arg_kernel(const float* __restrict__ gout,
                                                          const uint16_t* __restrict__ arg,
                                                          float* __restrict__ dx, float* __restrict__ dy,
-                                                         int C, int N, int M, int chunk) {
+                                                         int C, int N, int M, int chunk, unsigned magic) {
+    constexpr int U = 4;  // independent (c, n) elements in flight per lane: hides the HBM latency
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y;
     const int c0 = blockIdx.x * chunk;
     const int nc = (C - c0 < chunk) ? (C - c0) : chunk;
-    if (SELF) {
-        for (int c = 0; c < nc; ++c) {
-            const float* g = gout + ((size_t)b * 2 * C + 2 * (c0 + c)) * N;
-            for (int n = threadIdx.x; n < N; n += blockDim.x) lds[c * M + n] = g[n] - g[N + n];
-        }
-    } else {
-        for (int e = threadIdx.x; e < nc * M; e += blockDim.x) lds[e] = 0.f;
-    }
+    for (int e = threadIdx.x; e < nc * M; e += blockDim.x) lds[e] = 0.f;
     __syncthreads();
-    for (int c = 0; c < nc; ++c) {
-        const float* g = gout + ((size_t)b * 2 * C + 2 * (c0 + c)) * N;
-        const uint16_t* a = arg + ((size_t)b * C + c0 + c) * N;
-        float* acc = lds + c * M;
-        for (int n = threadIdx.x; n < N; n += blockDim.x) {
-            const float gm = g[N + n];
-            atomicAdd(&acc[a[n]], gm);
-            if (!SELF) dx[((size_t)b * C + c0 + c) * N + n] = g[n] - gm;
+    const unsigned total = (unsigned)nc * (unsigned)N;
+    const float* gbase = gout + ((size_t)b * 2 * C + 2 * c0) * N;
+    const uint16_t* abase = arg + ((size_t)b * C + c0) * N;
+    float* dxbase = dx + ((size_t)b * C + c0) * N;
+    for (unsigned base = 0; base < total; base += blockDim.x * U) {
+        float g0[U], g1[U];
+        unsigned cc[U], ee[U];
+        unsigned short a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned e = base + u * blockDim.x + threadIdx.x;
+            ee[u] = e;
+            const bool ok = e < total;
+            const unsigned c = (N == 1) ? e : __umulhi(e, magic);  // e / N; magic = ceil(2^32 / N), exact while e*N < 2^32
+            cc[u] = c;
+            const float* g = gbase + (size_t)e + (size_t)c * N;  // row 2c, column e - c*N
+            g0[u] = ok ? g[0] : 0.f;
+            g1[u] = ok ? g[N] : 0.f;
+            a[u] = ok ? abase[e] : (unsigned short)0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ee[u] >= total) continue;
+            const unsigned n = ee[u] - cc[u] * (unsigned)N;
+            float* acc = lds + cc[u] * M;
+            atomicAdd(&acc[a[u]], g1[u]);
+            if (SELF) atomicAdd(&acc[n], g0[u] - g1[u]);
+            else dxbase[ee[u]] = g0[u] - g1[u];
         }
     }
     __syncthreads();
@@ -374,15 +389,17 @@ extern "C" int nextou_mr_aggregate_bwd_arg(const float* gout, const uint16_t* ar
     if (chunk > C) chunk = C;
     while (chunk > 1 && (long long)cdiv(C, chunk) * B < 1024) chunk = (chunk + 1) / 2;
     chunk = cdiv(C, cdiv(C, chunk));
-    const int threads = ((N < 256 ? N : 256) + 63) / 64 * 64;
+    while (chunk > 1 && (unsigned long long)chunk * N * N >= 0x100000000ull) --chunk;  // keeps e / N by umulhi exact
+    const int threads = 256;
+    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)N - 1) / (unsigned)N);
     const double bytes = 8.0 * B * C * (double)N + 2.0 * B * C * (double)N + 4.0 * B * C * ((double)N + (self ? 0 : M));
     ProfScope prof(s, kBoundHbm, bytes, "mr_bwd_arg_kernel<%s>[B%d C%d N%d M%d]", self ? "self" : "xy", B, C, N, M);
     dim3 grid(cdiv(C, chunk), B);
     const size_t lds = (size_t)chunk * M * sizeof(float);
     if (self)
-        hipLaunchKernelGGL(mr_bwd_arg_kernel<true>, grid, dim3(threads), lds, s, gout, arg, dx, dy, C, N, M, chunk);
+        hipLaunchKernelGGL(mr_bwd_arg_kernel<true>, grid, dim3(threads), lds, s, gout, arg, dx, dy, C, N, M, chunk, magic);
     else
-        hipLaunchKernelGGL(mr_bwd_arg_kernel<false>, grid, dim3(threads), lds, s, gout, arg, dx, dy, C, N, M, chunk);
+        hipLaunchKernelGGL(mr_bwd_arg_kernel<false>, grid, dim3(threads), lds, s, gout, arg, dx, dy, C, N, M, chunk, magic);
     return check_launch("mr_bwd_arg_kernel");
 }
 
