@@ -125,7 +125,7 @@ def roofline_from(report):
     traffic = None
     tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):   # HBM bytes per launch from a committed rocprofv3 --pmc run
-        traffic = json.load(open(tpath)).get(top["kernel"].split("[")[0])
+        traffic = json.load(open(tpath)).get(top["kernel"])
     return {"bound": top["bound"], "achieved": round(achieved, 3), "peak": peak, "unit": unit,
             "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": top["kernel"],
             "launches": top["launches"], "avg_us": round(per_launch_s * 1e6, 2),
