@@ -107,19 +107,67 @@ def _query_pool_size(img_shape, img_min_shape):
     return [1 for _ in img_shape]
 
 
+def _bicubic_taps(n_in: int, n_out: int):
+    """Source rows and weights of torch's 1-D bicubic resize (align_corners=False, A = -0.75, border
+    clamped): ``out[o] = sum_k w[k][o] * in[idx[k][o]]``.  The coordinates and the cubic weights are
+    evaluated in float32 exactly as ATen's upsample_bicubic2d does for a float32 tensor — at 10 752
+    output rows the float32 coordinate carries ~1e-3 of rounding, which is part of the reference's
+    table (computing the taps in float64 would move the table by 2e-4)."""
+    f = np.float32
+    a = f(-0.75)
+    scale = f(n_in) / f(n_out)
+    src = scale * (np.arange(n_out, dtype=np.float32) + f(0.5)) - f(0.5)
+    i0 = np.floor(src)
+    t = (src - i0).astype(np.float32)
+    i0 = i0.astype(np.int64)
+
+    def inner(x):
+        return ((a + f(2)) * x - (a + f(3))) * x * x + f(1)
+
+    def outer(x):
+        return ((a * x - f(5) * a) * x + f(8) * a) * x - f(4) * a
+
+    weights = [outer(t + f(1)), inner(t), inner(f(1) - t), outer((f(1) - t) + f(1))]
+    index = [np.clip(i0 - 1 + k, 0, n_in - 1) for k in range(4)]
+    return index, [w.astype(np.float64) for w in weights]
+
+
+def _resample_rows(table: np.ndarray, n_out: int) -> np.ndarray:
+    index, weights = _bicubic_taps(table.shape[0], n_out)
+    return sum(w[:, None] * table[i] for i, w in zip(index, weights))
+
+
 @functools.lru_cache(maxsize=None)
-def _relative_pos_table(dim: int, channels: int, n: int, r: int) -> torch.Tensor:
+def _relative_pos_table(dim: int, channels: int, n: int, r: int, exact: bool = True) -> torch.Tensor:
     """Frozen position bias of a graph block, shape (1, n, n // r**dim), already negated.
 
-    float64 sin-cos table on the host -> float32 -> bicubic resize (reference :728-742,
-    :867-880; ``int(n ** (1/dim))`` is the reference's floating root).  Cached: the
-    encoder and decoder blocks of one resolution share (C, n, r), and the 10 648^2 float64
-    product behind the two largest tables is the bulk of model-build time.
+    Reference (:728-742, :867-880): float64 sin-cos table P (g**dim x C, ``g = int(n ** (1/dim))`` — the
+    reference's floating root) -> ``S = 2 P P^T / C`` -> float32 -> bicubic resize to
+    (n, n // r**dim) -> negate.  ``exact=True`` (default) does literally that, bit-identical to the
+    reference's tables: a 10 648^2 float64 matrix per stage-2/3 Pool block of cfg 2 (~4 s each on the
+    host), 24 389^2 = 4.8 GB for cfg 5.
+
+    ``exact=False`` (or NEXTOU_FAST_RELPOS=1) uses that the resize is linear and separable,
+    ``R S C^T = (2/C) (R P)(C P)^T``: two 4-tap row resamplings of P and one (n x C x m) product in
+    float64 — no g**dim-squared matrix.  It agrees with the literal order to 2e-5 (the float32
+    rounding of S and of the resize accumulations); since the kNN selection is discontinuous in the
+    bias, models built from scratch for parity use the exact path, and checkpoints carry the table
+    as a parameter anyway.  Cached: encoder and decoder blocks of one resolution share (C, n, r).
     """
+    import os
+    if os.environ.get("NEXTOU_FAST_RELPOS") == "1":
+        exact = False
     grid = int(n ** (1 / dim))
-    table = torch.from_numpy(np.float32(get_nd_relative_pos_embed(channels, grid, dim)))
-    table = F.interpolate(table[None, None], size=(n, n // (r ** dim)), mode='bicubic', align_corners=False)
-    return -table.squeeze(1)
+    m = n // (r ** dim)
+    if exact:
+        table = torch.from_numpy(np.float32(get_nd_relative_pos_embed(channels, grid, dim)))
+        table = F.interpolate(table[None, None], size=(n, m), mode='bicubic', align_corners=False)
+        return -table.squeeze(1)
+    from .pos_embed import _nd_sincos
+    p = _nd_sincos(channels, grid, dim)                       # (g**dim, C) float64
+    rows, cols = _resample_rows(p, n), _resample_rows(p, m)
+    table = (2.0 / p.shape[1]) * (rows @ cols.T)
+    return -torch.from_numpy(np.float32(table)).unsqueeze(0)
 
 
 class _GrapherBase(nn.Module):

@@ -34,6 +34,13 @@ def test_pos_embed_tables():
     np.testing.assert_allclose(_relative_pos_table(3, 132, 168, 1).numpy(), g["swin_c132_n168_r1"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(_relative_pos_table(3, 12, 256, 2).numpy(), g["pool_c12_n256_r2"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(_relative_pos_table(2, 8, 256, 2).numpy(), g["pool2d_c8_n256_r2"], rtol=0, atol=2e-6)
+    # the default follows the reference's order of operations literally: bit-identical tables
+    np.testing.assert_array_equal(_relative_pos_table(3, 12, 256, 2).numpy(), g["pool_c12_n256_r2"])
+    np.testing.assert_array_equal(_relative_pos_table(3, 132, 168, 1).numpy(), g["swin_c132_n168_r1"])
+    # the separable shortcut (no g^dim x g^dim matrix) stays within 2e-5 of it
+    for args in ((3, 12, 256, 2), (3, 132, 168, 1), (2, 8, 256, 2), (3, 24, 1344, 1)):
+        fast, exact = _relative_pos_table(*args, False), _relative_pos_table(*args, True)
+        assert float((fast - exact).abs().max()) <= 2e-5
 
 
 def test_window_partition_roundtrip_and_order():
