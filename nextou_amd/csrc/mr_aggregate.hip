@@ -176,46 +176,75 @@ __global__ __launch_bounds__(256) void mr_bwd_lds_kernel(
 //   One pass over (c, n), 4 independent elements in flight per lane.  SELF: the identity-branch
 //   term g_x - g_mr is added to the accumulator too and the accumulator is stored as dx.
 //   !SELF: dx = g_x - g_mr is written on the way and the accumulator is stored as dy.
-template <bool SELF>
+template <bool SELF, bool VEC4>
 __global__ __launch_bounds__(256) void mr_bwd_arg_kernel(const float* __restrict__ gout,
                                                          const uint16_t* __restrict__ arg,
                                                          float* __restrict__ dx, float* __restrict__ dy,
                                                          int C, int N, int M, int chunk, unsigned magic) {
-    constexpr int U = 4;  // independent (c, n) elements in flight per lane: hides the HBM latency
+    // VEC4 (N % 4 == 0, 16-B aligned rows): a lane owns 4 consecutive points of one channel row and
+    // moves them with two 16-B loads (g_x, g_mr), one 8-B load (4 arg ids) and one 16-B store.
+    constexpr int W = VEC4 ? 4 : 1;   // points per item
+    constexpr int U = VEC4 ? 2 : 4;   // independent items in flight per lane
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y;
     const int c0 = blockIdx.x * chunk;
     const int nc = (C - c0 < chunk) ? (C - c0) : chunk;
     for (int e = threadIdx.x; e < nc * M; e += blockDim.x) lds[e] = 0.f;
     __syncthreads();
-    const unsigned total = (unsigned)nc * (unsigned)N;
+    const unsigned row_items = (unsigned)N / W;          // items per channel row
+    const unsigned total = (unsigned)nc * row_items;
     const float* gbase = gout + ((size_t)b * 2 * C + 2 * c0) * N;
     const uint16_t* abase = arg + ((size_t)b * C + c0) * N;
     float* dxbase = dx + ((size_t)b * C + c0) * N;
     for (unsigned base = 0; base < total; base += blockDim.x * U) {
-        float g0[U], g1[U];
-        unsigned cc[U], ee[U];
-        unsigned short a[U];
+        float g0[U][W], g1[U][W];
+        unsigned short a[U][W];
+        unsigned cc[U], nn[U];
+        bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const unsigned e = base + u * blockDim.x + threadIdx.x;
-            ee[u] = e;
-            const bool ok = e < total;
-            const unsigned c = (N == 1) ? e : __umulhi(e, magic);  // e / N; magic = ceil(2^32 / N), exact while e*N < 2^32
+            const unsigned it = base + u * blockDim.x + threadIdx.x;
+            ok[u] = it < total;
+            const unsigned c = (row_items == 1) ? it : __umulhi(it, magic);  // it / row_items (exact, see host)
+            const unsigned n = (it - c * row_items) * W;
             cc[u] = c;
-            const float* g = gbase + (size_t)e + (size_t)c * N;  // row 2c, column e - c*N
-            g0[u] = ok ? g[0] : 0.f;
-            g1[u] = ok ? g[N] : 0.f;
-            a[u] = ok ? abase[e] : (unsigned short)0;
+            nn[u] = n;
+            const float* g = gbase + (size_t)2 * c * N + n;
+            const uint16_t* ap = abase + (size_t)c * N + n;
+            if (VEC4) {
+                float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                uint2 av = make_uint2(0u, 0u);
+                if (ok[u]) {
+                    v0 = *reinterpret_cast<const float4*>(g);
+                    v1 = *reinterpret_cast<const float4*>(g + N);
+                    av = *reinterpret_cast<const uint2*>(ap);
+                }
+                g0[u][0] = v0.x; g0[u][1 % W] = v0.y; g0[u][2 % W] = v0.z; g0[u][3 % W] = v0.w;
+                g1[u][0] = v1.x; g1[u][1 % W] = v1.y; g1[u][2 % W] = v1.z; g1[u][3 % W] = v1.w;
+                a[u][0] = (unsigned short)(av.x & 0xffffu); a[u][1 % W] = (unsigned short)(av.x >> 16);
+                a[u][2 % W] = (unsigned short)(av.y & 0xffffu); a[u][3 % W] = (unsigned short)(av.y >> 16);
+            } else {
+                g0[u][0] = ok[u] ? g[0] : 0.f;
+                g1[u][0] = ok[u] ? g[N] : 0.f;
+                a[u][0] = ok[u] ? ap[0] : (unsigned short)0;
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (ee[u] >= total) continue;
-            const unsigned n = ee[u] - cc[u] * (unsigned)N;
+            if (!ok[u]) continue;
             float* acc = lds + cc[u] * M;
-            atomicAdd(&acc[a[u]], g1[u]);
-            if (SELF) atomicAdd(&acc[n], g0[u] - g1[u]);
-            else dxbase[ee[u]] = g0[u] - g1[u];
+            float d[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                d[w] = g0[u][w] - g1[u][w];
+                atomicAdd(&acc[a[u][w]], g1[u][w]);
+                if (SELF) atomicAdd(&acc[nn[u] + w], d[w]);
+            }
+            if (!SELF) {
+                float* o = dxbase + (size_t)cc[u] * N + nn[u];
+                if (VEC4) *reinterpret_cast<float4*>(o) = make_float4(d[0], d[1 % W], d[2 % W], d[3 % W]);
+                else o[0] = d[0];
+            }
         }
     }
     __syncthreads();
@@ -391,15 +420,22 @@ extern "C" int nextou_mr_aggregate_bwd_arg(const float* gout, const uint16_t* ar
     chunk = cdiv(C, cdiv(C, chunk));
     while (chunk > 1 && (unsigned long long)chunk * N * N >= 0x100000000ull) --chunk;  // keeps e / N by umulhi exact
     const int threads = 256;
-    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)N - 1) / (unsigned)N);
+    const bool vec4 = (N % 4 == 0) && (((reinterpret_cast<uintptr_t>(gout) | reinterpret_cast<uintptr_t>(dx)) & 15u) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(arg) & 7u) == 0);
+    const unsigned row_items = (unsigned)(vec4 ? N / 4 : N);
+    const unsigned magic = (unsigned)((0x100000000ull + row_items - 1) / row_items);  // it / row_items by umulhi
     const double bytes = 8.0 * B * C * (double)N + 2.0 * B * C * (double)N + 4.0 * B * C * ((double)N + (self ? 0 : M));
     ProfScope prof(s, kBoundHbm, bytes, "mr_bwd_arg_kernel<%s>[B%d C%d N%d M%d]", self ? "self" : "xy", B, C, N, M);
     dim3 grid(cdiv(C, chunk), B);
     const size_t lds = (size_t)chunk * M * sizeof(float);
-    if (self)
-        hipLaunchKernelGGL(mr_bwd_arg_kernel<true>, grid, dim3(threads), lds, s, gout, arg, dx, dy, C, N, M, chunk, magic);
-    else
-        hipLaunchKernelGGL(mr_bwd_arg_kernel<false>, grid, dim3(threads), lds, s, gout, arg, dx, dy, C, N, M, chunk, magic);
+#define NEXTOU_MR_BWD_ARG(SELF, VEC)                                                                            \
+    hipLaunchKernelGGL((mr_bwd_arg_kernel<SELF, VEC>), grid, dim3(threads), lds, s, gout, arg, dx, dy, C, N, M, chunk, \
+                       magic)
+    if (self && vec4) NEXTOU_MR_BWD_ARG(true, true);
+    else if (self) NEXTOU_MR_BWD_ARG(true, false);
+    else if (vec4) NEXTOU_MR_BWD_ARG(false, true);
+    else NEXTOU_MR_BWD_ARG(false, false);
+#undef NEXTOU_MR_BWD_ARG
     return check_launch("mr_bwd_arg_kernel");
 }
 
