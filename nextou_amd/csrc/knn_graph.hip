@@ -285,36 +285,53 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
         }
     }
 
-    // merge the two half-waves' lists into the h == 0 lanes.  Each round the h == 1 lanes hand
-    // over the head of their (ascending) list and pop it; they only ever see (+inf, sentinel)
-    // pushes themselves, which leave a list untouched.  Kept as a rolled loop: code size O(KB).
-#pragma unroll 1
-    for (int round = 0; round < KB; ++round) {
-        float pd = __shfl_xor(top.d[0], 32);
-        int pi = __shfl_xor(top.i[0], 32);
-        if (h != 0) {
-            pd = INFINITY;
-            pi = kSentinelIdx;
+    // Merge the two half-waves' sorted lists (disjoint candidate sets of the same query) with a
+    // bitonic network held in registers: t[i] = min(mine[i], partner[KP-1-i]) is a bitonic sequence
+    // holding the KP smallest of the union; log2(KP) half-cleaner stages sort it.  ~KP/2*log2(KP)
+    // compare-exchanges instead of K rounds of K-slot inserts (which cost 40 % on top of the pushes
+    // when a workgroup only sees a few hundred candidates).  Comparisons are on (dist, index).
+    constexpr int KP = KB <= 8 ? 8 : (KB <= 16 ? 16 : 32);
+    float md[KP];
+    int mi[KP];
 #pragma unroll
-            for (int j = 0; j + 1 < KB; ++j) { top.d[j] = top.d[j + 1]; top.i[j] = top.i[j + 1]; }
-            top.d[KB - 1] = INFINITY;
-            top.i[KB - 1] = kSentinelIdx;
+    for (int j = 0; j < KP; ++j) {
+        const int pj = KP - 1 - j;
+        const float ad = (j < KB) ? top.d[j < KB ? j : 0] : INFINITY;
+        const int ai = (j < KB) ? top.i[j < KB ? j : 0] : kSentinelIdx;
+        float bd = INFINITY;
+        int bi = kSentinelIdx;
+        if (pj < KB) {
+            bd = __shfl_xor(top.d[pj < KB ? pj : 0], 32);
+            bi = __shfl_xor(top.i[pj < KB ? pj : 0], 32);
         }
-        const bool enters = (pd < top.d[KB - 1]) || (pd == top.d[KB - 1] && pi < top.i[KB - 1]);
-        if (!__any(enters)) break;  // partner entries only grow from here on
-        top.push_any(pd, pi);
+        const bool take_b = (bd < ad) || (bd == ad && bi < ai);
+        md[j] = take_b ? bd : ad;
+        mi[j] = take_b ? bi : ai;
+    }
+#pragma unroll
+    for (int stride = KP / 2; stride >= 1; stride >>= 1) {
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            if ((j & stride) == 0) {
+                const int q = j + stride;
+                const bool sw = (md[q] < md[j]) || (md[q] == md[j] && mi[q] < mi[j]);
+                const float lo = sw ? md[q] : md[j], hi = sw ? md[j] : md[q];
+                const int li = sw ? mi[q] : mi[j], hi_i = sw ? mi[j] : mi[q];
+                md[j] = lo; md[q] = hi; mi[j] = li; mi[q] = hi_i;
+            }
+        }
     }
     if (nvalid && h == 0) {
         if (n_splits == 1) {
             int32_t* o = out + ((size_t)b * N + n) * K;
 #pragma unroll
             for (int j = 0; j < KB; ++j)
-                if (j < K) o[j] = top.i[j];
+                if (j < K) o[j] = mi[j];
         } else {
             const size_t base = (((size_t)b * N + n) * n_splits + split) * K;
 #pragma unroll
             for (int j = 0; j < KB; ++j)
-                if (j < K) { part_d[base + j] = top.d[j]; part_i[base + j] = top.i[j]; }
+                if (j < K) { part_d[base + j] = md[j]; part_i[base + j] = mi[j]; }
         }
     }
 }

@@ -182,7 +182,10 @@ __global__ __launch_bounds__(256) void mr_bwd_arg_kernel(const float* __restrict
                                                          float* __restrict__ dx, float* __restrict__ dy,
                                                          int C, int N, int M, int chunk, unsigned magic) {
     // VEC4 (N % 4 == 0, 16-B aligned rows): a lane owns 4 consecutive points of one channel row and
-    // moves them with two 16-B loads (g_x, g_mr), one 8-B load (4 arg ids) and one 16-B store.
+    // moves them with 16-B loads / stores (8 B for the 4 arg ids).
+    // LDS float atomics retire ~0.5 lane per clock per CU on gfx950 (rocprofv3: SQ_LDS_IDX_ACTIVE ~ 120
+    // cycles per ds_add_f32 wave-instruction, profiles/r01_sq_counters.md), so only the scattered g_mr
+    // term goes through them; the identity term g_x - g_mr is added with plain arithmetic on the way out.
     constexpr int W = VEC4 ? 4 : 1;   // points per item
     constexpr int U = VEC4 ? 2 : 4;   // independent items in flight per lane
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(256) void mr_bwd_arg_kernel(const float* __restrict
     const float* gbase = gout + ((size_t)b * 2 * C + 2 * c0) * N;
     const uint16_t* abase = arg + ((size_t)b * C + c0) * N;
     float* dxbase = dx + ((size_t)b * C + c0) * N;
+    // phase 1: scatter g_mr into the accumulators (and, for the pooled graph, write dx = g_x - g_mr)
     for (unsigned base = 0; base < total; base += blockDim.x * U) {
         float g0[U][W], g1[U][W];
         unsigned short a[U][W];
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256) void mr_bwd_arg_kernel(const float* __restrict
                 float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
                 uint2 av = make_uint2(0u, 0u);
                 if (ok[u]) {
-                    v0 = *reinterpret_cast<const float4*>(g);
+                    if (!SELF) v0 = *reinterpret_cast<const float4*>(g);
                     v1 = *reinterpret_cast<const float4*>(g + N);
                     av = *reinterpret_cast<const uint2*>(ap);
                 }
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void mr_bwd_arg_kernel(const float* __restrict
                 a[u][0] = (unsigned short)(av.x & 0xffffu); a[u][1 % W] = (unsigned short)(av.x >> 16);
                 a[u][2 % W] = (unsigned short)(av.y & 0xffffu); a[u][3 % W] = (unsigned short)(av.y >> 16);
             } else {
-                g0[u][0] = ok[u] ? g[0] : 0.f;
+                g0[u][0] = (ok[u] && !SELF) ? g[0] : 0.f;
                 g1[u][0] = ok[u] ? g[N] : 0.f;
                 a[u][0] = ok[u] ? ap[0] : (unsigned short)0;
             }
@@ -233,22 +237,45 @@ __global__ __launch_bounds__(256) void mr_bwd_arg_kernel(const float* __restrict
         for (int u = 0; u < U; ++u) {
             if (!ok[u]) continue;
             float* acc = lds + cc[u] * M;
-            float d[W];
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                d[w] = g0[u][w] - g1[u][w];
-                atomicAdd(&acc[a[u][w]], g1[u][w]);
-                if (SELF) atomicAdd(&acc[nn[u] + w], d[w]);
-            }
+            for (int w = 0; w < W; ++w) atomicAdd(&acc[a[u][w]], g1[u][w]);
             if (!SELF) {
                 float* o = dxbase + (size_t)cc[u] * N + nn[u];
-                if (VEC4) *reinterpret_cast<float4*>(o) = make_float4(d[0], d[1 % W], d[2 % W], d[3 % W]);
-                else o[0] = d[0];
+                if (VEC4)
+                    *reinterpret_cast<float4*>(o) = make_float4(g0[u][0] - g1[u][0], g0[u][1 % W] - g1[u][1 % W],
+                                                                g0[u][2 % W] - g1[u][2 % W], g0[u][3 % W] - g1[u][3 % W]);
+                else
+                    o[0] = g0[u][0] - g1[u][0];
             }
         }
     }
     __syncthreads();
-    stage_rows((SELF ? dx : dy) + ((size_t)b * C + c0) * M, lds, nc * M);
+    if (!SELF) {
+        stage_rows(dy + ((size_t)b * C + c0) * M, lds, nc * M);
+        return;
+    }
+    // phase 2 (self graph): dx = scattered + (g_x - g_mr); g_mr is re-read (L2-hot)
+    for (unsigned base = 0; base < total; base += blockDim.x * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned it = base + u * blockDim.x + threadIdx.x;
+            if (it >= total) continue;
+            const unsigned c = (row_items == 1) ? it : __umulhi(it, magic);
+            const unsigned n = (it - c * row_items) * W;
+            const float* g = gbase + (size_t)2 * c * N + n;
+            const float* acc = lds + c * M + n;
+            float* o = dxbase + (size_t)c * N + n;
+            if (VEC4) {
+                const float4 v0 = *reinterpret_cast<const float4*>(g);
+                const float4 v1 = *reinterpret_cast<const float4*>(g + N);
+                const float4 s4 = *reinterpret_cast<const float4*>(acc);
+                *reinterpret_cast<float4*>(o) = make_float4(s4.x + (v0.x - v1.x), s4.y + (v0.y - v1.y),
+                                                            s4.z + (v0.z - v1.z), s4.w + (v0.w - v1.w));
+            } else {
+                o[0] = acc[0] + (g[0] - g[N]);
+            }
+        }
+    }
 }
 
 // generic backward: global atomics, arbitrary centre ids.  dx / dsrc pre-zeroed by the host.
