@@ -90,12 +90,17 @@ def move_to(trainer, device):
         trainer.loss = trainer._build_loss()      # interaction tensors follow the device
 
 
-def make_step(trainer, data, targets, averager):
+def make_step(trainer, data, targets, averager, bf16=False):
     params = [p for p in trainer.network.parameters() if p.requires_grad]
 
     def step():
         trainer.optimizer.zero_grad(set_to_none=True)
-        loss = trainer.loss(trainer.network(data), targets)
+        if bf16:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                outs = trainer.network(data)
+            loss = trainer.loss([o.float() for o in outs], targets)
+        else:
+            loss = trainer.loss(trainer.network(data), targets)
         loss.backward()
         if averager is not None:
             averager.finalize()
@@ -194,6 +199,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-miopen-find", action="store_true", help="disable MIOpen's find/benchmark mode")
     ap.add_argument("--bucket-mb", type=int, default=32)
+    ap.add_argument("--autocast-bf16", action="store_true",
+                    help="informational (cfg-5 regime): conv stages under bf16 autocast, graph ops stay fp32; "
+                         "never the headline number")
     ap.add_argument("--channels-last", action="store_true",
                     help="experiment: run the dense stages in channels_last_3d (NDHWC) memory format")
     args = ap.parse_args()
@@ -219,7 +227,7 @@ def main():
     targets = downsample_targets(target, _head_shapes(cfg))
     if args.channels_last:
         data = data.contiguous(memory_format=torch.channels_last_3d)
-    step = make_step(trainer, data, targets, averager)
+    step = make_step(trainer, data, targets, averager, bf16=args.autocast_bf16)
 
     for _ in range(args.warmup):
         step()
@@ -253,7 +261,7 @@ def main():
             "unit": "voxels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16-autocast(conv)/f32(graph)" if args.autocast_bf16 else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: 3D NexToU %s, base %d / max %d features, batch %d per GPU, "
                                    "%d classes, fp32, train-mode BN, %s; step = fwd+loss+bwd%s+clip+SGD"
                                    % ("x".join(map(str, cfg.patch_size)), cfg.UNet_base_num_features,
@@ -261,7 +269,7 @@ def main():
                                       "Dice+CE+BTI(Synapse) loss" if args.workload == "cfg4" else "deep-supervision CE loss",
                                       "+RCCL grad all-reduce" if world > 1 else ""),
                        "name": args.workload, "global_batch": world * batch,
-                       "parallelism": "dp%d" % world, "final_loss": float(loss)},
+                       "parallelism": "dp%d" % world, "final_loss": float(loss.detach())},
             "roofline": roof,
         }
         if cpu_copy_ok:
