@@ -209,10 +209,16 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     _lib.lib()  # fail loudly if the HIP extension is missing
-    rank, local_rank, world = init_process_group_from_env("nccl")
+    # RCCL ("nccl") is the product backend; NEXTOU_DIST_BACKEND=gloo lets the N > 1 code path be exercised
+    # by two ranks sharing the single GPU of a test box (tests/test_gpu_parity.py)
+    backend = os.environ.get("NEXTOU_DIST_BACKEND", "nccl")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend == "nccl" and torch.cuda.device_count() > local:
+        torch.cuda.set_device(local)
+    rank, local_rank, world = init_process_group_from_env(backend)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     torch.backends.cudnn.benchmark = not args.no_miopen_find
 

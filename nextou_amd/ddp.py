@@ -147,7 +147,7 @@ def init_process_group_from_env(backend: Optional[str] = None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend == "nccl":
+        if backend == "nccl" and torch.cuda.device_count() > local_rank:
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world

@@ -465,3 +465,27 @@ def test_bf16_autocast_keeps_graph_ops_in_fp32(ops):
     assert outs[0].dtype == torch.bfloat16                                 # ... while the conv stages ran in bf16
     assert torch.isfinite(loss) and all(torch.isfinite(o.float()).all() for o in outs)
     assert all(torch.isfinite(p.grad).all() for p in tr.network.parameters() if p.grad is not None)
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_share_one_gpu(ops):
+    """The N > 1 path of bench.py end to end (launcher env, bucketed overlapped gradient mean, barrier +
+    max-over-ranks timing, one JSON line from rank 0) with two ranks on this box's single GPU over gloo;
+    on the 8-GPU node the same code runs one rank per GPU over RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, NEXTOU_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--workload", "tiny", "--no-miopen-find"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == 2 and rec["value"] > 0
+    assert rec["config"]["global_batch"] == 4 and rec["roofline"]["launches"] > 0
+    assert "cpu_baseline" not in rec or rec["cpu_baseline"] is None
