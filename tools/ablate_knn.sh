@@ -6,13 +6,13 @@ set -e
 cd "$(dirname "$0")/.."
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -munsafe-fp-atomics"
 if [ "$1" = "run" ]; then
-  for n in 0 1 2 4 3 5 6; do
+  for n in ${ABLATE_SET:-0 1 2 4 3 5 6}; do
     echo "== ablate $n"; NEXTOU_HIP_LIB=$PWD/tools/_ablate/libnextou_hip_a$n.so python tools/kernel_bench.py --cfg 2 2>&1 | grep -E "knn_fused|knn_merge"
   done
   exit 0
 fi
 mkdir -p tools/_ablate
-for n in 0 1 2 4 3 5 6; do
+for n in ${ABLATE_SET:-0 1 2 4 3 5 6}; do
   hipcc $FLAGS -DNEXTOU_ABLATE=$n -shared nextou_amd/csrc/capi.hip nextou_amd/csrc/knn_graph.hip nextou_amd/csrc/mr_aggregate.hip nextou_amd/csrc/bti_critical.hip -o tools/_ablate/libnextou_hip_a$n.so &
 done
 wait
