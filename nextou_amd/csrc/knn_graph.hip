@@ -21,8 +21,7 @@
 
 // Experiment switch (tools/ablate_knn.sh builds side libraries with -DNEXTOU_ABLATE=n; the product
 // build leaves it 0):  1 = skip the top-K pushes, 2 = stage only the first slab of every chunk,
-// 4 = skip the MFMAs (results are wrong by construction with bits 1/2/4), 8 = no software-pipelined
-// staging (results stay correct).
+// 4 = skip the MFMAs.  Results are wrong by construction with any bit set.
 #ifndef NEXTOU_ABLATE
 #define NEXTOU_ABLATE 0
 #endif
@@ -215,61 +214,11 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
 
     // ---- slab staging plan -------------------------------------------------------------------
     // A self window that one workgroup covers completely (queries == candidates, one chunk) stages ONE
-    // slab and reads both MFMA operands from it.
+    // slab and reads both MFMA operands from it.  (A register-prefetch software pipeline of the staging
+    // was measured and dropped: +50 VGPRs cost more occupancy than the hidden latency bought —
+    // Pool s3 415 vs 326 us, Swin s2 195 vs 202 us, profiles/r01_knn_pipeline_ab.txt.)
     const bool share_ab = (yn == xn) && (QW == TM) && (n0 == 0) && (m_begin == 0) && (M <= TM);
     if (share_ab) ldsB = ldsA;
-    // Software pipeline (16-B path, <= PF items per lane): the next slab is fetched into registers while
-    // the MFMAs of the current one run, and written to LDS after the barrier.
-    // PF float4 registers per lane: 64-wide chunks (4 waves) need 6; 192-wide chunks are only pipelined
-    // in the shared-slab case, which needs 4 — more would push the 192-wide kernels past 256 VGPRs.
-    constexpr int PF = (TILES == 2) ? 6 : 4;
-    const int items_a = KS * (TM / 4);
-    const int items_b = share_ab ? 0 : KS * (QW / 4);
-    const bool pipelined = !(NEXTOU_ABLATE & 8) && vec && !(NEXTOU_ABLATE & 2) && (items_a + items_b <= PF * (int)blockDim.x);
-    float4 pf[PF];
-    const int w4b = QW / 4;
-    const int w4b_shift = (w4b & (w4b - 1)) == 0 ? (31 - __builtin_clz(w4b)) : -1;  // QW/4 = 8*nw
-    // item e of a slab -> (slab, row, col): candidates first, then queries; cheap enough to redo per slab
-    auto decode = [&](int e, bool& is_b, int& r, int& col) -> bool {
-        if (e < items_a) {
-            is_b = false;
-            r = e / (TM / 4);
-            col = (e - r * (TM / 4)) << 2;
-            return true;
-        }
-        const int eb = e - items_a;
-        is_b = true;
-        r = (w4b_shift >= 0) ? (eb >> w4b_shift) : (eb / w4b);
-        col = (eb - r * w4b) << 2;
-        return eb < items_b;
-    };
-    auto fetch = [&](int mc0, int c0) {
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            bool is_b;
-            int r, col;
-            const bool valid = decode(tid + i * (int)blockDim.x, is_b, r, col);
-            const float* src = is_b ? xb : yb;
-            const int ld = is_b ? N : M, col0 = is_b ? n0 : mc0, cols = is_b ? N : m_end;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid && c0 + r < C && col0 + col < cols)   // 16-B path: cols, col0 and col are multiples of 4
-                v = *reinterpret_cast<const float4*>(src + (size_t)(c0 + r) * ld + col0 + col);
-            pf[i] = v;
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            bool is_b;
-            int r, col;
-            if (decode(tid + i * (int)blockDim.x, is_b, r, col)) {
-                float* dst = is_b ? (ldsB + r * QW + col) : (ldsA + r * TM + col);
-                *reinterpret_cast<float4*>(dst) = pf[i];
-            }
-        }
-    };
-    if (pipelined) fetch(m_begin, 0);
-
     for (int mc0 = m_begin; mc0 < m_end; mc0 += TM) {
         f32x16 acc[TILES];
 #pragma unroll
@@ -279,19 +228,11 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
 
         for (int c0 = 0; c0 < C; c0 += KS) {
             __syncthreads();  // previous slab fully consumed
-            if (pipelined) {
-                commit();
-            } else if (!(NEXTOU_ABLATE & 2) || c0 == 0) {
+            if (!(NEXTOU_ABLATE & 2) || c0 == 0) {
                 stage_slab(ldsA, yb, M, c0, C, mc0, m_end, TM, vec, KS);
                 if (!share_ab) stage_slab(ldsB, xb, N, c0, C, n0, N, QW, vec, KS);
             }
             __syncthreads();
-            if (pipelined) {  // issue the next slab's loads; they land while the MFMAs below run
-                const bool more_slabs = c0 + KS < C;
-                const int next_c0 = more_slabs ? c0 + KS : 0;
-                const int next_mc0 = more_slabs ? mc0 : mc0 + TM;
-                if (next_mc0 < m_end) fetch(next_mc0, next_c0);
-            }
             int kmax = C - c0;
             if (kmax > KS) kmax = KS;
             kmax = (kmax + 1) & ~1;

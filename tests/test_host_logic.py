@@ -1,0 +1,121 @@
+"""Host-side logic of the plug-in surface (no GPU): trainer plug-ins, loss assembly, dilation, harness."""
+import numpy as np
+import pytest
+import torch
+
+import formula
+from nextou_amd.harness import (config_2d_nextou, config_3d_fullres_nextou, deep_supervision_weights,
+                                downsample_targets, synthetic_batch)
+
+
+def test_deep_supervision_weights_and_scales():
+    from nextou_amd.nnUNetTrainer.nnUNetTrainer_NexToU import nnUNetTrainer_NexToU
+    w = deep_supervision_weights(5)
+    np.testing.assert_allclose(w, np.array([8, 4, 2, 1, 0]) / 15.0)            # reference …BTI_Synapse.py:23-27
+    tr = nnUNetTrainer_NexToU(config_3d_fullres_nextou(), 14, log=None)
+    scales = tr._get_deep_supervision_scales()
+    assert len(scales) == 5 and scales[0] == [1.0, 1.0, 1.0] and scales[1] == [1.0, 0.5, 0.5]
+    assert scales[4] == [0.125, 0.0625, 0.0625]          # strides [1,1,1],[1,2,2],[2,2,2]x3 accumulated
+
+
+def test_build_network_architecture_follows_plans():
+    """features = min(base * 2^i, max); BatchNorm + LeakyReLU + bias; He init (reference :52-58,78-79,88)."""
+    from nextou_amd.nnUNetTrainer.nnUNetTrainer_NexToU import nnUNetTrainer_NexToU
+    cfg = config_3d_fullres_nextou(patch_size=(32, 128, 128), base=6, max_features=36)
+    tr = nnUNetTrainer_NexToU(cfg, 5, log=None)
+    net = tr.build_network_architecture(tr.plans_manager, {}, cfg, 2, True)
+    assert net.encoder.output_channels == [6, 12, 24, 36, 36, 36]
+    first = net.encoder.stages[0][0].convs[0]
+    assert isinstance(first.norm, torch.nn.BatchNorm3d) and isinstance(first.nonlin, torch.nn.LeakyReLU)
+    assert first.conv.in_channels == 2 and first.conv.bias is not None and float(first.conv.bias.detach().abs().max()) == 0.0
+    assert net.decoder.seg_layers[-1].out_channels == 5 and net.decoder.deep_supervision is True
+    frozen = [n for n, p in net.named_parameters() if not p.requires_grad]
+    assert frozen and all(n.endswith("relative_pos") for n in frozen)
+    single = tr.build_network_architecture(tr.plans_manager, {}, cfg, 2, False)
+    assert single.decoder.deep_supervision is False
+
+
+@pytest.mark.parametrize("name,dim,n_inter", [
+    ("nnUNetTrainer_NexToU_BTI_Synapse", 3, 12), ("nnUNetTrainer_NexToU_BTI_RAVIR", 2, 1),
+    ("nnUNetTrainer_NexToU_BTI_ICA_NoMirroring", 3, 17), ("nnUNetTrainer_NexToU_TI", 3, 6)])
+def test_bti_trainers_build_the_reference_loss(cpu_checker, name, dim, n_inter):
+    """_build_loss: connectivity 26 / lambda 1e-6 in 3-D, 8 / 1e-4 in 2-D; DS wrapper; runs on data."""
+    import importlib
+    cls = getattr(importlib.import_module("nextou_amd.nnUNetTrainer." + name), name)
+    cfg = config_3d_fullres_nextou(patch_size=(32, 128, 128), base=6, max_features=24, batch_size=1) if dim == 3 \
+        else config_2d_nextou(patch_size=(64, 64), base=8, max_features=32, n_stages=5, batch_size=1)
+    logged = []
+    tr = cls(cfg, 19 if "ICA" in name else 14, log=logged.append)
+    tr.dataset_json = {"labels": {"background": 0, "a": 1, "b": 2, "c": 3, "d": 4}}
+    loss = tr._build_loss()
+    inner = loss.loss
+    assert inner.weight_ti == (1e-6 if dim == 3 else 1e-4) and inner.ti.connectivity == (26 if dim == 3 else 8)
+    assert len(inner.ti.interaction_list) == n_inter and inner.weight_ce == 1 and inner.weight_dice == 1
+    assert any("lambda_ti" in str(l) for l in logged)
+    np.testing.assert_allclose(loss.weight_factors, deep_supervision_weights(len(tr._get_deep_supervision_scales())))
+    classes = tr.label_manager.num_segmentation_heads
+    shapes = [(1, classes) + tuple(s) for s in ([(8, 16, 16), (4, 8, 8)] if dim == 3 else [(32, 32), (16, 16)])]
+    outs = [formula.gaussian("hl.%d" % i, s).requires_grad_(True) for i, s in enumerate(shapes)]
+    target = torch.from_numpy(formula.blob_labels(shapes[0][2:], classes, n_seeds=10)).view(1, 1, *shapes[0][2:]).float()
+    value = DeepSup(loss, outs, downsample_targets(target, outs))
+    value.backward()
+    assert torch.isfinite(value) and outs[0].grad is not None and torch.isfinite(outs[0].grad).all()
+
+
+def DeepSup(loss, outs, targets):
+    # weights of a 2-scale list: pad the wrapper's weight list to the number of scales given
+    loss.weight_factors = tuple(loss.weight_factors[:len(outs)])
+    return loss(outs, targets)
+
+
+def test_compound_loss_composition_and_ignore_label(cpu_checker):
+    from nextou_amd.loss.compound_bti_loss import DC_and_CE_and_BTI_Loss
+    from nextou_amd.loss.nnunet_losses import MemoryEfficientSoftDiceLoss
+    ti = {'dim': 3, 'connectivity': 26, 'inclusion': [], 'exclusion': [[1, 2]], 'min_thick': 1}
+    dice = {'batch_dice': False, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}
+    x = formula.gaussian("cl.x", (2, 4, 6, 8, 8), scale=2.0)
+    y = torch.from_numpy(formula.blob_labels((6, 8, 8), 4, n_seeds=6)).view(1, 1, 6, 8, 8).float().repeat(2, 1, 1, 1, 1)
+    full = DC_and_CE_and_BTI_Loss(dice, {}, dict(ti), 1, 1, 1e-6, None, MemoryEfficientSoftDiceLoss)
+    parts = [DC_and_CE_and_BTI_Loss(dice, {}, dict(ti), a, b, c, None, MemoryEfficientSoftDiceLoss)(x, y)
+             for a, b, c in ((1, 0, 0), (0, 1, 0), (0, 0, 1))]
+    np.testing.assert_allclose(float(full(x, y)), float(parts[0] + parts[1] + 1e-6 * parts[2]), rtol=1e-6)
+    assert parts[2].dtype == torch.float64
+    # ignore label: ignored voxels carry no CE / Dice gradient (reference :40-51)
+    y_ign = y.clone()
+    y_ign[:, :, :2] = 3
+    ign = DC_and_CE_and_BTI_Loss(dice, {}, dict(ti), 1, 1, 0, 3, MemoryEfficientSoftDiceLoss)
+    xg = x[:, :3].clone().requires_grad_(True)
+    ign(xg, y_ign).backward()
+    assert float(xg.grad[:, :, :2].abs().max()) == 0.0 and float(xg.grad[:, :, 2:].abs().max()) > 0
+
+
+def test_dense_dilated_regular_and_stochastic(cpu_checker):
+    """reference torch_edge.py:126-136: regular = every d-th neighbour; stochastic + training: with
+    probability epsilon a random k-subset of the k*d nearest."""
+    from nextou_amd.network_architecture.torch_edge import DenseDilated, DenseDilatedKnnGraph
+    x = formula.gaussian("dd.x", (2, 8, 40, 1))
+    full = DenseDilatedKnnGraph(12, 1).eval()(x)
+    reg = DenseDilatedKnnGraph(4, 3, stochastic=True, epsilon=1.0).eval()(x)     # eval: never random
+    assert torch.equal(reg, full[:, :, :, ::3])
+    torch.manual_seed(0)
+    sto = DenseDilatedKnnGraph(4, 3, stochastic=True, epsilon=1.0).train()(x)    # epsilon 1: always random
+    assert sto.shape == reg.shape and torch.equal(sto[1], reg[1])
+    inside = (sto[0].unsqueeze(-1) == full[0].unsqueeze(-2)).any(-1)
+    assert inside.all()                                                           # a subset of the 12 nearest
+    ids = DenseDilatedKnnGraph(4, 3, stochastic=True, epsilon=0.0).train().neighbor_ids(x.squeeze(-1))
+    assert ids.dtype == torch.int32 and torch.equal(ids.long(), reg[0])
+    e = torch.arange(24).view(2, 1, 2, 6)
+    assert torch.equal(DenseDilated(3, 2)(e), e[..., ::2])
+
+
+def test_harness_train_step_decreases_loss(cpu_checker):
+    from nextou_amd.nnUNetTrainer.nnUNetTrainer_NexToU import nnUNetTrainer_NexToU
+    cfg = config_2d_nextou(patch_size=(64, 64), base=8, max_features=32, n_stages=5, batch_size=2)
+    torch.manual_seed(0)
+    tr = nnUNetTrainer_NexToU(cfg, 3, log=None).initialize()
+    data, target = synthetic_batch(cfg, 1, 3, 2, torch.device("cpu"), blob_labels=True)
+    with torch.no_grad():
+        outs = tr.network(data)
+    tg = downsample_targets(target, outs)
+    losses = [float(tr.train_step(data, tg)) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
