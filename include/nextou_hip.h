@@ -164,6 +164,21 @@ int nextou_bti_critical_map(const uint8_t* labels,
                             int connectivity, int min_thick,
                             nextou_stream_t stream);
 
+/* K5b  critical-voxel cross-entropy, float64 arithmetic (reference loss/bti_loss.py:141-143:
+ *   CrossEntropyLoss(reduction='none')(x.double(), y) * critical, summed over voxels).
+ *   fwd: partial[b, i], i < nextou_bti_ce_partials(), are block-wise sums of
+ *        critical[b,v] * (logsumexp_l x[b,l,v] - x[b,target[b,v],v]); the caller adds them (fixed order).
+ *   bwd: grad_logits[b,l,v] = scale_dev[b] * critical[b,v] * (softmax_l(x[b,:,v]) - [l == target[b,v]]),
+ *        fp32, every voxel written; scale_dev (B) are DEVICE doubles (the upstream gradient of every
+ *        sample's sum) so that no host synchronisation is needed.  target / critical: uint8 (B,V); targets >= L
+ *        contribute nothing. */
+int nextou_bti_ce_partials(void);
+int nextou_bti_ce_fwd(const float* logits, const uint8_t* target, const uint8_t* critical,
+                      double* partial, int B, int L, int64_t V, nextou_stream_t stream);
+int nextou_bti_ce_bwd(const float* logits, const uint8_t* target, const uint8_t* critical,
+                      const double* scale_dev, float* grad_logits, int B, int L, int64_t V,
+                      nextou_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

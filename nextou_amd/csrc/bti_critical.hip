@@ -109,9 +109,121 @@ __global__ __launch_bounds__(256) void bti_critical_kernel(
     critical[(size_t)b * V + v] = ((nc & a) | (na & c)) ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// critical-voxel cross-entropy in float64 (reference loss/bti_loss.py:141-143):
+//   ce[b,v] = logsumexp_l(double(x[b,l,v])) - double(x[b,target,v]);  loss[b] = sum_v critical * ce
+// Only critical voxels are touched: a wave whose 64 voxels are all non-critical skips its L loads
+// (critical voxels hug the organ interfaces, so most waves do).  Partial sums are written per block
+// and added up by the caller in a fixed order (no float64 atomics: bit-reproducible).
+// ---------------------------------------------------------------------------------------------
+constexpr int kCeBlocks = 1024;  // partial sums per batch element
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const long long bits = __double_as_longlong(v);
+        const int lo = __shfl_xor((int)(bits & 0xffffffffll), off);
+        const int hi = __shfl_xor((int)(bits >> 32), off);
+        v += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void bti_ce_fwd_kernel(const float* __restrict__ logits,
+                                                         const uint8_t* __restrict__ target,
+                                                         const uint8_t* __restrict__ critical,
+                                                         double* __restrict__ partial, int L, long long V) {
+    __shared__ double wsum[4];
+    const int b = blockIdx.y;
+    const float* lb = logits + (size_t)b * L * V;
+    const uint8_t* tb = target + (size_t)b * V;
+    const uint8_t* cb = critical + (size_t)b * V;
+    double acc = 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long v_end = (V + blockDim.x - 1) / blockDim.x * blockDim.x;  // keep waves converged for __any
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < v_end; v += stride) {
+        const bool crit = v < V && cb[v] != 0;
+        if (!__any(crit)) continue;
+        if (crit) {
+            const int y = tb[v];
+            double m = (double)lb[v], xy = (y == 0) ? m : 0.0;
+            for (int l = 1; l < L; ++l) {
+                const double x = (double)lb[(size_t)l * V + v];
+                if (l == y) xy = x;
+                m = fmax(m, x);
+            }
+            double s = 0.0;
+            for (int l = 0; l < L; ++l) s += exp((double)lb[(size_t)l * V + v] - m);
+            if (y < L) acc += (m + log(s)) - xy;
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// grad[b,l,v] = scale * critical[b,v] * (softmax_l(double x) - [l == target]), written for every voxel.
+__global__ __launch_bounds__(256) void bti_ce_bwd_kernel(const float* __restrict__ logits,
+                                                         const uint8_t* __restrict__ target,
+                                                         const uint8_t* __restrict__ critical,
+                                                         const double* __restrict__ scale_dev,
+                                                         float* __restrict__ grad, int L, long long V) {
+    const int b = blockIdx.y;
+    const float* lb = logits + (size_t)b * L * V;
+    float* gb = grad + (size_t)b * L * V;
+    const uint8_t* tb = target + (size_t)b * V;
+    const uint8_t* cb = critical + (size_t)b * V;
+    const double scale = scale_dev[b];  // upstream gradient of this sample's sum
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
+        if (cb[v] == 0) {
+            for (int l = 0; l < L; ++l) gb[(size_t)l * V + v] = 0.f;
+            continue;
+        }
+        const int y = tb[v];
+        double m = (double)lb[v];
+        for (int l = 1; l < L; ++l) m = fmax(m, (double)lb[(size_t)l * V + v]);
+        double s = 0.0;
+        for (int l = 0; l < L; ++l) s += exp((double)lb[(size_t)l * V + v] - m);
+        const double inv = (y < L) ? scale / s : 0.0;
+        for (int l = 0; l < L; ++l) {
+            const double p = exp((double)lb[(size_t)l * V + v] - m) * inv;
+            gb[(size_t)l * V + v] = (float)(l == y ? p - ((y < L) ? scale : 0.0) : p);
+        }
+    }
+}
+
 }  // namespace nextou
 
 using namespace nextou;
+
+extern "C" int nextou_bti_ce_partials(void) { return kCeBlocks; }
+
+extern "C" int nextou_bti_ce_fwd(const float* logits, const uint8_t* target, const uint8_t* critical,
+                                 double* partial, int B, int L, int64_t V, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(logits && target && critical && partial, "bti_ce_fwd: null pointer");
+    NEXTOU_REQUIRE(B > 0 && L > 0 && L <= 256 && V > 0 && B <= 65535, "bti_ce_fwd: bad size B=%d L=%d V=%lld", B, L, (long long)V);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(s, kBoundHbm, (4.0 * L + 2.0) * B * (double)V, "bti_ce_fwd_kernel[B%d L%d V%lld]", B, L, (long long)V);
+    hipLaunchKernelGGL(bti_ce_fwd_kernel, dim3(kCeBlocks, B), dim3(256), 0, s, logits, target, critical, partial, L,
+                       (long long)V);
+    return check_launch("bti_ce_fwd_kernel");
+}
+
+extern "C" int nextou_bti_ce_bwd(const float* logits, const uint8_t* target, const uint8_t* critical,
+                                 const double* scale_dev, float* grad_logits, int B, int L, int64_t V,
+                                 nextou_stream_t stream) {
+    NEXTOU_REQUIRE(logits && target && critical && scale_dev && grad_logits, "bti_ce_bwd: null pointer");
+    NEXTOU_REQUIRE(B > 0 && L > 0 && L <= 256 && V > 0 && B <= 65535, "bti_ce_bwd: bad size B=%d L=%d V=%lld", B, L, (long long)V);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(s, kBoundHbm, (8.0 * L + 2.0) * B * (double)V, "bti_ce_bwd_kernel[B%d L%d V%lld]", B, L, (long long)V);
+    long long blocks = cdiv64(V, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bti_ce_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, s, logits, target, critical, scale_dev,
+                       grad_logits, L, (long long)V);
+    return check_launch("bti_ce_bwd_kernel");
+}
 
 extern "C" int nextou_argmax_labels(const float* logits, uint8_t* labels, int B, int L, int64_t V,
                                     nextou_stream_t stream) {

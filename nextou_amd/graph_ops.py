@@ -28,7 +28,7 @@ from . import _lib
 
 __all__ = [
     "knn_graph", "pairwise_sq_distance", "edge_index_from_nn_idx", "mr_aggregate", "gather_neighbors",
-    "argmax_labels", "bti_critical_map", "install_cpu_checker", "IndexTape", "index_tape",
+    "argmax_labels", "bti_critical_map", "critical_cross_entropy", "install_cpu_checker", "IndexTape", "index_tape",
 ]
 
 
@@ -217,6 +217,31 @@ class _HipBackend:
         return out
 
 
+    @staticmethod
+    def bti_ce_fwd(logits, target, critical):
+        L_ = _lib.lib()
+        B, nl = logits.shape[:2]
+        V = logits[0, 0].numel()
+        partial = torch.empty((B, L_.nextou_bti_ce_partials()), dtype=torch.float64, device=logits.device)
+        with torch.cuda.device(logits.device):
+            rc = L_.nextou_bti_ce_fwd(logits.data_ptr(), target.data_ptr(), critical.data_ptr(), partial.data_ptr(),
+                                      B, nl, V, _stream_ptr(logits.device))
+        _lib.check(rc, "bti_ce_fwd")
+        return partial.sum(1)
+
+    @staticmethod
+    def bti_ce_bwd(logits, target, critical, scale):
+        L_ = _lib.lib()
+        B, nl = logits.shape[:2]
+        V = logits[0, 0].numel()
+        grad = torch.empty_like(logits)
+        with torch.cuda.device(logits.device):
+            rc = L_.nextou_bti_ce_bwd(logits.data_ptr(), target.data_ptr(), critical.data_ptr(), scale.data_ptr(),
+                                      grad.data_ptr(), B, nl, V, _stream_ptr(logits.device))
+        _lib.check(rc, "bti_ce_bwd")
+        return grad
+
+
 _HIP = _HipBackend()
 
 
@@ -381,6 +406,28 @@ class _Gather(torch.autograd.Function):
 def gather_neighbors(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """``out[b,c,n,j] = x[b,c,idx[b,n,j]]`` — x (B,C,M), idx (B,N,K) -> (B,C,N,K)."""
     return _Gather.apply(_f32c(x), idx.contiguous().to(torch.int32))
+
+
+class _CriticalCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, critical):
+        ctx.save_for_backward(logits, target, critical)
+        return _backend_for(logits).bti_ce_fwd(logits, target, critical)          # (B,) float64
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, critical = ctx.saved_tensors
+        scale = g.to(torch.float64).reshape(-1).contiguous()      # (B,) upstream gradient per sample
+        return _backend_for(logits).bti_ce_bwd(logits, target, critical, scale), None, None
+
+
+def critical_cross_entropy(logits: torch.Tensor, target: torch.Tensor, critical: torch.Tensor) -> torch.Tensor:
+    """``sum_v critical * CE_float64(logits, target)`` per batch element -> (B,) float64.
+
+    logits (B,L,*sp) float32, target / critical (B,*sp) uint8.  The fused replacement of
+    ``CrossEntropyLoss(reduction='none')(x.double(), y) * critical`` + sum (reference bti_loss.py:141-143).
+    """
+    return _CriticalCE.apply(_f32c(logits), target.contiguous(), critical.contiguous())
 
 
 @torch.no_grad()

@@ -10,7 +10,7 @@ pure bit logic: give every interaction one bit, look the two bit masks of a voxe
 table, OR them over the neighbourhood and test ``(OR_c & a) | (OR_a & c)``.  Here the label map
 comes from ``graph_ops.argmax_labels`` and the map from ``graph_ops.bti_critical_map`` (one HIP pass
 over the uint8 volume); only the float64 cross-entropy of :141-143, through which all gradient
-flows, stays on PyTorch.
+flows, is a second fused kernel (``graph_ops.critical_cross_entropy``).
 """
 from __future__ import annotations
 
@@ -106,9 +106,10 @@ class BTI_Loss(torch.nn.Module):
         """x: logits (B,L,*spatial); y: labels (B,1,*spatial) in [0,L) -> 0-dim float64 loss."""
         labels = graph_ops.argmax_labels(x)                      # argmax(softmax(x,1),1), :132-134
         critical = self.critical_voxels_from_labels(labels)
-        ce = F.cross_entropy(x.double(), y[:, 0].long(), reduction='none')   # :141
-        ce = ce * critical.to(ce.dtype)                                        # :142
-        return ce.sum(dim=self.sum_dim_list[:-1]).mean()                      # :143
+        # :141-143  CE(x.double(), y, 'none') * critical, summed over voxels, mean over the batch —
+        # one fused float64 kernel that only touches critical voxels
+        per_sample = graph_ops.critical_cross_entropy(x, y[:, 0].to(torch.uint8), critical)
+        return per_sample.mean()
 
 
 class TI_Loss(BTI_Loss):

@@ -144,6 +144,21 @@ class CanonicalBackend:
         return out
 
     @staticmethod
+    def bti_ce_fwd(logits, target, critical):
+        """reference bti_loss.py:141-143 op sequence (float64 CE 'none' * critical, summed per sample)."""
+        ce = torch.nn.functional.cross_entropy(logits.double(), target.long(), reduction='none')
+        return (ce * critical.double()).flatten(1).sum(1)
+
+    @staticmethod
+    def bti_ce_bwd(logits, target, critical, scale):
+        with torch.enable_grad():
+            x = logits.detach().requires_grad_(True)
+            ce = torch.nn.functional.cross_entropy(x.double(), target.long(), reduction='none')
+            per_sample = (ce * critical.double()).flatten(1).sum(1)
+            (grad,) = torch.autograd.grad((per_sample * scale.reshape(-1)).sum(), x)
+        return grad
+
+    @staticmethod
     def bti_critical(labels, lut_a, lut_c, connectivity, min_thick):
         if labels.dim() == 3:
             (B, H, W), D = labels.shape, 1

@@ -154,3 +154,13 @@ class TorchRefBackend:
     def bti_critical(labels, lut_a, lut_c, connectivity, min_thick):
         from . import CanonicalBackend
         return CanonicalBackend.bti_critical(labels, lut_a, lut_c, connectivity, min_thick)
+
+    @staticmethod
+    def bti_ce_fwd(logits, target, critical):
+        from . import CanonicalBackend
+        return CanonicalBackend.bti_ce_fwd(logits, target, critical)
+
+    @staticmethod
+    def bti_ce_bwd(logits, target, critical, scale):
+        from . import CanonicalBackend
+        return CanonicalBackend.bti_ce_bwd(logits, target, critical, scale)

@@ -489,3 +489,26 @@ def test_bench_two_ranks_share_one_gpu(ops):
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == 2 and rec["value"] > 0
     assert rec["config"]["global_batch"] == 4 and rec["roofline"]["launches"] > 0
     assert "cpu_baseline" not in rec or rec["cpu_baseline"] is None
+
+
+def test_critical_cross_entropy_kernel(ops, ora):
+    """Fused float64 CE x critical map: forward sums and fp32 logit gradients vs the reference op sequence."""
+    for (B, L, sp) in ((2, 14, (12, 20, 18)), (3, 5, (33, 21)), (1, 3, (7,))):
+        g = torch.Generator().manual_seed(sum(sp) + L)
+        logits = torch.randn((B, L) + sp, generator=g) * 3
+        target = torch.randint(0, L, (B,) + sp, generator=g, dtype=torch.uint8)
+        critical = (torch.rand((B,) + sp, generator=g) < 0.3).to(torch.uint8)
+        want = ora.bti_ce_fwd(logits, target, critical)
+        xd = logits.to(DEV).requires_grad_(True)
+        got = ops.critical_cross_entropy(xd, target.to(DEV), critical.to(DEV))
+        assert got.dtype == torch.float64 and got.shape == (B,)
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want.numpy(), rtol=1e-12)
+        w = torch.rand(B, generator=g, dtype=torch.float64) + 0.5
+        (grad,) = torch.autograd.grad((got * w.to(DEV)).sum(), xd)
+        ref = ora.bti_ce_bwd(logits, target, critical, w)
+        np.testing.assert_allclose(grad.cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-9)
+        assert float(grad.cpu()[critical.unsqueeze(1).expand_as(logits) == 0].abs().max()) == 0.0
+    # repeatable bit for bit (no atomics in the reduction)
+    a = ops.critical_cross_entropy(xd, target.to(DEV), critical.to(DEV))
+    b = ops.critical_cross_entropy(xd, target.to(DEV), critical.to(DEV))
+    assert torch.equal(a, b)
