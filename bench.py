@@ -58,6 +58,7 @@ WORKLOADS = {
     # name: (patch, base, max_features, batch/GPU, classes)
     "cfg2": ((64, 224, 192), 33, 324, 2, 14),
     "cfg4": ((64, 224, 192), 33, 324, 2, 14),      # cfg2 + Dice + CE + BTI loss, blob labels
+    "cfg5": ((96, 256, 256), 33, 324, 2, 14),      # BASELINE.json configs[4] shape (use with --autocast-bf16)
     "tiny": ((32, 128, 128), 6, 48, 2, 14),        # plumbing check only — never a reported number
 }
 
@@ -262,15 +263,16 @@ def main():
         if roof is not None:
             roof["own_kernels_ms_per_step"] = round(sum(r["ms"] for r in report) / args.steps, 3)
         line = {
-            "metric": "voxels/sec fwd+bwd, 3D 64x224x192 patch batch=2",
+            "metric": "voxels/sec fwd+bwd, 3D %s patch batch=%d" % ("x".join(map(str, cfg.patch_size)), batch),
             "value": round(voxels_per_step / (elapsed / args.steps), 1),
             "unit": "voxels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16-autocast(conv)/f32(graph)" if args.autocast_bf16 else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: 3D NexToU %s, base %d / max %d features, batch %d per GPU, "
+            "config": {"workload": "BASELINE.json configs[%d]: 3D NexToU %s, base %d / max %d features, batch %d per GPU, "
                                    "%d classes, fp32, train-mode BN, %s; step = fwd+loss+bwd%s+clip+SGD"
-                                   % ("x".join(map(str, cfg.patch_size)), cfg.UNet_base_num_features,
+                                   % ({"cfg4": 3, "cfg5": 4}.get(args.workload, 1), "x".join(map(str, cfg.patch_size)),
+                                      cfg.UNet_base_num_features,
                                       cfg.unet_max_num_features, batch, classes,
                                       "Dice+CE+BTI(Synapse) loss" if args.workload == "cfg4" else "deep-supervision CE loss",
                                       "+RCCL grad all-reduce" if world > 1 else ""),
