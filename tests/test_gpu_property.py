@@ -1,0 +1,74 @@
+"""Randomised shape sweeps (hypothesis, derandomised so that every run checks the same cases):
+HIP kernels vs the oracle on ragged, odd and degenerate sizes."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _ops_ora():
+    import oracle
+    from nextou_amd import graph_ops
+    return graph_ops, oracle.CanonicalBackend
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@settings(max_examples=30, deadline=None, derandomize=True)
+@given(B=st.integers(1, 5), C=st.integers(1, 70), N=st.integers(1, 400), M=st.one_of(st.none(), st.integers(1, 500)),
+       k=st.integers(1, 40), relpos=st.booleans(), normalize=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_knn_any_shape_bit_exact(B, C, N, M, k, relpos, normalize, seed):
+    ops, ora = _ops_ora()
+    k = min(k, M if M is not None else N)
+    x = _rand((B, C, N), seed)
+    y = None if M is None else _rand((B, C, M), seed + 1)
+    rp = _rand((N, M or N), seed + 2, 0.05) if relpos else None
+    want = ora.knn_graph(x, y, rp, k, normalize=normalize)
+    got = ops.knn_graph(x.to(DEV), None if y is None else y.to(DEV), None if rp is None else rp.to(DEV), k,
+                        normalize=normalize)
+    assert torch.equal(got.cpu(), want)
+
+
+@settings(max_examples=25, deadline=None, derandomize=True)
+@given(B=st.integers(1, 4), C=st.integers(1, 40), N=st.integers(1, 700), M=st.one_of(st.none(), st.integers(1, 300)),
+       K=st.integers(1, 34), step=st.integers(1, 3), seed=st.integers(0, 10 ** 6))
+def test_mr_aggregate_any_shape(B, C, N, M, K, step, seed):
+    ops, ora = _ops_ora()
+    x = _rand((B, C, N), seed)
+    y = None if M is None else _rand((B, C, M), seed + 1)
+    g = torch.Generator().manual_seed(seed + 2)
+    idx = torch.randint(0, M or N, (B, N, K * step), generator=g, dtype=torch.int32)
+    want, _ = ora.mr_fwd(x, y, idx, None, K, step)
+    xd = x.to(DEV).requires_grad_(True)
+    yd = None if y is None else y.to(DEV).requires_grad_(True)
+    out = ops.mr_aggregate(xd, idx.to(DEV), yd, k=K, idx_step=step)
+    assert torch.equal(out.detach().cpu(), want)
+    gout = _rand(out.shape, seed + 3)
+    grads = torch.autograd.grad(out, [xd] if yd is None else [xd, yd], gout.to(DEV))
+    dx, dy = ora.mr_bwd(gout, x, y, idx, None, K, step)
+    assert float((grads[0].cpu() - dx).abs().max()) <= 1e-5 * max(1.0, float(dx.abs().max()))
+    if dy is not None:
+        assert float((grads[1].cpu() - dy).abs().max()) <= 1e-5 * max(1.0, float(dy.abs().max()))
+
+
+@settings(max_examples=20, deadline=None, derandomize=True)
+@given(B=st.integers(1, 3), D=st.integers(1, 9), H=st.integers(1, 17), W=st.integers(1, 33), L=st.integers(2, 20),
+       conn3d=st.booleans(), full=st.booleans(), thick=st.integers(1, 2), seed=st.integers(0, 10 ** 6))
+def test_bti_any_shape(B, D, H, W, L, conn3d, full, thick, seed):
+    ops, ora = _ops_ora()
+    g = torch.Generator().manual_seed(seed)
+    shape = (B, D, H, W) if conn3d else (B, H, W)
+    conn = (26 if full else 6) if conn3d else (8 if full else 4)
+    labels = torch.randint(0, L, shape, generator=g, dtype=torch.uint8)
+    lut_a = torch.randint(0, 2 ** 31 - 1, (256,), generator=g, dtype=torch.int32)
+    lut_c = torch.randint(0, 2 ** 31 - 1, (256,), generator=g, dtype=torch.int32) & ~lut_a
+    want = ora.bti_critical(labels, lut_a, lut_c, conn, thick)
+    got = ops.bti_critical_map(labels.to(DEV), lut_a.to(DEV), lut_c.to(DEV), conn, thick)
+    assert torch.equal(got.cpu(), want)
+    logits = torch.randn((B, L) + shape[1:], generator=g)
+    assert torch.equal(ops.argmax_labels(logits.to(DEV)).cpu(), ora.argmax_labels(logits))
