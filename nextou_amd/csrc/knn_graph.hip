@@ -18,12 +18,10 @@
 // correctly rounded divide/sqrt.
 #include "common.h"
 #include <cmath>
-#include <cstdlib>
 
 // Experiment switch (tools/ablate_knn.sh builds side libraries with -DNEXTOU_ABLATE=n; the product
 // build leaves it 0):  1 = skip the top-K pushes, 2 = stage only the first slab of every chunk,
-// 4 = skip the MFMAs (results are wrong by construction with bits 1/2/4); 16 = no threshold pre-filter /
-// compaction in the top-K pushes (results stay correct).
+// 4 = skip the MFMAs.  Results are wrong by construction with any bit set.
 #ifndef NEXTOU_ABLATE
 #define NEXTOU_ABLATE 0
 #endif
@@ -189,13 +187,11 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
     int C, int N, int M, int K, int m_per_split, int vec_ok, int KS) {
     // KS = channels per LDS slab (even; 32 normally, 64 for latency-bound small grids)
     constexpr int TM = 32 * TILES;  // candidates per chunk
-    constexpr bool COMPACT = (KB >= 14) && !(NEXTOU_ABLATE & 16);  // threshold pre-filter + per-lane compaction
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int nw = blockDim.x >> 6;
     const int QW = nw * 32;
     float* ldsA = lds;            // [KS][TM]  candidates
     float* ldsB = lds + KS * TM;  // [KS][QW]  queries (aliases ldsA for a self window, see below)
-    float* sel = lds + KS * (TM + QW) + (threadIdx.x >> 6) * (16 * 64) + (threadIdx.x & 63);  // [16][64] per wave (COMPACT)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
@@ -220,7 +216,9 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
     // A self window that one workgroup covers completely (queries == candidates, one chunk) stages ONE
     // slab and reads both MFMA operands from it.  (A register-prefetch software pipeline of the staging
     // was measured and dropped: +50 VGPRs cost more occupancy than the hidden latency bought —
-    // Pool s3 415 vs 326 us, Swin s2 195 vs 202 us, profiles/r01_knn_pipeline_ab.txt.)
+    // Pool s3 415 vs 326 us, Swin s2 195 vs 202 us, profiles/r01_knn_pipeline_ab.txt.  So was a threshold
+    // pre-filter with per-lane compaction of the pushes: 460 vs 327 us on Pool s3 at 4 splits, break-even
+    // at 2-3 splits where the lost parallelism costs more, profiles/r01_knn_compaction_ab.txt.)
     const bool share_ab = (yn == xn) && (QW == TM) && (n0 == 0) && (m_begin == 0) && (M <= TM);
     if (share_ab) ldsB = ldsA;
     for (int mc0 = m_begin; mc0 < m_end; mc0 += TM) {
@@ -257,65 +255,6 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
         // epilogue: distances of this chunk -> running top-K (ascending m per lane)
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
-            if (COMPACT) {
-                // Long lists: a push costs 4*KB VALU slots, but once the list is full only candidates below
-                // the lane's current K-th distance can enter.  All 16 distances of the tile are formed first,
-                // the ones that pass are marked in a per-lane bit mask, and the wave then runs as many push
-                // rounds as its BUSIEST lane has passing candidates (each lane feeding its own next one),
-                // instead of 16.  Candidates still reach a lane in ascending m.
-                float dd[16];
-                unsigned pend = 0u;
-                const float tau = top.d[KB - 1];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int mbase = mc0 + t * 32 + 8 * g + 4 * h;
-                    float yv[4], rv[4];
-                    if (vec && mbase + 3 < m_end) {
-                        const float4 y4 = *reinterpret_cast<const float4*>(ysb + mbase);
-                        yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
-                        if (rp_row != nullptr) {
-                            const float4 r4 = *reinterpret_cast<const float4*>(rp_row + mbase);
-                            rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const bool ok = mbase + r < m_end;
-                            yv[r] = ok ? ysb[mbase + r] : 0.f;
-                            rv[r] = (ok && rp_row != nullptr) ? rp_row[mbase + r] : 0.f;
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float dist = INFINITY;
-                        if (nvalid && mbase + r < m_end) {
-                            dist = (xsv + (-2.0f * acc[t][4 * g + r])) + yv[r];
-                            if (rp_row != nullptr) dist = dist + rv[r];
-                        }
-                        dd[4 * g + r] = dist;
-                        pend |= (dist < tau) ? (1u << (4 * g + r)) : 0u;
-                    }
-                }
-                if (NEXTOU_ABLATE & 1) {
-                    top.d[0] = fminf(top.d[0], dd[0] + dd[5] + dd[10] + dd[15]);
-                    continue;
-                }
-                if (!__any(pend != 0u)) continue;
-                // park the tile's distances in this wave's LDS strip so that a lane can fetch the one its
-                // lowest pending bit names (registers cannot be indexed; a 16-way select tree costs 20+ VALU)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) sel[q * 64] = dd[q];
-#pragma unroll 1
-                for (int it = 0; it < 16; ++it) {
-                    if (!__any(pend != 0u)) break;
-                    const int r = pend ? (__ffs(pend) - 1) : 0;
-                    const float dist = pend ? sel[r * 64] : INFINITY;
-                    const int m = mc0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    pend &= pend - 1u;
-                    top.push_ascending(dist, m);
-                }
-                continue;
-            }
             f32x16 v = acc[t];
             for (int g = 0; g < 4; ++g) {
                 const int mbase = mc0 + t * 32 + 8 * g + 4 * h;
@@ -524,15 +463,6 @@ struct FusedPlan {
 // the 256 CUs.  Large grids take 192-wide chunks (fewest staging passes per MFMA); grids that
 // cannot fill the chip even so take 64-wide chunks (more splits) and 64-channel slabs (half the
 // barrier / global-load round trips: these launches are latency-bound, LDS is plentiful).
-static long long target_waves() {
-    static long long v = [] {
-        const char* e = getenv("NEXTOU_KNN_TARGET_WAVES");  // experiment knob; default 2 waves per SIMD
-        const long long n = e ? atoll(e) : 0;
-        return n > 0 ? n : 2048ll;
-    }();
-    return v;
-}
-
 static FusedPlan plan_fused(int B, int N, int M) {
     FusedPlan p;
     const int need = cdiv(N, 32);
@@ -543,7 +473,7 @@ static FusedPlan plan_fused(int B, int N, int M) {
     p.tiles = (small || w2 * 10 < ww * 9) ? 2 : 6;
     const int tm = 32 * p.tiles;
     const int chunks = cdiv(M, tm);
-    long long want = cdiv64(target_waves(), waves);
+    long long want = cdiv64(2048, waves);
     if (want > chunks) want = chunks;
     if (want > kMaxSplits) want = kMaxSplits;
     if (want < 1) want = 1;
@@ -551,7 +481,7 @@ static FusedPlan plan_fused(int B, int N, int M) {
     p.splits = cdiv(chunks, chunks_per_split);
     p.m_per_split = chunks_per_split * tm;
     p.ks = (waves * p.splits < 2048) ? 64 : 32;
-    if (((size_t)p.ks * (tm + 32 * p.nw) + 16 * 64 * p.nw) * sizeof(float) > 64 * 1024) p.ks = 32;  // dynamic-LDS limit
+    if ((size_t)p.ks * (tm + 32 * p.nw) * sizeof(float) > 64 * 1024) p.ks = 32;  // default dynamic-LDS limit
     return p;
 }
 
@@ -607,7 +537,7 @@ struct FusedArgs {
 template <int KB, int TILES>
 static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
     const int QW = 32 * p.nw;
-    const size_t lds = ((size_t)p.ks * (32 * TILES + QW) + (KB >= 14 ? 16 * 64 * p.nw : 0)) * sizeof(float);
+    const size_t lds = (size_t)p.ks * (32 * TILES + QW) * sizeof(float);
     dim3 grid(cdiv(a.N, QW), a.B, p.splits);
     // 16-B staging needs row strides and bases that keep every 4-float piece aligned
     const int vec_ok = (a.N % 4 == 0) && (a.M % 4 == 0) &&
