@@ -345,50 +345,37 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
     }
 }
 
-// S sorted partial lists per query -> the K best overall, by (dist, index).  A workgroup loads the
-// S*K (dist, id) pairs of `rows_per_block` queries into LDS with coalesced reads; one thread per pair
-// then finds its final position: its own position plus the number of entries of the OTHER lists that
-// sort before it (binary search in LDS; every candidate lives in exactly one list, so ranks are unique).
+// S sorted partial lists per query -> the K best overall, by (dist, index).  One thread per partial
+// entry: its final position is its own position plus the number of entries of the OTHER lists that
+// sort before it (binary search; every candidate lives in exactly one list, so ranks are unique).
 constexpr int kMaxSplits = 16;
 __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ part_d,
                                                         const int32_t* __restrict__ part_i,
                                                         int32_t* __restrict__ out, long long rows, int S,
-                                                        int K, int rows_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int per_row = S * K;
-    const int cap = rows_per_block * per_row;
-    float* sd = lds;
-    int* si = reinterpret_cast<int*>(lds + cap);
-    const long long row0 = (long long)blockIdx.x * rows_per_block;
-    long long n_here = rows - row0;
-    if (n_here > rows_per_block) n_here = rows_per_block;
-    const int count = (int)n_here * per_row;
-    const float* gd = part_d + (size_t)row0 * per_row;
-    const int32_t* gi = part_i + (size_t)row0 * per_row;
-    for (int e = threadIdx.x; e < count; e += blockDim.x) { sd[e] = gd[e]; si[e] = gi[e]; }
-    __syncthreads();
-    for (int e = threadIdx.x; e < count; e += blockDim.x) {
-        const int r = e / per_row, rem = e - r * per_row;
-        const int sp = rem / K, j = rem - sp * K;
-        const float d = sd[e];
-        const int i = si[e];
-        if (i == kSentinelIdx) continue;  // list shorter than K: not a candidate
-        const float* rd = sd + r * per_row;
-        const int* ri = si + r * per_row;
-        int rank = j;
-        for (int o = 0; o < S && rank < K; ++o) {
-            if (o == sp) continue;
-            int lo = 0, hi = K;  // first position in list o that does NOT sort before (d, i)
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                const float dm = rd[o * K + mid];
-                const int im = ri[o * K + mid];
-                if (dm < d || (dm == d && im < i)) lo = mid + 1; else hi = mid;
-            }
-            rank += lo;
+                                                        int K) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * S * K) return;
+    const long long row = e / ((long long)S * K);
+    const int rem = (int)(e - row * S * K);
+    const int sp = rem / K, j = rem - sp * K;
+    const float* pd = part_d + (size_t)row * S * K;
+    const int32_t* pi = part_i + (size_t)row * S * K;
+    const float d = pd[sp * K + j];
+    const int i = pi[sp * K + j];
+    if (i == kSentinelIdx) return;  // list shorter than K: not a candidate
+    int rank = j;
+    for (int o = 0; o < S && rank < K; ++o) {
+        if (o == sp) continue;
+        int lo = 0, hi = K;  // first position in list o that does NOT sort before (d, i)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const float dm = pd[o * K + mid];
+            const int im = pi[o * K + mid];
+            if (dm < d || (dm == d && im < i)) lo = mid + 1; else hi = mid;
         }
-        if (rank < K) out[(size_t)(row0 + r) * K + rank] = i;
+        rank += lo;
     }
+    if (rank < K) out[(size_t)row * K + rank] = i;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -568,12 +555,8 @@ static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
         const long long rows = (long long)a.B * a.N;
         ProfScope prof(s, kBoundHbm, 8.0 * rows * p.splits * a.K + 4.0 * rows * a.K, "knn_merge_kernel[B%d N%d S%d K%d]",
                        a.B, a.N, p.splits, a.K);
-        const int per_row = p.splits * a.K;
-        int rows_per_block = 2048 / per_row;  // ~2k pairs (16 KB of LDS) per 256-thread workgroup
-        if (rows_per_block < 1) rows_per_block = 1;
-        const size_t merge_lds = (size_t)rows_per_block * per_row * (sizeof(float) + sizeof(int));
-        hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)cdiv64(rows, rows_per_block)), dim3(256), merge_lds, s,
-                           a.part_d, a.part_i, a.out, rows, p.splits, a.K, rows_per_block);
+        hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)cdiv64(rows * p.splits * a.K, 256)), dim3(256), 0, s,
+                           a.part_d, a.part_i, a.out, rows, p.splits, a.K);
         return check_launch("knn_merge_kernel");
     }
     return 0;
