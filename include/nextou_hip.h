@@ -179,6 +179,47 @@ int nextou_bti_ce_bwd(const float* logits, const uint8_t* target, const uint8_t*
                       const double* scale_dev, float* grad_logits, int B, int L, int64_t V,
                       nextou_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K6  normalisation fused with LeakyReLU (batch norm and, with B = 1 and C = B*C, instance norm) —
+ * the (norm -> nonlin) tail of every conv block on the path: reference torch_nn.py:84-90 (BasicConv),
+ * NexToU_Encoder_Decoder.py:384-390 (FFN), :710-720 / :833-842 (fc1 / fc2) and the
+ * ConvDropoutNormReLU blocks of the conv stages (:125-136, :281-298).  Replaces
+ * batch_norm / instance_norm -> leaky_relu and their autograd.
+ *   x, y, gy, gx : (B, C, S) contiguous, dtype NEXTOU_DTYPE_F32 or NEXTOU_DTYPE_BF16
+ *   weight, bias : float (param_period ? param_period : C) or NULL (= 1 / 0); channel c uses entry
+ *                  c % param_period when param_period > 0 (instance norm: period = real channel count)
+ *   training != 0: batch statistics (biased variance for the normalisation); when running_mean /
+ *                  running_var are given they are updated in place,
+ *                  r = (1 - momentum) * r + momentum * stat (unbiased variance, as torch does).
+ *   training == 0: normalises with running_mean / running_var (required).
+ *   y = leaky_relu(x_hat * weight + bias, slope); slope = 1 is the plain normalisation.
+ *   save_mean / save_invstd (C floats, may be NULL for inference) feed the backward.
+ *   fwd traffic: 2 reads + 1 write of the tensor (training), 1 + 1 (inference).
+ *   bwd: gx, gweight[c] = sum dz * x_hat, gbias[c] = sum dz, with dz = gy * (z > 0 ? 1 : slope);
+ *        4 reads + 1 write.  gweight / gbias have C entries (the caller folds instance-norm
+ *        entries over the batch); either may be NULL.
+ *   workspace: nextou_norm_act_workspace_bytes() bytes of device scratch, contents irrelevant.
+ *   Sums are float64 in a fixed order: bit-reproducible.
+ * ---------------------------------------------------------------------------------------- */
+#define NEXTOU_DTYPE_F32  0
+#define NEXTOU_DTYPE_BF16 1
+
+size_t nextou_norm_act_workspace_bytes(int B, int C, int64_t S, int dtype);
+
+int nextou_norm_act_fwd(const void* x, const float* weight, const float* bias,
+                        float* running_mean, float* running_var,
+                        void* y, float* save_mean, float* save_invstd,
+                        void* workspace, size_t workspace_bytes,
+                        int B, int C, int64_t S, int param_period, int dtype, int training,
+                        float momentum, float eps, float slope, nextou_stream_t stream);
+
+int nextou_norm_act_bwd(const void* x, const void* gy, const float* weight, const float* bias,
+                        const float* save_mean, const float* save_invstd,
+                        void* gx, float* gweight, float* gbias,
+                        void* workspace, size_t workspace_bytes,
+                        int B, int C, int64_t S, int param_period, int dtype, int training,
+                        float slope, nextou_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 import torch  # noqa: F401  (must precede the dlopen, see module docstring)
 
@@ -21,6 +21,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NEXTOU_HIP_LIB") or os.path.join(_PKG_DIR, "libnextou_hip.so")
 
 KNN_AUTO, KNN_FUSED, KNN_NAIVE = 0, 1, 2
+DTYPE_F32, DTYPE_BF16 = 0, 1
 ABI_VERSION = 1
 
 # name -> (restype, argtypes); mirrors include/nextou_hip.h one to one
@@ -55,6 +56,13 @@ _SIGNATURES = {
                                   c_void_p]),
     "nextou_bti_critical_map": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                         c_int, c_int, c_int, c_int, c_void_p]),
+    "nextou_norm_act_workspace_bytes": (c_size_t, [c_int, c_int, c_int64, c_int]),
+    "nextou_norm_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_size_t, c_int, c_int, c_int64, c_int, c_int, c_int,
+                                    c_float, c_float, c_float, c_void_p]),
+    "nextou_norm_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_size_t, c_int, c_int, c_int64, c_int, c_int, c_int,
+                                    c_float, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

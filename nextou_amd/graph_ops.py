@@ -10,6 +10,8 @@ Each operator is the fused replacement of a run of ATen ops in the reference (SU
 ``gather_neighbors``   batched_index_select (reference torch_nn.py:94-115)
 ``bti_critical_map``   softmax/argmax + per-interaction isin/conv3d/where loop
                        (reference loss/bti_loss.py:132-134, 76-117)
+``norm_act``           batch_norm | instance_norm -> leaky_relu (reference torch_nn.py:84-90,
+                       NexToU_Encoder_Decoder.py:384-390 and the conv stages' norm -> nonlin)
 =====================  =====================================================================
 
 Device tensors go to the HIP kernels through the C-ABI (plain pointers + the current HIP stream).
@@ -28,7 +30,8 @@ from . import _lib
 
 __all__ = [
     "knn_graph", "pairwise_sq_distance", "edge_index_from_nn_idx", "mr_aggregate", "gather_neighbors",
-    "argmax_labels", "bti_critical_map", "critical_cross_entropy", "install_cpu_checker", "IndexTape", "index_tape",
+    "argmax_labels", "bti_critical_map", "critical_cross_entropy", "norm_act", "install_cpu_checker", "IndexTape",
+    "index_tape",
 ]
 
 
@@ -241,7 +244,44 @@ class _HipBackend:
         _lib.check(rc, "bti_ce_bwd")
         return grad
 
+    @staticmethod
+    def norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period):
+        """x (B,C,S) f32/bf16 -> (y, save_mean, save_invstd); running statistics updated in place."""
+        L_ = _lib.lib()
+        B, C, S = x.shape
+        dt = _NORM_DTYPES[x.dtype]
+        y = torch.empty_like(x)
+        save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((int(L_.nextou_norm_act_workspace_bytes(B, C, S, dt)),), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L_.nextou_norm_act_fwd(x.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                        y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), B, C, S, period, dt, int(training), float(momentum), float(eps),
+                                        float(slope), _stream_ptr(x.device))
+        _lib.check(rc, "norm_act_fwd")
+        return y, save_mean, save_invstd
 
+    @staticmethod
+    def norm_act_bwd(x, gy, weight, bias, save_mean, save_invstd, training, slope, period, eps=0.0):
+        """(``eps`` is only read by the CPU checker.)  -> (gx, gweight (C,), gbias (C,)) — per normalised channel; the caller folds instance-norm rows."""
+        L_ = _lib.lib()
+        B, C, S = x.shape
+        dt = _NORM_DTYPES[x.dtype]
+        gx = torch.empty_like(x)
+        gw = torch.empty((C,), dtype=torch.float32, device=x.device)
+        gb = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((int(L_.nextou_norm_act_workspace_bytes(B, C, S, dt)),), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L_.nextou_norm_act_bwd(x.data_ptr(), gy.data_ptr(), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
+                                        save_invstd.data_ptr(), gx.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), B, C, S, period, dt, int(training), float(slope),
+                                        _stream_ptr(x.device))
+        _lib.check(rc, "norm_act_bwd")
+        return gx, gw, gb
+
+
+_NORM_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16}
 _HIP = _HipBackend()
 
 
@@ -428,6 +468,59 @@ def critical_cross_entropy(logits: torch.Tensor, target: torch.Tensor, critical:
     ``CrossEntropyLoss(reduction='none')(x.double(), y) * critical`` + sum (reference bti_loss.py:141-143).
     """
     return _CriticalCE.apply(_f32c(logits), target.contiguous(), critical.contiguous())
+
+
+class _NormAct(torch.autograd.Function):
+    """(batch | instance) norm -> LeakyReLU as one op; saves only ``x`` and 2C floats for backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, instance):
+        shape = x.shape
+        B, C = shape[0], shape[1]
+        x3 = x.reshape(1, B * C, -1) if instance else x.reshape(B, C, -1)
+        period = C if instance else 0
+        be = _backend_for(x)
+        y, mean, invstd = be.norm_act_fwd(x3, weight, bias, running_mean, running_var, training, momentum, eps,
+                                          slope, period)
+        ctx.save_for_backward(x3, weight, bias, mean, invstd)
+        ctx.cfg = (bool(training), float(slope), period, shape, B, C, float(eps))
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x3, weight, bias, mean, invstd = ctx.saved_tensors
+        training, slope, period, shape, B, C, eps = ctx.cfg
+        gy3 = gy.contiguous().view(x3.shape)
+        if gy3.dtype != x3.dtype:
+            gy3 = gy3.to(x3.dtype)
+        gx, gw, gb = _backend_for(x3).norm_act_bwd(x3, gy3, weight, bias, mean, invstd, training, slope, period, eps)
+        if period:
+            gw, gb = gw.view(B, C).sum(0), gb.view(B, C).sum(0)
+        gw = gw.to(weight.dtype) if weight is not None and ctx.needs_input_grad[1] else None
+        gb = gb.to(bias.dtype) if bias is not None and ctx.needs_input_grad[2] else None
+        return gx.view(shape), gw, gb, None, None, None, None, None, None, None
+
+
+def norm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
+             running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], training: bool,
+             momentum: float, eps: float, negative_slope: float = 1.0, instance: bool = False) -> torch.Tensor:
+    """``leaky_relu(batch_norm(x) | instance_norm(x), negative_slope)`` on (B,C,*spatial) fp32 / bf16.
+
+    The fused replacement of ``norm -> act`` in the reference's BasicConv (torch_nn.py:84-90), FFN / fc1 / fc2
+    (NexToU_Encoder_Decoder.py:384-390, 710-720, 833-842) and the conv stages' ConvDropoutNormReLU.
+    ``negative_slope=1`` is the bare normalisation.  Running statistics are updated in place as
+    ``F.batch_norm`` does (unbiased variance, ``momentum``); ``training=False`` uses them.
+    """
+    if x.dtype not in _NORM_DTYPES:
+        raise TypeError("norm_act: dtype %s not in (float32, bfloat16)" % x.dtype)
+    if instance and not training:
+        raise ValueError("norm_act: instance norm always uses the statistics of its input")
+    if weight is not None and weight.dtype != torch.float32:
+        weight = weight.float()
+    if bias is not None and bias.dtype != torch.float32:
+        bias = bias.float()
+    return _NormAct.apply(x.contiguous(), weight, bias, running_mean, running_var, bool(training), float(momentum),
+                          float(eps), float(negative_slope), bool(instance))
 
 
 @torch.no_grad()

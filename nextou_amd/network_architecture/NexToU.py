@@ -14,6 +14,7 @@ from torch.nn.modules.dropout import _DropoutNd
 
 from .NexToU_Encoder_Decoder import NexToU_Decoder, NexToU_Encoder
 from .conv_blocks import convert_conv_op_to_dim
+from .norm_act import fuse_norm_act, fusion_enabled
 
 
 class NexToU(nn.Module):
@@ -56,6 +57,8 @@ class NexToU(nn.Module):
                                       return_skips=True, nonlin_first=nonlin_first)
         self.decoder = NexToU_Decoder(self.encoder, patch_size, strides, num_classes, n_conv_per_stage_decoder,
                                       deep_supervision, nonlin_first=nonlin_first)
+        if fusion_enabled():  # (norm -> LeakyReLU) pairs become one K6 launch; state_dict unchanged
+            fuse_norm_act(self)
 
     def forward(self, x):
         return self.decoder(self.encoder(x))

@@ -211,6 +211,13 @@ class FFN(nn.Module):
     def forward(self, x):
         return self.drop_path(self.fc2(self.act(self.fc1(x)))) + x
 
+    def _absorb_activation(self):
+        """norm_act.fuse_norm_act hook: fold the LeakyReLU between fc1 and fc2 into fc1's fused norm."""
+        norm = self.fc1[-1]
+        if type(self.act) is nn.LeakyReLU and getattr(norm, 'negative_slope', None) == 1.0:
+            norm.negative_slope = float(self.act.negative_slope)
+            self.act = nn.Identity()
+
 
 def _drop_path(rate):
     # drop_path is 0 in every constructible configuration (OptInit), i.e. always Identity

@@ -1,0 +1,129 @@
+"""Fused (norm -> LeakyReLU) modules of the NexToU path, backed by K6 of libnextou_hip.so.
+
+Every conv block on the path ends in ``norm -> nonlin``: the reference's ``BasicConv``
+(torch_nn.py:84-90), ``FFN`` (NexToU_Encoder_Decoder.py:384-390), the graphers' ``fc1`` / ``fc2``
+(:710-720, :833-842) and the conv stages' ``ConvDropoutNormReLU`` (:125-136, :281-298).  PyTorch-ROCm
+runs them as MIOpen batch norm + ``leaky_relu`` kernels — 44 ms of the 327 ms cfg-2 step.  The classes
+here are the stock ``nn.BatchNormNd`` / ``nn.InstanceNormNd`` with one extra attribute,
+``negative_slope`` (1.0 = no activation), and a ``forward`` that calls
+:func:`nextou_amd.graph_ops.norm_act`.  Parameters, buffers and ``state_dict`` keys are untouched, so
+checkpoints interchange with the reference.
+
+:func:`fuse_norm_act` converts a built model in place (class swap — no parameter is copied): every
+``BatchNorm`` / ``InstanceNorm`` that sits in an ``nn.Sequential`` becomes its fused class and a
+``LeakyReLU`` that directly follows it is absorbed (replaced by ``nn.Identity``).  ``NexToU.__init__``
+applies it unless ``NEXTOU_FUSE_NORM_ACT=0`` (kept for A/B measurements).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+from torch import nn
+
+from .. import graph_ops
+
+__all__ = ["BatchNormAct1d", "BatchNormAct2d", "BatchNormAct3d", "InstanceNormAct1d", "InstanceNormAct2d",
+           "InstanceNormAct3d", "fuse_norm_act", "fusion_enabled"]
+
+
+class _BatchNormAct:
+    negative_slope: float = 1.0
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._check_input_dim(x)
+        # same bookkeeping as torch.nn.modules.batchnorm._BatchNorm.forward
+        factor = 0.0 if self.momentum is None else self.momentum
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+            factor = 1.0 / float(self.num_batches_tracked) if self.momentum is None else self.momentum
+        use_batch_stats = self.training or (self.running_mean is None and self.running_var is None)
+        keep_running = (not self.training) or self.track_running_stats
+        return graph_ops.norm_act(x, self.weight, self.bias,
+                                  self.running_mean if keep_running else None,
+                                  self.running_var if keep_running else None,
+                                  use_batch_stats, factor, self.eps, self.negative_slope)
+
+    def extra_repr(self) -> str:
+        return super().extra_repr() + ", negative_slope=%g" % self.negative_slope
+
+
+class _InstanceNormAct:
+    negative_slope: float = 1.0
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._check_input_dim(x)
+        if self.track_running_stats:
+            raise NotImplementedError("InstanceNormAct: track_running_stats=True is not on the NexToU path")
+        if x.dim() == self._get_no_batch_dim():
+            return self.forward(x.unsqueeze(0)).squeeze(0)
+        return graph_ops.norm_act(x, self.weight, self.bias, None, None, True, 0.0, self.eps, self.negative_slope,
+                                  instance=True)
+
+    def extra_repr(self) -> str:
+        return super().extra_repr() + ", negative_slope=%g" % self.negative_slope
+
+
+class BatchNormAct1d(_BatchNormAct, nn.BatchNorm1d):
+    pass
+
+
+class BatchNormAct2d(_BatchNormAct, nn.BatchNorm2d):
+    pass
+
+
+class BatchNormAct3d(_BatchNormAct, nn.BatchNorm3d):
+    pass
+
+
+class InstanceNormAct1d(_InstanceNormAct, nn.InstanceNorm1d):
+    pass
+
+
+class InstanceNormAct2d(_InstanceNormAct, nn.InstanceNorm2d):
+    pass
+
+
+class InstanceNormAct3d(_InstanceNormAct, nn.InstanceNorm3d):
+    pass
+
+
+_FUSED = {
+    nn.BatchNorm1d: BatchNormAct1d, nn.BatchNorm2d: BatchNormAct2d, nn.BatchNorm3d: BatchNormAct3d,
+    nn.InstanceNorm1d: InstanceNormAct1d, nn.InstanceNorm2d: InstanceNormAct2d, nn.InstanceNorm3d: InstanceNormAct3d,
+}
+
+
+def fusion_enabled() -> bool:
+    return os.environ.get("NEXTOU_FUSE_NORM_ACT", "1") != "0"
+
+
+def _convert(norm: nn.Module) -> bool:
+    cls = _FUSED.get(type(norm))
+    if cls is None:
+        return False
+    if isinstance(norm, nn.modules.instancenorm._InstanceNorm) and norm.track_running_stats:
+        return False
+    norm.__class__ = cls
+    norm.negative_slope = 1.0
+    return True
+
+
+def fuse_norm_act(root: nn.Module) -> int:
+    """In-place conversion described in the module docstring; returns the number of norms converted."""
+    converted = 0
+    for m in list(root.modules()):
+        if isinstance(m, nn.Sequential):
+            names = list(m._modules)
+            for i, name in enumerate(names):
+                if not _convert(m._modules[name]):
+                    continue
+                converted += 1
+                if i + 1 < len(names) and type(m._modules[names[i + 1]]) is nn.LeakyReLU:
+                    m._modules[name].negative_slope = float(m._modules[names[i + 1]].negative_slope)
+                    m._modules[names[i + 1]] = nn.Identity()
+    for m in list(root.modules()):  # after the Sequentials: blocks whose activation sits beside one (FFN)
+        hook = getattr(m, "_absorb_activation", None)
+        if callable(hook):
+            hook()
+    return converted

@@ -168,3 +168,14 @@ class CanonicalBackend:
         _ok(lib().oracle_bti_critical(_p(labels), _p(lut_a), _p(lut_c), lut_a.numel(), _p(out), B, D, H, W,
                                       connectivity, min_thick), "bti_critical")
         return out
+
+    @staticmethod
+    def norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period):
+        from .ref_ops import norm_act_fwd_ref
+        return norm_act_fwd_ref(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period)
+
+    @staticmethod
+    def norm_act_bwd(x, gy, weight, bias, save_mean, save_invstd, training, slope, period, eps):
+        from .ref_ops import norm_act_bwd_ref
+        return norm_act_bwd_ref(x, gy, weight, bias, save_mean, save_invstd, training, slope, period, eps)
+

@@ -96,6 +96,56 @@ def bti_critical_ref(P, interactions, dim, connectivity, min_thick=1):
     return critical
 
 
+def _norm_act_ref(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period):
+    """The reference op sequence: batch_norm | instance_norm -> leaky_relu (torch_nn.py:84-90).
+
+    x (B,C,S); ``period`` > 0 means x is (1, B*period, S) holding an instance norm (weight index c % period).
+    """
+    F = torch.nn.functional
+    if period:
+        z = F.instance_norm(x.view(-1, period, x.shape[-1]), None, None, weight, bias, True, momentum, eps).view_as(x)
+    else:
+        z = F.batch_norm(x, running_mean, running_var, weight, bias, training, momentum, eps)
+    return z if slope == 1.0 else F.leaky_relu(z, slope)
+
+
+def norm_act_fwd_ref(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period):
+    with torch.no_grad():
+        y = _norm_act_ref(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period)
+        if training:
+            xd = x.double()
+            mean = xd.mean(dim=(0, 2))
+            invstd = 1.0 / torch.sqrt(xd.var(dim=(0, 2), unbiased=False) + eps)
+        else:
+            mean, invstd = running_mean.double(), 1.0 / torch.sqrt(running_var.double() + eps)
+    return y, mean.float(), invstd.float()
+
+
+def norm_act_bwd_ref(x, gy, weight, bias, save_mean, save_invstd, training, slope, period, eps):
+    """autograd of the reference op sequence; inference mode rebuilds the running statistics it was given."""
+    with torch.enable_grad():
+        xr = x.detach().requires_grad_(True)
+        C = x.shape[1]
+        npar = period if period else C
+        w = (torch.ones(npar) if weight is None else weight.detach().clone()).requires_grad_(True)
+        b = (torch.zeros(npar) if bias is None else bias.detach().clone()).requires_grad_(True)
+        if training:
+            y = _norm_act_ref(xr, w, b, None, None, True, 0.0, eps, slope, period)
+        else:
+            z = (xr - save_mean.view(1, -1, 1)) * save_invstd.view(1, -1, 1) * w.view(1, -1, 1) + b.view(1, -1, 1)
+            y = z if slope == 1.0 else torch.nn.functional.leaky_relu(z, slope)
+        gx, gw, gb = torch.autograd.grad(y, (xr, w, b), gy)
+    if period:  # the backend protocol returns per-normalised-channel sums; the caller folds them
+        B = C // period
+        with torch.no_grad():
+            xh = (x - save_mean.view(1, -1, 1)) * save_invstd.view(1, -1, 1)
+            wv = (torch.ones(npar) if weight is None else weight).repeat(B).view(1, -1, 1)
+            bv = (torch.zeros(npar) if bias is None else bias).repeat(B).view(1, -1, 1)
+            dz = torch.where(xh * wv + bv > 0, gy, gy * slope)
+            return gx, (dz * xh).sum(dim=(0, 2)), dz.sum(dim=(0, 2))
+    return gx, gw, gb
+
+
 class TorchRefBackend:
     """Backend protocol of nextou_amd.graph_ops with the reference's op sequence (CPU baseline)."""
 
@@ -164,3 +214,11 @@ class TorchRefBackend:
     def bti_ce_bwd(logits, target, critical, scale):
         from . import CanonicalBackend
         return CanonicalBackend.bti_ce_bwd(logits, target, critical, scale)
+
+    @staticmethod
+    def norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period):
+        return norm_act_fwd_ref(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period)
+
+    @staticmethod
+    def norm_act_bwd(x, gy, weight, bias, save_mean, save_invstd, training, slope, period, eps):
+        return norm_act_bwd_ref(x, gy, weight, bias, save_mean, save_invstd, training, slope, period, eps)

@@ -512,3 +512,129 @@ def test_critical_cross_entropy_kernel(ops, ora):
     a = ops.critical_cross_entropy(xd, target.to(DEV), critical.to(DEV))
     b = ops.critical_cross_entropy(xd, target.to(DEV), critical.to(DEV))
     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# K6  norm + LeakyReLU
+def _norm_reference(x, w, b, rm, rv, training, momentum, eps, slope, instance, gy):
+    """float64 torch reference of batch_norm | instance_norm -> leaky_relu and its gradients (CPU)."""
+    xd = x.double().requires_grad_(True)
+    wd = None if w is None else w.double().requires_grad_(True)
+    bd = None if b is None else b.double().requires_grad_(True)
+    rmd, rvd = (None, None) if rm is None else (rm.double().clone(), rv.double().clone())
+    if instance:
+        z = F.instance_norm(xd, None, None, wd, bd, True, momentum, eps)
+    else:
+        z = F.batch_norm(xd, rmd, rvd, wd, bd, training, momentum, eps)
+    y = F.leaky_relu(z, slope) if slope != 1.0 else z
+    grads = torch.autograd.grad(y, [t for t in (xd, wd, bd) if t is not None], gy.double())
+    return y.detach(), grads, rmd, rvd
+
+
+@pytest.mark.parametrize("shape,instance,training,slope,affine", [
+    ((2, 33, 8, 28, 24), False, True, 0.01, True),     # 16-byte path, column tiles
+    ((64, 12, 4, 7, 6), False, True, 0.01, True),      # window batch: short rows, row tiles
+    ((3, 5, 3, 5), False, True, 0.01, True),           # S = 15: scalar path
+    ((2, 7, 1031), False, True, 1.0, True),            # prime S, bare norm
+    ((2, 24, 6, 10, 12), False, False, 0.01, True),    # inference: running statistics
+    ((2, 24, 6, 10, 12), False, True, 0.2, False),     # no affine parameters
+    ((2, 18, 344), True, True, 0.01, True),            # instance norm (Pool-GNN BasicConv)
+    ((1, 6, 5, 9), True, True, 1.0, False),
+])
+def test_norm_act_vs_float64_reference(ops, shape, instance, training, slope, affine):
+    """K6 against the float64 op sequence.  Bars: outputs and input gradients within 4 fp32 ulp of the output /
+    gradient scale (the stock fp32 kernels are held to the same bar beside it), parameter gradients rtol 2e-5,
+    running statistics rtol 1e-6; bit-identical when repeated."""
+    g = torch.Generator().manual_seed(len(shape) * 1000 + shape[1])
+    C = shape[1]
+    x = torch.randn(shape, generator=g) * 1.7 + 0.4
+    w = (torch.rand(C, generator=g) + 0.5) if affine else None
+    b = (torch.randn(C, generator=g) * 0.3) if affine else None
+    rm, rv = (None, None) if instance else (torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5)
+    gy = torch.randn(shape, generator=g)
+    want_y, want_g, want_rm, want_rv = _norm_reference(x, w, b, rm, rv, training, 0.1, 1e-5, slope, instance, gy)
+
+    def run():
+        xd = x.to(DEV).requires_grad_(True)
+        wd = None if w is None else w.to(DEV).requires_grad_(True)
+        bd = None if b is None else b.to(DEV).requires_grad_(True)
+        rmd, rvd = (None, None) if rm is None else (rm.to(DEV), rv.to(DEV))
+        y = ops.norm_act(xd, wd, bd, rmd, rvd, training, 0.1, 1e-5, slope, instance=instance)
+        grads = torch.autograd.grad(y, [t for t in (xd, wd, bd) if t is not None], gy.to(DEV))
+        return y.detach(), grads, rmd, rvd
+
+    y, grads, rmd, rvd = run()
+    ulp = 2.0 ** -23
+    assert float((y.cpu().double() - want_y).abs().max()) <= 4 * ulp * float(want_y.abs().max())
+    assert float((grads[0].cpu().double() - want_g[0]).abs().max()) <= 8 * ulp * max(float(want_g[0].abs().max()), 1.0)
+    for got, want in zip(grads[1:], want_g[1:]):
+        np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=2e-5, atol=2e-5 * float(want.abs().max()))
+    if rm is not None:
+        np.testing.assert_allclose(rmd.cpu().double().numpy(), want_rm.numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(rvd.cpu().double().numpy(), want_rv.numpy(), rtol=1e-6, atol=1e-7)
+    y2, grads2, _, _ = run()
+    assert torch.equal(y, y2) and all(torch.equal(a, b_) for a, b_ in zip(grads, grads2))
+
+
+def test_norm_act_bf16_and_modules(ops):
+    """bf16 tensors (cfg 5's autocast conv stages) and the fused module classes against the stock modules on the GPU."""
+    from nextou_amd.network_architecture.norm_act import fuse_norm_act
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn((2, 16, 4, 12, 16), generator=g) * 2).to(DEV)
+    gy = torch.randn((2, 16, 4, 12, 16), generator=g).to(DEV)
+    w, b = (torch.rand(16, generator=g) + 0.5).to(DEV), torch.randn(16, generator=g).to(DEV)
+    xb = x.bfloat16().requires_grad_(True)
+    yb = ops.norm_act(xb, w, b, None, None, True, 0.1, 1e-5, 0.01)
+    (gb,) = torch.autograd.grad(yb, xb, gy.bfloat16())
+    assert yb.dtype == torch.bfloat16 and gb.dtype == torch.bfloat16
+    xf = xb.detach().float().requires_grad_(True)      # same (bf16-rounded) inputs in fp32
+    yf = F.leaky_relu(F.batch_norm(xf, None, None, w, b, True, 0.1, 1e-5), 0.01)
+    (gf,) = torch.autograd.grad(yf, xf, gy.bfloat16().float())
+    assert float((yb.float() - yf).abs().max().detach()) <= 2.0 ** -8 * float(yf.abs().max().detach())  # one bf16 rounding
+    assert float((gb.float() - gf).abs().max()) <= 2.0 ** -7 * float(gf.abs().max())
+
+    for make in (lambda: torch.nn.Sequential(torch.nn.Conv3d(4, 12, 3, padding=1), torch.nn.BatchNorm3d(12),
+                                             torch.nn.LeakyReLU(0.01, inplace=True)),
+                 lambda: torch.nn.Sequential(torch.nn.Conv2d(4, 12, 1), torch.nn.InstanceNorm2d(12, affine=True),
+                                             torch.nn.LeakyReLU(0.01)),
+                 lambda: torch.nn.Sequential(torch.nn.Conv3d(4, 12, 1), torch.nn.BatchNorm3d(12))):
+        torch.manual_seed(3)
+        stock = make().to(DEV)
+        torch.manual_seed(3)
+        fused = make().to(DEV)
+        assert fuse_norm_act(fused) == 1
+        assert list(fused.state_dict()) == list(stock.state_dict())
+        dims = 3 if isinstance(stock[0], torch.nn.Conv3d) else 2
+        inp = torch.randn((3, 4) + (6, 10, 8)[:dims], device=DEV)
+        for mode in ("train", "eval"):
+            getattr(stock, mode)(), getattr(fused, mode)()
+            a, b_ = stock(inp), fused(inp)
+            assert float((a - b_).abs().max()) <= 1e-5 * float(a.abs().max())
+            ga = torch.autograd.grad(a.square().sum(), list(stock.parameters()))
+            gb_ = torch.autograd.grad(b_.square().sum(), list(fused.parameters()))
+            scale = max(float(u.abs().max()) for u in ga)   # the conv bias gradient ahead of a norm is pure round-off
+            for u, v in zip(ga, gb_):
+                assert float((u - v).abs().max()) <= 2e-5 * scale
+        for (k1, v1), (k2, v2) in zip(stock.state_dict().items(), fused.state_dict().items()):
+            assert k1 == k2 and float((v1.double() - v2.double()).abs().max()) <= 1e-5, k1
+
+
+def test_norm_act_full_size_cfg2(ops):
+    """The largest norm call of cfg 2 (2 x 33 x 64 x 224 x 192): size-independent properties — per-channel mean 0 /
+    variance 1 of the normalised tensor, exact LeakyReLU sign structure, gradient orthogonality
+    (sum gx = 0 and sum gx * x_hat = 0 per channel, the two projections batch norm's backward removes)."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn((2, 33, 64, 224, 192), generator=g, device=DEV) * 3 + 1
+    x.requires_grad_(True)
+    y = ops.norm_act(x, None, None, None, None, True, 0.1, 1e-5, 1.0)
+    m = y.double().mean(dim=(0, 2, 3, 4))
+    v = y.double().var(dim=(0, 2, 3, 4), unbiased=False)
+    assert float(m.abs().max()) < 1e-6 and float((v - 1).abs().max()) < 1e-5
+    ya = ops.norm_act(x, None, None, None, None, True, 0.1, 1e-5, 0.01)
+    assert torch.equal(ya, torch.where(y > 0, y, y * 0.01))
+    gy = torch.randn(x.shape, generator=g, device=DEV)
+    (gx,) = torch.autograd.grad(ya, x, gy)
+    s1 = gx.double().sum(dim=(0, 2, 3, 4))
+    s2 = (gx.double() * y.double()).sum(dim=(0, 2, 3, 4))
+    n = x[:, 0].numel()
+    assert float(s1.abs().max()) / n < 1e-7 and float(s2.abs().max()) / n < 1e-7

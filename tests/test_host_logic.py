@@ -119,3 +119,48 @@ def test_harness_train_step_decreases_loss(cpu_checker):
     tg = downsample_targets(target, outs)
     losses = [float(tr.train_step(data, tg)) for _ in range(6)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_fuse_norm_act_keeps_state_dict_and_results(cpu_checker):
+    """The (norm -> LeakyReLU) fusion is a class swap: same keys, same numbers (the CPU checker runs the reference
+    op sequence for the fused op, so fused == unfused bit for bit here); NEXTOU_FUSE_NORM_ACT=0 disables it."""
+    import os
+    from torch import nn
+    import model_cases as mc
+    from nextou_amd.network_architecture import norm_act
+
+    def build():
+        torch.manual_seed(0)
+        return mc.build_model(mc.TINY_2D)
+
+    os.environ["NEXTOU_FUSE_NORM_ACT"] = "0"
+    try:
+        plain = build()
+    finally:
+        del os.environ["NEXTOU_FUSE_NORM_ACT"]
+    fused = build()
+    kinds = (norm_act._BatchNormAct, norm_act._InstanceNormAct)
+    n_fused = sum(isinstance(m, kinds) for m in fused.modules())
+    n_norms = sum(isinstance(m, (nn.modules.batchnorm._BatchNorm, nn.modules.instancenorm._InstanceNorm))
+                  for m in plain.modules())
+    assert n_fused == n_norms > 0
+    assert not any(isinstance(m, kinds) for m in plain.modules())
+    assert list(plain.state_dict()) == list(fused.state_dict())
+    fused.load_state_dict(plain.state_dict(), strict=True)
+    # LeakyReLUs that followed a norm are absorbed (slope 0.01); norms without activation keep slope 1
+    slopes = [m.negative_slope for m in fused.modules() if isinstance(m, kinds)]
+    assert 0.01 in slopes and 1.0 in slopes
+    n_act_plain = sum(type(m) is nn.LeakyReLU for m in plain.modules())
+    n_act_fused = sum(type(m) is nn.LeakyReLU for m in fused.modules())
+    assert n_act_fused < n_act_plain
+    x = torch.randn(2, 1, 64, 64)
+    a, b = plain(x), fused(x)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    ga = torch.autograd.grad(sum(t.square().mean() for t in a), [p for p in plain.parameters() if p.requires_grad],
+                             allow_unused=True)
+    gb = torch.autograd.grad(sum(t.square().mean() for t in b), [p for p in fused.parameters() if p.requires_grad],
+                             allow_unused=True)
+    for u, v in zip(ga, gb):
+        assert (u is None) == (v is None)
+        if u is not None:
+            assert float((u - v).abs().max()) <= 1e-5 * max(float(u.abs().max()), 1e-6)

@@ -27,7 +27,70 @@ CFG2 = [("s2 Pool", 2, 132, 10752, 168, 14), ("s2 Swin", 1024, 132, 168, None, 7
 CFG5 = [("s2 Pool", 2, 132, 24576, 384, 32), ("s2 Swin", 1024, 132, 384, None, 16),
         ("s3 Pool", 2, 264, 24576, 3072, 32), ("s3 Swin", 128, 264, 384, None, 32),
         ("s4 Pool", 2, 324, 3072, None, 32), ("s4 Swin", 16, 324, 384, None, 32)]
+# (label, B, C, S, instance norm?)  — the (norm -> LeakyReLU) calls of one cfg-2 step, largest first
+NORM2 = [("s0 conv BN+act", 2, 33, 64 * 224 * 192, False), ("s1 conv BN+act", 2, 66, 64 * 112 * 96, False),
+         ("s2 conv BN+act", 2, 132, 32 * 56 * 48, False), ("s2 FFN hidden", 2, 528, 32 * 56 * 48, False),
+         ("s2 Swin fc BN", 1024, 132, 168, False), ("s2 Swin graph BN", 1024, 264, 168, False),
+         ("s2 Pool graph IN", 2, 264, 10752, True), ("s3 conv BN+act", 2, 264, 16 * 28 * 24, False),
+         ("s4 conv BN+act", 2, 324, 8 * 14 * 12, False)]
 PEAK = {"mfma": 157.3e12, "hbm": 8000e9}
+
+
+def bench_norm(args, dev, L):
+    """K6 at the cfg-2 shapes, next to PyTorch-ROCm's batch_norm + leaky_relu (MIOpen) on the same tensors."""
+    F = torch.nn.functional
+    rows = []
+    print("%-18s %-52s %10s %12s %7s" % ("call", "kernel", "us/launch", "achieved", "frac"))
+    for label, B, C, S, inst in NORM2:
+        if args.only and args.only not in label:
+            continue
+        g = torch.Generator(device=dev).manual_seed(1)
+        x = torch.randn((B, C, S), generator=g, device=dev, requires_grad=True)
+        w = torch.rand((C,), generator=g, device=dev) + 0.5
+        b = torch.randn((C,), generator=g, device=dev) * 0.1
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        gy = torch.randn((B, C, S), generator=g, device=dev)
+
+        def ours():
+            y = graph_ops.norm_act(x, w, b, None if inst else rm, None if inst else rv, True, 0.1, 1e-5, 0.01, instance=inst)
+            torch.autograd.grad(y, x, gy)
+
+        def stock():
+            z = F.instance_norm(x, None, None, w, b, True, 0.1, 1e-5) if inst else F.batch_norm(x, rm, rv, w, b, True, 0.1, 1e-5)
+            torch.autograd.grad(F.leaky_relu(z, 0.01), x, gy)
+
+        for it in range(2 + args.iters):
+            if it == 2:
+                torch.cuda.synchronize()
+                L.nextou_profile_enable(8 * args.iters)
+            ours()
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 20)
+        L.nextou_profile_report(buf, len(buf))
+        L.nextou_profile_enable(0)
+        own_us = 0.0
+        for r in json.loads(buf.value.decode()):
+            per_s = r["ms"] / r["launches"] / 1e3
+            ach = r["work"] / r["launches"] / per_s
+            own_us += per_s * 1e6
+            rows.append({"call": label, "kernel": r["kernel"], "bound": r["bound"], "us": per_s * 1e6,
+                         "achieved": ach, "frac": ach / PEAK[r["bound"]]})
+            print("%-18s %-52s %10.1f %8.0f GB/s %6.1f%%" % (label, r["kernel"][:52], per_s * 1e6, ach / 1e9,
+                                                           100 * ach / PEAK["hbm"]))
+        for fn in (stock, stock):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            stock()
+        e1.record()
+        torch.cuda.synchronize()
+        stock_us = e0.elapsed_time(e1) * 1e3 / args.iters
+        print("%-18s own fwd+bwd %.1f us   PyTorch-ROCm batch_norm+leaky_relu fwd+bwd %.1f us   (%.2fx)" % (
+            label, own_us, stock_us, stock_us / own_us))
+        rows.append({"call": label, "own_us": own_us, "stock_us": stock_us})
+    if args.json:
+        json.dump(rows, open(args.json, "w"), indent=1)
 
 
 def main():
@@ -36,9 +99,12 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--json", default=None)
     ap.add_argument("--only", default=None, help="substring filter on the call label")
+    ap.add_argument("--norm", action="store_true", help="bench K6 (norm + LeakyReLU) instead of K1/K2")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     L = _lib.lib()
+    if args.norm:
+        return bench_norm(args, dev, L)
     calls = CFG2 if args.cfg == 2 else CFG5
     rows = []
     for label, B, C, N, M, k in calls:
