@@ -94,6 +94,8 @@ class StandaloneTrainerBase:
         self.enable_deep_supervision = enable_deep_supervision
         self._log = log
         self.network = self.loss = self.optimizer = None
+        # nnU-Net's default: mirror along every spatial axis at test time; the *_NoMirroring plug-ins set None
+        self.inference_allowed_mirroring_axes = tuple(range(len(configuration_manager.patch_size)))
 
     # -- hooks the plug-ins use -----------------------------------------------------------------
     def print_to_log_file(self, *args, **kwargs):
@@ -132,6 +134,20 @@ class StandaloneTrainerBase:
         self.optimizer = torch.optim.SGD(self.network.parameters(), self.initial_lr, weight_decay=self.weight_decay,
                                          momentum=self.momentum, nesterov=True)
         return self
+
+    def configure_rotation_dummyDA_mirroring_and_inital_patch_size(self):
+        """(rotation, dummy-2d flag, initial patch size, mirror axes) — only the mirror axes matter to the plug-ins."""
+        patch = tuple(self.configuration_manager.patch_size)
+        return None, False, patch, tuple(range(len(patch)))
+
+    def predict_logits(self, image: torch.Tensor, tile_step_size: float = 0.5, batch_size: int = 8,
+                       autocast_dtype=None) -> torch.Tensor:
+        """Sliding-window logits of one pre-processed case (C, *spatial), with this trainer's mirroring policy."""
+        from .inference import predict_sliding_window
+        self.configure_rotation_dummyDA_mirroring_and_inital_patch_size()   # lets *_NoMirroring veto the TTA
+        return predict_sliding_window(self.network, image.to(self.device), self.configuration_manager.patch_size,
+                                      tile_step_size, True, self.inference_allowed_mirroring_axes, batch_size,
+                                      autocast_dtype)
 
     def train_step(self, data: torch.Tensor, target: List[torch.Tensor]) -> torch.Tensor:
         """forward -> deep-supervision loss -> backward -> clip -> SGD, like nnU-Net's train_step."""

@@ -638,3 +638,22 @@ def test_norm_act_full_size_cfg2(ops):
     s2 = (gx.double() * y.double()).sum(dim=(0, 2, 3, 4))
     n = x[:, 0].numel()
     assert float(s1.abs().max()) / n < 1e-7 and float(s2.abs().max()) / n < 1e-7
+
+
+# ---------------------------------------------------------------------------------------------
+# inference
+def test_sliding_window_inference_on_gpu(ops):
+    """Batched tiles + mirror copies give the same logits as one forward per copy; eval mode, deep supervision off."""
+    from nextou_amd.inference import predict_sliding_window
+    torch.manual_seed(1)
+    net = mc.build_model(mc.TINY_3D).to(DEV)
+    for m in net.modules():                      # non-trivial running statistics
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    image = torch.randn(1, 40, 160, 128, device=DEV)
+    one = predict_sliding_window(net, image, mc.TINY_3D["patch"], 0.5, True, (0, 1, 2), batch_size=1)
+    many = predict_sliding_window(net, image, mc.TINY_3D["patch"], 0.5, True, (0, 1, 2), batch_size=8)
+    assert one.shape == (mc.TINY_3D["classes"], 40, 160, 128) and bool(torch.isfinite(one).all())
+    assert float((one - many).abs().max()) <= 1e-4 * float(one.abs().max())
+    assert net.training and net.decoder.deep_supervision is True
