@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NEXTOU_ABI_VERSION 1
+#define NEXTOU_ABI_VERSION 2
 
 #define NEXTOU_EINVAL   (-1)  /* bad argument (null pointer, non-positive size, k > M ...) */
 #define NEXTOU_ENOSPACE (-2)  /* workspace too small */
@@ -193,6 +193,11 @@ int nextou_bti_ce_bwd(const float* logits, const uint8_t* target, const uint8_t*
  *                  r = (1 - momentum) * r + momentum * stat (unbiased variance, as torch does).
  *   training == 0: normalises with running_mean / running_var (required).
  *   y = leaky_relu(x_hat * weight + bias, slope); slope = 1 is the plain normalisation.
+ *   pre_bias     : NULL, or the bias (indexed like weight) of the convolution that produced x when the
+ *                  caller ran that convolution WITHOUT its bias: norm(x + b) == norm(x) under batch
+ *                  statistics, so b only enters the running mean (training) and the shift (inference;
+ *                  save_mean then holds running_mean - b).  Its gradient is identically 0 in training
+ *                  and weight * invstd * gbias in inference — computed by the caller.
  *   save_mean / save_invstd (C floats, may be NULL for inference) feed the backward.
  *   fwd traffic: 2 reads + 1 write of the tensor (training), 1 + 1 (inference).
  *   bwd: gx, gweight[c] = sum dz * x_hat, gbias[c] = sum dz, with dz = gy * (z > 0 ? 1 : slope);
@@ -206,7 +211,7 @@ int nextou_bti_ce_bwd(const float* logits, const uint8_t* target, const uint8_t*
 
 size_t nextou_norm_act_workspace_bytes(int B, int C, int64_t S, int dtype);
 
-int nextou_norm_act_fwd(const void* x, const float* weight, const float* bias,
+int nextou_norm_act_fwd(const void* x, const float* weight, const float* bias, const float* pre_bias,
                         float* running_mean, float* running_var,
                         void* y, float* save_mean, float* save_invstd,
                         void* workspace, size_t workspace_bytes,

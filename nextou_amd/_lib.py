@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("NEXTOU_HIP_LIB") or os.path.join(_PKG_DIR, "libnextou
 
 KNN_AUTO, KNN_FUSED, KNN_NAIVE = 0, 1, 2
 DTYPE_F32, DTYPE_BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # name -> (restype, argtypes); mirrors include/nextou_hip.h one to one
 _SIGNATURES = {
@@ -58,7 +58,7 @@ _SIGNATURES = {
                                         c_int, c_int, c_int, c_int, c_void_p]),
     "nextou_norm_act_workspace_bytes": (c_size_t, [c_int, c_int, c_int64, c_int]),
     "nextou_norm_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_size_t, c_int, c_int, c_int64, c_int, c_int, c_int,
+                                    c_void_p, c_void_p, c_size_t, c_int, c_int, c_int64, c_int, c_int, c_int,
                                     c_float, c_float, c_float, c_void_p]),
     "nextou_norm_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_int, c_int, c_int64, c_int, c_int, c_int,

@@ -189,10 +189,14 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T* __restrict_
 struct ChannelAffine { float scale, shift, mean, invstd; };
 
 // training: batch statistics from the tile partials; inference: the running statistics.
+// pre_bias: the bias of the convolution that produced x, folded in here instead of being added to x
+// (x + b has the same batch-normalised value as x; only the running mean and the inference shift see b).
 __device__ inline ChannelAffine channel_affine(const double2* partial, int tiles, int c, int wmod, double count,
-                                               const float* weight, const float* bias, const float* running_mean,
-                                               const float* running_var, int training, float eps, double* var_out) {
+                                               const float* weight, const float* bias, const float* pre_bias,
+                                               const float* running_mean, const float* running_var, int training,
+                                               float eps, double* var_out) {
     ChannelAffine a;
+    const int pc = wmod > 0 ? c % wmod : c;
     if (training) {
         double s, q;
         channel_sums(partial + (size_t)c * tiles, tiles, s, q);
@@ -203,11 +207,10 @@ __device__ inline ChannelAffine channel_affine(const double2* partial, int tiles
         a.invstd = (float)(1.0 / sqrt(var + (double)eps));
         *var_out = var;
     } else {
-        a.mean = running_mean[c];
+        a.mean = running_mean[c] - (pre_bias ? pre_bias[pc] : 0.f);
         a.invstd = 1.0f / sqrtf(running_var[c] + eps);
         *var_out = 0.0;
     }
-    const int pc = wmod > 0 ? c % wmod : c;
     const float w = weight ? weight[pc] : 1.f, b = bias ? bias[pc] : 0.f;
     a.scale = w * a.invstd;
     a.shift = fmaf(-a.mean, a.scale, b);
@@ -218,6 +221,7 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                             const double2* __restrict__ partial,
                                                             const float* __restrict__ weight, const float* __restrict__ bias,
+                                                            const float* __restrict__ pre_bias,
                                                             float* running_mean, float* running_var,
                                                             float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                             int B, int C, long long cols, int row_len, long long col_len,
@@ -225,14 +229,15 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const T* __restrict_
                                                             int training, float momentum, float eps, float slope) {
     const int c = C - 1 - blockIdx.y;
     double var;
-    const ChannelAffine a = channel_affine(partial, gridDim.x, c, wmod, count, weight, bias, running_mean, running_var,
-                                           training, eps, &var);
+    const ChannelAffine a = channel_affine(partial, gridDim.x, c, wmod, count, weight, bias, pre_bias, running_mean,
+                                           running_var, training, eps, &var);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (save_mean) save_mean[c] = a.mean;
         if (save_invstd) save_invstd[c] = a.invstd;
         if (training && running_mean) {
             const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
-            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * (double)a.mean);
+            const double batch_mean = (double)a.mean + (pre_bias ? (double)pre_bias[wmod > 0 ? c % wmod : c] : 0.0);
+            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * batch_mean);
             running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
         }
     }
@@ -392,7 +397,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 struct NormArgs {
     const void *x, *gy;
     void *y, *gx;
-    const float *weight, *bias;
+    const float *weight, *bias, *pre_bias;
     float *running_mean, *running_var, *save_mean, *save_invstd, *gweight, *gbias;
     double2* partial;
     int B, C;
@@ -413,7 +418,7 @@ void launch_fwd(const NormArgs& a, const TilePlan& p, hipStream_t s, const char*
     }
     ProfScope prof(s, kBoundHbm, 2.0 * bytes, "bn_apply_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
     hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), grid, dim3(kThreads), 0, s, (const T*)a.x, (T*)a.y, a.partial, a.weight,
-                       a.bias, a.running_mean, a.running_var, a.save_mean, a.save_invstd, a.B, a.C, p.cols, p.row_len,
+                       a.bias, a.pre_bias, a.running_mean, a.running_var, a.save_mean, a.save_invstd, a.B, a.C, p.cols, p.row_len,
                        p.col_len, p.col_tiles, p.tw_log2, a.wmod, count, a.training, a.momentum, a.eps, a.slope);
 }
 
@@ -462,8 +467,8 @@ extern "C" size_t nextou_norm_act_workspace_bytes(int B, int C, int64_t S, int d
     return (size_t)C * 1024 * sizeof(double2);  // plan_tiles never cuts a channel into more than 1024 tiles
 }
 
-extern "C" int nextou_norm_act_fwd(const void* x, const float* weight, const float* bias, float* running_mean,
-                                   float* running_var, void* y, float* save_mean, float* save_invstd, void* ws,
+extern "C" int nextou_norm_act_fwd(const void* x, const float* weight, const float* bias, const float* pre_bias,
+                                   float* running_mean, float* running_var, void* y, float* save_mean, float* save_invstd, void* ws,
                                    size_t ws_bytes, int B, int C, int64_t S, int param_period, int dtype, int training,
                                    float momentum, float eps, float slope, nextou_stream_t stream) {
     NEXTOU_REQUIRE(x && y, "norm_act_fwd: null pointer");
@@ -478,7 +483,7 @@ extern "C" int nextou_norm_act_fwd(const void* x, const float* weight, const flo
             return fail(NEXTOU_ENOSPACE, "norm_act_fwd: workspace %zu < %zu bytes", ws_bytes, (size_t)C * p.tiles * sizeof(double2));
     }
     NormArgs a{};
-    a.x = x; a.y = y; a.weight = weight; a.bias = bias; a.running_mean = running_mean; a.running_var = running_var;
+    a.x = x; a.y = y; a.weight = weight; a.bias = bias; a.pre_bias = pre_bias; a.running_mean = running_mean; a.running_var = running_var;
     a.save_mean = save_mean; a.save_invstd = save_invstd; a.partial = (double2*)ws; a.B = B; a.C = C; a.S = S;
     a.wmod = param_period; a.training = training; a.momentum = momentum; a.eps = eps; a.slope = slope;
     norm_dispatch<true>(a, p, dtype, (hipStream_t)stream);

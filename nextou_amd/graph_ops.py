@@ -245,7 +245,8 @@ class _HipBackend:
         return grad
 
     @staticmethod
-    def norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period):
+    def norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period,
+                     pre_bias=None):
         """x (B,C,S) f32/bf16 -> (y, save_mean, save_invstd); running statistics updated in place."""
         L_ = _lib.lib()
         B, C, S = x.shape
@@ -255,7 +256,8 @@ class _HipBackend:
         save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
         ws = torch.empty((int(L_.nextou_norm_act_workspace_bytes(B, C, S, dt)),), dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):
-            rc = L_.nextou_norm_act_fwd(x.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+            rc = L_.nextou_norm_act_fwd(x.data_ptr(), _ptr(weight), _ptr(bias), _ptr(pre_bias), _ptr(running_mean),
+                                        _ptr(running_var),
                                         y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(),
                                         ws.numel(), B, C, S, period, dt, int(training), float(momentum), float(eps),
                                         float(slope), _stream_ptr(x.device))
@@ -474,15 +476,17 @@ class _NormAct(torch.autograd.Function):
     """(batch | instance) norm -> LeakyReLU as one op; saves only ``x`` and 2C floats for backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, instance):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, instance,
+                pre_bias):
         shape = x.shape
         B, C = shape[0], shape[1]
         x3 = x.reshape(1, B * C, -1) if instance else x.reshape(B, C, -1)
         period = C if instance else 0
         be = _backend_for(x)
         y, mean, invstd = be.norm_act_fwd(x3, weight, bias, running_mean, running_var, training, momentum, eps,
-                                          slope, period)
+                                          slope, period, pre_bias)
         ctx.save_for_backward(x3, weight, bias, mean, invstd)
+        ctx.pre_bias_like = pre_bias
         ctx.cfg = (bool(training), float(slope), period, shape, B, C, float(eps))
         return y.view(shape)
 
@@ -496,15 +500,28 @@ class _NormAct(torch.autograd.Function):
         gx, gw, gb = _backend_for(x3).norm_act_bwd(x3, gy3, weight, bias, mean, invstd, training, slope, period, eps)
         if period:
             gw, gb = gw.view(B, C).sum(0), gb.view(B, C).sum(0)
+        gpre = None
+        if ctx.pre_bias_like is not None and ctx.needs_input_grad[10]:
+            # d/d(pre_bias): under batch statistics the output does not depend on it at all; with running
+            # statistics z = (x + b - rm) * invstd * w + beta, so the gradient is w * invstd * sum(dz)
+            if training:
+                gpre = torch.zeros_like(ctx.pre_bias_like)
+            else:
+                gpre = (gb * invstd * (weight if weight is not None else 1.0)).to(ctx.pre_bias_like.dtype)
         gw = gw.to(weight.dtype) if weight is not None and ctx.needs_input_grad[1] else None
         gb = gb.to(bias.dtype) if bias is not None and ctx.needs_input_grad[2] else None
-        return gx.view(shape), gw, gb, None, None, None, None, None, None, None
+        return gx.view(shape), gw, gb, None, None, None, None, None, None, None, gpre
 
 
 def norm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
              running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], training: bool,
-             momentum: float, eps: float, negative_slope: float = 1.0, instance: bool = False) -> torch.Tensor:
-    """``leaky_relu(batch_norm(x) | instance_norm(x), negative_slope)`` on (B,C,*spatial) fp32 / bf16.
+             momentum: float, eps: float, negative_slope: float = 1.0, instance: bool = False,
+             pre_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``leaky_relu(batch_norm(x [+ pre_bias]) | instance_norm(x), negative_slope)`` on (B,C,*spatial) fp32 / bf16.
+
+    ``pre_bias`` (C,) is the bias of the convolution that produced ``x`` when that convolution was run without it:
+    a per-channel constant does not survive batch statistics, so it only has to enter the running mean (training) or
+    the shift (inference) — the conv's bias-gradient reduction over the whole tensor disappears with it.
 
     The fused replacement of ``norm -> act`` in the reference's BasicConv (torch_nn.py:84-90), FFN / fc1 / fc2
     (NexToU_Encoder_Decoder.py:384-390, 710-720, 833-842) and the conv stages' ConvDropoutNormReLU.
@@ -519,8 +536,10 @@ def norm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[tor
         weight = weight.float()
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
+    if pre_bias is not None and pre_bias.dtype != torch.float32:
+        pre_bias = pre_bias.float()
     return _NormAct.apply(x.contiguous(), weight, bias, running_mean, running_var, bool(training), float(momentum),
-                          float(eps), float(negative_slope), bool(instance))
+                          float(eps), float(negative_slope), bool(instance), pre_bias)
 
 
 @torch.no_grad()

@@ -11,8 +11,9 @@ checkpoints interchange with the reference.
 
 :func:`fuse_norm_act` converts a built model in place (class swap — no parameter is copied): every
 ``BatchNorm`` / ``InstanceNorm`` that sits in an ``nn.Sequential`` becomes its fused class and a
-``LeakyReLU`` that directly follows it is absorbed (replaced by ``nn.Identity``).  ``NexToU.__init__``
-applies it unless ``NEXTOU_FUSE_NORM_ACT=0`` (kept for A/B measurements).
+``LeakyReLU`` that directly follows it is absorbed (replaced by ``nn.Identity``); a convolution directly in front of it
+runs without its bias, which the norm folds in (:class:`_ConvBiasFolded`).  ``NexToU.__init__`` applies it unless
+``NEXTOU_FUSE_NORM_ACT=0`` (kept for A/B measurements).
 """
 from __future__ import annotations
 
@@ -24,7 +25,43 @@ from torch import nn
 from .. import graph_ops
 
 __all__ = ["BatchNormAct1d", "BatchNormAct2d", "BatchNormAct3d", "InstanceNormAct1d", "InstanceNormAct2d",
-           "InstanceNormAct3d", "fuse_norm_act", "fusion_enabled"]
+           "InstanceNormAct3d", "ConvBiasFolded1d", "ConvBiasFolded2d", "ConvBiasFolded3d", "fuse_norm_act",
+           "fusion_enabled"]
+
+
+def _pre_bias(norm: nn.Module):
+    """bias of the (bias-free running) convolution in front of ``norm`` — see :class:`_ConvBiasFolded`."""
+    src = getattr(norm, "_pre_bias_src", None)
+    return None if src is None else src[0].bias
+
+
+class _ConvBiasFolded:
+    """A convolution directly followed by a fused norm: its bias is not added to the output tensor.
+
+    ``norm(conv(x) + b)`` does not depend on ``b`` under batch / instance statistics (the mean absorbs it), and with
+    running statistics it is one more term of the shift.  The conv therefore runs bias-free, the fused norm reads
+    ``conv.bias`` (K6's ``pre_bias``) and autograd never launches the bias-gradient reduction over the conv output —
+    a full read of every activation gradient of the network (5.4 ms of the cfg-2 step).  ``bias`` stays a parameter
+    of this module (same ``state_dict`` key); its gradient comes from the norm's backward (exactly 0 in training).
+    """
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._conv_forward(x, self.weight, None)
+
+
+class ConvBiasFolded1d(_ConvBiasFolded, nn.Conv1d):
+    pass
+
+
+class ConvBiasFolded2d(_ConvBiasFolded, nn.Conv2d):
+    pass
+
+
+class ConvBiasFolded3d(_ConvBiasFolded, nn.Conv3d):
+    pass
+
+
+_FOLDED = {nn.Conv1d: ConvBiasFolded1d, nn.Conv2d: ConvBiasFolded2d, nn.Conv3d: ConvBiasFolded3d}
 
 
 class _BatchNormAct:
@@ -42,7 +79,7 @@ class _BatchNormAct:
         return graph_ops.norm_act(x, self.weight, self.bias,
                                   self.running_mean if keep_running else None,
                                   self.running_var if keep_running else None,
-                                  use_batch_stats, factor, self.eps, self.negative_slope)
+                                  use_batch_stats, factor, self.eps, self.negative_slope, pre_bias=_pre_bias(self))
 
     def extra_repr(self) -> str:
         return super().extra_repr() + ", negative_slope=%g" % self.negative_slope
@@ -58,7 +95,7 @@ class _InstanceNormAct:
         if x.dim() == self._get_no_batch_dim():
             return self.forward(x.unsqueeze(0)).squeeze(0)
         return graph_ops.norm_act(x, self.weight, self.bias, None, None, True, 0.0, self.eps, self.negative_slope,
-                                  instance=True)
+                                  instance=True, pre_bias=_pre_bias(self))
 
     def extra_repr(self) -> str:
         return super().extra_repr() + ", negative_slope=%g" % self.negative_slope
@@ -109,6 +146,10 @@ def _convert(norm: nn.Module) -> bool:
     return True
 
 
+def norm_of(seq: nn.Sequential, name: str) -> nn.Module:
+    return seq._modules[name]
+
+
 def fuse_norm_act(root: nn.Module) -> int:
     """In-place conversion described in the module docstring; returns the number of norms converted."""
     converted = 0
@@ -119,6 +160,10 @@ def fuse_norm_act(root: nn.Module) -> int:
                 if not _convert(m._modules[name]):
                     continue
                 converted += 1
+                prev = m._modules[names[i - 1]] if i > 0 else None
+                if type(prev) in _FOLDED and prev.bias is not None and getattr(norm_of(m, name), "_pre_bias_src", None) is None:
+                    prev.__class__ = _FOLDED[type(prev)]
+                    norm_of(m, name)._pre_bias_src = (prev,)       # a tuple: not registered as a sub-module
                 if i + 1 < len(names) and type(m._modules[names[i + 1]]) is nn.LeakyReLU:
                     m._modules[name].negative_slope = float(m._modules[names[i + 1]].negative_slope)
                     m._modules[names[i + 1]] = nn.Identity()

@@ -170,9 +170,11 @@ class CanonicalBackend:
         return out
 
     @staticmethod
-    def norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period):
+    def norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period,
+                     pre_bias=None):
         from .ref_ops import norm_act_fwd_ref
-        return norm_act_fwd_ref(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period)
+        return norm_act_fwd_ref(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period,
+                                pre_bias)
 
     @staticmethod
     def norm_act_bwd(x, gy, weight, bias, save_mean, save_invstd, training, slope, period, eps):

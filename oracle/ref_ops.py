@@ -109,7 +109,11 @@ def _norm_act_ref(x, weight, bias, running_mean, running_var, training, momentum
     return z if slope == 1.0 else F.leaky_relu(z, slope)
 
 
-def norm_act_fwd_ref(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period):
+def norm_act_fwd_ref(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period,
+                     pre_bias=None):
+    if pre_bias is not None:    # the reference adds the conv bias to the tensor itself (conv -> norm)
+        reps = x.shape[1] // pre_bias.numel()
+        x = x + pre_bias.repeat(reps).view(1, -1, 1)
     with torch.no_grad():
         y = _norm_act_ref(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period)
         if training:
@@ -118,6 +122,8 @@ def norm_act_fwd_ref(x, weight, bias, running_mean, running_var, training, momen
             invstd = 1.0 / torch.sqrt(xd.var(dim=(0, 2), unbiased=False) + eps)
         else:
             mean, invstd = running_mean.double(), 1.0 / torch.sqrt(running_var.double() + eps)
+        if pre_bias is not None:   # the backward protocol works on the bias-free tensor: fold b into the saved mean
+            mean = mean - pre_bias.double().repeat(x.shape[1] // pre_bias.numel())
     return y, mean.float(), invstd.float()
 
 
@@ -216,8 +222,10 @@ class TorchRefBackend:
         return CanonicalBackend.bti_ce_bwd(logits, target, critical, scale)
 
     @staticmethod
-    def norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period):
-        return norm_act_fwd_ref(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period)
+    def norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period,
+                     pre_bias=None):
+        return norm_act_fwd_ref(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period,
+                                pre_bias)
 
     @staticmethod
     def norm_act_bwd(x, gy, weight, bias, save_mean, save_invstd, training, slope, period, eps):

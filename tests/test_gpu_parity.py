@@ -655,5 +655,42 @@ def test_sliding_window_inference_on_gpu(ops):
     one = predict_sliding_window(net, image, mc.TINY_3D["patch"], 0.5, True, (0, 1, 2), batch_size=1)
     many = predict_sliding_window(net, image, mc.TINY_3D["patch"], 0.5, True, (0, 1, 2), batch_size=8)
     assert one.shape == (mc.TINY_3D["classes"], 40, 160, 128) and bool(torch.isfinite(one).all())
-    assert float((one - many).abs().max()) <= 1e-4 * float(one.abs().max())
+    # MIOpen picks its algorithms per batch size, and the network is discontinuous in its kNN decisions (SURVEY §7
+    # hard part 0), so batched == sequential only up to round-off amplified by a few flipped neighbours:
+    scale = float(one.abs().max())
+    assert float((one - many).abs().mean()) <= 1e-4 * scale, float((one - many).abs().mean()) / scale
+    assert float((one.argmax(0) == many.argmax(0)).float().mean()) >= 0.995
     assert net.training and net.decoder.deep_supervision is True
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_norm_act_folds_the_conv_bias(ops, training):
+    """norm_act(x, pre_bias=b) == norm(x + b): outputs, running statistics, and every gradient incl. d/db
+    (identically 0 under batch statistics, w * invstd * sum(dz) with running statistics) vs float64."""
+    g = torch.Generator().manual_seed(21)
+    shape, C = (3, 10, 6, 8, 12), 10
+    x = torch.randn(shape, generator=g)
+    pb = torch.randn(C, generator=g) * 2
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    gy = torch.randn(shape, generator=g)
+    xd = x.double().requires_grad_(True)
+    pbd, wd, bd = (t.double().requires_grad_(True) for t in (pb, w, b))
+    rmd, rvd = rm.double().clone(), rv.double().clone()
+    z = F.batch_norm(xd + pbd.view(1, -1, 1, 1, 1), rmd, rvd, wd, bd, training, 0.1, 1e-5)
+    want = F.leaky_relu(z, 0.01)
+    wg = torch.autograd.grad(want, (xd, wd, bd, pbd), gy.double())
+
+    xg = x.to(DEV).requires_grad_(True)
+    pbg, wgp, bgp = (t.to(DEV).requires_grad_(True) for t in (pb, w, b))
+    rmg, rvg = rm.to(DEV), rv.to(DEV)
+    y = ops.norm_act(xg, wgp, bgp, rmg, rvg, training, 0.1, 1e-5, 0.01, pre_bias=pbg)
+    got = torch.autograd.grad(y, (xg, wgp, bgp, pbg), gy.to(DEV))
+    ulp = 2.0 ** -23
+    assert float((y.detach().cpu().double() - want.detach()).abs().max()) <= 8 * ulp * float(want.abs().max())
+    for a, r in zip(got, wg):
+        assert float((a.cpu().double() - r).abs().max()) <= 3e-5 * max(float(r.abs().max()), 1.0)
+    if training:
+        assert float(got[3].abs().max()) == 0.0
+    np.testing.assert_allclose(rmg.cpu().double().numpy(), rmd.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rvg.cpu().double().numpy(), rvd.numpy(), rtol=1e-6, atol=1e-7)

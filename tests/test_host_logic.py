@@ -155,12 +155,16 @@ def test_fuse_norm_act_keeps_state_dict_and_results(cpu_checker):
     assert n_act_fused < n_act_plain
     x = torch.randn(2, 1, 64, 64)
     a, b = plain(x), fused(x)
-    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    # the folded conv bias is added after the convolution instead of inside it: a few ulp, not bit-identical
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max()) <= 2e-5 * float(u.abs().max()), float((u - v).abs().max())
+    assert any(type(m).__name__ == "ConvBiasFolded2d" for m in fused.modules())
     ga = torch.autograd.grad(sum(t.square().mean() for t in a), [p for p in plain.parameters() if p.requires_grad],
                              allow_unused=True)
     gb = torch.autograd.grad(sum(t.square().mean() for t in b), [p for p in fused.parameters() if p.requires_grad],
                              allow_unused=True)
+    gscale = max(float(u.abs().max()) for u in ga if u is not None)
     for u, v in zip(ga, gb):
         assert (u is None) == (v is None)
-        if u is not None:
-            assert float((u - v).abs().max()) <= 1e-5 * max(float(u.abs().max()), 1e-6)
+        if u is not None:   # (a folded conv bias has gradient exactly 0; the reference's is round-off around 0)
+            assert float((u - v).abs().max()) <= 1e-4 * gscale

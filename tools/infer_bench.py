@@ -44,11 +44,7 @@ def main():
     for bs in args.batch:
         kw = dict(tile_step_size=0.5, use_gaussian=True, mirror_axes=axes, batch_size=bs,
                   autocast_dtype=torch.bfloat16 if args.bf16 else None)
-        predict_sliding_window(net, image[:, :cfg.patch_size[0], :cfg.patch_size[1], :cfg.patch_size[2]],
-                               cfg.patch_size, **{**kw, "mirror_axes": None, "batch_size": 1})  # MIOpen find, batch 1
-        if bs > 1:
-            predict_sliding_window(net, image[:, :cfg.patch_size[0], :cfg.patch_size[1], :cfg.patch_size[2] * 2],
-                                   cfg.patch_size, **kw)                                      # find at this batch
+        predict_sliding_window(net, image, cfg.patch_size, **kw)   # warm-up: MIOpen find for every batch size used
         torch.cuda.synchronize()
         t0 = time.time()
         out = predict_sliding_window(net, image, cfg.patch_size, **kw)
