@@ -185,7 +185,9 @@ int nextou_bti_ce_bwd(const float* logits, const uint8_t* target, const uint8_t*
  * NexToU_Encoder_Decoder.py:384-390 (FFN), :710-720 / :833-842 (fc1 / fc2) and the
  * ConvDropoutNormReLU blocks of the conv stages (:125-136, :281-298).  Replaces
  * batch_norm / instance_norm -> leaky_relu and their autograd.
- *   x, y, gy, gx : (B, C, S) contiguous, dtype NEXTOU_DTYPE_F32 or NEXTOU_DTYPE_BF16
+ *   x, y, gy, gx : (B, C, S) contiguous (channels_last = 0), or (B, S, C) contiguous — PyTorch's channels_last /
+ *                  channels_last_3d memory format of the same logical tensor (channels_last = 1; C <= 256,
+ *                  param_period = 0); dtype NEXTOU_DTYPE_F32 or NEXTOU_DTYPE_BF16
  *   weight, bias : float (param_period ? param_period : C) or NULL (= 1 / 0); channel c uses entry
  *                  c % param_period when param_period > 0 (instance norm: period = real channel count)
  *   training != 0: batch statistics (biased variance for the normalisation); when running_mean /
@@ -215,15 +217,22 @@ int nextou_norm_act_fwd(const void* x, const float* weight, const float* bias, c
                         float* running_mean, float* running_var,
                         void* y, float* save_mean, float* save_invstd,
                         void* workspace, size_t workspace_bytes,
-                        int B, int C, int64_t S, int param_period, int dtype, int training,
-                        float momentum, float eps, float slope, nextou_stream_t stream);
+                        int B, int C, int64_t S, int param_period, int dtype, int channels_last,
+                        int training, float momentum, float eps, float slope, nextou_stream_t stream);
 
 int nextou_norm_act_bwd(const void* x, const void* gy, const float* weight, const float* bias,
                         const float* save_mean, const float* save_invstd,
                         void* gx, float* gweight, float* gbias,
                         void* workspace, size_t workspace_bytes,
-                        int B, int C, int64_t S, int param_period, int dtype, int training,
-                        float slope, nextou_stream_t stream);
+                        int B, int C, int64_t S, int param_period, int dtype, int channels_last,
+                        int training, float slope, nextou_stream_t stream);
+
+/* Per-channel sum over batch and space: out[c] = sum_{b,s} x[b,c,s] (float64 accumulation, fixed order) — the bias
+ * gradient of a convolution that is not followed by a norm (segmentation heads, transposed convolutions), which
+ * PyTorch-ROCm computes with a generic reduction that collapses on channels-last tensors (5.5 ms for 727 MB).
+ * Same layouts / dtypes / workspace as nextou_norm_act_fwd. */
+int nextou_channel_sum(const void* x, float* out, void* workspace, size_t workspace_bytes,
+                       int B, int C, int64_t S, int dtype, int channels_last, nextou_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -392,6 +392,298 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const T* __restr
     }
 }
 
+
+// ======================================================================================================
+// Channels-last (N,D,H,W,C) variants — the layout MIOpen's CK convolutions run in natively, used for the
+// full-resolution stages where NCDHW costs a transpose of every activation around every convolution
+// (tools/conv_probe.py: 33 -> 33 channels at 64x224x192: 6.05 ms forward in NCDHW, 3.33 ms in NDHWC).
+// x is R = B*S rows of C contiguous channels.  q = 256 / C rows are covered by the q*C active threads of a workgroup
+// with one 16-byte access each, so a thread owns VEC fixed channels ((t*VEC + j) mod C: every block span and the
+// per-iteration stride are multiples of C) and keeps their sums in registers; the q*VEC partials of each channel meet
+// in LDS in a fixed order.  Per-channel finalisation runs in its own C-workgroup launch between the two passes.
+// ======================================================================================================
+constexpr int kClMaxBlocks = 2048;
+
+struct ClPlan {
+    int vec, tact, blocks;
+    long long span;  // elements per workgroup (multiple of tact * vec)
+};
+
+static ClPlan plan_cl(long long total, int C, int vec_full, bool aligned) {
+    ClPlan p;
+    p.vec = (aligned && total % vec_full == 0) ? vec_full : 1;
+    p.tact = (kThreads / C) * C;
+    const long long per_iter = (long long)p.tact * p.vec;
+    long long iters = cdiv64(total, (long long)kClMaxBlocks * per_iter);
+    if (iters < 4) iters = 4;
+    p.span = iters * per_iter;
+    p.blocks = (int)cdiv64(total, p.span);
+    return p;
+}
+
+template <int VEC>
+__device__ inline void cl_channels(int C, int (&ch)[VEC]) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) ch[j] = (threadIdx.x * VEC + j) % C;
+}
+
+// LDS meeting point: thread c < C adds the q*VEC partials of channel c in index order.
+template <int VEC>
+__device__ inline void cl_block_sums(const double (&a)[VEC], const double (&b)[VEC], int C, int tact, double2* partial,
+                                     int nblocks) {
+    extern __shared__ double2 cl_red[];
+    if ((int)threadIdx.x < tact) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) cl_red[threadIdx.x * VEC + j] = make_double2(a[j], b[j]);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        double s = 0.0, q = 0.0;
+        for (int i = threadIdx.x; i < tact * VEC; i += C) { s += cl_red[i].x; q += cl_red[i].y; }
+        partial[(size_t)threadIdx.x * nblocks + blockIdx.x] = make_double2(s, q);
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void bn_cl_stats_kernel(const T* __restrict__ x, double2* __restrict__ partial,
+                                                               long long total, int C, int tact, long long span) {
+    double s[VEC], q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = q[j] = 0.0;
+    if ((int)threadIdx.x < tact) {
+        const long long base = (long long)blockIdx.x * span;
+        const long long end = min(total, base + span);
+        const long long stride = (long long)tact * VEC;
+        long long e = base + (long long)threadIdx.x * VEC;
+        for (; e + 3 * stride < end; e += 4 * stride) {
+            Pack<T, VEC> p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u].load(x + e + u * stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { const double v = (double)p[u].v[j]; s[j] += v; q[j] = fma(v, v, q[j]); }
+        }
+        for (; e < end; e += stride) {
+            Pack<T, VEC> p;
+            p.load(x + e);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { const double v = (double)p.v[j]; s[j] += v; q[j] = fma(v, v, q[j]); }
+        }
+    }
+    cl_block_sums<VEC>(s, q, C, tact, partial, gridDim.x);
+}
+
+// One wave per channel: statistics -> save_mean / save_invstd (+ running statistics), shared by both layouts' callers.
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const double2* __restrict__ partial, int tiles, double count,
+                                                         const float* __restrict__ pre_bias, float* running_mean,
+                                                         float* running_var, float* __restrict__ save_mean,
+                                                         float* __restrict__ save_invstd, int training, float momentum,
+                                                         float eps) {
+    const int c = blockIdx.x;
+    float mean, invstd;
+    double var = 0.0;
+    if (training) {
+        double s, q;
+        channel_sums(partial + (size_t)c * tiles, tiles, s, q);
+        const double m = s / count;
+        var = q / count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+        mean = running_mean[c] - (pre_bias ? pre_bias[c] : 0.f);
+        invstd = 1.0f / sqrtf(running_var[c] + eps);
+    }
+    if (threadIdx.x == 0) {
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+        if (training && running_mean) {
+            const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            const double batch_mean = (double)mean + (pre_bias ? (double)pre_bias[c] : 0.0);
+            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * batch_mean);
+            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+        }
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void bn_cl_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                               const float* __restrict__ weight, const float* __restrict__ bias,
+                                                               const float* __restrict__ save_mean,
+                                                               const float* __restrict__ save_invstd, long long total, int C,
+                                                               int tact, long long span, float slope) {
+    if ((int)threadIdx.x >= tact) return;
+    int ch[VEC];
+    cl_channels<VEC>(C, ch);
+    float scale[VEC], shift[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const float w = weight ? weight[ch[j]] : 1.f, b = bias ? bias[ch[j]] : 0.f;
+        scale[j] = w * save_invstd[ch[j]];
+        shift[j] = fmaf(-save_mean[ch[j]], scale[j], b);
+    }
+    const long long base = (long long)blockIdx.x * span;
+    const long long end = min(total, base + span);
+    const long long stride = (long long)tact * VEC;
+    long long e = base + (long long)threadIdx.x * VEC;
+    for (; e + 3 * stride < end; e += 4 * stride) {
+        Pack<T, VEC> p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u].load(x + e + u * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) p[u].v[j] = leaky(fmaf(p[u].v[j], scale[j], shift[j]), slope);
+            p[u].store(y + e + u * stride);
+        }
+    }
+    for (; e < end; e += stride) {
+        Pack<T, VEC> p;
+        p.load(x + e);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) p.v[j] = leaky(fmaf(p.v[j], scale[j], shift[j]), slope);
+        p.store(y + e);
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void bn_cl_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ gy,
+                                                                    double2* __restrict__ partial,
+                                                                    const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                    const float* __restrict__ save_mean,
+                                                                    const float* __restrict__ save_invstd, long long total,
+                                                                    int C, int tact, long long span, float slope) {
+    double s1[VEC], s2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.0;
+    if ((int)threadIdx.x < tact) {
+        int ch[VEC];
+        cl_channels<VEC>(C, ch);
+        float scale[VEC], shift[VEC], mean[VEC], invstd[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float w = weight ? weight[ch[j]] : 1.f, b = bias ? bias[ch[j]] : 0.f;
+            mean[j] = save_mean[ch[j]];
+            invstd[j] = save_invstd[ch[j]];
+            scale[j] = w * invstd[j];
+            shift[j] = fmaf(-mean[j], scale[j], b);
+        }
+        const long long base = (long long)blockIdx.x * span;
+        const long long end = min(total, base + span);
+        const long long stride = (long long)tact * VEC;
+        long long e = base + (long long)threadIdx.x * VEC;
+        for (; e + stride < end; e += 2 * stride) {
+            Pack<T, VEC> p[2], g[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { p[u].load(x + e + u * stride); g[u].load(gy + e + u * stride); }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float z = fmaf(p[u].v[j], scale[j], shift[j]);
+                    const float dz = z > 0.f ? g[u].v[j] : g[u].v[j] * slope;
+                    const float xh = (p[u].v[j] - mean[j]) * invstd[j];
+                    s1[j] += (double)dz;
+                    s2[j] = fma((double)dz, (double)xh, s2[j]);
+                }
+        }
+        for (; e < end; e += stride) {
+            Pack<T, VEC> p, g;
+            p.load(x + e);
+            g.load(gy + e);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float z = fmaf(p.v[j], scale[j], shift[j]);
+                const float dz = z > 0.f ? g.v[j] : g.v[j] * slope;
+                const float xh = (p.v[j] - mean[j]) * invstd[j];
+                s1[j] += (double)dz;
+                s2[j] = fma((double)dz, (double)xh, s2[j]);
+            }
+        }
+    }
+    cl_block_sums<VEC>(s1, s2, C, tact, partial, gridDim.x);
+}
+
+// One wave per channel: (sum dz, sum dz*xhat) -> the two projection coefficients + the parameter gradients.
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double2* __restrict__ partial, int tiles, double count,
+                                                             float2* __restrict__ coeff, float* __restrict__ gweight,
+                                                             float* __restrict__ gbias, int training) {
+    const int c = blockIdx.x;
+    double s1, s2;
+    channel_sums(partial + (size_t)c * tiles, tiles, s1, s2);
+    if (threadIdx.x == 0) {
+        coeff[c] = training ? make_float2((float)(s1 / count), (float)(s2 / count)) : make_float2(0.f, 0.f);
+        if (gweight) gweight[c] = (float)s2;
+        if (gbias) gbias[c] = (float)s1;
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void bn_cl_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ gy,
+                                                                   T* __restrict__ gx, const float2* __restrict__ coeff,
+                                                                   const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                   const float* __restrict__ save_mean,
+                                                                   const float* __restrict__ save_invstd, long long total,
+                                                                   int C, int tact, long long span, float slope) {
+    if ((int)threadIdx.x >= tact) return;
+    int ch[VEC];
+    cl_channels<VEC>(C, ch);
+    float scale[VEC], shift[VEC], mean[VEC], invstd[VEC], k1[VEC], k2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const float w = weight ? weight[ch[j]] : 1.f, b = bias ? bias[ch[j]] : 0.f;
+        mean[j] = save_mean[ch[j]];
+        invstd[j] = save_invstd[ch[j]];
+        scale[j] = w * invstd[j];
+        shift[j] = fmaf(-mean[j], scale[j], b);
+        const float2 k = coeff[ch[j]];
+        k1[j] = k.x;
+        k2[j] = k.y;
+    }
+    const long long base = (long long)blockIdx.x * span;
+    const long long end = min(total, base + span);
+    const long long stride = (long long)tact * VEC;
+    long long e = base + (long long)threadIdx.x * VEC;
+    for (; e + stride < end; e += 2 * stride) {
+        Pack<T, VEC> p[2], g[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { p[u].load(x + e + u * stride); g[u].load(gy + e + u * stride); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float z = fmaf(p[u].v[j], scale[j], shift[j]);
+                const float dz = z > 0.f ? g[u].v[j] : g[u].v[j] * slope;
+                const float xh = (p[u].v[j] - mean[j]) * invstd[j];
+                g[u].v[j] = scale[j] * ((dz - k1[j]) - xh * k2[j]);
+            }
+            g[u].store(gx + e + u * stride);
+        }
+    }
+    for (; e < end; e += stride) {
+        Pack<T, VEC> p, g;
+        p.load(x + e);
+        g.load(gy + e);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float z = fmaf(p.v[j], scale[j], shift[j]);
+            const float dz = z > 0.f ? g.v[j] : g.v[j] * slope;
+            const float xh = (p.v[j] - mean[j]) * invstd[j];
+            g.v[j] = scale[j] * ((dz - k1[j]) - xh * k2[j]);
+        }
+        g.store(gx + e);
+    }
+}
+
+// Per-channel sum as float (the bias gradient of a convolution that is not followed by a norm).
+__global__ __launch_bounds__(64) void channel_sum_finalize_kernel(const double2* __restrict__ partial, int tiles,
+                                                                  float* __restrict__ out) {
+    double s, q;
+    channel_sums(partial + (size_t)blockIdx.x * tiles, tiles, s, q);
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)s;
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 struct NormArgs {
@@ -450,11 +742,66 @@ static void norm_dispatch(const NormArgs& a, const TilePlan& p, int dtype, hipSt
     }
 }
 
-static int check_common(const char* what, int B, int C, int64_t S, int param_period, int dtype) {
+static int check_common(const char* what, int B, int C, int64_t S, int param_period, int dtype, int channels_last) {
     NEXTOU_REQUIRE(B > 0 && C > 0 && C <= 65535 && S > 0, "%s: bad size B=%d C=%d S=%lld", what, B, C, (long long)S);
     NEXTOU_REQUIRE(dtype == NEXTOU_DTYPE_F32 || dtype == NEXTOU_DTYPE_BF16, "%s: dtype %d not in {f32, bf16}", what, dtype);
     NEXTOU_REQUIRE(param_period >= 0, "%s: param_period=%d", what, param_period);
+    if (channels_last) {
+        if (C > kThreads) return fail(NEXTOU_ENOTSUP, "%s: channels-last layout supports C <= %d (got %d)", what, kThreads, C);
+        if (param_period) return fail(NEXTOU_ENOTSUP, "%s: channels-last layout has no instance-norm mode", what);
+    }
     return 0;
+}
+
+constexpr size_t kCoeffOffset(int C) { return (size_t)C * kClMaxBlocks * sizeof(double2); }
+
+template <typename T, int VEC>
+void launch_cl_fwd(const NormArgs& a, const ClPlan& p, hipStream_t s, const char* tname) {
+    const long long total = (long long)a.B * a.C * a.S;
+    const double bytes = (double)total * sizeof(T);
+    const double count = (double)a.B * (double)a.S;
+    const size_t lds = (size_t)p.tact * VEC * sizeof(double2);
+    if (a.training) {
+        ProfScope prof(s, kBoundHbm, bytes, "bn_cl_stats_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
+        hipLaunchKernelGGL((bn_cl_stats_kernel<T, VEC>), dim3(p.blocks), dim3(kThreads), lds, s, (const T*)a.x, a.partial,
+                           total, a.C, p.tact, p.span);
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(64), 0, s, a.partial, p.blocks, count, a.pre_bias,
+                       a.running_mean, a.running_var, a.save_mean, a.save_invstd, a.training, a.momentum, a.eps);
+    ProfScope prof(s, kBoundHbm, 2.0 * bytes, "bn_cl_apply_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
+    hipLaunchKernelGGL((bn_cl_apply_kernel<T, VEC>), dim3(p.blocks), dim3(kThreads), 0, s, (const T*)a.x, (T*)a.y, a.weight,
+                       a.bias, a.save_mean, a.save_invstd, total, a.C, p.tact, p.span, a.slope);
+}
+
+template <typename T, int VEC>
+void launch_cl_bwd(const NormArgs& a, const ClPlan& p, hipStream_t s, const char* tname) {
+    const long long total = (long long)a.B * a.C * a.S;
+    const double bytes = (double)total * sizeof(T);
+    const double count = (double)a.B * (double)a.S;
+    const size_t lds = (size_t)p.tact * VEC * sizeof(double2);
+    float2* coeff = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.partial) + kCoeffOffset(a.C));
+    {
+        ProfScope prof(s, kBoundHbm, 2.0 * bytes, "bn_cl_bwd_reduce_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
+        hipLaunchKernelGGL((bn_cl_bwd_reduce_kernel<T, VEC>), dim3(p.blocks), dim3(kThreads), lds, s, (const T*)a.x,
+                           (const T*)a.gy, a.partial, a.weight, a.bias, a.save_mean, a.save_invstd, total, a.C, p.tact,
+                           p.span, a.slope);
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.C), dim3(64), 0, s, a.partial, p.blocks, count, coeff, a.gweight,
+                       a.gbias, a.training);
+    ProfScope prof(s, kBoundHbm, 3.0 * bytes, "bn_cl_bwd_apply_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
+    hipLaunchKernelGGL((bn_cl_bwd_apply_kernel<T, VEC>), dim3(p.blocks), dim3(kThreads), 0, s, (const T*)a.x, (const T*)a.gy,
+                       (T*)a.gx, coeff, a.weight, a.bias, a.save_mean, a.save_invstd, total, a.C, p.tact, p.span, a.slope);
+}
+
+template <bool FWD>
+static void norm_dispatch_cl(const NormArgs& a, const ClPlan& p, int dtype, hipStream_t s) {
+    if (dtype == NEXTOU_DTYPE_F32) {
+        if (p.vec == 4) FWD ? launch_cl_fwd<float, 4>(a, p, s, "f32") : launch_cl_bwd<float, 4>(a, p, s, "f32");
+        else FWD ? launch_cl_fwd<float, 1>(a, p, s, "f32,scalar") : launch_cl_bwd<float, 1>(a, p, s, "f32,scalar");
+    } else {
+        if (p.vec == 8) FWD ? launch_cl_fwd<__hip_bfloat16, 8>(a, p, s, "bf16") : launch_cl_bwd<__hip_bfloat16, 8>(a, p, s, "bf16");
+        else FWD ? launch_cl_fwd<__hip_bfloat16, 1>(a, p, s, "bf16,scalar") : launch_cl_bwd<__hip_bfloat16, 1>(a, p, s, "bf16,scalar");
+    }
 }
 
 }  // namespace nextou
@@ -464,28 +811,37 @@ using namespace nextou;
 extern "C" size_t nextou_norm_act_workspace_bytes(int B, int C, int64_t S, int dtype) {
     (void)B; (void)S; (void)dtype;
     if (C <= 0) return 0;
-    return (size_t)C * 1024 * sizeof(double2);  // plan_tiles never cuts a channel into more than 1024 tiles
+    // tile partials (NCDHW: <= 1024 tiles per channel, channels-last: <= 2048 workgroups) + the backward's coefficients
+    return kCoeffOffset(C) + (size_t)C * sizeof(float2) + 256;
 }
 
 extern "C" int nextou_norm_act_fwd(const void* x, const float* weight, const float* bias, const float* pre_bias,
                                    float* running_mean, float* running_var, void* y, float* save_mean, float* save_invstd, void* ws,
-                                   size_t ws_bytes, int B, int C, int64_t S, int param_period, int dtype, int training,
-                                   float momentum, float eps, float slope, nextou_stream_t stream) {
+                                   size_t ws_bytes, int B, int C, int64_t S, int param_period, int dtype, int channels_last,
+                                   int training, float momentum, float eps, float slope, nextou_stream_t stream) {
     NEXTOU_REQUIRE(x && y, "norm_act_fwd: null pointer");
-    if (int rc = check_common("norm_act_fwd", B, C, S, param_period, dtype)) return rc;
+    if (int rc = check_common("norm_act_fwd", B, C, S, param_period, dtype, channels_last)) return rc;
     NEXTOU_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "norm_act_fwd: running_mean / running_var must come together");
     NEXTOU_REQUIRE(training || running_mean, "norm_act_fwd: inference needs the running statistics");
     const int esz = dtype == NEXTOU_DTYPE_BF16 ? 2 : 4;
+    NormArgs a{};
+    a.x = x; a.y = y; a.weight = weight; a.bias = bias; a.pre_bias = pre_bias; a.running_mean = running_mean; a.running_var = running_var;
+    a.save_mean = save_mean; a.save_invstd = save_invstd; a.partial = (double2*)ws; a.B = B; a.C = C; a.S = S;
+    a.wmod = param_period; a.training = training; a.momentum = momentum; a.eps = eps; a.slope = slope;
+    if (channels_last) {
+        NEXTOU_REQUIRE(save_mean && save_invstd, "norm_act_fwd: the channels-last path needs save_mean / save_invstd");
+        NEXTOU_REQUIRE(!training || (ws && ws_bytes >= nextou_norm_act_workspace_bytes(B, C, S, dtype)),
+                       "norm_act_fwd: workspace %zu < %zu bytes", ws_bytes, nextou_norm_act_workspace_bytes(B, C, S, dtype));
+        const ClPlan p = plan_cl((long long)B * C * S, C, 16 / esz, aligned16(x) && aligned16(y));
+        norm_dispatch_cl<true>(a, p, dtype, (hipStream_t)stream);
+        return check_launch("bn_cl_apply_kernel");
+    }
     const TilePlan p = plan_tiles(B, C, S, 16 / esz, aligned16(x) && aligned16(y));
     if (training) {
         NEXTOU_REQUIRE(ws, "norm_act_fwd: null workspace");
         if (ws_bytes < (size_t)C * p.tiles * sizeof(double2))
             return fail(NEXTOU_ENOSPACE, "norm_act_fwd: workspace %zu < %zu bytes", ws_bytes, (size_t)C * p.tiles * sizeof(double2));
     }
-    NormArgs a{};
-    a.x = x; a.y = y; a.weight = weight; a.bias = bias; a.pre_bias = pre_bias; a.running_mean = running_mean; a.running_var = running_var;
-    a.save_mean = save_mean; a.save_invstd = save_invstd; a.partial = (double2*)ws; a.B = B; a.C = C; a.S = S;
-    a.wmod = param_period; a.training = training; a.momentum = momentum; a.eps = eps; a.slope = slope;
     norm_dispatch<true>(a, p, dtype, (hipStream_t)stream);
     return check_launch("bn_apply_kernel");
 }
@@ -493,18 +849,66 @@ extern "C" int nextou_norm_act_fwd(const void* x, const float* weight, const flo
 extern "C" int nextou_norm_act_bwd(const void* x, const void* gy, const float* weight, const float* bias,
                                    const float* save_mean, const float* save_invstd, void* gx, float* gweight,
                                    float* gbias, void* ws, size_t ws_bytes, int B, int C, int64_t S, int param_period,
-                                   int dtype, int training, float slope, nextou_stream_t stream) {
+                                   int dtype, int channels_last, int training, float slope, nextou_stream_t stream) {
     NEXTOU_REQUIRE(x && gy && gx && save_mean && save_invstd && ws, "norm_act_bwd: null pointer");
-    if (int rc = check_common("norm_act_bwd", B, C, S, param_period, dtype)) return rc;
+    if (int rc = check_common("norm_act_bwd", B, C, S, param_period, dtype, channels_last)) return rc;
     const int esz = dtype == NEXTOU_DTYPE_BF16 ? 2 : 4;
-    const TilePlan p = plan_tiles(B, C, S, 16 / esz, aligned16(x) && aligned16(gy) && aligned16(gx));
-    if (ws_bytes < (size_t)C * p.tiles * sizeof(double2))
-        return fail(NEXTOU_ENOSPACE, "norm_act_bwd: workspace %zu < %zu bytes", ws_bytes, (size_t)C * p.tiles * sizeof(double2));
     NormArgs a{};
     a.x = x; a.gy = gy; a.gx = gx; a.weight = weight; a.bias = bias;
     a.save_mean = const_cast<float*>(save_mean); a.save_invstd = const_cast<float*>(save_invstd);
     a.gweight = gweight; a.gbias = gbias; a.partial = (double2*)ws; a.B = B; a.C = C; a.S = S; a.wmod = param_period;
     a.training = training; a.slope = slope;
+    if (channels_last) {
+        if (ws_bytes < nextou_norm_act_workspace_bytes(B, C, S, dtype))
+            return fail(NEXTOU_ENOSPACE, "norm_act_bwd: workspace %zu < %zu bytes", ws_bytes, nextou_norm_act_workspace_bytes(B, C, S, dtype));
+        const ClPlan p = plan_cl((long long)B * C * S, C, 16 / esz, aligned16(x) && aligned16(gy) && aligned16(gx));
+        norm_dispatch_cl<false>(a, p, dtype, (hipStream_t)stream);
+        return check_launch("bn_cl_bwd_apply_kernel");
+    }
+    const TilePlan p = plan_tiles(B, C, S, 16 / esz, aligned16(x) && aligned16(gy) && aligned16(gx));
+    if (ws_bytes < (size_t)C * p.tiles * sizeof(double2))
+        return fail(NEXTOU_ENOSPACE, "norm_act_bwd: workspace %zu < %zu bytes", ws_bytes, (size_t)C * p.tiles * sizeof(double2));
     norm_dispatch<false>(a, p, dtype, (hipStream_t)stream);
     return check_launch("bn_bwd_apply_kernel");
+}
+
+extern "C" int nextou_channel_sum(const void* x, float* out, void* ws, size_t ws_bytes, int B, int C, int64_t S, int dtype,
+                                  int channels_last, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(x && out && ws, "channel_sum: null pointer");
+    if (int rc = check_common("channel_sum", B, C, S, 0, dtype, channels_last)) return rc;
+    if (ws_bytes < nextou_norm_act_workspace_bytes(B, C, S, dtype))
+        return fail(NEXTOU_ENOSPACE, "channel_sum: workspace %zu < %zu bytes", ws_bytes, nextou_norm_act_workspace_bytes(B, C, S, dtype));
+    hipStream_t s = (hipStream_t)stream;
+    const int esz = dtype == NEXTOU_DTYPE_BF16 ? 2 : 4;
+    const double bytes = (double)B * C * (double)S * esz;
+    double2* partial = (double2*)ws;
+    int tiles;
+    ProfScope prof(s, kBoundHbm, bytes, "channel_sum<%s,%s>[B%d C%d S%lld]", esz == 2 ? "bf16" : "f32",
+                   channels_last ? "ndhwc" : "ncdhw", B, C, (long long)S);
+    if (channels_last) {
+        const long long total = (long long)B * C * S;
+        const ClPlan p = plan_cl(total, C, 16 / esz, aligned16(x));
+        tiles = p.blocks;
+        const size_t lds = (size_t)p.tact * p.vec * sizeof(double2);
+        if (esz == 4) {
+            if (p.vec == 4) hipLaunchKernelGGL((bn_cl_stats_kernel<float, 4>), dim3(p.blocks), dim3(kThreads), lds, s, (const float*)x, partial, total, C, p.tact, p.span);
+            else hipLaunchKernelGGL((bn_cl_stats_kernel<float, 1>), dim3(p.blocks), dim3(kThreads), lds, s, (const float*)x, partial, total, C, p.tact, p.span);
+        } else {
+            if (p.vec == 8) hipLaunchKernelGGL((bn_cl_stats_kernel<__hip_bfloat16, 8>), dim3(p.blocks), dim3(kThreads), lds, s, (const __hip_bfloat16*)x, partial, total, C, p.tact, p.span);
+            else hipLaunchKernelGGL((bn_cl_stats_kernel<__hip_bfloat16, 1>), dim3(p.blocks), dim3(kThreads), lds, s, (const __hip_bfloat16*)x, partial, total, C, p.tact, p.span);
+        }
+    } else {
+        const TilePlan p = plan_tiles(B, C, S, 16 / esz, aligned16(x));
+        tiles = p.tiles;
+        const dim3 grid(p.tiles, C);
+        if (esz == 4) {
+            if (p.vec == 4) hipLaunchKernelGGL((bn_stats_kernel<float, 4>), grid, dim3(kThreads), 0, s, (const float*)x, partial, B, C, p.cols, p.row_len, p.col_len, p.col_tiles, p.tw_log2);
+            else hipLaunchKernelGGL((bn_stats_kernel<float, 1>), grid, dim3(kThreads), 0, s, (const float*)x, partial, B, C, p.cols, p.row_len, p.col_len, p.col_tiles, p.tw_log2);
+        } else {
+            if (p.vec == 8) hipLaunchKernelGGL((bn_stats_kernel<__hip_bfloat16, 8>), grid, dim3(kThreads), 0, s, (const __hip_bfloat16*)x, partial, B, C, p.cols, p.row_len, p.col_len, p.col_tiles, p.tw_log2);
+            else hipLaunchKernelGGL((bn_stats_kernel<__hip_bfloat16, 1>), grid, dim3(kThreads), 0, s, (const __hip_bfloat16*)x, partial, B, C, p.cols, p.row_len, p.col_len, p.col_tiles, p.tw_log2);
+        }
+    }
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C), dim3(64), 0, s, partial, tiles, out);
+    return check_launch("channel_sum");
 }

@@ -246,10 +246,12 @@ class _HipBackend:
 
     @staticmethod
     def norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period,
-                     pre_bias=None):
-        """x (B,C,S) f32/bf16 -> (y, save_mean, save_invstd); running statistics updated in place."""
+                     pre_bias=None, channels_last=False):
+        """x (B,C,S) f32/bf16 — or, with ``channels_last``, a dense channels_last(_3d) tensor (B,C,*sp) —
+        -> (y, save_mean, save_invstd); running statistics updated in place."""
         L_ = _lib.lib()
-        B, C, S = x.shape
+        B, C = x.shape[:2]
+        S = x.numel() // (B * C)
         dt = _NORM_DTYPES[x.dtype]
         y = torch.empty_like(x)
         save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
@@ -259,16 +261,19 @@ class _HipBackend:
             rc = L_.nextou_norm_act_fwd(x.data_ptr(), _ptr(weight), _ptr(bias), _ptr(pre_bias), _ptr(running_mean),
                                         _ptr(running_var),
                                         y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(),
-                                        ws.numel(), B, C, S, period, dt, int(training), float(momentum), float(eps),
-                                        float(slope), _stream_ptr(x.device))
+                                        ws.numel(), B, C, S, period, dt, int(channels_last), int(training),
+                                        float(momentum), float(eps), float(slope), _stream_ptr(x.device))
         _lib.check(rc, "norm_act_fwd")
         return y, save_mean, save_invstd
 
     @staticmethod
-    def norm_act_bwd(x, gy, weight, bias, save_mean, save_invstd, training, slope, period, eps=0.0):
-        """(``eps`` is only read by the CPU checker.)  -> (gx, gweight (C,), gbias (C,)) — per normalised channel; the caller folds instance-norm rows."""
+    def norm_act_bwd(x, gy, weight, bias, save_mean, save_invstd, training, slope, period, eps=0.0,
+                     channels_last=False):
+        """(``eps`` is only read by the CPU checker.)  -> (gx, gweight (C,), gbias (C,)) — per normalised channel;
+        the caller folds instance-norm rows.  ``gy`` must have the memory layout of ``x``."""
         L_ = _lib.lib()
-        B, C, S = x.shape
+        B, C = x.shape[:2]
+        S = x.numel() // (B * C)
         dt = _NORM_DTYPES[x.dtype]
         gx = torch.empty_like(x)
         gw = torch.empty((C,), dtype=torch.float32, device=x.device)
@@ -277,10 +282,25 @@ class _HipBackend:
         with torch.cuda.device(x.device):
             rc = L_.nextou_norm_act_bwd(x.data_ptr(), gy.data_ptr(), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
                                         save_invstd.data_ptr(), gx.data_ptr(), gw.data_ptr(), gb.data_ptr(),
-                                        ws.data_ptr(), ws.numel(), B, C, S, period, dt, int(training), float(slope),
-                                        _stream_ptr(x.device))
+                                        ws.data_ptr(), ws.numel(), B, C, S, period, dt, int(channels_last),
+                                        int(training), float(slope), _stream_ptr(x.device))
         _lib.check(rc, "norm_act_bwd")
         return gx, gw, gb
+
+    @staticmethod
+    def channel_sum(x, channels_last=False):
+        """(C,) float32 sums over batch and space of x (B,C,*sp) in either memory layout."""
+        L_ = _lib.lib()
+        B, C = x.shape[:2]
+        S = x.numel() // (B * C)
+        dt = _NORM_DTYPES[x.dtype]
+        out = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((int(L_.nextou_norm_act_workspace_bytes(B, C, S, dt)),), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L_.nextou_channel_sum(x.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, C, S, dt,
+                                       int(channels_last), _stream_ptr(x.device))
+        _lib.check(rc, "channel_sum")
+        return out
 
 
 _NORM_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16}
@@ -480,24 +500,37 @@ class _NormAct(torch.autograd.Function):
                 pre_bias):
         shape = x.shape
         B, C = shape[0], shape[1]
-        x3 = x.reshape(1, B * C, -1) if instance else x.reshape(B, C, -1)
         period = C if instance else 0
         be = _backend_for(x)
-        y, mean, invstd = be.norm_act_fwd(x3, weight, bias, running_mean, running_var, training, momentum, eps,
-                                          slope, period, pre_bias)
-        ctx.save_for_backward(x3, weight, bias, mean, invstd)
+        cl = _dense_channels_last(x) if (x.is_cuda and not instance and C <= 256) else None
+        if cl is not None:      # NDHWC / NHWC memory goes to the channels-last kernels as it is
+            y, mean, invstd = be.norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps,
+                                              slope, 0, pre_bias, channels_last=True)
+            ctx.save_for_backward(x, weight, bias, mean, invstd)
+        else:
+            x3 = x.contiguous()
+            x3 = x3.view(1, B * C, -1) if instance else x3.view(B, C, -1)
+            y, mean, invstd = be.norm_act_fwd(x3, weight, bias, running_mean, running_var, training, momentum, eps,
+                                              slope, period, pre_bias)
+            y = y.view(shape)
+            ctx.save_for_backward(x3, weight, bias, mean, invstd)
         ctx.pre_bias_like = pre_bias
-        ctx.cfg = (bool(training), float(slope), period, shape, B, C, float(eps))
-        return y.view(shape)
+        ctx.cfg = (bool(training), float(slope), period, shape, B, C, float(eps), cl)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
         x3, weight, bias, mean, invstd = ctx.saved_tensors
-        training, slope, period, shape, B, C, eps = ctx.cfg
-        gy3 = gy.contiguous().view(x3.shape)
-        if gy3.dtype != x3.dtype:
-            gy3 = gy3.to(x3.dtype)
-        gx, gw, gb = _backend_for(x3).norm_act_bwd(x3, gy3, weight, bias, mean, invstd, training, slope, period, eps)
+        training, slope, period, shape, B, C, eps, cl = ctx.cfg
+        if gy.dtype != x3.dtype:
+            gy = gy.to(x3.dtype)
+        if cl is not None:
+            gx, gw, gb = _backend_for(x3).norm_act_bwd(x3, gy.contiguous(memory_format=cl), weight, bias, mean, invstd,
+                                                       training, slope, 0, eps, channels_last=True)
+        else:
+            gx, gw, gb = _backend_for(x3).norm_act_bwd(x3, gy.contiguous().view(x3.shape), weight, bias, mean, invstd,
+                                                       training, slope, period, eps)
+            gx = gx.view(shape)
         if period:
             gw, gb = gw.view(B, C).sum(0), gb.view(B, C).sum(0)
         gpre = None
@@ -510,7 +543,7 @@ class _NormAct(torch.autograd.Function):
                 gpre = (gb * invstd * (weight if weight is not None else 1.0)).to(ctx.pre_bias_like.dtype)
         gw = gw.to(weight.dtype) if weight is not None and ctx.needs_input_grad[1] else None
         gb = gb.to(bias.dtype) if bias is not None and ctx.needs_input_grad[2] else None
-        return gx.view(shape), gw, gb, None, None, None, None, None, None, None, gpre
+        return gx, gw, gb, None, None, None, None, None, None, None, gpre
 
 
 def norm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
@@ -538,8 +571,59 @@ def norm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[tor
         bias = bias.float()
     if pre_bias is not None and pre_bias.dtype != torch.float32:
         pre_bias = pre_bias.float()
-    return _NormAct.apply(x.contiguous(), weight, bias, running_mean, running_var, bool(training), float(momentum),
+    return _NormAct.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum),
                           float(eps), float(negative_slope), bool(instance), pre_bias)
+
+
+def _dense_channels_last(x: torch.Tensor):
+    """torch.channels_last(_3d) when ``x`` is stored (B,*spatial,C)-contiguous with C > 1 and is NOT also
+    (B,C,*spatial)-contiguous; ``None`` otherwise (C = 1 and 1x1.. tensors are the same bytes in both layouts)."""
+    mf = {4: torch.channels_last, 5: torch.channels_last_3d}.get(x.dim())
+    if mf is None or x.shape[1] == 1 or x.is_contiguous() or not x.is_contiguous(memory_format=mf):
+        return None
+    return mf
+
+
+class _ConvOwnBiasGrad(torch.autograd.Function):
+    """``aten.convolution`` whose bias gradient is K6's per-channel sum instead of ATen's generic reduction (which
+    collapses on channels-last tensors: 5.5 ms for the 727 MB gradient of cfg 2's full-resolution stage)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation, transposed, output_padding, groups):
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_dtype("cuda")
+            x, weight = x.to(dt), weight.to(dt)
+            bias_c = None if bias is None else bias.to(dt)
+        else:
+            bias_c = bias
+        with torch.autocast("cuda", enabled=False):
+            y = torch.ops.aten.convolution(x, weight, bias_c, stride, padding, dilation, transposed, output_padding, groups)
+        ctx.save_for_backward(x, weight)
+        ctx.conf = (stride, padding, dilation, transposed, output_padding, groups)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, padding, dilation, transposed, output_padding, groups = ctx.conf
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        cl = _dense_channels_last(gy)
+        if cl is None:
+            gy = gy.contiguous()
+        gx, gw, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, stride, padding, dilation, transposed,
+                                                        output_padding, groups,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        gb = None
+        if ctx.needs_input_grad[2]:
+            gb = _backend_for(gy).channel_sum(gy, channels_last=cl is not None)
+        return gx, gw, gb, None, None, None, None, None, None
+
+
+def conv_own_bias_grad(x, weight, bias, stride, padding, dilation, transposed, output_padding, groups):
+    """N-d (transposed) convolution with bias on the GPU; see :class:`_ConvOwnBiasGrad`."""
+    return _ConvOwnBiasGrad.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation), bool(transposed),
+                                  tuple(output_padding), int(groups))
 
 
 @torch.no_grad()

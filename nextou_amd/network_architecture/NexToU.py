@@ -14,6 +14,7 @@ from torch.nn.modules.dropout import _DropoutNd
 
 from .NexToU_Encoder_Decoder import NexToU_Decoder, NexToU_Encoder
 from .conv_blocks import convert_conv_op_to_dim
+from .layout import channels_last_stages
 from .norm_act import fuse_norm_act, fusion_enabled
 
 
@@ -59,6 +60,8 @@ class NexToU(nn.Module):
                                       deep_supervision, nonlin_first=nonlin_first)
         if fusion_enabled():  # (norm -> LeakyReLU) pairs become one K6 launch; state_dict unchanged
             fuse_norm_act(self)
+            # the plain conv stages run channels-last on the GPU (layout.py); needs K6's NDHWC kernels, hence here
+            self.encoder.channels_last_stages = channels_last_stages(conv_op, self.encoder.n_conv_stages)
 
     def forward(self, x):
         return self.decoder(self.encoder(x))

@@ -33,6 +33,7 @@ from torch.nn.modules.dropout import _DropoutNd
 
 from .. import graph_ops
 from .conv_blocks import StackedConvBlocks, get_matching_convtransp, maybe_convert_scalar_to_list
+from .layout import set_stage_layout
 from .pos_embed import get_2d_relative_pos_embed, get_3d_relative_pos_embed  # noqa: F401 (re-export)
 from .pos_embed import get_nd_relative_pos_embed
 from .torch_edge import DenseDilatedKnnGraph
@@ -574,10 +575,12 @@ class NexToU_Encoder(nn.Module):
         self.conv_bias = conv_bias
         self.kernel_sizes = kernel_sizes
 
+    channels_last_stages = frozenset()   # set by NexToU.__init__ (network_architecture/layout.py)
+
     def forward(self, x):
         skips = []
-        for stage in self.stages:
-            x = stage(x)
+        for s, stage in enumerate(self.stages):
+            x = stage(set_stage_layout(x, s in self.channels_last_stages))
             skips.append(x)
         return skips if self.return_skips else skips[-1]
 
@@ -658,6 +661,8 @@ class NexToU_Decoder(nn.Module):
         outputs = []
         last = len(self.stages) - 1
         for s, stage in enumerate(self.stages):
+            # decoder stage s works at the resolution (and in the memory layout) of encoder stage last - s
+            x = set_stage_layout(x, (last - s) in self.encoder.channels_last_stages)
             x = self.transpconvs[s](x)
             x = stage(torch.cat((x, skips[-(s + 2)]), 1))
             if self.deep_supervision:

@@ -1,0 +1,48 @@
+"""Memory-layout policy of the conv stages: which resolution stages run channels-last (N,D,H,W,C).
+
+MIOpen's CK convolutions are NDHWC kernels; fed NCDHW tensors, every convolution is wrapped in
+``batched_transpose`` launches (35 ms of the cfg-2 step, profiles/r01_cfg2_step_kernel_trace_k6.md).  At the
+full-resolution stages that wrapper costs as much as the convolution itself (tools/conv_probe.py: 33 -> 33 channels
+at 64x224x192, forward 6.05 ms NCDHW vs 3.33 ms NDHWC), so the plain conv stages (no graph blocks) of 3-D models keep
+their activations channels-last from the stage input to the stage output; the graph stages need (B, C, N) rows and
+stay NCDHW.  What made channels-last unusable on stock PyTorch-ROCm — MIOpen's NHWC batch norm and ATen's bias-gradient
+reduction (170 ms on the two stages, tools/layout_probe.py) — is K6's job here (csrc/norm_act.hip).
+
+``NEXTOU_CHANNELS_LAST_STAGES``: ``auto`` (default), ``none``, or a comma list of stage indices.
+"""
+from __future__ import annotations
+
+import os
+from typing import FrozenSet
+
+import torch
+from torch import nn
+
+
+def channels_last_stages(conv_op, n_plain_conv_stages: int) -> FrozenSet[int]:
+    spec = os.environ.get("NEXTOU_CHANNELS_LAST_STAGES", "auto").strip().lower()
+    if spec in ("none", "", "0x"):
+        return frozenset()
+    if spec == "auto":
+        return frozenset(range(n_plain_conv_stages)) if conv_op is nn.Conv3d else frozenset()
+    return frozenset(int(t) for t in spec.split(",") if t.strip() != "")
+
+
+def to_channels_last(x: torch.Tensor) -> torch.Tensor:
+    """channels_last / channels_last_3d view or copy of (B,C,*spatial).  A single-channel tensor is the same bytes in
+    both layouts; it is re-strided (stride 1 on the channel axis) so that the convolution that consumes it picks the
+    channels-last kernels and produces a channels-last output."""
+    mf = {4: torch.channels_last, 5: torch.channels_last_3d}[x.dim()]
+    if x.shape[1] == 1:
+        x = x.contiguous()
+        strides = list(x.stride())
+        strides[1] = 1
+        return x.as_strided(x.shape, strides)
+    return x.contiguous(memory_format=mf)
+
+
+def set_stage_layout(x: torch.Tensor, channels_last: bool) -> torch.Tensor:
+    """Layout conversion at a stage boundary; only device tensors are ever moved (the CPU checker path is NCDHW)."""
+    if not x.is_cuda:
+        return x
+    return to_channels_last(x) if channels_last else x.contiguous()

@@ -25,8 +25,8 @@ from torch import nn
 from .. import graph_ops
 
 __all__ = ["BatchNormAct1d", "BatchNormAct2d", "BatchNormAct3d", "InstanceNormAct1d", "InstanceNormAct2d",
-           "InstanceNormAct3d", "ConvBiasFolded1d", "ConvBiasFolded2d", "ConvBiasFolded3d", "fuse_norm_act",
-           "fusion_enabled"]
+           "InstanceNormAct3d", "ConvBiasFolded1d", "ConvBiasFolded2d", "ConvBiasFolded3d", "ConvOwnBias2d",
+           "ConvOwnBias3d", "ConvTransposeOwnBias2d", "ConvTransposeOwnBias3d", "fuse_norm_act", "fusion_enabled"]
 
 
 def _pre_bias(norm: nn.Module):
@@ -62,6 +62,47 @@ class ConvBiasFolded3d(_ConvBiasFolded, nn.Conv3d):
 
 
 _FOLDED = {nn.Conv1d: ConvBiasFolded1d, nn.Conv2d: ConvBiasFolded2d, nn.Conv3d: ConvBiasFolded3d}
+
+
+class _ConvOwnBias:
+    """A biased convolution that is NOT followed by a norm (segmentation heads, transposed convolutions): same
+    forward, but the bias gradient is K6's per-channel sum (graph_ops.conv_own_bias_grad) — ATen's generic reduction
+    needs 5.5 ms for the 727 MB channels-last gradient of cfg 2's full-resolution transposed convolution."""
+
+    def _own(self, x):
+        return x.is_cuda and self.bias is not None and not isinstance(self.padding, str) and \
+            getattr(self, "padding_mode", "zeros") == "zeros"
+
+    def forward(self, x: torch.Tensor, *args) -> torch.Tensor:
+        if not self._own(x) or args:
+            return super().forward(x, *args)
+        n = len(self.stride)
+        if self.transposed:
+            out_pad = self._output_padding(x, None, self.stride, self.padding, self.kernel_size, n, self.dilation)
+        else:
+            out_pad = (0,) * n
+        return graph_ops.conv_own_bias_grad(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                                            self.transposed, out_pad, self.groups)
+
+
+class ConvOwnBias2d(_ConvOwnBias, nn.Conv2d):
+    pass
+
+
+class ConvOwnBias3d(_ConvOwnBias, nn.Conv3d):
+    pass
+
+
+class ConvTransposeOwnBias2d(_ConvOwnBias, nn.ConvTranspose2d):
+    pass
+
+
+class ConvTransposeOwnBias3d(_ConvOwnBias, nn.ConvTranspose3d):
+    pass
+
+
+_OWN_BIAS = {nn.Conv2d: ConvOwnBias2d, nn.Conv3d: ConvOwnBias3d, nn.ConvTranspose2d: ConvTransposeOwnBias2d,
+             nn.ConvTranspose3d: ConvTransposeOwnBias3d}
 
 
 class _BatchNormAct:
@@ -171,4 +212,7 @@ def fuse_norm_act(root: nn.Module) -> int:
         hook = getattr(m, "_absorb_activation", None)
         if callable(hook):
             hook()
+    for m in list(root.modules()):  # what is left with a bias was not folded into a norm: own bias gradient
+        if type(m) in _OWN_BIAS and m.bias is not None:
+            m.__class__ = _OWN_BIAS[type(m)]
     return converted

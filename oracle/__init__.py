@@ -181,3 +181,6 @@ class CanonicalBackend:
         from .ref_ops import norm_act_bwd_ref
         return norm_act_bwd_ref(x, gy, weight, bias, save_mean, save_invstd, training, slope, period, eps)
 
+    @staticmethod
+    def channel_sum(x, channels_last=False):
+        return x.double().sum(dim=[0] + list(range(2, x.dim()))).float()

@@ -230,3 +230,7 @@ class TorchRefBackend:
     @staticmethod
     def norm_act_bwd(x, gy, weight, bias, save_mean, save_invstd, training, slope, period, eps):
         return norm_act_bwd_ref(x, gy, weight, bias, save_mean, save_invstd, training, slope, period, eps)
+
+    @staticmethod
+    def channel_sum(x, channels_last=False):
+        return x.double().sum(dim=[0] + list(range(2, x.dim()))).float()

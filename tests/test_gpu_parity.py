@@ -694,3 +694,120 @@ def test_norm_act_folds_the_conv_bias(ops, training):
         assert float(got[3].abs().max()) == 0.0
     np.testing.assert_allclose(rmg.cpu().double().numpy(), rmd.numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(rvg.cpu().double().numpy(), rvd.numpy(), rtol=1e-6, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------
+# channels-last stages: K6 NDHWC kernels, per-channel sums, own-bias-gradient convolutions, layout policy
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last_3d if t.dim() == 5 else torch.channels_last)
+
+
+@pytest.mark.parametrize("shape,training,slope,dtype", [
+    ((2, 33, 8, 28, 24), True, 0.01, torch.float32),    # 7 rows x 33 channels per workgroup pass, 16-byte accesses
+    ((2, 66, 4, 6, 10), True, 0.01, torch.float32),
+    ((3, 14, 5, 7, 9), True, 1.0, torch.float32),       # 13230 elements: not a multiple of 4 -> scalar path
+    ((2, 200, 3, 4, 4), True, 0.2, torch.float32),      # one row per pass, 56 idle lanes
+    ((2, 12, 16, 20), True, 0.01, torch.float32),       # 2-D channels_last
+    ((2, 33, 8, 28, 24), False, 0.01, torch.float32),   # inference
+    ((2, 24, 4, 12, 16), True, 0.01, torch.bfloat16),
+])
+def test_norm_act_channels_last(ops, shape, training, slope, dtype):
+    """The NDHWC kernels give what the NCDHW kernels give on the same logical tensor (both are held to the float64
+    reference elsewhere): outputs / gradients within a few ulp, statistics within 1e-6, layout preserved."""
+    g = torch.Generator().manual_seed(shape[1])
+    C = shape[1]
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(dtype)
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    pb = torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    gy = torch.randn(shape, generator=g).to(dtype)
+
+    def run(channels_last):
+        xd = x.to(DEV)
+        xd = (_cl(xd) if channels_last else xd).requires_grad_(True)
+        wd, bd, pbd = (t.to(DEV).requires_grad_(True) for t in (w, b, pb))
+        rmd, rvd = rm.to(DEV), rv.to(DEV)
+        y = ops.norm_act(xd, wd, bd, rmd, rvd, training, 0.1, 1e-5, slope, pre_bias=pbd)
+        gyd = gy.to(DEV)
+        grads = torch.autograd.grad(y, (xd, wd, bd, pbd), _cl(gyd) if channels_last else gyd)
+        return y.detach(), grads, rmd, rvd
+
+    y0, g0, rm0, rv0 = run(False)
+    y1, g1, rm1, rv1 = run(True)
+    assert ops._dense_channels_last(y1) is not None and ops._dense_channels_last(g1[0]) is not None
+    tol = 2.0 ** -7 if dtype == torch.bfloat16 else 4 * 2.0 ** -23
+    assert float((y0.float() - y1.float()).abs().max()) <= tol * float(y0.float().abs().max())
+    assert float((g0[0].float() - g1[0].float()).abs().max()) <= 2 * tol * max(float(g0[0].float().abs().max()), 1.0)
+    for a, c in zip(g0[1:], g1[1:]):
+        np.testing.assert_allclose(c.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-5 * max(float(a.abs().max()), 1e-3))
+    np.testing.assert_allclose(rm1.cpu().numpy(), rm0.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rv1.cpu().numpy(), rv0.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    y2, g2, _, _ = run(True)
+    assert torch.equal(y1, y2) and torch.equal(g1[0], g2[0])
+
+
+def test_channel_sum_and_own_bias_convolutions(ops):
+    from nextou_amd.network_architecture.layout import to_channels_last
+    g = torch.Generator().manual_seed(9)
+    for shape in ((2, 33, 6, 10, 12), (3, 14, 5, 7, 9), (2, 300, 2, 3, 4), (4, 6, 11)):
+        x = torch.randn(shape, generator=g)
+        want = x.double().sum(dim=[0] + list(range(2, x.dim())))
+        got = ops._HIP.channel_sum(x.to(DEV))
+        np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=1e-6, atol=1e-5)
+        if x.dim() >= 4 and shape[1] <= 256:
+            got = ops._HIP.channel_sum(_cl(x.to(DEV)), channels_last=True)
+            np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=1e-6, atol=1e-5)
+    # a single-channel image re-strided as channels-last makes the first convolution produce NDHWC
+    img = torch.randn(2, 1, 6, 20, 16, generator=g).to(DEV)
+    conv = torch.nn.Conv3d(1, 8, (1, 3, 3), padding=(0, 1, 1)).to(DEV)
+    out = conv(to_channels_last(img))
+    assert ops._dense_channels_last(out) is torch.channels_last_3d
+    assert float((out - conv(img)).abs().max()) <= 1e-5 * float(out.abs().max())
+    # convolutions with their own bias gradient == stock autograd, both layouts, plain and transposed
+    for transposed in (False, True):
+        for cl in (False, True):
+            torch.manual_seed(4)
+            m = (torch.nn.ConvTranspose3d(12, 6, (1, 2, 2), (1, 2, 2)) if transposed else torch.nn.Conv3d(12, 5, 1)).to(DEV)
+            x = torch.randn(2, 12, 4, 6, 8, generator=g).to(DEV)
+            x = (_cl(x) if cl else x).requires_grad_(True)
+            y_ref = m(x)
+            gy = torch.randn(y_ref.shape, generator=g).to(DEV)
+            ref = torch.autograd.grad(y_ref, (x, m.weight, m.bias), gy)
+            out_pad = (0, 0, 0)
+            y = ops.conv_own_bias_grad(x, m.weight, m.bias, m.stride, m.padding, m.dilation, transposed, out_pad, 1)
+            got = torch.autograd.grad(y, (x, m.weight, m.bias), _cl(gy) if cl else gy)
+            assert float((y - y_ref).abs().max()) <= 1e-5 * float(y_ref.abs().max())
+            for a, r in zip(got, ref):
+                assert float((a - r).abs().max()) <= 2e-5 * max(float(r.abs().max()), 1.0)
+
+
+def test_channels_last_policy_changes_layout_not_results(ops, monkeypatch):
+    """Stage policy 'auto' (plain conv stages NDHWC) vs 'none' on the tiny 3-D model: same weights, same recorded
+    kNN / arg-max decisions -> same logits and gradients up to conv round-off; and the stage-0 skip really is NDHWC."""
+    from nextou_amd.graph_ops import IndexTape, index_tape
+    x = torch.randn(1, 1, 32, 128, 128, generator=torch.Generator().manual_seed(3)).to(DEV)
+    results = {}
+    tape = IndexTape()
+    for policy in ("auto", "none"):
+        monkeypatch.setenv("NEXTOU_CHANNELS_LAST_STAGES", policy)
+        torch.manual_seed(0)
+        net = mc.build_model(mc.TINY_3D).to(DEV)
+        assert net.encoder.channels_last_stages == (frozenset({0, 1}) if policy == "auto" else frozenset())
+        skips = net.encoder(x)
+        assert (ops._dense_channels_last(skips[0]) is not None) == (policy == "auto")
+        assert ops._dense_channels_last(skips[2]) is None          # graph stages stay NCDHW
+        if policy == "none":
+            tape = IndexTape(tape.entries)                          # replay the decisions of the first run
+        with index_tape(tape):
+            outs = net(x)
+        loss = sum(o.square().mean() for o in outs)
+        grads = torch.autograd.grad(loss, [p for p in net.parameters() if p.requires_grad], allow_unused=True)
+        results[policy] = ([o.detach() for o in outs], grads)
+    (oa, ga), (on, gn) = results["auto"], results["none"]
+    for a, b in zip(oa, on):
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max())
+    scale = max(float(t.abs().max()) for t in gn if t is not None)
+    for a, b in zip(ga, gn):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert float((a - b).abs().max()) <= 5e-3 * scale

@@ -45,11 +45,17 @@ def bench_norm(args, dev, L):
         if args.only and args.only not in label:
             continue
         g = torch.Generator(device=dev).manual_seed(1)
-        x = torch.randn((B, C, S), generator=g, device=dev, requires_grad=True)
+        x = torch.randn((B, C, S), generator=g, device=dev)
+        gy = torch.randn((B, C, S), generator=g, device=dev)
+        if args.cl:
+            if inst or C > 256:
+                continue
+            x = x.view(B, C, S, 1).contiguous(memory_format=torch.channels_last)
+            gy = gy.view(B, C, S, 1).contiguous(memory_format=torch.channels_last)
+        x.requires_grad_(True)
         w = torch.rand((C,), generator=g, device=dev) + 0.5
         b = torch.randn((C,), generator=g, device=dev) * 0.1
         rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-        gy = torch.randn((B, C, S), generator=g, device=dev)
 
         def ours():
             y = graph_ops.norm_act(x, w, b, None if inst else rm, None if inst else rv, True, 0.1, 1e-5, 0.01, instance=inst)
@@ -100,6 +106,7 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--only", default=None, help="substring filter on the call label")
     ap.add_argument("--norm", action="store_true", help="bench K6 (norm + LeakyReLU) instead of K1/K2")
+    ap.add_argument("--cl", action="store_true", help="with --norm: channels-last tensors")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     L = _lib.lib()
