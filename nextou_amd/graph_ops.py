@@ -608,9 +608,11 @@ class _ConvOwnBiasGrad(torch.autograd.Function):
         stride, padding, dilation, transposed, output_padding, groups = ctx.conf
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
-        cl = _dense_channels_last(gy)
-        if cl is None:
-            gy = gy.contiguous()
+        # the gradient takes the layout of the convolution's INPUT: what arrives may be a channel slice of a
+        # concatenation's gradient (dense in neither layout), and converting that to NCDHW under a channels-last
+        # convolution costs two passes over the tensor instead of one
+        cl = _dense_channels_last(x)
+        gy = gy.contiguous(memory_format=cl) if cl is not None else gy.contiguous()
         gx, gw, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, stride, padding, dilation, transposed,
                                                         output_padding, groups,
                                                         [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])

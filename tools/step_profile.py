@@ -13,7 +13,9 @@ from nextou_amd.harness import downsample_targets, synthetic_batch  # noqa: E402
 
 
 def main():
-    workload = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    shapes = "--shapes" in sys.argv      # group the data-movement operators by input shape (layout conversions)
+    workload = args[0] if args else "cfg2"
     dev = torch.device("cuda:0")
     torch.backends.cudnn.benchmark = True
     trainer, cfg, batch, classes = bench.build_trainer(workload, dev, False)
@@ -24,11 +26,19 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=shapes) as prof:
         for _ in range(2):
             step()
         torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=60))
+    if shapes:
+        movers = ("aten::copy_", "aten::contiguous", "aten::clone", "aten::cat", "aten::add", "aten::add_",
+                  "aten::_to_copy", "aten::fill_", "aten::zero_")
+        rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in movers]
+        rows.sort(key=lambda e: -e.self_device_time_total)
+        print("\ndata-movement operators by input shape (2 steps), self GPU time:")
+        for e in rows[:40]:
+            print("%-18s %5d calls %9.3f ms  %s" % (e.key, e.count, e.self_device_time_total / 1e3, e.input_shapes))
 
 
 if __name__ == "__main__":
