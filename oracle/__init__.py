@@ -55,6 +55,18 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def _in(t, dtype=None):
+    """Input normalisation at the C boundary: liboracle.so reads raw pointers and assumes dense row-major
+    (B, C, ...) storage of a fixed dtype.  A channels-last or otherwise strided tensor (e.g. the logits of a model whose
+    full-resolution stage runs NDHWC) would be read in the wrong order without this — silently, in the CHECKER."""
+    if t is None:
+        return None
+    t = t.detach()
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous(memory_format=torch.contiguous_format)
+
+
 def _ok(rc, what):
     if rc != 0:
         raise RuntimeError("oracle.%s rejected its arguments (rc=%d)" % (what, rc))
@@ -67,6 +79,7 @@ class CanonicalBackend:
 
     @staticmethod
     def knn_graph(x, y, relpos, k_total, algo=0, normalize=True):
+        x, y, relpos = _in(x, torch.float32), _in(y, torch.float32), _in(relpos, torch.float32)
         B, C, N = x.shape
         M = N if y is None else y.shape[2]
         out = torch.empty((B, N, k_total), dtype=torch.int32)
@@ -76,6 +89,7 @@ class CanonicalBackend:
 
     @staticmethod
     def pairwise_distance(x, y, row_start, row_end):
+        x, y = _in(x, torch.float32), _in(y, torch.float32)
         B, C, N = x.shape
         M = N if y is None else y.shape[2]
         out = torch.empty((B, row_end - row_start, M), dtype=torch.float32)
@@ -96,6 +110,8 @@ class CanonicalBackend:
 
     @staticmethod
     def mr_fwd(x, y, nn_idx, center, K, idx_step, want_arg=False):
+        x, y = _in(x, torch.float32), _in(y, torch.float32)
+        nn_idx, center = _in(nn_idx, torch.int32), _in(center, torch.int32)
         B, C, N = x.shape
         M = N if y is None else y.shape[2]
         out = torch.empty((B, 2 * C, N), dtype=torch.float32)
@@ -106,6 +122,7 @@ class CanonicalBackend:
 
     @staticmethod
     def mr_bwd_arg(gout, arg, M, has_y):
+        gout, arg = _in(gout, torch.float32), _in(arg)
         B, C, N = arg.shape
         dx = torch.empty((B, C, N), dtype=torch.float32)
         dy = torch.empty((B, C, M), dtype=torch.float32) if has_y else None
@@ -114,9 +131,11 @@ class CanonicalBackend:
 
     @staticmethod
     def mr_bwd(gout, x, y, nn_idx, center, K, idx_step):
+        gout, x, y = _in(gout, torch.float32), _in(x, torch.float32), _in(y, torch.float32)
+        nn_idx, center = _in(nn_idx, torch.int32), _in(center, torch.int32)
         B, C, N = x.shape
         M = N if y is None else y.shape[2]
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(x)            # row-major: x was normalised above
         dy = None if y is None else torch.empty_like(y)
         _ok(lib().oracle_mr_bwd(_p(gout), _p(x), _p(y), _p(nn_idx), _p(center), _p(dx), _p(dy), B, C, N, M,
                                 K, nn_idx.shape[2], idx_step), "mr_bwd")
@@ -137,6 +156,7 @@ class CanonicalBackend:
 
     @staticmethod
     def argmax_labels(logits):
+        logits = _in(logits, torch.float32)     # channels-last logits (NDHWC stages) become (B, L, V) row-major here
         B, L = logits.shape[:2]
         V = logits[0, 0].numel()
         out = torch.empty((B,) + tuple(logits.shape[2:]), dtype=torch.uint8)
@@ -160,11 +180,12 @@ class CanonicalBackend:
 
     @staticmethod
     def bti_critical(labels, lut_a, lut_c, connectivity, min_thick):
+        labels, lut_a, lut_c = _in(labels, torch.uint8), _in(lut_a), _in(lut_c)
         if labels.dim() == 3:
             (B, H, W), D = labels.shape, 1
         else:
             B, D, H, W = labels.shape
-        out = torch.empty_like(labels)
+        out = torch.empty_like(labels)      # row-major: labels was normalised above
         _ok(lib().oracle_bti_critical(_p(labels), _p(lut_a), _p(lut_c), lut_a.numel(), _p(out), B, D, H, W,
                                       connectivity, min_thick), "bti_critical")
         return out

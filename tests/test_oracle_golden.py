@@ -149,3 +149,32 @@ def test_bti_conv_formulation_equals_bit_logic(oracle_lib):
         P = torch.from_numpy(g[name + "_labels"]).unsqueeze(1).double()
         crit = bti_critical_ref(P, inter, dim, conn, 1)
         np.testing.assert_array_equal(crit.squeeze(1).numpy().astype(np.uint8), g[name + "_critical"])
+
+
+def test_oracle_c_entry_points_normalise_strided_inputs(oracle_lib):
+    """liboracle.so reads raw pointers as dense row-major tensors.  Channels-last logits (the full-resolution stage
+    runs NDHWC on the GPU) or any other strided view must give the answer of their row-major copy — the binding
+    normalises at the boundary; before that a channels-last tensor was silently read in the wrong order."""
+    ora = oracle_lib.CanonicalBackend
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(2, 5, 3, 6, 4, generator=g)
+    want = ora.argmax_labels(logits)
+    assert torch.equal(want, logits.argmax(1).to(torch.uint8))
+    cl = logits.contiguous(memory_format=torch.channels_last_3d)
+    assert not cl.is_contiguous()
+    assert torch.equal(ora.argmax_labels(cl), want)
+    assert torch.equal(ora.argmax_labels(logits.double()), want)                  # dtype normalised as well
+    x = torch.randn(2, 6, 40, generator=g)
+    xt = x.transpose(1, 2).contiguous().transpose(1, 2)                              # same values, (B, N, C) storage
+    assert not xt.is_contiguous()
+    assert torch.equal(ora.knn_graph(xt, None, None, 5), ora.knn_graph(x, None, None, 5))
+    idx = ora.knn_graph(x, None, None, 5)
+    a, _ = ora.mr_fwd(x, None, idx, None, 5, 1)
+    b, _ = ora.mr_fwd(xt, None, idx.to(torch.int64), None, 5, 1)
+    assert torch.equal(a, b)
+    labels = torch.randint(0, 4, (2, 3, 5, 4), generator=g, dtype=torch.uint8)
+    lut_a = torch.tensor([0, 1, 0, 0], dtype=torch.int32)
+    lut_c = torch.tensor([0, 0, 1, 0], dtype=torch.int32)
+    lt = labels.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)
+    assert not lt.is_contiguous()
+    assert torch.equal(ora.bti_critical(lt, lut_a, lut_c, 26, 1), ora.bti_critical(labels, lut_a, lut_c, 26, 1))
