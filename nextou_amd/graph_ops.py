@@ -590,7 +590,7 @@ class _ConvOwnBiasGrad(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, transposed, output_padding, groups):
-        if torch.is_autocast_enabled():
+        if torch.is_autocast_enabled("cuda"):
             dt = torch.get_autocast_dtype("cuda")
             x, weight = x.to(dt), weight.to(dt)
             bias_c = None if bias is None else bias.to(dt)

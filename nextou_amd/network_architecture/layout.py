@@ -8,7 +8,9 @@ their activations channels-last from the stage input to the stage output; the gr
 stay NCDHW.  What made channels-last unusable on stock PyTorch-ROCm — MIOpen's NHWC batch norm and ATen's bias-gradient
 reduction (170 ms on the two stages, tools/layout_probe.py) — is K6's job here (csrc/norm_act.hip).
 
-``NEXTOU_CHANNELS_LAST_STAGES``: ``auto`` (default), ``none``, or a comma list of stage indices.
+``NEXTOU_CHANNELS_LAST_STAGES``: ``auto`` (default), ``none``, or a comma list of stage indices.  Whatever the set, a
+stage only goes channels-last when its convolutions run in fp32 (:func:`runs_in_fp32`): under bf16 autocast the same
+policy is a 125 ms *loss* on cfg 2.
 """
 from __future__ import annotations
 
@@ -41,8 +43,24 @@ def to_channels_last(x: torch.Tensor) -> torch.Tensor:
     return x.contiguous(memory_format=mf)
 
 
+def runs_in_fp32(x: torch.Tensor) -> bool:
+    """True when the convolutions fed by ``x`` will execute in fp32: an fp32 tensor outside reduced-precision autocast.
+
+    The channels-last policy is an fp32 result.  Measured on MI355X, cfg 2 (profiles/r01_bf16_regression_ab.md):
+    fp32 291.3 ms NCDHW -> 270.7 ms NDHWC, but under bf16 autocast 184.6 ms NCDHW -> 309.3 ms NDHWC — MIOpen's bf16
+    channels-last 3-D solvers for 33 / 66 channels are far slower than its bf16 NCDHW ones.  So reduced precision
+    keeps NCDHW.
+    """
+    if x.dtype != torch.float32:
+        return False
+    if x.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") != torch.float32:
+        return False
+    return True
+
+
 def set_stage_layout(x: torch.Tensor, channels_last: bool) -> torch.Tensor:
-    """Layout conversion at a stage boundary; only device tensors are ever moved (the CPU checker path is NCDHW)."""
+    """Layout conversion at a stage boundary; only device tensors are ever moved (the CPU checker path is NCDHW).
+    Encoder and decoder call this with the same stage set in the same forward, so they agree on every skip."""
     if not x.is_cuda:
         return x
-    return to_channels_last(x) if channels_last else x.contiguous()
+    return to_channels_last(x) if (channels_last and runs_in_fp32(x)) else x.contiguous()

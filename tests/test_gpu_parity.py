@@ -811,3 +811,27 @@ def test_channels_last_policy_changes_layout_not_results(ops, monkeypatch):
         assert (a is None) == (b is None)
         if a is not None:
             assert float((a - b).abs().max()) <= 5e-3 * scale
+
+
+def test_channels_last_policy_is_fp32_only(ops):
+    """Under bf16 autocast the plain conv stages must stay NCDHW: MIOpen's bf16 NDHWC 3-D solvers made cfg 2
+    309 ms / step against 185 ms NCDHW (profiles/r01_bf16_regression_ab.md), while fp32 gains 20 ms from NDHWC.
+    Encoder and decoder take the decision from the same predicate, so a mixed-precision forward stays consistent."""
+    from nextou_amd.network_architecture.layout import runs_in_fp32
+    torch.manual_seed(0)
+    net = mc.build_model(mc.TINY_3D).to(DEV)
+    assert net.encoder.channels_last_stages == frozenset({0, 1})
+    x = torch.randn(1, 1, 32, 128, 128, device=DEV)
+    assert runs_in_fp32(x) and not runs_in_fp32(x.bfloat16()) and not runs_in_fp32(x.half())
+    assert ops._dense_channels_last(net.encoder(x)[0]) is torch.channels_last_3d
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert not runs_in_fp32(x)
+        skips = net.encoder(x)
+        assert ops._dense_channels_last(skips[0]) is None and ops._dense_channels_last(skips[1]) is None
+        outs = net(x)
+    assert all(bool(torch.isfinite(o.float()).all()) for o in outs)
+    assert ops._dense_channels_last(outs[0]) is None
+    loss = sum(o.float().square().mean() for o in outs)
+    grads = torch.autograd.grad(loss, [p for p in net.parameters() if p.requires_grad], allow_unused=True)
+    assert all(bool(torch.isfinite(g_).all()) for g_ in grads if g_ is not None)
+    assert ops._dense_channels_last(net.encoder(x)[0]) is torch.channels_last_3d        # back to fp32: NDHWC again
