@@ -18,6 +18,7 @@
 // read last is what it finds in the 256 MB Infinity Cache first.
 // Sums are float64 and combined in a fixed order: results are bit-reproducible run to run.
 #include "common.h"
+#include <cstdlib>
 #include <hip/hip_bf16.h>
 
 namespace nextou {
@@ -402,7 +403,24 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const T* __restr
 // per-iteration stride are multiples of C) and keeps their sums in registers; the q*VEC partials of each channel meet
 // in LDS in a fixed order.  Per-channel finalisation runs in its own C-workgroup launch between the two passes.
 // ======================================================================================================
-constexpr int kClMaxBlocks = 2048;
+// Workgroups per launch.  2048 (x 4 waves = exactly one residency of the chip) is the measured optimum of the WHOLE op:
+// finer grids speed the streaming kernels up (s0 call: 1183 -> 1129 us at 8192) but every wave of the per-channel
+// finalize kernels then walks 4x the partials, and the wall time of forward + backward gets worse (1200 -> 1211 us;
+// profiles/r01_kernel_bench_norm_cl_blocks.txt).  A parallel finalisation would unlock the finer grid — next round.
+// NEXTOU_CL_BLOCKS (<= kClMaxBlocks) overrides the default for experiments; the workspace is sized by the active value.
+constexpr int kClMaxBlocks = 8192;
+constexpr int kClDefaultBlocks = 2048;
+
+static int cl_target_blocks() {
+    static const int v = [] {
+        const char* e = getenv("NEXTOU_CL_BLOCKS");
+        int n = e ? atoi(e) : kClDefaultBlocks;
+        if (n < 64) n = 64;
+        if (n > kClMaxBlocks) n = kClMaxBlocks;
+        return n;
+    }();
+    return v;
+}
 
 struct ClPlan {
     int vec, tact, blocks;
@@ -414,7 +432,7 @@ static ClPlan plan_cl(long long total, int C, int vec_full, bool aligned) {
     p.vec = (aligned && total % vec_full == 0) ? vec_full : 1;
     p.tact = (kThreads / C) * C;
     const long long per_iter = (long long)p.tact * p.vec;
-    long long iters = cdiv64(total, (long long)kClMaxBlocks * per_iter);
+    long long iters = cdiv64(total, (long long)cl_target_blocks() * per_iter);
     if (iters < 4) iters = 4;
     p.span = iters * per_iter;
     p.blocks = (int)cdiv64(total, p.span);
@@ -753,7 +771,11 @@ static int check_common(const char* what, int B, int C, int64_t S, int param_per
     return 0;
 }
 
-constexpr size_t kCoeffOffset(int C) { return (size_t)C * kClMaxBlocks * sizeof(double2); }
+// partial sums: the NCDHW plan cuts a channel into <= 1024 tiles, the channels-last plan launches cl_target_blocks()
+static size_t kCoeffOffset(int C) {
+    const int slots = cl_target_blocks() > 1024 ? cl_target_blocks() : 1024;
+    return (size_t)C * slots * sizeof(double2);
+}
 
 template <typename T, int VEC>
 void launch_cl_fwd(const NormArgs& a, const ClPlan& p, hipStream_t s, const char* tname) {
