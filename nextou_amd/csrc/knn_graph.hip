@@ -114,6 +114,11 @@ struct TopK {
     // For a sorted list the shifted-in distance of slot j is the median of (v, d[j-1], d[j]):
     // one v_med3_f32 instead of two selects.
     __device__ __forceinline__ void push_ascending(float v, int vi) {
+        // Compiled form per slot: v_cmp, v_med3, s_nop 0, v_cndmask, v_cndmask — the s_nop covers the VALU-writes-VCC ->
+        // v_cndmask-reads-VCC hazard (1 issue slot in 5; 857 of the 7908 instructions of the <28,2> kernel).  Hoisting all
+        // KB compares in front of the loop in the SOURCE changes nothing: the compiler sinks them back and emits
+        // byte-identical ISA (checked, round 1).  Only per-slot SGPR masks (inline asm) would remove it, and 28 mask
+        // pairs do not fit next to the kernel's 86 SGPRs.
         bool before_hi = v < d[KB - 1];
 #pragma unroll
         for (int j = KB - 1; j >= 1; --j) {

@@ -12,8 +12,10 @@ if [ "$1" = "run" ]; then
   exit 0
 fi
 mkdir -p tools/_ablate
+# the source list comes from nextou_amd/build.py, so a side library exports every symbol _lib.py binds
+SRCS=$(python -c "from nextou_amd import build as b; import os; print(' '.join(os.path.join(b.CSRC, s) for s in b.HIP_SOURCES))")
 for n in ${ABLATE_SET:-0 1 2 4 3 5 6}; do
-  hipcc $FLAGS -DNEXTOU_ABLATE=$n -shared nextou_amd/csrc/capi.hip nextou_amd/csrc/knn_graph.hip nextou_amd/csrc/mr_aggregate.hip nextou_amd/csrc/bti_critical.hip -o tools/_ablate/libnextou_hip_a$n.so &
+  hipcc $FLAGS -DNEXTOU_ABLATE=$n -shared $SRCS -o tools/_ablate/libnextou_hip_a$n.so &
 done
 wait
 ls -la tools/_ablate
