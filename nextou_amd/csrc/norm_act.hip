@@ -154,6 +154,33 @@ __device__ inline void channel_sums(const double2* partial, int tiles, double& a
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
 }
 
+// Workgroup version for the per-channel finalize launches (kFinThreads threads, one workgroup per channel): thread t adds
+// partials t, t + kFinThreads, ... with four loads in flight, then a fixed-shape combine (butterfly per wave, waves in
+// index order).  The single-wave loop above walks `tiles / 64` dependent L2 round trips per lane — 128 of them at 8192
+// workgroups, which cost more than the finer grid gained (profiles/r01_kernel_bench_norm_cl_blocks.txt).
+constexpr int kFinThreads = 256;
+__device__ inline void channel_sums_block(const double2* partial, int tiles, double& a, double& b) {
+    __shared__ double fin_red[2][kFinThreads / 64];
+    double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0, s2 = 0.0, q2 = 0.0, s3 = 0.0, q3 = 0.0;
+    int i = threadIdx.x;
+    for (; i + 3 * kFinThreads < tiles; i += 4 * kFinThreads) {
+        const double2 p0 = partial[i], p1 = partial[i + kFinThreads], p2 = partial[i + 2 * kFinThreads],
+                      p3 = partial[i + 3 * kFinThreads];
+        s0 += p0.x; q0 += p0.y; s1 += p1.x; q1 += p1.y; s2 += p2.x; q2 += p2.y; s3 += p3.x; q3 += p3.y;
+    }
+    for (; i < tiles; i += kFinThreads) { const double2 p = partial[i]; s0 += p.x; q0 += p.y; }
+    a = (s0 + s1) + (s2 + s3);
+    b = (q0 + q1) + (q2 + q3);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { fin_red[0][w] = a; fin_red[1][w] = b; }
+    __syncthreads();
+    a = fin_red[0][0]; b = fin_red[1][0];
+#pragma unroll
+    for (int k = 1; k < kFinThreads / 64; ++k) { a += fin_red[0][k]; b += fin_red[1][k]; }
+}
+
 __device__ inline float leaky(float z, float slope) { return z > 0.f ? z : z * slope; }
 
 // ------------------------------------------------------------------------------------------------------
@@ -403,19 +430,21 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const T* __restr
 // per-iteration stride are multiples of C) and keeps their sums in registers; the q*VEC partials of each channel meet
 // in LDS in a fixed order.  Per-channel finalisation runs in its own C-workgroup launch between the two passes.
 // ======================================================================================================
-// Workgroups per launch.  2048 (x 4 waves = exactly one residency of the chip) is the measured optimum of the WHOLE op:
-// finer grids speed the streaming kernels up (s0 call: 1183 -> 1129 us at 8192) but every wave of the per-channel
-// finalize kernels then walks 4x the partials, and the wall time of forward + backward gets worse (1200 -> 1211 us;
-// profiles/r01_kernel_bench_norm_cl_blocks.txt).  A parallel finalisation would unlock the finer grid — next round.
-// NEXTOU_CL_BLOCKS (<= kClMaxBlocks) overrides the default for experiments; the workspace is sized by the active value.
+// Workgroups per launch: as many as give each one >= kClItersPerBlock passes over its span, at most kClMaxBlocks.
+// Measured on MI355X with wall-clock timing of forward + backward (profiles/r01_kernel_bench_norm_cl_blocks.txt): the
+// 727 MB stage-0 tensor wants the finest grid (1137 us at 2048 workgroups, 1090 us at 8192 — 2048 x 4 waves is exactly one
+// residency of the chip and leaves a drain tail), the 91 MB stage-2 tensor the coarsest (143 us at 2048, 164 us at 8192:
+// five passes per workgroup are too few).  ~20 passes per workgroup reproduces the best point of all three shapes.
+// That only pays since the per-channel finalisation is parallel over the partials (channel_sums_block); with the
+// single-wave finalize the finer grid was a net loss.  NEXTOU_CL_BLOCKS pins the count for experiments.
 constexpr int kClMaxBlocks = 8192;
-constexpr int kClDefaultBlocks = 2048;
+constexpr int kClItersPerBlock = 20;
 
-static int cl_target_blocks() {
+static int cl_pinned_blocks() {      // 0 = not pinned
     static const int v = [] {
         const char* e = getenv("NEXTOU_CL_BLOCKS");
-        int n = e ? atoi(e) : kClDefaultBlocks;
-        if (n < 64) n = 64;
+        int n = e ? atoi(e) : 0;
+        if (n < 0) n = 0;
         if (n > kClMaxBlocks) n = kClMaxBlocks;
         return n;
     }();
@@ -432,8 +461,15 @@ static ClPlan plan_cl(long long total, int C, int vec_full, bool aligned) {
     p.vec = (aligned && total % vec_full == 0) ? vec_full : 1;
     p.tact = (kThreads / C) * C;
     const long long per_iter = (long long)p.tact * p.vec;
-    long long iters = cdiv64(total, (long long)cl_target_blocks() * per_iter);
-    if (iters < 4) iters = 4;
+    long long iters;
+    if (cl_pinned_blocks() > 0) {
+        iters = cdiv64(total, (long long)cl_pinned_blocks() * per_iter);
+        if (iters < 4) iters = 4;
+    } else {
+        iters = kClItersPerBlock;
+        const long long floor_iters = cdiv64(total, (long long)kClMaxBlocks * per_iter);   // never more than kClMaxBlocks
+        if (iters < floor_iters) iters = floor_iters;
+    }
     p.span = iters * per_iter;
     p.blocks = (int)cdiv64(total, p.span);
     return p;
@@ -492,8 +528,8 @@ __global__ __launch_bounds__(kThreads) void bn_cl_stats_kernel(const T* __restri
     cl_block_sums<VEC>(s, q, C, tact, partial, gridDim.x);
 }
 
-// One wave per channel: statistics -> save_mean / save_invstd (+ running statistics), shared by both layouts' callers.
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const double2* __restrict__ partial, int tiles, double count,
+// One workgroup per channel: statistics -> save_mean / save_invstd (+ running statistics), shared by both layouts' callers.
+__global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(const double2* __restrict__ partial, int tiles, double count,
                                                          const float* __restrict__ pre_bias, float* running_mean,
                                                          float* running_var, float* __restrict__ save_mean,
                                                          float* __restrict__ save_invstd, int training, float momentum,
@@ -503,7 +539,7 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double2* __restri
     double var = 0.0;
     if (training) {
         double s, q;
-        channel_sums(partial + (size_t)c * tiles, tiles, s, q);
+        channel_sums_block(partial + (size_t)c * tiles, tiles, s, q);
         const double m = s / count;
         var = q / count - m * m;
         if (var < 0.0) var = 0.0;
@@ -623,13 +659,13 @@ __global__ __launch_bounds__(kThreads) void bn_cl_bwd_reduce_kernel(const T* __r
     cl_block_sums<VEC>(s1, s2, C, tact, partial, gridDim.x);
 }
 
-// One wave per channel: (sum dz, sum dz*xhat) -> the two projection coefficients + the parameter gradients.
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double2* __restrict__ partial, int tiles, double count,
+// One workgroup per channel: (sum dz, sum dz*xhat) -> the two projection coefficients + the parameter gradients.
+__global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(const double2* __restrict__ partial, int tiles, double count,
                                                              float2* __restrict__ coeff, float* __restrict__ gweight,
                                                              float* __restrict__ gbias, int training) {
     const int c = blockIdx.x;
     double s1, s2;
-    channel_sums(partial + (size_t)c * tiles, tiles, s1, s2);
+    channel_sums_block(partial + (size_t)c * tiles, tiles, s1, s2);
     if (threadIdx.x == 0) {
         coeff[c] = training ? make_float2((float)(s1 / count), (float)(s2 / count)) : make_float2(0.f, 0.f);
         if (gweight) gweight[c] = (float)s2;
@@ -695,10 +731,10 @@ __global__ __launch_bounds__(kThreads) void bn_cl_bwd_apply_kernel(const T* __re
 }
 
 // Per-channel sum as float (the bias gradient of a convolution that is not followed by a norm).
-__global__ __launch_bounds__(64) void channel_sum_finalize_kernel(const double2* __restrict__ partial, int tiles,
+__global__ __launch_bounds__(kFinThreads) void channel_sum_finalize_kernel(const double2* __restrict__ partial, int tiles,
                                                                   float* __restrict__ out) {
     double s, q;
-    channel_sums(partial + (size_t)blockIdx.x * tiles, tiles, s, q);
+    channel_sums_block(partial + (size_t)blockIdx.x * tiles, tiles, s, q);
     if (threadIdx.x == 0) out[blockIdx.x] = (float)s;
 }
 
@@ -771,11 +807,17 @@ static int check_common(const char* what, int B, int C, int64_t S, int param_per
     return 0;
 }
 
-// partial sums: the NCDHW plan cuts a channel into <= 1024 tiles, the channels-last plan launches cl_target_blocks()
-static size_t kCoeffOffset(int C) {
-    const int slots = cl_target_blocks() > 1024 ? cl_target_blocks() : 1024;
-    return (size_t)C * slots * sizeof(double2);
+// Workspace layout: [C x slots] double2 partial sums, then C float2 backward coefficients.  `slots` covers both plans of a
+// call with these sizes: <= 1024 tiles per channel (NCDHW), plan_cl().blocks workgroups (channels-last, C <= 256).
+static size_t partial_slots(int B, int C, long long S) {
+    size_t slots = 1024;
+    if (C <= kThreads) {
+        const size_t cl = (size_t)plan_cl((long long)B * C * S, C, 1, false).blocks;   // the scalar plan has the most blocks
+        if (cl > slots) slots = cl;
+    }
+    return slots;
 }
+static size_t kCoeffOffset(int B, int C, long long S) { return (size_t)C * partial_slots(B, C, S) * sizeof(double2); }
 
 template <typename T, int VEC>
 void launch_cl_fwd(const NormArgs& a, const ClPlan& p, hipStream_t s, const char* tname) {
@@ -788,7 +830,7 @@ void launch_cl_fwd(const NormArgs& a, const ClPlan& p, hipStream_t s, const char
         hipLaunchKernelGGL((bn_cl_stats_kernel<T, VEC>), dim3(p.blocks), dim3(kThreads), lds, s, (const T*)a.x, a.partial,
                            total, a.C, p.tact, p.span);
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(64), 0, s, a.partial, p.blocks, count, a.pre_bias,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(kFinThreads), 0, s, a.partial, p.blocks, count, a.pre_bias,
                        a.running_mean, a.running_var, a.save_mean, a.save_invstd, a.training, a.momentum, a.eps);
     ProfScope prof(s, kBoundHbm, 2.0 * bytes, "bn_cl_apply_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
     hipLaunchKernelGGL((bn_cl_apply_kernel<T, VEC>), dim3(p.blocks), dim3(kThreads), 0, s, (const T*)a.x, (T*)a.y, a.weight,
@@ -801,14 +843,14 @@ void launch_cl_bwd(const NormArgs& a, const ClPlan& p, hipStream_t s, const char
     const double bytes = (double)total * sizeof(T);
     const double count = (double)a.B * (double)a.S;
     const size_t lds = (size_t)p.tact * VEC * sizeof(double2);
-    float2* coeff = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.partial) + kCoeffOffset(a.C));
+    float2* coeff = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.partial) + kCoeffOffset(a.B, a.C, a.S));
     {
         ProfScope prof(s, kBoundHbm, 2.0 * bytes, "bn_cl_bwd_reduce_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
         hipLaunchKernelGGL((bn_cl_bwd_reduce_kernel<T, VEC>), dim3(p.blocks), dim3(kThreads), lds, s, (const T*)a.x,
                            (const T*)a.gy, a.partial, a.weight, a.bias, a.save_mean, a.save_invstd, total, a.C, p.tact,
                            p.span, a.slope);
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.C), dim3(64), 0, s, a.partial, p.blocks, count, coeff, a.gweight,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.C), dim3(kFinThreads), 0, s, a.partial, p.blocks, count, coeff, a.gweight,
                        a.gbias, a.training);
     ProfScope prof(s, kBoundHbm, 3.0 * bytes, "bn_cl_bwd_apply_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
     hipLaunchKernelGGL((bn_cl_bwd_apply_kernel<T, VEC>), dim3(p.blocks), dim3(kThreads), 0, s, (const T*)a.x, (const T*)a.gy,
@@ -831,10 +873,10 @@ static void norm_dispatch_cl(const NormArgs& a, const ClPlan& p, int dtype, hipS
 using namespace nextou;
 
 extern "C" size_t nextou_norm_act_workspace_bytes(int B, int C, int64_t S, int dtype) {
-    (void)B; (void)S; (void)dtype;
-    if (C <= 0) return 0;
+    (void)dtype;
+    if (B <= 0 || C <= 0 || S <= 0) return 0;
     // tile partials (NCDHW: <= 1024 tiles per channel, channels-last: <= 2048 workgroups) + the backward's coefficients
-    return kCoeffOffset(C) + (size_t)C * sizeof(float2) + 256;
+    return kCoeffOffset(B, C, S) + (size_t)C * sizeof(float2) + 256;
 }
 
 extern "C" int nextou_norm_act_fwd(const void* x, const float* weight, const float* bias, const float* pre_bias,
@@ -931,6 +973,6 @@ extern "C" int nextou_channel_sum(const void* x, float* out, void* ws, size_t ws
             else hipLaunchKernelGGL((bn_stats_kernel<__hip_bfloat16, 1>), grid, dim3(kThreads), 0, s, (const __hip_bfloat16*)x, partial, B, C, p.cols, p.row_len, p.col_len, p.col_tiles, p.tw_log2);
         }
     }
-    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C), dim3(64), 0, s, partial, tiles, out);
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C), dim3(kFinThreads), 0, s, partial, tiles, out);
     return check_launch("channel_sum");
 }
