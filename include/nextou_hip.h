@@ -187,7 +187,7 @@ int nextou_bti_ce_bwd(const float* logits, const uint8_t* target, const uint8_t*
  * batch_norm / instance_norm -> leaky_relu and their autograd.
  *   x, y, gy, gx : (B, C, S) contiguous (channels_last = 0), or (B, S, C) contiguous — PyTorch's channels_last /
  *                  channels_last_3d memory format of the same logical tensor (channels_last = 1; C <= 256,
- *                  param_period = 0); dtype NEXTOU_DTYPE_F32 or NEXTOU_DTYPE_BF16
+ *                  param_period = 0); dtype NEXTOU_DTYPE_F32, NEXTOU_DTYPE_BF16 or NEXTOU_DTYPE_F16
  *   weight, bias : float (param_period ? param_period : C) or NULL (= 1 / 0); channel c uses entry
  *                  c % param_period when param_period > 0 (instance norm: period = real channel count)
  *   training != 0: batch statistics (biased variance for the normalisation); when running_mean /
@@ -210,6 +210,7 @@ int nextou_bti_ce_bwd(const float* logits, const uint8_t* target, const uint8_t*
  * ---------------------------------------------------------------------------------------- */
 #define NEXTOU_DTYPE_F32  0
 #define NEXTOU_DTYPE_BF16 1
+#define NEXTOU_DTYPE_F16  2   /* IEEE half: torch.autocast("cuda")'s default dtype, what nnU-Net v2 trains under */
 
 size_t nextou_norm_act_workspace_bytes(int B, int C, int64_t S, int dtype);
 

@@ -21,7 +21,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NEXTOU_HIP_LIB") or os.path.join(_PKG_DIR, "libnextou_hip.so")
 
 KNN_AUTO, KNN_FUSED, KNN_NAIVE = 0, 1, 2
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 ABI_VERSION = 2
 
 # name -> (restype, argtypes); mirrors include/nextou_hip.h one to one

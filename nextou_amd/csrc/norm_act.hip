@@ -20,6 +20,7 @@
 #include "common.h"
 #include <cstdlib>
 #include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 
 namespace nextou {
 
@@ -105,6 +106,32 @@ template <> struct Pack<__hip_bfloat16, 1> {
     float v[1];
     __device__ void load(const __hip_bfloat16* p) { v[0] = bf16_to_f32(*reinterpret_cast<const unsigned short*>(p)); }
     __device__ void store(__hip_bfloat16* p) const { *reinterpret_cast<unsigned short*>(p) = f32_to_bf16(v[0]); }
+};
+
+// fp16 (nnU-Net's default autocast dtype): v_cvt_f32_f16 / v_cvt_f16_f32 (round to nearest even)
+template <> struct Pack<__half, 8> {
+    float v[8];
+    __device__ void load(const __half* p) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __half2float(__ushort_as_half((unsigned short)(w[i] & 0xffffu)));
+            v[2 * i + 1] = __half2float(__ushort_as_half((unsigned short)(w[i] >> 16)));
+        }
+    }
+    __device__ void store(__half* p) const {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = (unsigned)__half_as_ushort(__float2half_rn(v[2 * i])) | ((unsigned)__half_as_ushort(__float2half_rn(v[2 * i + 1])) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+template <> struct Pack<__half, 1> {
+    float v[1];
+    __device__ void load(const __half* p) { v[0] = __half2float(*p); }
+    __device__ void store(__half* p) const { *p = __float2half_rn(v[0]); }
 };
 
 struct Tile {
@@ -790,6 +817,9 @@ static void norm_dispatch(const NormArgs& a, const TilePlan& p, int dtype, hipSt
     if (dtype == NEXTOU_DTYPE_F32) {
         if (p.vec == 4) FWD ? launch_fwd<float, 4>(a, p, s, "f32") : launch_bwd<float, 4>(a, p, s, "f32");
         else FWD ? launch_fwd<float, 1>(a, p, s, "f32,scalar") : launch_bwd<float, 1>(a, p, s, "f32,scalar");
+    } else if (dtype == NEXTOU_DTYPE_F16) {
+        if (p.vec == 8) FWD ? launch_fwd<__half, 8>(a, p, s, "f16") : launch_bwd<__half, 8>(a, p, s, "f16");
+        else FWD ? launch_fwd<__half, 1>(a, p, s, "f16,scalar") : launch_bwd<__half, 1>(a, p, s, "f16,scalar");
     } else {
         if (p.vec == 8) FWD ? launch_fwd<__hip_bfloat16, 8>(a, p, s, "bf16") : launch_bwd<__hip_bfloat16, 8>(a, p, s, "bf16");
         else FWD ? launch_fwd<__hip_bfloat16, 1>(a, p, s, "bf16,scalar") : launch_bwd<__hip_bfloat16, 1>(a, p, s, "bf16,scalar");
@@ -798,7 +828,8 @@ static void norm_dispatch(const NormArgs& a, const TilePlan& p, int dtype, hipSt
 
 static int check_common(const char* what, int B, int C, int64_t S, int param_period, int dtype, int channels_last) {
     NEXTOU_REQUIRE(B > 0 && C > 0 && C <= 65535 && S > 0, "%s: bad size B=%d C=%d S=%lld", what, B, C, (long long)S);
-    NEXTOU_REQUIRE(dtype == NEXTOU_DTYPE_F32 || dtype == NEXTOU_DTYPE_BF16, "%s: dtype %d not in {f32, bf16}", what, dtype);
+    NEXTOU_REQUIRE(dtype == NEXTOU_DTYPE_F32 || dtype == NEXTOU_DTYPE_BF16 || dtype == NEXTOU_DTYPE_F16,
+                   "%s: dtype %d not in {f32, bf16, f16}", what, dtype);
     NEXTOU_REQUIRE(param_period >= 0, "%s: param_period=%d", what, param_period);
     if (channels_last) {
         if (C > kThreads) return fail(NEXTOU_ENOTSUP, "%s: channels-last layout supports C <= %d (got %d)", what, kThreads, C);
@@ -862,6 +893,9 @@ static void norm_dispatch_cl(const NormArgs& a, const ClPlan& p, int dtype, hipS
     if (dtype == NEXTOU_DTYPE_F32) {
         if (p.vec == 4) FWD ? launch_cl_fwd<float, 4>(a, p, s, "f32") : launch_cl_bwd<float, 4>(a, p, s, "f32");
         else FWD ? launch_cl_fwd<float, 1>(a, p, s, "f32,scalar") : launch_cl_bwd<float, 1>(a, p, s, "f32,scalar");
+    } else if (dtype == NEXTOU_DTYPE_F16) {
+        if (p.vec == 8) FWD ? launch_cl_fwd<__half, 8>(a, p, s, "f16") : launch_cl_bwd<__half, 8>(a, p, s, "f16");
+        else FWD ? launch_cl_fwd<__half, 1>(a, p, s, "f16,scalar") : launch_cl_bwd<__half, 1>(a, p, s, "f16,scalar");
     } else {
         if (p.vec == 8) FWD ? launch_cl_fwd<__hip_bfloat16, 8>(a, p, s, "bf16") : launch_cl_bwd<__hip_bfloat16, 8>(a, p, s, "bf16");
         else FWD ? launch_cl_fwd<__hip_bfloat16, 1>(a, p, s, "bf16,scalar") : launch_cl_bwd<__hip_bfloat16, 1>(a, p, s, "bf16,scalar");
@@ -887,7 +921,7 @@ extern "C" int nextou_norm_act_fwd(const void* x, const float* weight, const flo
     if (int rc = check_common("norm_act_fwd", B, C, S, param_period, dtype, channels_last)) return rc;
     NEXTOU_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "norm_act_fwd: running_mean / running_var must come together");
     NEXTOU_REQUIRE(training || running_mean, "norm_act_fwd: inference needs the running statistics");
-    const int esz = dtype == NEXTOU_DTYPE_BF16 ? 2 : 4;
+    const int esz = dtype == NEXTOU_DTYPE_F32 ? 4 : 2;
     NormArgs a{};
     a.x = x; a.y = y; a.weight = weight; a.bias = bias; a.pre_bias = pre_bias; a.running_mean = running_mean; a.running_var = running_var;
     a.save_mean = save_mean; a.save_invstd = save_invstd; a.partial = (double2*)ws; a.B = B; a.C = C; a.S = S;
@@ -916,7 +950,7 @@ extern "C" int nextou_norm_act_bwd(const void* x, const void* gy, const float* w
                                    int dtype, int channels_last, int training, float slope, nextou_stream_t stream) {
     NEXTOU_REQUIRE(x && gy && gx && save_mean && save_invstd && ws, "norm_act_bwd: null pointer");
     if (int rc = check_common("norm_act_bwd", B, C, S, param_period, dtype, channels_last)) return rc;
-    const int esz = dtype == NEXTOU_DTYPE_BF16 ? 2 : 4;
+    const int esz = dtype == NEXTOU_DTYPE_F32 ? 4 : 2;
     NormArgs a{};
     a.x = x; a.gy = gy; a.gx = gx; a.weight = weight; a.bias = bias;
     a.save_mean = const_cast<float*>(save_mean); a.save_invstd = const_cast<float*>(save_invstd);
@@ -943,11 +977,11 @@ extern "C" int nextou_channel_sum(const void* x, float* out, void* ws, size_t ws
     if (ws_bytes < nextou_norm_act_workspace_bytes(B, C, S, dtype))
         return fail(NEXTOU_ENOSPACE, "channel_sum: workspace %zu < %zu bytes", ws_bytes, nextou_norm_act_workspace_bytes(B, C, S, dtype));
     hipStream_t s = (hipStream_t)stream;
-    const int esz = dtype == NEXTOU_DTYPE_BF16 ? 2 : 4;
+    const int esz = dtype == NEXTOU_DTYPE_F32 ? 4 : 2;
     const double bytes = (double)B * C * (double)S * esz;
     double2* partial = (double2*)ws;
     int tiles;
-    ProfScope prof(s, kBoundHbm, bytes, "channel_sum<%s,%s>[B%d C%d S%lld]", esz == 2 ? "bf16" : "f32",
+    ProfScope prof(s, kBoundHbm, bytes, "channel_sum<%s,%s>[B%d C%d S%lld]", dtype == NEXTOU_DTYPE_F32 ? "f32" : (dtype == NEXTOU_DTYPE_F16 ? "f16" : "bf16"),
                    channels_last ? "ndhwc" : "ncdhw", B, C, (long long)S);
     if (channels_last) {
         const long long total = (long long)B * C * S;
@@ -957,6 +991,9 @@ extern "C" int nextou_channel_sum(const void* x, float* out, void* ws, size_t ws
         if (esz == 4) {
             if (p.vec == 4) hipLaunchKernelGGL((bn_cl_stats_kernel<float, 4>), dim3(p.blocks), dim3(kThreads), lds, s, (const float*)x, partial, total, C, p.tact, p.span);
             else hipLaunchKernelGGL((bn_cl_stats_kernel<float, 1>), dim3(p.blocks), dim3(kThreads), lds, s, (const float*)x, partial, total, C, p.tact, p.span);
+        } else if (dtype == NEXTOU_DTYPE_F16) {
+            if (p.vec == 8) hipLaunchKernelGGL((bn_cl_stats_kernel<__half, 8>), dim3(p.blocks), dim3(kThreads), lds, s, (const __half*)x, partial, total, C, p.tact, p.span);
+            else hipLaunchKernelGGL((bn_cl_stats_kernel<__half, 1>), dim3(p.blocks), dim3(kThreads), lds, s, (const __half*)x, partial, total, C, p.tact, p.span);
         } else {
             if (p.vec == 8) hipLaunchKernelGGL((bn_cl_stats_kernel<__hip_bfloat16, 8>), dim3(p.blocks), dim3(kThreads), lds, s, (const __hip_bfloat16*)x, partial, total, C, p.tact, p.span);
             else hipLaunchKernelGGL((bn_cl_stats_kernel<__hip_bfloat16, 1>), dim3(p.blocks), dim3(kThreads), lds, s, (const __hip_bfloat16*)x, partial, total, C, p.tact, p.span);
@@ -968,6 +1005,9 @@ extern "C" int nextou_channel_sum(const void* x, float* out, void* ws, size_t ws
         if (esz == 4) {
             if (p.vec == 4) hipLaunchKernelGGL((bn_stats_kernel<float, 4>), grid, dim3(kThreads), 0, s, (const float*)x, partial, B, C, p.cols, p.row_len, p.col_len, p.col_tiles, p.tw_log2);
             else hipLaunchKernelGGL((bn_stats_kernel<float, 1>), grid, dim3(kThreads), 0, s, (const float*)x, partial, B, C, p.cols, p.row_len, p.col_len, p.col_tiles, p.tw_log2);
+        } else if (dtype == NEXTOU_DTYPE_F16) {
+            if (p.vec == 8) hipLaunchKernelGGL((bn_stats_kernel<__half, 8>), grid, dim3(kThreads), 0, s, (const __half*)x, partial, B, C, p.cols, p.row_len, p.col_len, p.col_tiles, p.tw_log2);
+            else hipLaunchKernelGGL((bn_stats_kernel<__half, 1>), grid, dim3(kThreads), 0, s, (const __half*)x, partial, B, C, p.cols, p.row_len, p.col_len, p.col_tiles, p.tw_log2);
         } else {
             if (p.vec == 8) hipLaunchKernelGGL((bn_stats_kernel<__hip_bfloat16, 8>), grid, dim3(kThreads), 0, s, (const __hip_bfloat16*)x, partial, B, C, p.cols, p.row_len, p.col_len, p.col_tiles, p.tw_log2);
             else hipLaunchKernelGGL((bn_stats_kernel<__hip_bfloat16, 1>), grid, dim3(kThreads), 0, s, (const __hip_bfloat16*)x, partial, B, C, p.cols, p.row_len, p.col_len, p.col_tiles, p.tw_log2);

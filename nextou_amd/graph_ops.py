@@ -303,7 +303,7 @@ class _HipBackend:
         return out
 
 
-_NORM_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16}
+_NORM_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
 _HIP = _HipBackend()
 
 
@@ -550,7 +550,8 @@ def norm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[tor
              running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], training: bool,
              momentum: float, eps: float, negative_slope: float = 1.0, instance: bool = False,
              pre_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``leaky_relu(batch_norm(x [+ pre_bias]) | instance_norm(x), negative_slope)`` on (B,C,*spatial) fp32 / bf16.
+    """``leaky_relu(batch_norm(x [+ pre_bias]) | instance_norm(x), negative_slope)`` on (B,C,*spatial) fp32 / bf16 / fp16
+    (statistics and the normalisation itself are always computed in fp32 / fp64; only loads and stores are narrow).
 
     ``pre_bias`` (C,) is the bias of the convolution that produced ``x`` when that convolution was run without it:
     a per-channel constant does not survive batch statistics, so it only has to enter the running mean (training) or
@@ -562,7 +563,7 @@ def norm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[tor
     ``F.batch_norm`` does (unbiased variance, ``momentum``); ``training=False`` uses them.
     """
     if x.dtype not in _NORM_DTYPES:
-        raise TypeError("norm_act: dtype %s not in (float32, bfloat16)" % x.dtype)
+        raise TypeError("norm_act: dtype %s not in (float32, bfloat16, float16)" % x.dtype)
     if instance and not training:
         raise ValueError("norm_act: instance norm always uses the statistics of its input")
     if weight is not None and weight.dtype != torch.float32:
@@ -612,6 +613,8 @@ class _ConvOwnBiasGrad(torch.autograd.Function):
         # concatenation's gradient (dense in neither layout), and converting that to NCDHW under a channels-last
         # convolution costs two passes over the tensor instead of one
         cl = _dense_channels_last(x)
+        if cl is not None and gy.shape[1] > 256 and ctx.needs_input_grad[2]:
+            cl = None       # the channels-last reduction of K6 covers C <= 256; wider bias gradients take the NCDHW kernels
         gy = gy.contiguous(memory_format=cl) if cl is not None else gy.contiguous()
         gx, gw, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, stride, padding, dilation, transposed,
                                                         output_padding, groups,

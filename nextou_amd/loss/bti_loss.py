@@ -54,8 +54,16 @@ class BTI_Loss(torch.nn.Module):
         # same bookkeeping as the reference (:38-49): [is_inclusion, A, C]
         self.interaction_list = [[True, inc[0], inc[1]] for inc in inclusion] + \
                                 [[False, exc[0], exc[1]] for exc in exclusion]
+        for _, spec_a, spec_c in self.interaction_list:
+            for label in _label_set(spec_a) + _label_set(spec_c):
+                if not 0 <= label < 256:   # the label map is uint8; the reference (float64 compare) has no such limit
+                    raise ValueError("BTI_Loss: interaction label %d outside [0, 256) is not representable in the "
+                                     "uint8 label map of the HIP critical-voxel kernel" % label)
         self._luts = self._build_luts(self.interaction_list)
         self._device_luts = {}
+        # one host sync per call; the reference raises IndexError from its CrossEntropyLoss for such targets
+        # (bti_loss.py:141) — switch off only when the targets are known to be clean
+        self.validate_targets = True
 
     @staticmethod
     def _build_luts(interactions: Sequence) -> List[np.ndarray]:
@@ -104,6 +112,13 @@ class BTI_Loss(torch.nn.Module):
 
     def forward(self, x, y):
         """x: logits (B,L,*spatial); y: labels (B,1,*spatial) in [0,L) -> 0-dim float64 loss."""
+        n_classes = x.shape[1]
+        if n_classes > 256:
+            raise ValueError("BTI_Loss: %d classes do not fit the uint8 label map (at most 256)" % n_classes)
+        if self.validate_targets:
+            lo, hi = (float(v) for v in torch.stack(torch.aminmax(y.detach())).tolist())
+            if lo < 0 or hi >= n_classes:
+                raise IndexError("Target %d is out of bounds." % int(hi if hi >= n_classes else lo))
         labels = graph_ops.argmax_labels(x)                      # argmax(softmax(x,1),1), :132-134
         critical = self.critical_voxels_from_labels(labels)
         # :141-143  CE(x.double(), y, 'none') * critical, summed over voxels, mean over the batch —
@@ -115,3 +130,7 @@ class BTI_Loss(torch.nn.Module):
 class TI_Loss(BTI_Loss):
     """All-pairs topological interaction loss (reference loss/ti_loss.py:8-145): the same module with
     scalar labels; more than 32 interactions run as several kernel passes OR-ed together."""
+
+    def topological_interaction_module(self, P):
+        """Reference name of the critical-voxel module in loss/ti_loss.py:76-117."""
+        return self.binary_topological_interaction_module(P)

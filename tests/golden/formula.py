@@ -5,6 +5,7 @@ of being stored: ``torch.manual_seed`` streams are not a contract, numpy's PCG64
 """
 from __future__ import annotations
 
+import contextlib
 import zlib
 
 import numpy as np
@@ -68,3 +69,43 @@ def blob_labels(shape, n_classes: int, n_seeds: int = 40, seed: int = 4321) -> n
     r = np.sqrt((((coords - centre) / (np.asarray(shape, dtype=np.float32) / 2)) ** 2).sum(1))
     lab[r > 0.9] = 0
     return lab.reshape(shape)
+
+
+def coherent_logits(tag: str, n_classes: int, shape, batch: int = 2):
+    """(logits (B,L,*shape) float32, target (B,1,*shape) float32): gaussian logits with a per-class bias from blob
+    labels, so that the arg-max label map is spatially coherent, and an independent blob label map as the target."""
+    shape = tuple(shape)
+    logits = gaussian(tag + ".logits", (batch, n_classes) + shape, scale=2.0)
+    for b in range(batch):
+        lab = torch.from_numpy(blob_labels(shape, n_classes, n_seeds=12, seed=100 + b))
+        logits[b].scatter_add_(0, lab.unsqueeze(0), torch.full((1,) + shape, 3.0))
+    target = torch.from_numpy(np.stack([blob_labels(shape, n_classes, n_seeds=12, seed=200 + b)
+                                        for b in range(batch)])).unsqueeze(1).float()
+    return logits, target
+
+
+_CONV_FUNCTIONS = ("conv1d", "conv2d", "conv3d", "conv_transpose1d", "conv_transpose2d", "conv_transpose3d")
+
+
+@contextlib.contextmanager
+def convs_in_float64():
+    """While active every ``torch.nn.functional`` (transposed) convolution computes in float64 and rounds its result
+    back to the input dtype: the convolution arithmetic becomes the same on every backend (oneDNN, MIOpen / CK,
+    rocBLAS) up to one final rounding, so what is left of a CPU-vs-GPU difference is NOT the dense stages' library.
+    Used by make_golden.py on the reference and by the equal-convolution parity tests on nextou_amd."""
+    import torch.nn.functional as F
+
+    def wrap(fn):
+        def conv(input, weight, bias=None, *args, **kwargs):
+            out = fn(input.double(), weight.double(), None if bias is None else bias.double(), *args, **kwargs)
+            return out.to(input.dtype)
+        return conv
+
+    saved = {n: getattr(F, n) for n in _CONV_FUNCTIONS}
+    for n, fn in saved.items():
+        setattr(F, n, wrap(fn))
+    try:
+        yield
+    finally:
+        for n, fn in saved.items():
+            setattr(F, n, fn)

@@ -75,6 +75,22 @@ def load_reference():
     ns.encdec = _load(os.path.join(arch, "NexToU_Encoder_Decoder.py"), prefix + ".NexToU_Encoder_Decoder")
     ns.nextou = _load(os.path.join(arch, "NexToU.py"), prefix + ".NexToU")
     ns.bti = _load(os.path.join(REF, "loss", "bti_loss.py"), "ref_bti_loss")
+    ns.ti = _load(os.path.join(REF, "loss", "ti_loss.py"), "ref_ti_loss")
+    # compound losses: the reference imports Dice / CE / softmax helper from the un-vendored nnunetv2 — provided by
+    # this repo's restatement (nextou_amd/loss/nnunet_losses.py) on BOTH sides ("parity unpinned" for them); the
+    # ignore-label / weighting glue and the (B)TI term are the reference's own code
+    from nextou_amd.loss import nnunet_losses
+    assert not nnunet_losses.HAVE_NNUNET
+    for name in ("nnunetv2.training.loss", "nnunetv2.utilities"):
+        pkg(name)
+    dice = pkg("nnunetv2.training.loss.dice")
+    dice.SoftDiceLoss, dice.MemoryEfficientSoftDiceLoss = nnunet_losses.SoftDiceLoss, nnunet_losses.MemoryEfficientSoftDiceLoss
+    pkg("nnunetv2.training.loss.robust_ce_loss").RobustCrossEntropyLoss = nnunet_losses.RobustCrossEntropyLoss
+    pkg("nnunetv2.utilities.helpers").softmax_helper_dim1 = nnunet_losses.softmax_helper_dim1
+    sys.modules["nnunetv2.training.loss.bti_loss"] = ns.bti
+    sys.modules["nnunetv2.training.loss.ti_loss"] = ns.ti
+    ns.compound_bti = _load(os.path.join(REF, "loss", "compound_bti_loss.py"), "ref_compound_bti_loss")
+    ns.compound_ti = _load(os.path.join(REF, "loss", "compound_ti_loss.py"), "ref_compound_ti_loss")
     return ns
 
 
@@ -333,6 +349,103 @@ def g_bti(ref):
     save("g7_bti", **out)
 
 
+def g_ti(ref):
+    """G7b: the all-pairs TI loss of loss/ti_loss.py (scalar labels, `P == label`): the 78 pairs of the 13 foreground
+    classes the `*_TI` trainers build (nnUNetTrainer_NexToU_TI.py:10-13,48), a 2-D 8-connected case, one inclusion."""
+    from itertools import combinations
+
+    def tens(lists):
+        if not lists:
+            return lists
+        if isinstance(lists[0], list):
+            return [tens(s) for s in lists]
+        return torch.tensor(lists)
+
+    cases = [  # name, dim, conn, classes, inclusion, exclusion, spatial
+        ("ti78_26", 3, 26, 14, [], [list(c) for c in combinations(range(1, 14), 2)], (12, 20, 18)),
+        ("ti78_6", 3, 6, 14, [], [list(c) for c in combinations(range(1, 14), 2)], (12, 20, 18)),
+        ("ti10_8", 2, 8, 6, [], [list(c) for c in combinations(range(1, 6), 2)], (24, 28)),
+        ("ti_incl", 3, 26, 5, [[1, 2]], [[3, 4]], (8, 10, 12)),
+    ]
+    out = {}
+    for name, dim, conn, L, inc, exc, sp in cases:
+        loss = ref.ti.TI_Loss(dim=dim, connectivity=conn, inclusion=tens(inc), exclusion=tens(exc), min_thick=1)
+        logits, target = formula.coherent_logits("g7b.%s" % name, L, sp)
+        logits.requires_grad_(True)
+        value = loss(logits, target)
+        (grad,) = torch.autograd.grad(value, logits)
+        with torch.no_grad():
+            P = torch.argmax(torch.softmax(logits, 1), 1).unsqueeze(1).double()
+            crit = loss.topological_interaction_module(P)
+        # logits / target are formula.coherent_logits("g7b.<name>", L, sp) on both sides: not stored
+        out.update({name + "_labels": P.squeeze(1).numpy().astype(np.uint8),
+                    name + "_critical": crit.squeeze(1).numpy().astype(np.uint8),
+                    name + "_loss": value.detach().numpy(), name + "_grad": grad.numpy(),
+                    name + "_n_interactions": len(loss.interaction_list)})
+    save("g7b_ti", **out)
+
+
+def g_compound(ref):
+    """G7c: DC_and_CE_and_BTI_Loss / DC_and_CE_and_TI_Loss (compound_bti_loss.py:33-61): value and logit gradient with
+    and without an ignore label.  Dice / CE are this repo's restatement of nnU-Net's on both sides (see load_reference)."""
+    from itertools import combinations
+    from nextou_amd.loss.nnunet_losses import MemoryEfficientSoftDiceLoss
+    synapse = [[[1, 3, 5, 7, 8, 11, 13], [2, 4, 6, 9, 10, 12]], [[1, 3, 11, 13], [5, 7, 8]], [[1, 3], [11, 13]],
+               [1, 3], [11, 13], [[5, 8], [7]], [5, 8], [[4, 6, 10], [2, 9, 12]], [[4, 6], [10]], [4, 6],
+               [[9, 12], [2]], [9, 12]]
+
+    def tens(lists):
+        if not lists:
+            return lists
+        if isinstance(lists[0], list):
+            return [tens(s) for s in lists]
+        return torch.tensor(lists)
+
+    dice = {'batch_dice': False, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}
+    out = {}
+    for name, cls, exc, ignore, batch_dice in (
+            ("bti", ref.compound_bti.DC_and_CE_and_BTI_Loss, synapse, None, False),
+            ("bti_ignore", ref.compound_bti.DC_and_CE_and_BTI_Loss, synapse, 13, False),
+            ("bti_batchdice", ref.compound_bti.DC_and_CE_and_BTI_Loss, synapse, None, True),
+            ("ti", ref.compound_ti.DC_and_CE_and_TI_Loss, [list(c) for c in combinations(range(1, 14), 2)], None, False)):
+        L, sp = 14, (12, 20, 18)
+        ti = {'dim': 3, 'connectivity': 26, 'inclusion': [], 'exclusion': tens(exc), 'min_thick': 1}
+        loss = cls(dict(dice, batch_dice=batch_dice), {}, ti, weight_ce=1, weight_dice=1, weight_ti=1e-6,
+                   ignore_label=ignore, dice_class=MemoryEfficientSoftDiceLoss)
+        logits, target = formula.coherent_logits("g7c.%s" % name, L, sp)
+        if ignore is not None:
+            # a slab of ignored voxels.  The ignore label must be < L here: with nnU-Net's usual encoding (ignore ==
+            # number of classes) the reference's (B)TI term raises IndexError("Target 14 is out of bounds") from its
+            # float64 CrossEntropyLoss (bti_loss.py:141) as soon as one ignored voxel is present
+            target[:, :, :3] = float(ignore)
+        logits.requires_grad_(True)
+        value = loss(logits, target)
+        (grad,) = torch.autograd.grad(value, logits)
+        out.update({name + "_loss": value.detach().numpy(), name + "_grad": grad.numpy(),
+                    name + "_ignore": -1 if ignore is None else ignore, name + "_batch_dice": int(batch_dice)})
+    save("g7c_compound", **out)
+
+
+def g_ffn(ref):
+    """G5b: FFN (NexToU_Encoder_Decoder.py:368-390) forward + input gradient, train and eval."""
+    out = {}
+    for mode in ("train", "eval"):
+        ffn = ref.encdec.FFN(12, 48, act='leakyrelu', drop_path=0.0, conv_op=nn.Conv3d, norm_op=nn.BatchNorm3d,
+                             norm_op_kwargs={'eps': 1e-5, 'affine': True})
+        formula.fill_module_(ffn, seed=6)
+        ffn.train(mode == "train")
+        x = formula.gaussian("g5b.ffn.x", (2, 12, 4, 8, 8)).requires_grad_(True)
+        y = ffn(x)
+        g = formula.gaussian("g5b.ffn.g", y.shape)
+        (dx,) = torch.autograd.grad(y, x, g)
+        out["ffn_%s_out" % mode] = y.detach().numpy()
+        out["ffn_%s_dx" % mode] = dx.numpy()
+        if mode == "train":
+            out["ffn_train_running_mean_fc1"] = ffn.fc1[1].running_mean.numpy().copy()
+            out["ffn_train_running_var_fc1"] = ffn.fc1[1].running_var.numpy().copy()
+    save("g5b_ffn", **out)
+
+
 def build_ref_model(ref, cfg):
     return ref.nextou.NexToU(
         input_channels=cfg["in_ch"], patch_size=cfg["patch"], n_stages=len(cfg["kernels"]),
@@ -371,7 +484,21 @@ def g_models(ref):
         floor = max(float((a - b).abs().max()) for a, b in zip(outs, noisy))
         absmax = max(float(o.abs().max()) for o in outs)
         print("   %s: max|logit| %.2f, self-noise floor (1e-7 input noise, teacher-forced) %.3e" % (name, absmax, floor))
+        # the same reference model with every convolution computed in float64 (formula.convs_in_float64), teacher-forced
+        # with the decisions of the fp32 run: the "equal convolution arithmetic" target of the GPU parity test
+        rep = Replayer(model, ref, rec.entries)
+        with torch.no_grad(), formula.convs_in_float64():
+            outs64 = model(x)
+        rep.close()
+        assert rep.cursor == len(rec.entries)
+        print("   %s: fp64-conv vs fp32-conv reference logits differ by %.3e" % (
+            name, max(float((a - b).abs().max()) for a, b in zip(outs, outs64))))
         arrays = {"x": x.numpy(), "n_tape": len(rec.entries), "self_noise_floor": floor, "logit_absmax": absmax}
+        for i, o in enumerate(outs64):
+            if o.numel() <= 300_000:
+                arrays["f64conv_logits%d" % i] = o.numpy()
+            else:
+                arrays["f64conv_logits%d_sample" % i] = o.reshape(-1)[::97].numpy()
         for i, e in enumerate(rec.entries):
             arrays["tape%d" % i] = e.numpy()
         for i, o in enumerate(outs):
@@ -429,7 +556,7 @@ def main():
     torch.set_num_threads(8)
     ref = load_reference()
     only = set(sys.argv[1:])
-    for fn in (g_knn, g_distance, g_mrconv, g_pos_embed, g_blocks, g_bti, g_models, g_config_table):
+    for fn in (g_knn, g_distance, g_mrconv, g_pos_embed, g_blocks, g_ffn, g_bti, g_ti, g_compound, g_models, g_config_table):
         if only and fn.__name__ not in only:
             continue
         print("==", fn.__name__)

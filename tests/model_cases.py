@@ -61,7 +61,28 @@ def run_block(name, mode, device, teacher_forced):
         torch.from_numpy(g["%s_%s_dx" % (name, mode)]), tape, entries
 
 
-def run_model(name, cfg, batch, device, teacher_forced):
+import contextlib
+
+
+@contextlib.contextmanager
+def float64_convolutions():
+    """formula.convs_in_float64 for a nextou_amd model: besides ``torch.nn.functional`` it covers the product's direct
+    ``aten.convolution`` call (graph_ops.conv_own_bias_grad: seg heads and transposed convolutions on the GPU)."""
+    def conv64(x, weight, bias, stride, padding, dilation, transposed, output_padding, groups):
+        y = torch.ops.aten.convolution(x.double(), weight.double(), None if bias is None else bias.double(),
+                                       list(stride), list(padding), list(dilation), bool(transposed),
+                                       list(output_padding), int(groups))
+        return y.to(x.dtype)
+    saved = graph_ops.conv_own_bias_grad
+    graph_ops.conv_own_bias_grad = conv64
+    try:
+        with formula.convs_in_float64():
+            yield
+    finally:
+        graph_ops.conv_own_bias_grad = saved
+
+
+def run_model(name, cfg, batch, device, teacher_forced, float64_convs=False):
     g = load_golden(name)
     model = build_model(cfg)
     formula.fill_module_(model, seed=1)
@@ -69,6 +90,17 @@ def run_model(name, cfg, batch, device, teacher_forced):
     x = formula.gaussian(name + ".x", [batch, cfg["in_ch"]] + cfg["patch"]).to(device)
     entries = [torch.from_numpy(g["tape%d" % i]) for i in range(int(g["n_tape"]))]
     tape = graph_ops.IndexTape(entries if teacher_forced else None)
-    with torch.no_grad(), graph_ops.index_tape(tape):
+    with torch.no_grad(), graph_ops.index_tape(tape), (float64_convolutions() if float64_convs else contextlib.nullcontext()):
         outs = model(x)
     return [o.cpu() for o in outs], g, tape, entries, model
+
+
+def worst_logit_diff(outs, g, prefix="logits"):
+    """max |logit - golden| over the heads of a g8 fixture (full heads, or the strided sample of the large ones)."""
+    worst = 0.0
+    for i, o in enumerate(outs):
+        if "%s%d" % (prefix, i) in g.files:
+            worst = max(worst, float((o - torch.from_numpy(g["%s%d" % (prefix, i)])).abs().max()))
+        else:
+            worst = max(worst, float((o.reshape(-1)[::97] - torch.from_numpy(g["%s%d_sample" % (prefix, i)])).abs().max()))
+    return worst

@@ -160,6 +160,17 @@ def test_tiny_models_teacher_forced(cpu_checker, name, cfg, batch):
             assert abs(float(o.abs().max()) - float(g["logits%d_absmax" % i])) <= 1e-3
 
 
+@pytest.mark.parametrize("name,cfg,batch", [("g8_tiny2d", mc.TINY_2D, 2), ("g8_tiny3d", mc.TINY_3D, 1)])
+def test_tiny_models_equal_convolution_arithmetic(cpu_checker, name, cfg, batch):
+    """north_star's <= 1e-3 max |dlogit| with the convolution arithmetic held equal: every convolution on both sides in
+    float64 (formula.convs_in_float64; the reference run is make_golden.py:g_models 'f64conv_logits'), everything else
+    — norms, activations, graph ops — in each side's own fp32.  The reference's own fp32-conv and fp64-conv logits
+    differ by 0.97e-3 / 1.03e-3 on these fixtures: 1e-3 IS the rounding noise of the fp32 dense stages."""
+    outs, g, tape, entries, _ = mc.run_model(name, cfg, batch, torch.device("cpu"), teacher_forced=True, float64_convs=True)
+    assert tape.cursor == len(entries)
+    assert mc.worst_logit_diff(outs, g, "f64conv_logits") <= 1e-3
+
+
 def test_deep_supervision_off_returns_first_head(cpu_checker):
     model = mc.build_model(mc.TINY_2D)
     formula.fill_module_(model, seed=1)
