@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NEXTOU_ABI_VERSION 2
+#define NEXTOU_ABI_VERSION 3
 
 #define NEXTOU_EINVAL   (-1)  /* bad argument (null pointer, non-positive size, k > M ...) */
 #define NEXTOU_ENOSPACE (-2)  /* workspace too small */
@@ -186,7 +186,7 @@ int nextou_bti_ce_bwd(const float* logits, const uint8_t* target, const uint8_t*
  * ConvDropoutNormReLU blocks of the conv stages (:125-136, :281-298).  Replaces
  * batch_norm / instance_norm -> leaky_relu and their autograd.
  *   x, y, gy, gx : (B, C, S) contiguous (channels_last = 0), or (B, S, C) contiguous — PyTorch's channels_last /
- *                  channels_last_3d memory format of the same logical tensor (channels_last = 1; C <= 256,
+ *                  channels_last_3d memory format of the same logical tensor (channels_last = 1; any C,
  *                  param_period = 0); dtype NEXTOU_DTYPE_F32, NEXTOU_DTYPE_BF16 or NEXTOU_DTYPE_F16
  *   weight, bias : float (param_period ? param_period : C) or NULL (= 1 / 0); channel c uses entry
  *                  c % param_period when param_period > 0 (instance norm: period = real channel count)
@@ -234,6 +234,39 @@ int nextou_norm_act_bwd(const void* x, const void* gy, const float* weight, cons
  * Same layouts / dtypes / workspace as nextou_norm_act_fwd. */
 int nextou_channel_sum(const void* x, float* out, void* workspace, size_t workspace_bytes,
                        int B, int C, int64_t S, int dtype, int channels_last, nextou_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3 / K4  data movement around the graph kernels, fused with the layout change between the dense stages'
+ * channels-last activations x_cl (B, D, H, W, C) — PyTorch's channels_last_3d memory of a (B, C, D, H, W) tensor; 2-D
+ * models pass D = 1 — and the graph kernels' channel-major rows (B', C, N).  float32.  HBM-bound: one read + one
+ * write of the tensor.
+ *
+ * nextou_window_gather    replaces torch.roll(x, -shift) -> window_partition (reference
+ *     NexToU_Encoder_Decoder.py:781-790, :634-660):  out_cm[b * nWin + win, c, p] = x_cl[b, pos(win, p) + shift mod size, c],
+ *     windows enumerated row-major over (D/wd, H/wh, W/ww), points row-major inside a window; 0 <= shift < size.
+ * nextou_window_scatter   the inverse, replacing window_reverse -> torch.roll(x, +shift) [-> + shortcut]
+ *     (:807-817, :662-693): out_cl[b, pos, c] = src_cm[...] (+ residual_cl[b, pos, c] when residual_cl != NULL).
+ *     Each is the other's backward.
+ * nextou_pool_rows        replaces MaxPool{2,3}d(pool, stride = pool, return_indices = True) (:524-530):
+ *     values_cm[b, c, n] = max over the (pd, ph, pw) cell of pooled point n (row-major over (D/pd, H/ph, W/pw)),
+ *     cell[b, n, c] (uint8, points-major) = the winning position inside the cell, (kd * ph + kh) * pw + kw; first
+ *     maximum in scan order wins, NaN wins (ATen's rule).
+ * nextou_cell_scatter     replaces MaxUnpool{2,3}d(out, cat(indices, indices)) (:536-549): out_cl (B, D, H, W, C2), C2 = C
+ *     or 2C, is written completely — src_cm[b, c2, n] at the cell position cell[b, n, c2 mod C], zeros elsewhere (no
+ *     memset, no index concatenation).  Also the backward of nextou_pool_rows (C2 = C).
+ * nextou_cell_gather      out_cm[b, c2, n] = x_cl[b, cellpos(n, cell[b, n, c2 mod C]), c2]: the backward of
+ *     nextou_cell_scatter, and the replay of recorded arg-max cells.
+ * ---------------------------------------------------------------------------------------- */
+int nextou_window_gather(const float* x_cl, float* out_cm, int B, int C, int D, int H, int W,
+                         int wd, int wh, int ww, int sd, int sh, int sw, nextou_stream_t stream);
+int nextou_window_scatter(const float* src_cm, const float* residual_cl, float* out_cl, int B, int C, int D, int H, int W,
+                          int wd, int wh, int ww, int sd, int sh, int sw, nextou_stream_t stream);
+int nextou_pool_rows(const float* x_cl, float* values_cm, uint8_t* cell, int B, int C, int D, int H, int W,
+                     int pd, int ph, int pw, nextou_stream_t stream);
+int nextou_cell_gather(const float* x_cl, const uint8_t* cell, float* out_cm, int B, int C2, int C, int D, int H, int W,
+                       int pd, int ph, int pw, nextou_stream_t stream);
+int nextou_cell_scatter(const float* src_cm, const uint8_t* cell, float* out_cl, int B, int C2, int C, int D, int H, int W,
+                        int pd, int ph, int pw, nextou_stream_t stream);
 
 #ifdef __cplusplus
 }

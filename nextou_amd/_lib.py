@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("NEXTOU_HIP_LIB") or os.path.join(_PKG_DIR, "libnextou
 
 KNN_AUTO, KNN_FUSED, KNN_NAIVE = 0, 1, 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # name -> (restype, argtypes); mirrors include/nextou_hip.h one to one
 _SIGNATURES = {
@@ -65,6 +65,11 @@ _SIGNATURES = {
                                     c_float, c_void_p]),
     "nextou_channel_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int64, c_int, c_int,
                                    c_void_p]),
+    "nextou_window_gather": (c_int, [c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
+    "nextou_window_scatter": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
+    "nextou_pool_rows": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "nextou_cell_gather": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "nextou_cell_scatter": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -1,0 +1,285 @@
+// K3 / K4 — the data movement around the graph kernels, for gfx950: window shift + partition / reverse, and the
+// query max-pool / max-unpool of the Pool-GNN blocks, each fused with the layout change between the dense stages'
+// channels-last activations (B, D, H, W, C — the layout MIOpen's CK convolutions run in natively) and the graph kernels'
+// channel-major rows (B', C, N).
+//
+// Reference op sequences replaced (network_architecture/NexToU_Encoder_Decoder.py):
+//   window_gather   torch.roll(x, -shift) -> window_partition (einops rearrange + contiguous)          :781-790, :634-660
+//   window_scatter  window_reverse -> torch.roll(x, +shift) -> drop_path(x) + shortcut                :807-817, :662-693
+//   pool_rows       MaxPool{2,3}d(pool, return_indices=True)                                          :524-530
+//   cell_scatter    MaxUnpool{2,3}d(out, cat(indices, indices))  (182 MB of mostly zeros at cfg-2 s2) :536-549
+//   cell_gather     the backward of the unpool / the teacher-forced replay of recorded arg-max cells
+// Every element has to move once anyway; doing the index math here removes the roll copies, the permute copies, the
+// index concatenation, the zero fill and the NCDHW <-> NDHWC transposes that otherwise wrap every convolution of the
+// graph stages.  Bound: HBM (pure data movement); algorithmic bytes = one read + one write of the tensor.
+//
+// Pattern of every kernel: a workgroup owns a tile of T points x Cc channels.  The channels-last side is accessed with
+// lanes along the channels (consecutive addresses inside a row of C floats), the channel-major side with lanes along
+// the points (consecutive addresses inside a row of N floats); the tile turns around in LDS with an odd row stride
+// (conflict-free both ways).
+#include "common.h"
+
+namespace nextou {
+
+constexpr int kLayThreads = 256;
+constexpr int kTileChannels = 64;   // channels per tile (LDS row = 65 floats)
+constexpr int kTilePoints = 64;     // points per tile of the pool / unpool kernels
+
+struct Vol {
+    int D, H, W;    // channels-last volume
+};
+struct Win {
+    int wd, wh, ww, sd, sh, sw;   // window size, cyclic shift
+};
+
+// row index (without batch) of point p of window `win` after the cyclic shift: the partitioned tensor is roll(x, -shift),
+// i.e. window coordinate (d, h, w) reads x at ((d + sd) mod D, ...)
+__device__ __forceinline__ long long window_point_row(int win, int p, const Vol& v, const Win& w, int nH, int nW) {
+    const int wi_w = win % nW, t = win / nW;
+    const int wi_h = t % nH, wi_d = t / nH;
+    const int pw = p % w.ww, t2 = p / w.ww;
+    const int ph = t2 % w.wh, pd = t2 / w.wh;
+    int d = wi_d * w.wd + pd + w.sd, h = wi_h * w.wh + ph + w.sh, x = wi_w * w.ww + pw + w.sw;
+    if (d >= v.D) d -= v.D;
+    if (h >= v.H) h -= v.H;
+    if (x >= v.W) x -= v.W;
+    return ((long long)d * v.H + h) * v.W + x;
+}
+
+// grid = (windows per sample, channel tiles, B); LDS = Nw * (Cc + 1) floats
+// GATHER:  out_cm[(b * nWin + win), c, p] = x_cl[b, row(win, p), c]
+// !GATHER: out_cl[b, row(win, p), c] = src_cm[(b * nWin + win), c, p] (+ residual_cl[b, row, c])
+template <bool GATHER>
+__global__ __launch_bounds__(kLayThreads) void window_move_kernel(const float* __restrict__ src, const float* __restrict__ residual,
+                                                                  float* __restrict__ dst, Vol v, Win w, int C, int nH, int nW,
+                                                                  int n_win, int Nw) {
+    extern __shared__ float tile[];
+    const int win = blockIdx.x, b = blockIdx.z;
+    const int c0 = blockIdx.y * kTileChannels;
+    const int cc = min(kTileChannels, C - c0);
+    const int ld = kTileChannels + 1;
+    const long long vol_rows = (long long)v.D * v.H * v.W;
+    const float* cl = (GATHER ? src : residual);
+    float* cm_base = nullptr;
+    const size_t cm_off = ((size_t)(b * n_win + win) * C + c0) * Nw;
+    if (GATHER) {
+        // channels-last rows -> LDS (lanes along the channels)
+        for (int e = threadIdx.x; e < Nw * cc; e += kLayThreads) {
+            const int p = e / cc, c = e - p * cc;
+            const long long r = (long long)b * vol_rows + window_point_row(win, p, v, w, nH, nW);
+            tile[p * ld + c] = cl[r * C + c0 + c];
+        }
+        __syncthreads();
+        cm_base = dst + cm_off;
+        for (int e = threadIdx.x; e < cc * Nw; e += kLayThreads) {   // LDS -> channel-major rows (lanes along the points)
+            const int c = e / Nw, p = e - c * Nw;
+            cm_base[(size_t)c * Nw + p] = tile[p * ld + c];
+        }
+    } else {
+        const float* cm = src + cm_off;
+        for (int e = threadIdx.x; e < cc * Nw; e += kLayThreads) {
+            const int c = e / Nw, p = e - c * Nw;
+            tile[p * ld + c] = cm[(size_t)c * Nw + p];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < Nw * cc; e += kLayThreads) {
+            const int p = e / cc, c = e - p * cc;
+            const long long r = (long long)b * vol_rows + window_point_row(win, p, v, w, nH, nW);
+            float val = tile[p * ld + c];
+            if (residual != nullptr) val += residual[r * C + c0 + c];
+            dst[r * C + c0 + c] = val;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// pooled points: n = (dz * H2 + hy) * W2 + wx over the pooled volume; cell k = (kd * ph + kh) * pw + kw
+// ------------------------------------------------------------------------------------------------------
+struct Pool {
+    int pd, ph, pw, D2, H2, W2;
+};
+__device__ __forceinline__ long long cell_row(int n, int k, const Vol& v, const Pool& q) {
+    const int wx = n % q.W2, t = n / q.W2;
+    const int hy = t % q.H2, dz = t / q.H2;
+    const int kw = k % q.pw, t2 = k / q.pw;
+    const int kh = t2 % q.ph, kd = t2 / q.ph;
+    return ((long long)(dz * q.pd + kd) * v.H + (hy * q.ph + kh)) * v.W + (wx * q.pw + kw);
+}
+
+// Max pool of channels-last rows -> channel-major values + the winning cell (uint8, points-major (B, N, C)).
+// First maximum in (d, h, w) scan order wins, NaN wins (ATen's max_pool3d_with_indices rule).
+// grid = (point tiles, channel tiles, B); LDS = T * 65 floats
+__global__ __launch_bounds__(kLayThreads) void pool_rows_kernel(const float* __restrict__ x_cl, float* __restrict__ val_cm,
+                                                                uint8_t* __restrict__ cell, Vol v, Pool q, int C, int N) {
+    __shared__ float tile[kTilePoints * (kTileChannels + 1)];
+    const int b = blockIdx.z, c0 = blockIdx.y * kTileChannels, n0 = blockIdx.x * kTilePoints;
+    const int cc = min(kTileChannels, C - c0), tn = min(kTilePoints, N - n0);
+    const int ld = kTileChannels + 1, cells = q.pd * q.ph * q.pw;
+    const long long vol_rows = (long long)v.D * v.H * v.W;
+    for (int e = threadIdx.x; e < tn * cc; e += kLayThreads) {
+        const int i = e / cc, c = e - i * cc;
+        const float* base = x_cl + (long long)b * vol_rows * C + c0 + c;
+        float best = base[cell_row(n0 + i, 0, v, q) * C];
+        int arg = 0;
+        for (int k = 1; k < cells; ++k) {
+            const float val = base[cell_row(n0 + i, k, v, q) * C];
+            if (val > best || val != val) { best = val; arg = k; }
+        }
+        tile[i * ld + c] = best;
+        cell[((size_t)b * N + n0 + i) * C + c0 + c] = (uint8_t)arg;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cc * tn; e += kLayThreads) {
+        const int c = e / tn, i = e - c * tn;
+        val_cm[((size_t)b * C + c0 + c) * N + n0 + i] = tile[i * ld + c];
+    }
+}
+
+// out_cm[b, c2, n] = x_cl[b, cell_row(n, cell[b, n, c2 mod C]), c2]      (C2 = C or 2C channels)
+__global__ __launch_bounds__(kLayThreads) void cell_gather_kernel(const float* __restrict__ x_cl, const uint8_t* __restrict__ cell,
+                                                                  float* __restrict__ out_cm, Vol v, Pool q, int C2, int C, int N) {
+    __shared__ float tile[kTilePoints * (kTileChannels + 1)];
+    const int b = blockIdx.z, c0 = blockIdx.y * kTileChannels, n0 = blockIdx.x * kTilePoints;
+    const int cc = min(kTileChannels, C2 - c0), tn = min(kTilePoints, N - n0);
+    const int ld = kTileChannels + 1;
+    const long long vol_rows = (long long)v.D * v.H * v.W;
+    for (int e = threadIdx.x; e < tn * cc; e += kLayThreads) {
+        const int i = e / cc, c = e - i * cc;
+        const int c2 = c0 + c;
+        const int k = cell[((size_t)b * N + n0 + i) * C + (c2 >= C ? c2 - C : c2)];
+        tile[i * ld + c] = x_cl[((long long)b * vol_rows + cell_row(n0 + i, k, v, q)) * C2 + c2];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cc * tn; e += kLayThreads) {
+        const int c = e / tn, i = e - c * tn;
+        out_cm[((size_t)b * C2 + c0 + c) * N + n0 + i] = tile[i * ld + c];
+    }
+}
+
+// out_cl[b, cell_row(n, k), c2] = (cell[b, n, c2 mod C] == k) ? src_cm[b, c2, n] : 0   for every cell k: the full tensor is
+// written exactly once, zeros included (no memset, no index concatenation)
+__global__ __launch_bounds__(kLayThreads) void cell_scatter_kernel(const float* __restrict__ src_cm, const uint8_t* __restrict__ cell,
+                                                                   float* __restrict__ out_cl, Vol v, Pool q, int C2, int C, int N) {
+    __shared__ float tile[kTilePoints * (kTileChannels + 1)];
+    const int b = blockIdx.z, c0 = blockIdx.y * kTileChannels, n0 = blockIdx.x * kTilePoints;
+    const int cc = min(kTileChannels, C2 - c0), tn = min(kTilePoints, N - n0);
+    const int ld = kTileChannels + 1, cells = q.pd * q.ph * q.pw;
+    const long long vol_rows = (long long)v.D * v.H * v.W;
+    for (int e = threadIdx.x; e < cc * tn; e += kLayThreads) {
+        const int c = e / tn, i = e - c * tn;
+        tile[i * ld + c] = src_cm[((size_t)b * C2 + c0 + c) * N + n0 + i];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < tn * cc; e += kLayThreads) {
+        const int i = e / cc, c = e - i * cc;
+        const int c2 = c0 + c;
+        const int arg = cell[((size_t)b * N + n0 + i) * C + (c2 >= C ? c2 - C : c2)];
+        const float val = tile[i * ld + c];
+        float* base = out_cl + (long long)b * vol_rows * C2 + c2;
+        for (int k = 0; k < cells; ++k) base[cell_row(n0 + i, k, v, q) * C2] = (k == arg) ? val : 0.f;
+    }
+}
+
+static int check_vol(const char* who, int B, int C, int D, int H, int W) {
+    NEXTOU_REQUIRE(B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && B <= 65535, "%s: bad size B=%d C=%d D=%d H=%d W=%d", who, B, C, D, H, W);
+    NEXTOU_REQUIRE((long long)D * H * W < (1ll << 31) && cdiv(C, kTileChannels) <= 65535, "%s: volume / channel count out of range", who);
+    return 0;
+}
+
+static int launch_window(bool gather, const float* src, const float* residual, float* dst, int B, int C, int D, int H, int W,
+                         int wd, int wh, int ww, int sd, int sh, int sw, hipStream_t s) {
+    const char* who = gather ? "window_gather" : "window_scatter";
+    NEXTOU_REQUIRE(src && dst, "%s: null pointer", who);
+    if (int e = check_vol(who, B, C, D, H, W)) return e;
+    NEXTOU_REQUIRE(wd > 0 && wh > 0 && ww > 0 && D % wd == 0 && H % wh == 0 && W % ww == 0,
+                   "%s: window (%d,%d,%d) does not tile the volume (%d,%d,%d)", who, wd, wh, ww, D, H, W);
+    NEXTOU_REQUIRE(sd >= 0 && sd < D && sh >= 0 && sh < H && sw >= 0 && sw < W, "%s: shift (%d,%d,%d) out of range", who, sd, sh, sw);
+    const int Nw = wd * wh * ww;
+    const size_t lds = (size_t)Nw * (kTileChannels + 1) * sizeof(float);
+    if (lds > 160 * 1024) return fail(NEXTOU_ENOTSUP, "%s: a window of %d points does not fit the LDS tile", who, Nw);
+    const int nD = D / wd, nH = H / wh, nW = W / ww, n_win = nD * nH * nW;
+    const Vol v{D, H, W};
+    const Win w{wd, wh, ww, sd, sh, sw};
+    const dim3 grid(n_win, cdiv(C, kTileChannels), B);
+    const double bytes = (gather || residual == nullptr ? 2.0 : 3.0) * 4.0 * B * (double)C * D * H * W;
+    ProfScope prof(s, kBoundHbm, bytes, "%s[B%d C%d %dx%dx%d win %dx%dx%d]", gather ? "window_gather_kernel" : "window_scatter_kernel",
+                   B, C, D, H, W, wd, wh, ww);
+    if (gather) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_move_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(window_move_kernel<true>, grid, dim3(kLayThreads), lds, s, src, (const float*)nullptr, dst, v, w, C, nH, nW, n_win, Nw);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_move_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(window_move_kernel<false>, grid, dim3(kLayThreads), lds, s, src, residual, dst, v, w, C, nH, nW, n_win, Nw);
+    }
+    return check_launch(who);
+}
+
+static int make_pool(const char* who, int D, int H, int W, int pd, int ph, int pw, Pool* q) {
+    NEXTOU_REQUIRE(pd > 0 && ph > 0 && pw > 0 && pd * ph * pw <= 255 && D % pd == 0 && H % ph == 0 && W % pw == 0,
+                   "%s: pool (%d,%d,%d) does not tile the volume (%d,%d,%d)", who, pd, ph, pw, D, H, W);
+    *q = Pool{pd, ph, pw, D / pd, H / ph, W / pw};
+    return 0;
+}
+
+}  // namespace nextou
+
+using namespace nextou;
+
+extern "C" int nextou_window_gather(const float* x_cl, float* out_cm, int B, int C, int D, int H, int W, int wd, int wh, int ww,
+                                    int sd, int sh, int sw, nextou_stream_t stream) {
+    return launch_window(true, x_cl, nullptr, out_cm, B, C, D, H, W, wd, wh, ww, sd, sh, sw, (hipStream_t)stream);
+}
+
+extern "C" int nextou_window_scatter(const float* src_cm, const float* residual_cl, float* out_cl, int B, int C, int D, int H, int W,
+                                     int wd, int wh, int ww, int sd, int sh, int sw, nextou_stream_t stream) {
+    return launch_window(false, src_cm, residual_cl, out_cl, B, C, D, H, W, wd, wh, ww, sd, sh, sw, (hipStream_t)stream);
+}
+
+extern "C" int nextou_pool_rows(const float* x_cl, float* values_cm, uint8_t* cell, int B, int C, int D, int H, int W, int pd, int ph,
+                                int pw, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(x_cl && values_cm && cell, "pool_rows: null pointer");
+    if (int e = check_vol("pool_rows", B, C, D, H, W)) return e;
+    Pool q;
+    if (int e = make_pool("pool_rows", D, H, W, pd, ph, pw, &q)) return e;
+    const int N = q.D2 * q.H2 * q.W2;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(s, kBoundHbm, 4.0 * B * (double)C * D * H * W + 5.0 * B * (double)C * N, "pool_rows_kernel[B%d C%d %dx%dx%d pool %dx%dx%d]",
+                   B, C, D, H, W, pd, ph, pw);
+    hipLaunchKernelGGL(pool_rows_kernel, dim3(cdiv(N, kTilePoints), cdiv(C, kTileChannels), B), dim3(kLayThreads), 0, s, x_cl, values_cm,
+                       cell, Vol{D, H, W}, q, C, N);
+    return check_launch("pool_rows_kernel");
+}
+
+extern "C" int nextou_cell_gather(const float* x_cl, const uint8_t* cell, float* out_cm, int B, int C2, int C, int D, int H, int W, int pd,
+                                  int ph, int pw, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(x_cl && cell && out_cm, "cell_gather: null pointer");
+    NEXTOU_REQUIRE(C2 == C || C2 == 2 * C, "cell_gather: C2=%d must be C=%d or 2C", C2, C);
+    if (int e = check_vol("cell_gather", B, C2, D, H, W)) return e;
+    Pool q;
+    if (int e = make_pool("cell_gather", D, H, W, pd, ph, pw, &q)) return e;
+    const int N = q.D2 * q.H2 * q.W2;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(s, kBoundHbm, 4.0 * B * (double)C2 * D * H * W + 4.0 * B * (double)C2 * N + 1.0 * B * (double)C * N,
+                   "cell_gather_kernel[B%d C%d %dx%dx%d pool %dx%dx%d]", B, C2, D, H, W, pd, ph, pw);
+    hipLaunchKernelGGL(cell_gather_kernel, dim3(cdiv(N, kTilePoints), cdiv(C2, kTileChannels), B), dim3(kLayThreads), 0, s, x_cl, cell, out_cm,
+                       Vol{D, H, W}, q, C2, C, N);
+    return check_launch("cell_gather_kernel");
+}
+
+extern "C" int nextou_cell_scatter(const float* src_cm, const uint8_t* cell, float* out_cl, int B, int C2, int C, int D, int H, int W, int pd,
+                                   int ph, int pw, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(src_cm && cell && out_cl, "cell_scatter: null pointer");
+    NEXTOU_REQUIRE(C2 == C || C2 == 2 * C, "cell_scatter: C2=%d must be C=%d or 2C", C2, C);
+    if (int e = check_vol("cell_scatter", B, C2, D, H, W)) return e;
+    Pool q;
+    if (int e = make_pool("cell_scatter", D, H, W, pd, ph, pw, &q)) return e;
+    const int N = q.D2 * q.H2 * q.W2;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(s, kBoundHbm, 4.0 * B * (double)C2 * D * H * W + 4.0 * B * (double)C2 * N + 1.0 * B * (double)C * N,
+                   "cell_scatter_kernel[B%d C%d %dx%dx%d pool %dx%dx%d]", B, C2, D, H, W, pd, ph, pw);
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3(cdiv(N, kTilePoints), cdiv(C2, kTileChannels), B), dim3(kLayThreads), 0, s, src_cm, cell, out_cl,
+                       Vol{D, H, W}, q, C2, C, N);
+    return check_launch("cell_scatter_kernel");
+}

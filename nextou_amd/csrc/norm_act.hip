@@ -832,7 +832,6 @@ static int check_common(const char* what, int B, int C, int64_t S, int param_per
                    "%s: dtype %d not in {f32, bf16, f16}", what, dtype);
     NEXTOU_REQUIRE(param_period >= 0, "%s: param_period=%d", what, param_period);
     if (channels_last) {
-        if (C > kThreads) return fail(NEXTOU_ENOTSUP, "%s: channels-last layout supports C <= %d (got %d)", what, kThreads, C);
         if (param_period) return fail(NEXTOU_ENOTSUP, "%s: channels-last layout has no instance-norm mode", what);
     }
     return 0;
@@ -888,6 +887,303 @@ void launch_cl_bwd(const NormArgs& a, const ClPlan& p, hipStream_t s, const char
                        (T*)a.gx, coeff, a.weight, a.bias, a.save_mean, a.save_invstd, total, a.C, p.tact, p.span, a.slope);
 }
 
+
+// ======================================================================================================
+// Channels-last, WIDE rows (C > 256: the graph stages' 264 / 324 / 528 / 648 / 1056 / 1296-channel tensors, and any C
+// when NEXTOU_CLW=1).  x is R = B*S rows of C contiguous channels, cut into column blocks of CW = cx * VEC channels and
+// row blocks; a workgroup is cx lanes across the channels x 256 / cx lanes down the rows, so a thread owns VEC fixed
+// channels (scale / shift in registers), every access is a 16-byte piece of a >= 128-byte run, and the partial sums of a
+// channel meet in LDS in a fixed order (bit-reproducible).  cx is picked per C for lane utilisation: C = 264 -> 8 lanes
+// (9 blocks of 32 channels, 92 %), C = 1056 -> 32 lanes (9 blocks of 128, 92 %).  Same finalize kernels as above.
+// ======================================================================================================
+struct ClwPlan {
+    int vec, cx_log2, ncb, nrb;
+    long long rows_per_block;
+};
+
+static ClwPlan plan_clw(long long rows, int C, int vec_full, bool aligned) {
+    ClwPlan p;
+    p.vec = (aligned && C % vec_full == 0) ? vec_full : 1;
+    double best = -1.0;
+    p.cx_log2 = 3;
+    for (int lg = 3; lg <= 6; ++lg) {       // 8 .. 64 lanes across the channels; ties go to the wider run
+        const int cw = (1 << lg) * p.vec;
+        const double util = (double)C / ((double)cdiv(C, cw) * cw);
+        if (util >= best - 0.03) { if (util > best) best = util; p.cx_log2 = lg; }
+    }
+    p.ncb = cdiv(C, (1 << p.cx_log2) * p.vec);
+    const int ry = kThreads >> p.cx_log2;
+    long long nrb = cdiv64(4096, p.ncb);                       // ~4096 workgroups ...
+    const long long max_by_rows = cdiv64(rows, (long long)ry * 8);   // ... of at least 8 rows per thread
+    if (nrb > max_by_rows) nrb = max_by_rows;
+    if (nrb > 1024) nrb = 1024;                                // partial_slots()
+    if (nrb < 1) nrb = 1;
+    p.rows_per_block = cdiv64(rows, nrb);
+    p.nrb = (int)cdiv64(rows, p.rows_per_block);
+    return p;
+}
+
+struct ClwThread {
+    int cx, ry, nry, ch0;        // lane across channels, lane down the rows, rows lanes, first owned channel
+    long long r0, r1;
+    bool active;
+};
+template <int VEC>
+__device__ inline ClwThread clw_decode(long long rows, int C, int cx_log2, long long rows_per_block) {
+    ClwThread t;
+    t.cx = threadIdx.x & ((1 << cx_log2) - 1);
+    t.ry = threadIdx.x >> cx_log2;
+    t.nry = kThreads >> cx_log2;
+    t.ch0 = (blockIdx.y << cx_log2) * VEC + t.cx * VEC;
+    t.r0 = (long long)blockIdx.x * rows_per_block;
+    t.r1 = min(rows, t.r0 + rows_per_block);
+    t.active = t.ch0 < C;        // C % VEC == 0 on the vector path; VEC == 1 otherwise
+    return t;
+}
+
+// combine the row-lanes' partials of every owned channel in ry order; lanes with ry == 0 write them out
+template <int VEC>
+__device__ inline void clw_block_sums(const double (&a)[VEC], const double (&b)[VEC], const ClwThread& t, int cx_log2, int C,
+                                      double2* partial, int nrb) {
+    extern __shared__ double2 clw_red[];       // [nry][cx * VEC]
+    const int cw = (1 << cx_log2) * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) clw_red[t.ry * cw + t.cx * VEC + j] = make_double2(a[j], b[j]);
+    __syncthreads();
+    if (t.ry == 0 && t.active) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            double s = 0.0, q = 0.0;
+            for (int r = 0; r < t.nry; ++r) { const double2 v = clw_red[r * cw + t.cx * VEC + j]; s += v.x; q += v.y; }
+            partial[(size_t)(t.ch0 + j) * nrb + blockIdx.x] = make_double2(s, q);
+        }
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void bn_clw_stats_kernel(const T* __restrict__ x, double2* __restrict__ partial,
+                                                                long long rows, int C, int cx_log2, long long rows_per_block) {
+    const ClwThread t = clw_decode<VEC>(rows, C, cx_log2, rows_per_block);
+    double s[VEC], q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = q[j] = 0.0;
+    if (t.active) {
+        const T* base = x + t.ch0;
+        long long r = t.r0 + t.ry;
+        for (; r + 3ll * t.nry < t.r1; r += 4ll * t.nry) {
+            Pack<T, VEC> p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u].load(base + (r + (long long)u * t.nry) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { const double v = (double)p[u].v[j]; s[j] += v; q[j] = fma(v, v, q[j]); }
+        }
+        for (; r < t.r1; r += t.nry) {
+            Pack<T, VEC> p;
+            p.load(base + r * C);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { const double v = (double)p.v[j]; s[j] += v; q[j] = fma(v, v, q[j]); }
+        }
+    }
+    clw_block_sums<VEC>(s, q, t, cx_log2, C, partial, gridDim.x);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void bn_clw_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                                const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                const float* __restrict__ save_mean,
+                                                                const float* __restrict__ save_invstd, long long rows, int C,
+                                                                int cx_log2, long long rows_per_block, float slope) {
+    const ClwThread t = clw_decode<VEC>(rows, C, cx_log2, rows_per_block);
+    if (!t.active) return;
+    float scale[VEC], shift[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int c = t.ch0 + j;
+        const float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
+        scale[j] = w * save_invstd[c];
+        shift[j] = fmaf(-save_mean[c], scale[j], b);
+    }
+    long long r = t.r0 + t.ry;
+    for (; r + 3ll * t.nry < t.r1; r += 4ll * t.nry) {
+        Pack<T, VEC> p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u].load(x + (r + (long long)u * t.nry) * C + t.ch0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) p[u].v[j] = leaky(fmaf(p[u].v[j], scale[j], shift[j]), slope);
+            p[u].store(y + (r + (long long)u * t.nry) * C + t.ch0);
+        }
+    }
+    for (; r < t.r1; r += t.nry) {
+        Pack<T, VEC> p;
+        p.load(x + r * C + t.ch0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) p.v[j] = leaky(fmaf(p.v[j], scale[j], shift[j]), slope);
+        p.store(y + r * C + t.ch0);
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void bn_clw_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ gy,
+                                                                     double2* __restrict__ partial,
+                                                                     const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                     const float* __restrict__ save_mean,
+                                                                     const float* __restrict__ save_invstd, long long rows,
+                                                                     int C, int cx_log2, long long rows_per_block, float slope) {
+    const ClwThread t = clw_decode<VEC>(rows, C, cx_log2, rows_per_block);
+    double s1[VEC], s2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.0;
+    if (t.active) {
+        float scale[VEC], shift[VEC], mean[VEC], invstd[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = t.ch0 + j;
+            const float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
+            mean[j] = save_mean[c];
+            invstd[j] = save_invstd[c];
+            scale[j] = w * invstd[j];
+            shift[j] = fmaf(-mean[j], scale[j], b);
+        }
+        long long r = t.r0 + t.ry;
+        for (; r + t.nry < t.r1; r += 2ll * t.nry) {
+            Pack<T, VEC> p[2], g[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                p[u].load(x + (r + (long long)u * t.nry) * C + t.ch0);
+                g[u].load(gy + (r + (long long)u * t.nry) * C + t.ch0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float z = fmaf(p[u].v[j], scale[j], shift[j]);
+                    const float dz = z > 0.f ? g[u].v[j] : g[u].v[j] * slope;
+                    const float xh = (p[u].v[j] - mean[j]) * invstd[j];
+                    s1[j] += (double)dz;
+                    s2[j] = fma((double)dz, (double)xh, s2[j]);
+                }
+        }
+        for (; r < t.r1; r += t.nry) {
+            Pack<T, VEC> p, g;
+            p.load(x + r * C + t.ch0);
+            g.load(gy + r * C + t.ch0);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float z = fmaf(p.v[j], scale[j], shift[j]);
+                const float dz = z > 0.f ? g.v[j] : g.v[j] * slope;
+                const float xh = (p.v[j] - mean[j]) * invstd[j];
+                s1[j] += (double)dz;
+                s2[j] = fma((double)dz, (double)xh, s2[j]);
+            }
+        }
+    }
+    clw_block_sums<VEC>(s1, s2, t, cx_log2, C, partial, gridDim.x);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void bn_clw_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ gy,
+                                                                    T* __restrict__ gx, const float2* __restrict__ coeff,
+                                                                    const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                    const float* __restrict__ save_mean,
+                                                                    const float* __restrict__ save_invstd, long long rows,
+                                                                    int C, int cx_log2, long long rows_per_block, float slope) {
+    const ClwThread t = clw_decode<VEC>(rows, C, cx_log2, rows_per_block);
+    if (!t.active) return;
+    float scale[VEC], shift[VEC], mean[VEC], invstd[VEC], k1[VEC], k2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int c = t.ch0 + j;
+        const float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
+        mean[j] = save_mean[c];
+        invstd[j] = save_invstd[c];
+        scale[j] = w * invstd[j];
+        shift[j] = fmaf(-mean[j], scale[j], b);
+        k1[j] = coeff[c].x;
+        k2[j] = coeff[c].y;
+    }
+    for (long long r = t.r0 + t.ry; r < t.r1; r += t.nry) {
+        Pack<T, VEC> p, g;
+        p.load(x + r * C + t.ch0);
+        g.load(gy + r * C + t.ch0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float z = fmaf(p.v[j], scale[j], shift[j]);
+            const float dz = z > 0.f ? g.v[j] : g.v[j] * slope;
+            const float xh = (p.v[j] - mean[j]) * invstd[j];
+            g.v[j] = scale[j] * ((dz - k1[j]) - xh * k2[j]);
+        }
+        g.store(gx + r * C + t.ch0);
+    }
+}
+
+template <typename T, int VEC>
+void launch_clw_fwd(const NormArgs& a, const ClwPlan& p, hipStream_t s, const char* tname) {
+    const long long rows = (long long)a.B * a.S;
+    const double bytes = (double)rows * a.C * sizeof(T);
+    const double count = (double)rows;
+    const dim3 grid(p.nrb, p.ncb);
+    const size_t lds = (size_t)kThreads * VEC * sizeof(double2);
+    if (a.training) {
+        ProfScope prof(s, kBoundHbm, bytes, "bn_clw_stats_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
+        hipLaunchKernelGGL((bn_clw_stats_kernel<T, VEC>), grid, dim3(kThreads), lds, s, (const T*)a.x, a.partial, rows, a.C,
+                           p.cx_log2, p.rows_per_block);
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(kFinThreads), 0, s, a.partial, p.nrb, count, a.pre_bias,
+                       a.running_mean, a.running_var, a.save_mean, a.save_invstd, a.training, a.momentum, a.eps);
+    ProfScope prof(s, kBoundHbm, 2.0 * bytes, "bn_clw_apply_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
+    hipLaunchKernelGGL((bn_clw_apply_kernel<T, VEC>), grid, dim3(kThreads), 0, s, (const T*)a.x, (T*)a.y, a.weight, a.bias,
+                       a.save_mean, a.save_invstd, rows, a.C, p.cx_log2, p.rows_per_block, a.slope);
+}
+
+template <typename T, int VEC>
+void launch_clw_bwd(const NormArgs& a, const ClwPlan& p, hipStream_t s, const char* tname) {
+    const long long rows = (long long)a.B * a.S;
+    const double bytes = (double)rows * a.C * sizeof(T);
+    const double count = (double)rows;
+    const dim3 grid(p.nrb, p.ncb);
+    const size_t lds = (size_t)kThreads * VEC * sizeof(double2);
+    float2* coeff = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.partial) + kCoeffOffset(a.B, a.C, a.S));
+    {
+        ProfScope prof(s, kBoundHbm, 2.0 * bytes, "bn_clw_bwd_reduce_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
+        hipLaunchKernelGGL((bn_clw_bwd_reduce_kernel<T, VEC>), grid, dim3(kThreads), lds, s, (const T*)a.x, (const T*)a.gy,
+                           a.partial, a.weight, a.bias, a.save_mean, a.save_invstd, rows, a.C, p.cx_log2, p.rows_per_block,
+                           a.slope);
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.C), dim3(kFinThreads), 0, s, a.partial, p.nrb, count, coeff, a.gweight,
+                       a.gbias, a.training);
+    ProfScope prof(s, kBoundHbm, 3.0 * bytes, "bn_clw_bwd_apply_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
+    hipLaunchKernelGGL((bn_clw_bwd_apply_kernel<T, VEC>), grid, dim3(kThreads), 0, s, (const T*)a.x, (const T*)a.gy, (T*)a.gx,
+                       coeff, a.weight, a.bias, a.save_mean, a.save_invstd, rows, a.C, p.cx_log2, p.rows_per_block, a.slope);
+}
+
+template <bool FWD>
+static void norm_dispatch_clw(const NormArgs& a, const ClwPlan& p, int dtype, hipStream_t s) {
+    if (dtype == NEXTOU_DTYPE_F32) {
+        if (p.vec == 4) FWD ? launch_clw_fwd<float, 4>(a, p, s, "f32") : launch_clw_bwd<float, 4>(a, p, s, "f32");
+        else FWD ? launch_clw_fwd<float, 1>(a, p, s, "f32,scalar") : launch_clw_bwd<float, 1>(a, p, s, "f32,scalar");
+    } else if (dtype == NEXTOU_DTYPE_F16) {
+        if (p.vec == 8) FWD ? launch_clw_fwd<__half, 8>(a, p, s, "f16") : launch_clw_bwd<__half, 8>(a, p, s, "f16");
+        else FWD ? launch_clw_fwd<__half, 1>(a, p, s, "f16,scalar") : launch_clw_bwd<__half, 1>(a, p, s, "f16,scalar");
+    } else {
+        if (p.vec == 8) FWD ? launch_clw_fwd<__hip_bfloat16, 8>(a, p, s, "bf16") : launch_clw_bwd<__hip_bfloat16, 8>(a, p, s, "bf16");
+        else FWD ? launch_clw_fwd<__hip_bfloat16, 1>(a, p, s, "bf16,scalar") : launch_clw_bwd<__hip_bfloat16, 1>(a, p, s, "bf16,scalar");
+    }
+}
+
+// which channels-last scheme a call takes: the row-packing kernels need C <= 256 and keep only C of their 256 lanes busy
+// once a row no longer fits twice (C > 128: 52 % at C = 132, where the column-blocked scheme reaches 82 %).
+// NEXTOU_CLW=1 forces the wide scheme for every C, NEXTOU_CLW=2 restricts it to C > 256 (A/B).
+static bool use_clw(int C) {
+    static const int mode = [] { const char* e = getenv("NEXTOU_CLW"); return e ? atoi(e) : 0; }();
+    if (mode == 1) return true;
+    if (mode == 2) return C > kThreads;
+    return C > kThreads / 2;
+}
+
 template <bool FWD>
 static void norm_dispatch_cl(const NormArgs& a, const ClPlan& p, int dtype, hipStream_t s) {
     if (dtype == NEXTOU_DTYPE_F32) {
@@ -930,6 +1226,10 @@ extern "C" int nextou_norm_act_fwd(const void* x, const float* weight, const flo
         NEXTOU_REQUIRE(save_mean && save_invstd, "norm_act_fwd: the channels-last path needs save_mean / save_invstd");
         NEXTOU_REQUIRE(!training || (ws && ws_bytes >= nextou_norm_act_workspace_bytes(B, C, S, dtype)),
                        "norm_act_fwd: workspace %zu < %zu bytes", ws_bytes, nextou_norm_act_workspace_bytes(B, C, S, dtype));
+        if (use_clw(C)) {
+            norm_dispatch_clw<true>(a, plan_clw((long long)B * S, C, 16 / esz, aligned16(x) && aligned16(y)), dtype, (hipStream_t)stream);
+            return check_launch("bn_clw_apply_kernel");
+        }
         const ClPlan p = plan_cl((long long)B * C * S, C, 16 / esz, aligned16(x) && aligned16(y));
         norm_dispatch_cl<true>(a, p, dtype, (hipStream_t)stream);
         return check_launch("bn_cl_apply_kernel");
@@ -959,6 +1259,11 @@ extern "C" int nextou_norm_act_bwd(const void* x, const void* gy, const float* w
     if (channels_last) {
         if (ws_bytes < nextou_norm_act_workspace_bytes(B, C, S, dtype))
             return fail(NEXTOU_ENOSPACE, "norm_act_bwd: workspace %zu < %zu bytes", ws_bytes, nextou_norm_act_workspace_bytes(B, C, S, dtype));
+        if (use_clw(C)) {
+            norm_dispatch_clw<false>(a, plan_clw((long long)B * S, C, 16 / esz, aligned16(x) && aligned16(gy) && aligned16(gx)), dtype,
+                                     (hipStream_t)stream);
+            return check_launch("bn_clw_bwd_apply_kernel");
+        }
         const ClPlan p = plan_cl((long long)B * C * S, C, 16 / esz, aligned16(x) && aligned16(gy) && aligned16(gx));
         norm_dispatch_cl<false>(a, p, dtype, (hipStream_t)stream);
         return check_launch("bn_cl_bwd_apply_kernel");
@@ -983,7 +1288,18 @@ extern "C" int nextou_channel_sum(const void* x, float* out, void* ws, size_t ws
     int tiles;
     ProfScope prof(s, kBoundHbm, bytes, "channel_sum<%s,%s>[B%d C%d S%lld]", dtype == NEXTOU_DTYPE_F32 ? "f32" : (dtype == NEXTOU_DTYPE_F16 ? "f16" : "bf16"),
                    channels_last ? "ndhwc" : "ncdhw", B, C, (long long)S);
-    if (channels_last) {
+    if (channels_last && use_clw(C)) {
+        const long long rows = (long long)B * S;
+        const ClwPlan p = plan_clw(rows, C, 16 / esz, aligned16(x));
+        tiles = p.nrb;
+        const dim3 grid(p.nrb, p.ncb);
+        const size_t lds = (size_t)kThreads * p.vec * sizeof(double2);
+#define NEXTOU_CLW_SUM(T, V) hipLaunchKernelGGL((bn_clw_stats_kernel<T, V>), grid, dim3(kThreads), lds, s, (const T*)x, partial, rows, C, p.cx_log2, p.rows_per_block)
+        if (esz == 4) { if (p.vec == 4) NEXTOU_CLW_SUM(float, 4); else NEXTOU_CLW_SUM(float, 1); }
+        else if (dtype == NEXTOU_DTYPE_F16) { if (p.vec == 8) NEXTOU_CLW_SUM(__half, 8); else NEXTOU_CLW_SUM(__half, 1); }
+        else { if (p.vec == 8) NEXTOU_CLW_SUM(__hip_bfloat16, 8); else NEXTOU_CLW_SUM(__hip_bfloat16, 1); }
+#undef NEXTOU_CLW_SUM
+    } else if (channels_last) {
         const long long total = (long long)B * C * S;
         const ClPlan p = plan_cl(total, C, 16 / esz, aligned16(x));
         tiles = p.blocks;

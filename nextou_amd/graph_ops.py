@@ -31,7 +31,7 @@ from . import _lib
 __all__ = [
     "knn_graph", "pairwise_sq_distance", "edge_index_from_nn_idx", "mr_aggregate", "gather_neighbors",
     "argmax_labels", "bti_critical_map", "critical_cross_entropy", "norm_act", "install_cpu_checker", "IndexTape",
-    "index_tape",
+    "index_tape", "window_gather", "window_scatter", "pool_rows", "cell_scatter",
 ]
 
 
@@ -303,6 +303,95 @@ class _HipBackend:
         return out
 
 
+    # ---- K3 / K4: window / pool data movement between channels-last volumes and channel-major rows ----
+    @staticmethod
+    def window_gather(x_cl, window, shift):
+        """x_cl: dense channels_last(_3d) (B,C,*sp) -> (B * n_windows, C, Nw) contiguous."""
+        L_ = _lib.lib()
+        B, C = x_cl.shape[:2]
+        D, H, W = _dhw(x_cl.shape[2:])
+        wd, wh, ww = _dhw(window)
+        sd, sh, sw = _dhw(shift, fill=0)
+        n_win = (D // wd) * (H // wh) * (W // ww)
+        out = torch.empty((B * n_win, C, wd * wh * ww), dtype=torch.float32, device=x_cl.device)
+        with torch.cuda.device(x_cl.device):
+            rc = L_.nextou_window_gather(x_cl.data_ptr(), out.data_ptr(), B, C, D, H, W, wd, wh, ww, sd, sh, sw,
+                                         _stream_ptr(x_cl.device))
+        _lib.check(rc, "window_gather")
+        return out
+
+    @staticmethod
+    def window_scatter(src_cm, residual_cl, spatial, window, shift):
+        """(B * n_windows, C, Nw) [+ residual_cl] -> channels_last(_3d) tensor (B,C,*spatial)."""
+        L_ = _lib.lib()
+        D, H, W = _dhw(spatial)
+        wd, wh, ww = _dhw(window)
+        sd, sh, sw = _dhw(shift, fill=0)
+        n_win = (D // wd) * (H // wh) * (W // ww)
+        B, C = src_cm.shape[0] // n_win, src_cm.shape[1]
+        out = _empty_channels_last((B, C) + tuple(spatial), src_cm.device)
+        with torch.cuda.device(src_cm.device):
+            rc = L_.nextou_window_scatter(src_cm.data_ptr(), _ptr(residual_cl), out.data_ptr(), B, C, D, H, W, wd, wh, ww,
+                                          sd, sh, sw, _stream_ptr(src_cm.device))
+        _lib.check(rc, "window_scatter")
+        return out
+
+    @staticmethod
+    def pool_rows(x_cl, pool):
+        """channels-last (B,C,*sp) -> (values (B,C,N) contiguous, cell (B,N,C) uint8)."""
+        L_ = _lib.lib()
+        B, C = x_cl.shape[:2]
+        D, H, W = _dhw(x_cl.shape[2:])
+        pd, ph, pw = _dhw(pool)
+        N = (D // pd) * (H // ph) * (W // pw)
+        values = torch.empty((B, C, N), dtype=torch.float32, device=x_cl.device)
+        cell = torch.empty((B, N, C), dtype=torch.uint8, device=x_cl.device)
+        with torch.cuda.device(x_cl.device):
+            rc = L_.nextou_pool_rows(x_cl.data_ptr(), values.data_ptr(), cell.data_ptr(), B, C, D, H, W, pd, ph, pw,
+                                     _stream_ptr(x_cl.device))
+        _lib.check(rc, "pool_rows")
+        return values, cell
+
+    @staticmethod
+    def cell_gather(x_cl, cell, pool):
+        L_ = _lib.lib()
+        B, C2 = x_cl.shape[:2]
+        D, H, W = _dhw(x_cl.shape[2:])
+        pd, ph, pw = _dhw(pool)
+        N, C = cell.shape[1], cell.shape[2]
+        out = torch.empty((B, C2, N), dtype=torch.float32, device=x_cl.device)
+        with torch.cuda.device(x_cl.device):
+            rc = L_.nextou_cell_gather(x_cl.data_ptr(), cell.data_ptr(), out.data_ptr(), B, C2, C, D, H, W, pd, ph, pw,
+                                       _stream_ptr(x_cl.device))
+        _lib.check(rc, "cell_gather")
+        return out
+
+    @staticmethod
+    def cell_scatter(src_cm, cell, spatial, pool):
+        L_ = _lib.lib()
+        B, C2 = src_cm.shape[:2]
+        D, H, W = _dhw(spatial)
+        pd, ph, pw = _dhw(pool)
+        C = cell.shape[2]
+        out = _empty_channels_last((B, C2) + tuple(spatial), src_cm.device)
+        with torch.cuda.device(src_cm.device):
+            rc = L_.nextou_cell_scatter(src_cm.data_ptr(), cell.data_ptr(), out.data_ptr(), B, C2, C, D, H, W, pd, ph, pw,
+                                        _stream_ptr(src_cm.device))
+        _lib.check(rc, "cell_scatter")
+        return out
+
+
+def _dhw(sizes, fill=1):
+    """(H,W) or (D,H,W) -> (D,H,W): 2-D volumes are one slice thick."""
+    sizes = [int(v) for v in sizes]
+    return tuple([fill] * (3 - len(sizes)) + sizes)
+
+
+def _empty_channels_last(shape, device):
+    mf = {4: torch.channels_last, 5: torch.channels_last_3d}[len(shape)]
+    return torch.empty(shape, dtype=torch.float32, device=device, memory_format=mf)
+
+
 _NORM_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
 _HIP = _HipBackend()
 
@@ -346,6 +435,14 @@ def index_tape(tape: IndexTape):
 
 def taped(compute: Callable[[], torch.Tensor], device) -> torch.Tensor:
     return compute() if _tape is None else _tape.take(compute, device)
+
+
+def tape_active() -> bool:
+    return _tape is not None
+
+
+def tape_replaying() -> bool:
+    return _tape is not None and _tape.replay
 
 
 # ----------------------------------------------------------------------------------------------
@@ -502,7 +599,7 @@ class _NormAct(torch.autograd.Function):
         B, C = shape[0], shape[1]
         period = C if instance else 0
         be = _backend_for(x)
-        cl = _dense_channels_last(x) if (x.is_cuda and not instance and C <= 256) else None
+        cl = _dense_channels_last(x) if (x.is_cuda and not instance) else None
         if cl is not None:      # NDHWC / NHWC memory goes to the channels-last kernels as it is
             y, mean, invstd = be.norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps,
                                               slope, 0, pre_bias, channels_last=True)
@@ -613,8 +710,6 @@ class _ConvOwnBiasGrad(torch.autograd.Function):
         # concatenation's gradient (dense in neither layout), and converting that to NCDHW under a channels-last
         # convolution costs two passes over the tensor instead of one
         cl = _dense_channels_last(x)
-        if cl is not None and gy.shape[1] > 256 and ctx.needs_input_grad[2]:
-            cl = None       # the channels-last reduction of K6 covers C <= 256; wider bias gradients take the NCDHW kernels
         gy = gy.contiguous(memory_format=cl) if cl is not None else gy.contiguous()
         gx, gw, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, stride, padding, dilation, transposed,
                                                         output_padding, groups,
@@ -647,3 +742,132 @@ def bti_critical_map(labels: torch.Tensor, lut_a: torch.Tensor, lut_c: torch.Ten
         raise TypeError("bti_critical_map: labels must be uint8, got %s" % labels.dtype)
     return _backend_for(labels).bti_critical(labels, lut_a.contiguous(), lut_c.contiguous(),
                                              int(connectivity), int(min_thick))
+
+
+# ----------------------------------------------------------------------------------------------
+# K3 / K4: window shift + partition / reverse and query max-pool / unpool, fused with the layout change between the dense
+# stages' channels-last volumes and the graph kernels' channel-major rows
+# ----------------------------------------------------------------------------------------------
+def as_channels_last_rows(x: torch.Tensor) -> torch.Tensor:
+    """float32 tensor whose MEMORY is (B, *spatial, C)-contiguous (a no-op for a dense channels-last tensor)."""
+    mf = {4: torch.channels_last, 5: torch.channels_last_3d}[x.dim()]
+    if x.dtype != torch.float32:
+        x = x.float()
+    if x.shape[1] == 1:          # one channel: NCDHW and NDHWC are the same bytes
+        return x.contiguous()
+    return x.contiguous(memory_format=mf)
+
+
+class _WindowGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, window, shift):
+        ctx.conf = (tuple(x.shape[2:]), window, shift)
+        return _backend_for(x).window_gather(x, window, shift)
+
+    @staticmethod
+    def backward(ctx, g):
+        spatial, window, shift = ctx.conf
+        return _backend_for(g).window_scatter(g.contiguous(), None, spatial, window, shift), None, None
+
+
+class _WindowScatter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, residual, spatial, window, shift):
+        ctx.conf = (window, shift, residual is not None)
+        return _backend_for(src).window_scatter(src, residual, spatial, window, shift)
+
+    @staticmethod
+    def backward(ctx, g):
+        window, shift, has_res = ctx.conf
+        g = as_channels_last_rows(g)
+        return _backend_for(g).window_gather(g, window, shift), (g if has_res else None), None, None, None
+
+
+def window_gather(x: torch.Tensor, window, shift) -> torch.Tensor:
+    """``window_partition(torch.roll(x, -shift))`` (reference NexToU_Encoder_Decoder.py:781-790, :634-660) of a
+    channels-last volume x (B,C,*spatial) -> (B * n_windows, C, prod(window)) channel-major rows."""
+    return _WindowGather.apply(as_channels_last_rows(x), tuple(int(v) for v in window), tuple(int(v) for v in shift))
+
+
+def window_scatter(windows: torch.Tensor, spatial, window, shift, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``torch.roll(window_reverse(windows), +shift) [+ residual]`` (reference :807-817, :662-693): (B * n_windows, C, Nw)
+    -> channels-last (B,C,*spatial)."""
+    res = None if residual is None else as_channels_last_rows(residual)
+    return _WindowScatter.apply(_f32c(windows), res, tuple(int(v) for v in spatial), tuple(int(v) for v in window),
+                                tuple(int(v) for v in shift))
+
+
+class _PoolRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pool, forced_cell):
+        be = _backend_for(x)
+        if forced_cell is None:
+            values, cell = be.pool_rows(x, pool)
+        else:                                   # teacher-forced arg-max cells (test hook): a plain gather
+            values, cell = be.cell_gather(x, forced_cell, pool), forced_cell
+        ctx.save_for_backward(cell)
+        ctx.conf = (tuple(x.shape[2:]), pool)
+        ctx.mark_non_differentiable(cell)
+        return values, cell
+
+    @staticmethod
+    def backward(ctx, g, _):
+        (cell,) = ctx.saved_tensors
+        spatial, pool = ctx.conf
+        return _backend_for(g).cell_scatter(_f32c(g), cell, spatial, pool), None, None
+
+
+def pool_rows(x: torch.Tensor, pool, forced_cell: Optional[torch.Tensor] = None):
+    """``MaxPool(pool, stride=pool, return_indices=True)`` (reference :524-530) of a channels-last volume ->
+    (values (B,C,N) channel-major, cell (B,N,C) uint8 = winning position inside each pooling cell)."""
+    return _PoolRows.apply(as_channels_last_rows(x), tuple(int(v) for v in pool), forced_cell)
+
+
+class _CellScatter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, cell, spatial, pool):
+        ctx.save_for_backward(cell)
+        ctx.pool = pool
+        return _backend_for(src).cell_scatter(src, cell, spatial, pool)
+
+    @staticmethod
+    def backward(ctx, g):
+        (cell,) = ctx.saved_tensors
+        g = as_channels_last_rows(g)
+        return _backend_for(g).cell_gather(g, cell, ctx.pool), None, None, None
+
+
+def cell_scatter(src: torch.Tensor, cell: torch.Tensor, spatial, pool) -> torch.Tensor:
+    """``MaxUnpool(out, cat(indices, indices))`` (reference :536-549): src (B,C2,N), C2 = C or 2C, -> channels-last
+    (B,C2,*spatial) with src at the recorded cell position of channel c2 mod C and zeros elsewhere."""
+    return _CellScatter.apply(_f32c(src), cell, tuple(int(v) for v in spatial), tuple(int(v) for v in pool))
+
+
+def cells_to_flat_indices(cell: torch.Tensor, spatial, pool) -> torch.Tensor:
+    """cell (B,N,C) uint8 -> the reference's MaxPool ``indices`` (B,C,*pooled) int64 (flat position in the un-pooled
+    spatial volume).  Only used to record / replay the index tape (test hook)."""
+    spatial, pool = [int(v) for v in spatial], [int(v) for v in pool]
+    pooled = [s // p for s, p in zip(spatial, pool)]
+    B, N, C = cell.shape
+    k = cell.long().permute(0, 2, 1).reshape(B, C, *pooled)
+    flat, stride, rem_k = torch.zeros_like(k), 1, k
+    coords = torch.meshgrid(*[torch.arange(n, device=cell.device) for n in pooled], indexing="ij")
+    for axis in reversed(range(len(spatial))):
+        kk = rem_k % pool[axis]
+        rem_k = rem_k // pool[axis]
+        flat = flat + (coords[axis] * pool[axis] + kk) * stride
+        stride *= spatial[axis]
+    return flat
+
+
+def flat_indices_to_cells(indices: torch.Tensor, spatial, pool) -> torch.Tensor:
+    """inverse of :func:`cells_to_flat_indices` -> cell (B,N,C) uint8."""
+    spatial, pool = [int(v) for v in spatial], [int(v) for v in pool]
+    B, C = indices.shape[:2]
+    rem, k, mult = indices.long(), torch.zeros_like(indices, dtype=torch.long), 1
+    for axis in reversed(range(len(spatial))):
+        pos = rem % spatial[axis]
+        rem = rem // spatial[axis]
+        k = k + (pos % pool[axis]) * mult
+        mult *= pool[axis]
+    return k.reshape(B, C, -1).permute(0, 2, 1).contiguous().to(torch.uint8)

@@ -61,7 +61,7 @@ class NexToU(nn.Module):
         if fusion_enabled():  # (norm -> LeakyReLU) pairs become one K6 launch; state_dict unchanged
             fuse_norm_act(self)
             # the plain conv stages run channels-last on the GPU (layout.py); needs K6's NDHWC kernels, hence here
-            self.encoder.channels_last_stages = channels_last_stages(conv_op, self.encoder.n_conv_stages)
+            self.encoder.channels_last_stages = channels_last_stages(conv_op, self.encoder.n_conv_stages, n_stages)
 
     def forward(self, x):
         return self.decoder(self.encoder(x))

@@ -33,7 +33,7 @@ from torch.nn.modules.dropout import _DropoutNd
 
 from .. import graph_ops
 from .conv_blocks import StackedConvBlocks, get_matching_convtransp, maybe_convert_scalar_to_list
-from .layout import set_stage_layout
+from .layout import is_channels_last_volume, set_stage_layout
 from .pos_embed import get_2d_relative_pos_embed, get_3d_relative_pos_embed  # noqa: F401 (re-export)
 from .pos_embed import get_nd_relative_pos_embed
 from .torch_edge import DenseDilatedKnnGraph
@@ -320,8 +320,29 @@ class PoolDyGraphConv(DyGraphConv):
             self.max_pool_input = nn.MaxPool3d(self.pool_size, stride=self.pool_size, return_indices=True)
             self.max_unpool_output = nn.MaxUnpool3d(self.pool_size, stride=self.pool_size)
 
+    def _forward_channels_last(self, x, relative_pos):
+        """x: dense channels-last device tensor.  The query max-pool reads the volume's rows and emits channel-major
+        values plus the winning cell of every pooling window (uint8); the unpool writes the channels-last output once,
+        zeros included (graph_ops.pool_rows / cell_scatter) — no int64 indices, no cat, no memset, no layout copies."""
+        b, c = x.shape[:2]
+        full_spatial = tuple(x.shape[2:])
+        if not any(p != 1 for p in self.pool_size):     # small stages: plain layout change around the graph op
+            out = self._graph_forward(x.contiguous(), relative_pos).reshape(b, -1, *full_spatial)
+            return out.contiguous(memory_format=torch.channels_last if x.dim() == 4 else torch.channels_last_3d)
+        values, cell = graph_ops.pool_rows(x, self.pool_size)
+        if graph_ops.tape_active():                     # test hook: record / replay the reference's MaxPool indices
+            flat = graph_ops.taped(lambda: graph_ops.cells_to_flat_indices(cell, full_spatial, self.pool_size), x.device)
+            if graph_ops.tape_replaying():
+                values, cell = graph_ops.pool_rows(
+                    x, self.pool_size, forced_cell=graph_ops.flat_indices_to_cells(flat, full_spatial, self.pool_size))
+        pooled_spatial = tuple(s // p for s, p in zip(full_spatial, self.pool_size))
+        out = self._graph_forward(values.view(b, c, *pooled_spatial), relative_pos)
+        return graph_ops.cell_scatter(out.reshape(b, out.shape[1], -1), cell, full_spatial, self.pool_size)
+
     def forward(self, x, relative_pos=None):
         _conv_dim(self.conv_op)
+        if is_channels_last_volume(x):
+            return self._forward_channels_last(x, relative_pos)
         pooled = any(p != 1 for p in self.pool_size)
         if pooled:
             full_spatial = x.shape[2:]
@@ -426,6 +447,16 @@ class SwinGrapher(_GrapherBase):
         shortcut = x
         size_tuple = tuple(x.shape[2:])
         assert size_tuple == tuple(self.img_shape), "input features has wrong size"
+        if is_channels_last_volume(x) and isinstance(self.drop_path, nn.Identity):
+            # shift + partition read the channels-last volume once and emit channel-major windows; reverse + unshift +
+            # the residual add write it once (graph_ops.window_gather / window_scatter)
+            shift = tuple(self.shift_size) if max(self.shift_size) > 0 else (0,) * dim
+            windows = graph_ops.window_gather(x, self.window_size, shift)
+            h = self.fc1(windows.view(windows.shape[0], windows.shape[1], *self.window_size))
+            h = self.graph_conv(h, self._get_relative_pos(self.relative_pos, tuple(h.shape[2:])))
+            h = self.fc2(h)
+            return graph_ops.window_scatter(h.reshape(h.shape[0], h.shape[1], -1), size_tuple, self.window_size, shift,
+                                            residual=shortcut)
         axes = tuple(range(2, 2 + dim))
         shifted = max(self.shift_size) > 0
         if shifted:

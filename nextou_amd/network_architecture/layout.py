@@ -8,9 +8,15 @@ their activations channels-last from the stage input to the stage output; the gr
 stay NCDHW.  What made channels-last unusable on stock PyTorch-ROCm — MIOpen's NHWC batch norm and ATen's bias-gradient
 reduction (170 ms on the two stages, tools/layout_probe.py) — is K6's job here (csrc/norm_act.hip).
 
-``NEXTOU_CHANNELS_LAST_STAGES``: ``auto`` (default), ``none``, or a comma list of stage indices.  Whatever the set, a
-stage only goes channels-last when its convolutions run in fp32 (:func:`runs_in_fp32`): under bf16 autocast the same
-policy is a 125 ms *loss* on cfg 2.
+Round 2: the graph stages follow.  Their 3x3x3 convolutions are CK NDHWC kernels too (7.3 ms of ``batched_transpose``
+per cfg-2 step around them), and what pinned them to NCDHW — the graph kernels' channel-major rows (B', C, N) — is handled
+where the data has to move anyway: the window shift / partition / reverse and the query max-pool / unpool are HIP kernels
+(csrc/layout_ops.hip) that read or write the channels-last volume directly, and K6 has column-blocked kernels for rows
+wider than 256 channels.  So with ``auto`` every stage of a 3-D model is channels-last from the network input to the logits.
+
+``NEXTOU_CHANNELS_LAST_STAGES``: ``auto`` (default: all stages), ``plain`` (round 1: only the stages without graph blocks),
+``none``, or a comma list of stage indices.  Whatever the set, a stage only goes channels-last when its convolutions run
+in fp32 (:func:`runs_in_fp32`): under bf16 autocast the same policy is a 125 ms *loss* on cfg 2.
 """
 from __future__ import annotations
 
@@ -21,13 +27,24 @@ import torch
 from torch import nn
 
 
-def channels_last_stages(conv_op, n_plain_conv_stages: int) -> FrozenSet[int]:
+def channels_last_stages(conv_op, n_plain_conv_stages: int, n_stages: int = None) -> FrozenSet[int]:
     spec = os.environ.get("NEXTOU_CHANNELS_LAST_STAGES", "auto").strip().lower()
     if spec in ("none", "", "0x"):
         return frozenset()
-    if spec == "auto":
+    if spec == "plain" or (spec == "auto" and n_stages is None):
         return frozenset(range(n_plain_conv_stages)) if conv_op is nn.Conv3d else frozenset()
+    if spec == "auto":
+        return frozenset(range(n_stages)) if conv_op is nn.Conv3d else frozenset()
     return frozenset(int(t) for t in spec.split(",") if t.strip() != "")
+
+
+def is_channels_last_volume(x: torch.Tensor) -> bool:
+    """True for a float32 device tensor (B,C,*spatial), C > 1, stored (B,*spatial,C)-contiguous: what the fused window /
+    pool kernels of the graph blocks take as it is."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() not in (4, 5) or x.shape[1] == 1:
+        return False
+    mf = torch.channels_last if x.dim() == 4 else torch.channels_last_3d
+    return x.is_contiguous(memory_format=mf) and not x.is_contiguous()
 
 
 def to_channels_last(x: torch.Tensor) -> torch.Tensor:

@@ -205,3 +205,29 @@ class CanonicalBackend:
     @staticmethod
     def channel_sum(x, channels_last=False):
         return x.double().sum(dim=[0] + list(range(2, x.dim()))).float()
+
+    # K3 / K4: the reference's roll / rearrange / MaxPool / MaxUnpool op sequences (ref_ops.py)
+    @staticmethod
+    def window_gather(x, window, shift):
+        from .ref_ops import window_gather_ref
+        return window_gather_ref(x, window, shift)
+
+    @staticmethod
+    def window_scatter(src, residual, spatial, window, shift):
+        from .ref_ops import window_scatter_ref
+        return window_scatter_ref(src, residual, spatial, window, shift)
+
+    @staticmethod
+    def pool_rows(x, pool):
+        from .ref_ops import pool_rows_ref
+        return pool_rows_ref(x, pool)
+
+    @staticmethod
+    def cell_gather(x, cell, pool):
+        from .ref_ops import cell_gather_ref
+        return cell_gather_ref(x, cell, pool)
+
+    @staticmethod
+    def cell_scatter(src, cell, spatial, pool):
+        from .ref_ops import cell_scatter_ref
+        return cell_scatter_ref(src, cell, spatial, pool)

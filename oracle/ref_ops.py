@@ -158,6 +158,26 @@ class TorchRefBackend:
     name = "oracle-torch-ref"
 
     @staticmethod
+    def window_gather(x, window, shift):
+        return window_gather_ref(x, window, shift)
+
+    @staticmethod
+    def window_scatter(src, residual, spatial, window, shift):
+        return window_scatter_ref(src, residual, spatial, window, shift)
+
+    @staticmethod
+    def pool_rows(x, pool):
+        return pool_rows_ref(x, pool)
+
+    @staticmethod
+    def cell_gather(x, cell, pool):
+        return cell_gather_ref(x, cell, pool)
+
+    @staticmethod
+    def cell_scatter(src, cell, spatial, pool):
+        return cell_scatter_ref(src, cell, spatial, pool)
+
+    @staticmethod
     def knn_graph(x, y, relpos, k_total, algo=0, normalize=True):
         return knn_graph_ref(x, y, relpos, k_total, normalize).to(torch.int32)
 
@@ -234,3 +254,81 @@ class TorchRefBackend:
     @staticmethod
     def channel_sum(x, channels_last=False):
         return x.double().sum(dim=[0] + list(range(2, x.dim()))).float()
+
+
+# ----------------------------------------------------------------------------------------------
+# K3 / K4 checkers: the reference's own op sequences for the window / pool data movement
+# (NexToU_Encoder_Decoder.py:781-790 + :634-660, :807-817 + :662-693, :524-549), in PyTorch-CPU.
+# ----------------------------------------------------------------------------------------------
+def _partition(x, window):
+    """'b (s p1) (h p2) (w p3) c -> (b s h w) p1 p2 p3 c' of the channel-last permutation, permuted back (:634-660)."""
+    import einops
+    if x.dim() == 4:
+        w = einops.rearrange(x.permute(0, 2, 3, 1), 'b (h p1) (w p2) c -> (b h w) p1 p2 c', p1=window[0], p2=window[1])
+        return w.permute(0, 3, 1, 2)
+    w = einops.rearrange(x.permute(0, 2, 3, 4, 1), 'b (s p1) (h p2) (w p3) c -> (b s h w) p1 p2 p3 c',
+                         p1=window[0], p2=window[1], p3=window[2])
+    return w.permute(0, 4, 1, 2, 3)
+
+
+def _reverse(windows, window, spatial):
+    import einops
+    if windows.dim() == 4:
+        H, W = spatial
+        b = int(windows.shape[0] / (H * W / window[0] / window[1]))
+        x = einops.rearrange(windows.permute(0, 2, 3, 1), '(b h w) p1 p2 c -> b (h p1) (w p2) c', p1=window[0],
+                             p2=window[1], b=b, h=H // window[0], w=W // window[1])
+        return x.permute(0, 3, 1, 2)
+    S, H, W = spatial
+    b = int(windows.shape[0] / (S * H * W / window[0] / window[1] / window[2]))
+    x = einops.rearrange(windows.permute(0, 2, 3, 4, 1), '(b s h w) p1 p2 p3 c -> b (s p1) (h p2) (w p3) c',
+                         p1=window[0], p2=window[1], p3=window[2], b=b, s=S // window[0], h=H // window[1],
+                         w=W // window[2])
+    return x.permute(0, 4, 1, 2, 3)
+
+
+def window_gather_ref(x, window, shift):
+    dims = tuple(range(2, x.dim()))
+    if max(shift) > 0:
+        x = torch.roll(x, shifts=tuple(-s for s in shift), dims=dims)
+    w = _partition(x, window)
+    return w.reshape(w.shape[0], w.shape[1], -1).contiguous()
+
+
+def window_scatter_ref(src, residual, spatial, window, shift):
+    dims = tuple(range(2, 2 + len(spatial)))
+    x = _reverse(src.reshape(src.shape[0], src.shape[1], *window), window, spatial)
+    if max(shift) > 0:
+        x = torch.roll(x, shifts=tuple(shift), dims=dims)
+    return (x if residual is None else x + residual).contiguous()
+
+
+def _pool_fn(dim):
+    import torch.nn.functional as F
+    return (F.max_pool2d, F.max_unpool2d) if dim == 2 else (F.max_pool3d, F.max_unpool3d)
+
+
+def pool_rows_ref(x, pool):
+    from nextou_amd.graph_ops import flat_indices_to_cells
+    pool_fn, _ = _pool_fn(x.dim() - 2)
+    values, indices = pool_fn(x, pool, pool, return_indices=True)
+    return values.reshape(values.shape[0], values.shape[1], -1).contiguous(), flat_indices_to_cells(indices, x.shape[2:], pool)
+
+
+def cell_scatter_ref(src, cell, spatial, pool):
+    """MaxUnpool(out, cat(indices, indices)) (:536-549)."""
+    from nextou_amd.graph_ops import cells_to_flat_indices
+    _, unpool_fn = _pool_fn(len(spatial))
+    indices = cells_to_flat_indices(cell, spatial, pool)
+    pooled = [s // p for s, p in zip(spatial, pool)]
+    reps = src.shape[1] // indices.shape[1]
+    idx = torch.cat([indices] * reps, 1)
+    return unpool_fn(src.reshape(src.shape[0], src.shape[1], *pooled), idx, pool, pool, output_size=list(spatial))
+
+
+def cell_gather_ref(x, cell, pool):
+    from nextou_amd.graph_ops import cells_to_flat_indices
+    indices = cells_to_flat_indices(cell, x.shape[2:], pool)
+    reps = x.shape[1] // indices.shape[1]
+    idx = torch.cat([indices] * reps, 1)
+    return x.flatten(2).gather(2, idx.flatten(2)).contiguous()

@@ -33,7 +33,7 @@ LAYERS = [
     ("enc s1 conv1 66->66", "ndhwc", False, 2, 66, 66, (64, 112, 96), (3, 3, 3), (1, 1, 1), 1),
     ("dec s1 conv0 132->66", "ndhwc", False, 2, 132, 66, (64, 112, 96), (3, 3, 3), (1, 1, 1), 1),
     ("dec s1 conv1 66->66", "ndhwc", False, 2, 66, 66, (64, 112, 96), (3, 3, 3), (1, 1, 1), 1),
-    ("enc s2 conv 66->132 /2", "ncdhw", False, 2, 66, 132, (64, 112, 96), (3, 3, 3), (2, 2, 2), 1),
+    ("enc s2 conv 66->132 /2", "ndhwc", False, 2, 66, 132, (64, 112, 96), (3, 3, 3), (2, 2, 2), 1),
     ("dec s2 conv 264->132", "ncdhw", False, 2, 264, 132, (32, 56, 48), (3, 3, 3), (1, 1, 1), 1),
     ("enc s3 conv 132->264 /2", "ncdhw", False, 2, 132, 264, (32, 56, 48), (3, 3, 3), (2, 2, 2), 1),
     ("dec s3 conv 528->264", "ncdhw", False, 2, 528, 264, (16, 28, 24), (3, 3, 3), (1, 1, 1), 1),
@@ -53,6 +53,11 @@ LAYERS = [
 
 # padded twins: (label of the layer, padded Cin, padded Cout)
 PADS = {
+    "enc s0 conv0 1->33": [(1, 40), (4, 40), (8, 40)],
+    "enc s2 conv 66->132 /2": [(72, 132), (72, 136)],
+    "up s1->s0 66->33 T(1,2,2)": [(72, 40), (80, 40)],
+    "up s2->s1 132->66 T2": [(132, 72), (136, 72)],
+    "head s0 1x1 33->14": [(40, 14), (40, 16)],
     "enc s0 conv1 33->33": [(40, 40), (48, 48), (64, 64)],
     "dec s0 conv0 66->33": [(80, 40), (96, 48), (128, 64)],
     "enc s1 conv1 66->66": [(72, 72), (80, 80), (96, 96), (128, 128)],

@@ -6,9 +6,10 @@ the raw counter CSV of a find-mode run is > 100 MB and must not travel back thro
 
 Per kernel name (of ONE steady-state step when --steady is given): dispatches, mean duration, mean counter values and,
 when the counters are present, the matrix-pipe occupancy
-    mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE)
-(SQ_VALU_MFMA_BUSY_CYCLES counts per-SIMD busy cycles summed over the chip's 1024 SIMDs, MI355X_MICROARCH.md; GRBM_GUI_ACTIVE
-= shader-clock cycles the kernel was resident).  Deletes nothing; the caller removes the raw directory.
+    mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)
+(SQ_VALU_MFMA_BUSY_CYCLES counts per-SIMD busy cycles summed over the chip's 1024 SIMDs — 64 per v_mfma_f32_32x32x2_f32,
+checked against SQ_INSTS_MFMA; GRBM_GUI_ACTIVE is reported summed over the 8 XCDs: a 7.87 ms kernel shows 1.47e8 = 8 x
+7.87 ms x 2.34 GHz).  Deletes nothing; the caller removes the raw directory.
 """
 import collections
 import csv
@@ -74,7 +75,7 @@ def main():
                 cells.append("-")
         busy = "-"
         if mean.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in mean:
-            busy = "%.1f %%" % (100.0 * mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * mean["GRBM_GUI_ACTIVE"]))
+            busy = "%.1f %%" % (100.0 * mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * mean["GRBM_GUI_ACTIVE"] / 8.0))
         short = name.replace("void ", "")
         short = short if len(short) <= 110 else short[:107] + "..."
         lines.append("| `%s` | %d | %.3f | %.2f | %s | %s |" % (short, len(ds), sum(ds) / 1e3, sum(ds) / len(ds), " | ".join(cells), busy))
