@@ -13,6 +13,7 @@ from torch.nn.modules.conv import _ConvNd
 from torch.nn.modules.dropout import _DropoutNd
 
 from .NexToU_Encoder_Decoder import NexToU_Decoder, NexToU_Encoder
+from .channel_pad import pad_multiple, pad_plain_stage_channels
 from .conv_blocks import convert_conv_op_to_dim
 from .layout import channels_last_stages
 from .norm_act import fuse_norm_act, fusion_enabled
@@ -62,6 +63,8 @@ class NexToU(nn.Module):
             fuse_norm_act(self)
             # the plain conv stages run channels-last on the GPU (layout.py); needs K6's NDHWC kernels, hence here
             self.encoder.channels_last_stages = channels_last_stages(conv_op, self.encoder.n_conv_stages, n_stages)
+            # 33 -> 40 / 66 -> 72 channels inside the plain conv stages (channel_pad.py): parameters keep their shapes
+            self.padded_modules = pad_plain_stage_channels(self, pad_multiple())
 
     def forward(self, x):
         return self.decoder(self.encoder(x))

@@ -1,0 +1,216 @@
+"""Internal channel padding of the plain conv stages: 33 -> 40 and 66 -> 72 channels inside the network, nowhere else.
+
+MIOpen's CK implicit-GEMM kernels run the fp32 convolutions of cfg 2's full-resolution stages (33 and 66 channels) at
+15-24 % of the fp32 MFMA peak while the matrix pipe is ~40 % busy: the kernels pad 33 / 66 to their own tile sizes
+internally.  The same layers with the channel count zero-padded to a multiple of 8 *before* they reach MIOpen pick better
+tiles and run 1.4-1.7x faster although they compute more (measured, profiles/r02_conv_evidence_padding_ab.md:
+33 -> 33 at 64x224x192 fwd+dgrad+wgrad 12.3 ms -> 8.7 ms at 40 -> 40; 66 -> 66 at 64x112x96 28.2 ms -> 18.7 ms at 72 -> 72).
+The convolutions themselves stay on PyTorch-ROCm, as BASELINE.json's north_star prescribes — this only changes the shapes
+they are handed.
+
+Mechanics.  Parameters and buffers keep the reference's shapes (``state_dict`` interchange, ``InitWeights_He``, DDP buckets
+and optimizer state see 33 / 66).  On the forward pass a padded module builds its padded weight / bias / norm parameters on
+the fly (``F.pad`` / ``cat`` of a few KB — autograd slices the gradients back) and the activations between the padded
+modules carry ``pad`` extra all-zero channels:
+
+* an *entry* module (first convolution of stage 0) decides per call: it pads its output iff its input is a device tensor
+  whose convolutions run in fp32 (the CPU checker path and reduced-precision autocast stay un-padded);
+* every other padded module looks at the channel count it receives — the real count means "not padded", the padded count
+  means "padded" — and follows suit on its output;
+* *exit* modules (segmentation heads, the first convolution of the first graph stage) always emit the real channel count.
+
+Zero channels stay exactly zero through conv (zero filters) -> batch norm (mean 0, variance 0, weight 1, bias 0 -> 0) ->
+LeakyReLU, and receive exactly zero gradient (the next layer's columns for them are zero), so the function and its
+gradients are those of the un-padded network up to the summation order inside the convolution kernels.
+``NEXTOU_PAD_CHANNELS``: ``auto`` (default, multiple of 8), ``0`` / ``none`` (off), or the multiple to pad to.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .layout import runs_in_fp32
+
+
+_force_entry: Optional[bool] = None     # test hook: True / False overrides the entry modules' per-call decision
+
+
+class force_padding:
+    """``with force_padding(True):`` makes the entry modules pad whatever the device (CPU equivalence tests);
+    ``force_padding(False)`` switches the padded regime off for a built model (A/B on the GPU)."""
+
+    def __init__(self, flag: Optional[bool]):
+        self.flag = flag
+
+    def __enter__(self):
+        global _force_entry
+        self.prev, _force_entry = _force_entry, self.flag
+        return self
+
+    def __exit__(self, *exc):
+        global _force_entry
+        _force_entry = self.prev
+        return False
+
+
+def pad_multiple() -> int:
+    spec = os.environ.get("NEXTOU_PAD_CHANNELS", "auto").strip().lower()
+    if spec in ("0", "none", "off", ""):
+        return 0
+    return 8 if spec == "auto" else int(spec)
+
+
+def padded(c: int, multiple: int) -> int:
+    return -(-c // multiple) * multiple
+
+
+@dataclass(frozen=True)
+class ConvPad:
+    in_blocks: Tuple[int, ...]      # real channel counts of the concatenated inputs (one block unless fed by a cat)
+    multiple: int
+    entry: bool = False             # decides whether the padded regime starts here
+    exit: bool = False              # always emits the real output channel count
+    pad_input: bool = True          # False: the input is never padded (network input, graph-stage features)
+
+
+def _pad_axis(t: torch.Tensor, axis: int, new: int, value: float = 0.0) -> torch.Tensor:
+    n = new - t.shape[axis]
+    if n == 0:
+        return t
+    return F.pad(t, [0, 0] * (t.dim() - 1 - axis) + [0, n], value=value)
+
+
+def _pad_blocks(t: torch.Tensor, axis: int, blocks, multiple: int) -> torch.Tensor:
+    if len(blocks) == 1:
+        return _pad_axis(t, axis, padded(blocks[0], multiple))
+    pieces = t.split(list(blocks), dim=axis)
+    return torch.cat([_pad_axis(p, axis, padded(b, multiple)) for p, b in zip(pieces, blocks)], axis)
+
+
+def conv_pad_plan(module: nn.Module, x: torch.Tensor):
+    """-> (pad_in, pad_out) for this call of a convolution carrying a ``_pad_spec``."""
+    spec: ConvPad = module._pad_spec
+    real_in = sum(spec.in_blocks)
+    padded_in = sum(padded(b, spec.multiple) for b in spec.in_blocks) if spec.pad_input else real_in
+    cin = x.shape[1]
+    if cin == real_in:
+        pad_in = False
+    elif cin == padded_in:
+        pad_in = True
+    else:
+        raise RuntimeError("channel padding: %s received %d channels, expected %d (real) or %d (padded)"
+                           % (type(module).__name__, cin, real_in, padded_in))
+    if spec.exit:
+        pad_out = False
+    elif spec.entry:
+        pad_out = bool(x.is_cuda and runs_in_fp32(x)) if _force_entry is None else _force_entry
+    else:
+        pad_out = pad_in
+    return pad_in, pad_out
+
+
+def padded_conv_params(module: nn.Module, x: torch.Tensor, with_bias: bool):
+    """(weight, bias) of a (transposed) convolution for this call: the module's own parameters, zero-padded along the
+    input-channel axis when ``x`` arrives padded and along the output-channel axis when the output is to be padded."""
+    spec: Optional[ConvPad] = getattr(module, "_pad_spec", None)
+    bias = module.bias if with_bias else None
+    if spec is None:
+        return module.weight, bias
+    pad_in, pad_out = conv_pad_plan(module, x)
+    w = module.weight
+    in_axis, out_axis = (0, 1) if module.transposed else (1, 0)
+    if pad_in:
+        w = _pad_blocks(w, in_axis, spec.in_blocks, spec.multiple)
+    if pad_out:
+        w = _pad_axis(w, out_axis, padded(w.shape[out_axis], spec.multiple))
+        if bias is not None:
+            bias = _pad_axis(bias, 0, w.shape[out_axis])
+    return w, bias
+
+
+def padded_norm_params(norm: nn.Module, x: torch.Tensor, pre_bias):
+    """-> (weight, bias, running_mean, running_var, pre_bias, write_back) for a fused norm whose input may carry padding
+    channels.  ``write_back()`` copies the updated running statistics of the real channels into the module's buffers."""
+    multiple = getattr(norm, "_pad_multiple", 0)
+    c_real = norm.num_features
+    if not multiple or x.shape[1] == c_real:
+        return norm.weight, norm.bias, norm.running_mean, norm.running_var, pre_bias, None
+    c_pad = padded(c_real, multiple)
+    if x.shape[1] != c_pad:
+        raise RuntimeError("channel padding: norm over %d channels received %d (padded count is %d)" % (c_real, x.shape[1], c_pad))
+    w = None if norm.weight is None else _pad_axis(norm.weight, 0, c_pad, 1.0)
+    b = None if norm.bias is None else _pad_axis(norm.bias, 0, c_pad)
+    pb = None if pre_bias is None else _pad_axis(pre_bias, 0, c_pad)
+    rm = rv = None
+    write_back = None
+    if norm.running_mean is not None:
+        rm, rv = _pad_axis(norm.running_mean, 0, c_pad), _pad_axis(norm.running_var, 0, c_pad, 1.0)
+
+        def write_back():
+            norm.running_mean.copy_(rm[:c_real])
+            norm.running_var.copy_(rv[:c_real])
+    return w, b, rm, rv, pb, write_back
+
+
+def _conv_of(block) -> nn.Module:
+    return block.conv
+
+
+def pad_plain_stage_channels(model: nn.Module, multiple: int) -> int:
+    """Attach padding specs to the plain conv stages of a built (and norm-fused) NexToU; returns the number of modules
+    marked.  Only 3-D models with at least one plain conv stage whose feature count is not a multiple already."""
+    enc, dec = model.encoder, model.decoder
+    n_conv = enc.n_conv_stages
+    feats = list(enc.output_channels)
+    if multiple <= 0 or enc.conv_op is not nn.Conv3d or n_conv == 0:
+        return 0
+    if all(f % multiple == 0 for f in feats[:n_conv]):
+        return 0
+    from . import norm_act as na
+    plan = []           # (module, attribute, value): applied only if every module involved can carry it
+
+    def mark_conv(conv, in_blocks, **kw):
+        plan.append((conv, "_pad_spec", ConvPad(tuple(int(b) for b in in_blocks), multiple, **kw)))
+
+    def mark_norm(block):
+        plan.append((getattr(block, "norm", None), "_pad_multiple", multiple))
+
+    # encoder: plain stages, then the first convolution of the first graph stage (exit)
+    c_prev = None
+    for s in range(n_conv):
+        blocks = enc.stages[s][0].convs
+        for i, blk in enumerate(blocks):
+            if s == 0 and i == 0:
+                mark_conv(blk.conv, [blk.conv.in_channels], entry=True, pad_input=False)
+            else:
+                mark_conv(blk.conv, [c_prev])
+            mark_norm(blk)
+            c_prev = blk.conv.out_channels
+    first_graph = enc.stages[n_conv][0][0].convs[0]
+    mark_conv(first_graph.conv, [c_prev], exit=True)
+    # decoder: stage j mirrors encoder level n_enc - (j + 2)
+    n_enc = len(feats)
+    for j in range(len(dec.stages)):
+        level = n_enc - (j + 2)
+        up = dec.transpconvs[j]
+        if level < n_conv:                      # output feeds a plain stage: padded; input padded iff it comes from one
+            from_plain = level + 1 < n_conv
+            mark_conv(up, [up.in_channels], pad_input=from_plain, entry=not from_plain)
+            blocks = dec.stages[j].convs
+            mark_conv(blocks[0].conv, [feats[level], feats[level]])
+            mark_norm(blocks[0])
+            for blk in blocks[1:]:
+                mark_conv(blk.conv, [feats[level]])
+                mark_norm(blk)
+            mark_conv(dec.seg_layers[j], [feats[level]], exit=True)
+    capable = (na.ConvBiasFolded3d, na.ConvOwnBias3d, na.ConvTransposeOwnBias3d, na.BatchNormAct3d)
+    if not all(isinstance(m, capable) for m, _, _ in plan):
+        return 0        # e.g. conv_bias=False or another norm: those module classes do not know about padding
+    for m, attr, value in plan:
+        setattr(m, attr, value)
+    return len(plan)

@@ -23,6 +23,7 @@ import torch
 from torch import nn
 
 from .. import graph_ops
+from .channel_pad import padded_conv_params, padded_norm_params
 
 __all__ = ["BatchNormAct1d", "BatchNormAct2d", "BatchNormAct3d", "InstanceNormAct1d", "InstanceNormAct2d",
            "InstanceNormAct3d", "ConvBiasFolded1d", "ConvBiasFolded2d", "ConvBiasFolded3d", "ConvOwnBias2d",
@@ -46,7 +47,8 @@ class _ConvBiasFolded:
     """
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self._conv_forward(x, self.weight, None)
+        weight, _ = padded_conv_params(self, x, with_bias=False)      # channel_pad.py: zero-padded 33 -> 40 / 66 -> 72
+        return self._conv_forward(x, weight, None)
 
 
 class ConvBiasFolded1d(_ConvBiasFolded, nn.Conv1d):
@@ -74,15 +76,20 @@ class _ConvOwnBias:
             getattr(self, "padding_mode", "zeros") == "zeros"
 
     def forward(self, x: torch.Tensor, *args) -> torch.Tensor:
-        if not self._own(x) or args:
+        if args or (not self._own(x) and getattr(self, "_pad_spec", None) is None):
             return super().forward(x, *args)
         n = len(self.stride)
         if self.transposed:
             out_pad = self._output_padding(x, None, self.stride, self.padding, self.kernel_size, n, self.dilation)
         else:
             out_pad = (0,) * n
-        return graph_ops.conv_own_bias_grad(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                                            self.transposed, out_pad, self.groups)
+        weight, bias = padded_conv_params(self, x, with_bias=True)
+        if self._own(x):
+            return graph_ops.conv_own_bias_grad(x, weight, bias, self.stride, self.padding, self.dilation,
+                                                self.transposed, out_pad, self.groups)
+        # CPU checker path of a padded module: the same convolution through ATen's autograd
+        return torch.convolution(x, weight, bias, self.stride, self.padding, self.dilation, self.transposed, out_pad,
+                                 self.groups)
 
 
 class ConvOwnBias2d(_ConvOwnBias, nn.Conv2d):
@@ -117,10 +124,12 @@ class _BatchNormAct:
             factor = 1.0 / float(self.num_batches_tracked) if self.momentum is None else self.momentum
         use_batch_stats = self.training or (self.running_mean is None and self.running_var is None)
         keep_running = (not self.training) or self.track_running_stats
-        return graph_ops.norm_act(x, self.weight, self.bias,
-                                  self.running_mean if keep_running else None,
-                                  self.running_var if keep_running else None,
-                                  use_batch_stats, factor, self.eps, self.negative_slope, pre_bias=_pre_bias(self))
+        weight, bias, rm, rv, pre_bias, write_back = padded_norm_params(self, x, _pre_bias(self))
+        y = graph_ops.norm_act(x, weight, bias, rm if keep_running else None, rv if keep_running else None,
+                               use_batch_stats, factor, self.eps, self.negative_slope, pre_bias=pre_bias)
+        if write_back is not None and keep_running and use_batch_stats:
+            write_back()
+        return y
 
     def extra_repr(self) -> str:
         return super().extra_repr() + ", negative_slope=%g" % self.negative_slope

@@ -782,8 +782,9 @@ def test_channel_sum_and_own_bias_convolutions(ops):
 
 
 def test_channels_last_policy_changes_layout_not_results(ops, monkeypatch):
-    """Stage policy 'auto' (plain conv stages NDHWC) vs 'none' on the tiny 3-D model: same weights, same recorded
-    kNN / arg-max decisions -> same logits and gradients up to conv round-off; and the stage-0 skip really is NDHWC."""
+    """Stage policy 'auto' (every stage NDHWC, graph stages through the fused window / pool kernels; plain stages with
+    internally padded channels) vs 'none' (NCDHW, no padding) on the tiny 3-D model: same weights, same recorded kNN /
+    arg-max decisions -> same logits and gradients up to conv round-off; the skips really are NDHWC / padded."""
     from nextou_amd.graph_ops import IndexTape, index_tape
     x = torch.randn(1, 1, 32, 128, 128, generator=torch.Generator().manual_seed(3)).to(DEV)
     results = {}
@@ -792,16 +793,21 @@ def test_channels_last_policy_changes_layout_not_results(ops, monkeypatch):
         monkeypatch.setenv("NEXTOU_CHANNELS_LAST_STAGES", policy)
         torch.manual_seed(0)
         net = mc.build_model(mc.TINY_3D).to(DEV)
-        assert net.encoder.channels_last_stages == (frozenset({0, 1}) if policy == "auto" else frozenset())
-        skips = net.encoder(x)
+        assert net.encoder.channels_last_stages == (frozenset(range(6)) if policy == "auto" else frozenset())
+        from nextou_amd.network_architecture.channel_pad import force_padding
+        with force_padding(None if policy == "auto" else False):
+            skips = net.encoder(x)
         assert (ops._dense_channels_last(skips[0]) is not None) == (policy == "auto")
-        assert ops._dense_channels_last(skips[2]) is None          # graph stages stay NCDHW
+        assert (ops._dense_channels_last(skips[2]) is not None) == (policy == "auto")   # graph stages follow the policy
+        assert skips[0].shape[1] == (8 if policy == "auto" else 6) and skips[2].shape[1] == 24   # 6 -> 8 inside stage 0 only
+        if policy == "auto":
+            assert float(skips[0][:, 6:].abs().max()) == 0.0 and float(skips[1][:, 12:].abs().max()) == 0.0
         if policy == "none":
             tape = IndexTape(tape.entries)                          # replay the decisions of the first run
-        with index_tape(tape):
+        with index_tape(tape), force_padding(None if policy == "auto" else False):
             outs = net(x)
-        loss = sum(o.square().mean() for o in outs)
-        grads = torch.autograd.grad(loss, [p for p in net.parameters() if p.requires_grad], allow_unused=True)
+            loss = sum(o.square().mean() for o in outs)
+            grads = torch.autograd.grad(loss, [p for p in net.parameters() if p.requires_grad], allow_unused=True)
         results[policy] = ([o.detach() for o in outs], grads)
     (oa, ga), (on, gn) = results["auto"], results["none"]
     for a, b in zip(oa, on):
@@ -820,7 +826,7 @@ def test_channels_last_policy_is_fp32_only(ops):
     from nextou_amd.network_architecture.layout import runs_in_fp32
     torch.manual_seed(0)
     net = mc.build_model(mc.TINY_3D).to(DEV)
-    assert net.encoder.channels_last_stages == frozenset({0, 1})
+    assert net.encoder.channels_last_stages == frozenset(range(6))
     x = torch.randn(1, 1, 32, 128, 128, device=DEV)
     assert runs_in_fp32(x) and not runs_in_fp32(x.bfloat16()) and not runs_in_fp32(x.half())
     assert ops._dense_channels_last(net.encoder(x)[0]) is torch.channels_last_3d
@@ -828,6 +834,7 @@ def test_channels_last_policy_is_fp32_only(ops):
         assert not runs_in_fp32(x)
         skips = net.encoder(x)
         assert ops._dense_channels_last(skips[0]) is None and ops._dense_channels_last(skips[1]) is None
+        assert skips[0].shape[1] == 6 and skips[1].shape[1] == 12          # ... and un-padded
         outs = net(x)
     assert all(bool(torch.isfinite(o.float()).all()) for o in outs)
     assert ops._dense_channels_last(outs[0]) is None
