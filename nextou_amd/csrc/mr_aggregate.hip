@@ -12,6 +12,7 @@
 // channels interleaved [x_0, mr_0, x_1, mr_1, ...] (reference :409).
 #include "common.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace nextou {
 
@@ -75,6 +76,111 @@ __global__ __launch_bounds__(256) void mr_fwd_lds_kernel(
                 for (int j = 1; j < KB; ++j) mx = fmaxf(mx, row[id[j]]);
                 o[0] = xv;
                 o[N] = mx - xv;  // == max_j (src_j - x): rounding is monotone
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward, channel quads.  Same decomposition as above, but the LDS tile interleaves FOUR channels per source point:
+// tile[q][m] is a float4 holding channels c0+4q .. c0+4q+3 of point m, so one ds_read_b128 gathers four channels of a
+// neighbour (the random gather is the cost of this op: 16-B gathers spread 16 lanes over 16 bank groups — measured
+// SQ_LDS_BANK_CONFLICT of the dword version: 1.4e7 of 2e7 LDS cycles on Pool s3) and the index arithmetic is shared by the
+// four.  Staging stays coalesced (lanes along m, four row loads, one conflict-free ds_write_b128), the stores stay
+// coalesced (lanes along n).  grid = (n_tiles, quad blocks, B); LDS = quads * M float4.
+// ---------------------------------------------------------------------------------------------
+template <int KB, bool SELF, bool WITH_ARG>
+__global__ __launch_bounds__(512) void mr_fwd_q4_kernel(
+    const float* __restrict__ x, const float* __restrict__ src, const int32_t* __restrict__ idx,
+    float* __restrict__ out, uint16_t* __restrict__ arg, int C, int N, int M, int K, int idx_stride,
+    int idx_step, int quads, int n_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float4 tile4[];
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * quads * 4;
+    int nq = (C - c0 + 3) >> 2;
+    if (nq > quads) nq = quads;
+    const float* sb = src + ((size_t)b * C + c0) * M;
+    for (int e = threadIdx.x; e < nq * M; e += blockDim.x) {
+        const int q = e / M, m = e - q * M;
+        const int c = 4 * q;
+        const float* p = sb + (size_t)c * M + m;
+        float4 v;
+        v.x = p[0];
+        v.y = (c0 + c + 1 < C) ? p[(size_t)M] : 0.f;
+        v.z = (c0 + c + 2 < C) ? p[(size_t)2 * M] : 0.f;
+        v.w = (c0 + c + 3 < C) ? p[(size_t)3 * M] : 0.f;
+        tile4[e] = v;
+    }
+    __syncthreads();
+    const int n_begin = blockIdx.x * n_per_block;
+    int n_end = n_begin + n_per_block;
+    if (n_end > N) n_end = N;
+    for (int n = n_begin + threadIdx.x; n < n_end; n += blockDim.x) {
+        int id[KB];
+        const int32_t* irow = idx + ((size_t)b * N + n) * idx_stride;
+        if (idx_step == 1) {    // immediate offsets: 32 scalar offset registers would otherwise stay live across the loop
+#pragma unroll
+            for (int j = 0; j < KB; ++j) id[j] = irow[j < K ? j : 0];
+        } else {
+#pragma unroll
+            for (int j = 0; j < KB; ++j) id[j] = irow[(j < K ? j : 0) * idx_step];
+        }
+        for (int q = 0; q < nq; ++q) {
+            const float4* row = tile4 + q * M;
+            const int c = c0 + 4 * q;
+            const bool v1 = c + 1 < C, v2 = c + 2 < C, v3 = c + 3 < C;
+            float4 xv;
+            if (SELF) {
+                xv = row[n];
+            } else {
+                const float* xp = x + ((size_t)b * C + c) * N + n;
+                xv.x = xp[0];
+                xv.y = v1 ? xp[(size_t)N] : 0.f;
+                xv.z = v2 ? xp[(size_t)2 * N] : 0.f;
+                xv.w = v3 ? xp[(size_t)3 * N] : 0.f;
+            }
+            float4 mx;
+            int a0, a1, a2, a3;
+            {
+                const float4 s = row[id[0]];
+                mx.x = s.x - xv.x; mx.y = s.y - xv.y; mx.z = s.z - xv.z; mx.w = s.w - xv.w;
+                a0 = a1 = a2 = a3 = id[0];
+            }
+            // groups of four gathers in flight: 16 VGPRs of payload and 16 compare masks at a time (the fully unrolled
+            // K = 32 loop kept 128 payload VGPRs and spilled 269 SGPRs of masks)
+#pragma unroll
+            for (int j0 = 1; j0 < KB; j0 += 4) {
+                float4 sv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sv[u] = row[id[(j0 + u < KB) ? j0 + u : 0]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (j0 + u >= KB) continue;
+                    const int idj = id[(j0 + u < KB) ? j0 + u : 0];
+                    const float d0 = sv[u].x - xv.x, d1 = sv[u].y - xv.y, d2 = sv[u].z - xv.z, d3 = sv[u].w - xv.w;
+                    if (WITH_ARG) {     // strict >: the first maximum of the rounded differences wins (autograd's max)
+                        if (d0 > mx.x) { mx.x = d0; a0 = idj; }
+                        if (d1 > mx.y) { mx.y = d1; a1 = idj; }
+                        if (d2 > mx.z) { mx.z = d2; a2 = idj; }
+                        if (d3 > mx.w) { mx.w = d3; a3 = idj; }
+                    } else {
+                        mx.x = fmaxf(mx.x, d0); mx.y = fmaxf(mx.y, d1); mx.z = fmaxf(mx.z, d2); mx.w = fmaxf(mx.w, d3);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);     // keep the groups apart: do not hoist the next group's gathers
+            }
+            float* o = out + ((size_t)b * 2 * C + 2 * c) * N + n;
+            o[0] = xv.x;
+            o[(size_t)N] = mx.x;
+            if (v1) { o[(size_t)2 * N] = xv.y; o[(size_t)3 * N] = mx.y; }
+            if (v2) { o[(size_t)4 * N] = xv.z; o[(size_t)5 * N] = mx.z; }
+            if (v3) { o[(size_t)6 * N] = xv.w; o[(size_t)7 * N] = mx.w; }
+            if (WITH_ARG) {
+                uint16_t* ap = arg + ((size_t)b * C + c) * N + n;
+                ap[0] = (uint16_t)a0;
+                if (v1) ap[(size_t)N] = (uint16_t)a1;
+                if (v2) ap[(size_t)2 * N] = (uint16_t)a2;
+                if (v3) ap[(size_t)3 * N] = (uint16_t)a3;
             }
         }
     }
@@ -366,6 +472,44 @@ static bool plan_lds(int B, int C, int N, int M, int floats_per_channel, bool ti
     return p->c_chunks <= 65535 && B <= 65535;
 }
 
+// Work decomposition of mr_fwd_q4_kernel.  One channel quad costs 16 * M bytes of LDS.  Small source sets (windows) take
+// ~20 KB tiles so that many workgroups share a CU; long ones (pooled candidate sets of 1344 / 3072 points) take what fits
+// 48 KB, and the query range is cut into tiles until the grid has a few workgroups per CU.
+struct Q4Plan {
+    int quads, q_blocks, n_tiles, n_per_block, threads;
+    size_t lds;
+};
+static bool plan_q4(int B, int C, int N, int M, Q4Plan* p) {
+    if (getenv("NEXTOU_MR_FWD_V1")) return false;        // A/B switch: the dword-gather kernel of round 1
+    const size_t per_quad = (size_t)M * 16;
+    if (per_quad > 152 * 1024) return false;
+    const int total_quads = (C + 3) / 4;
+    size_t budget = M <= 512 ? 20 * 1024 : 48 * 1024;
+    int quads = (int)(budget / per_quad);
+    if (quads < 1) quads = 1;
+    if (quads > total_quads) quads = total_quads;
+    quads = cdiv(total_quads, cdiv(total_quads, quads));      // balance the last block
+    p->quads = quads;
+    p->q_blocks = cdiv(total_quads, quads);
+    p->lds = (size_t)quads * per_quad;
+    int threads = N >= 512 ? 512 : ((N + 63) / 64) * 64;
+    int n_per_block = N, n_tiles = 1;
+    if (N > 1024) {
+        // >= ~3 workgroups per CU, at least 2 queries per lane so that the staged tile is reused
+        long long want = cdiv64(768, (long long)p->q_blocks * B);
+        long long max_tiles = N / (2 * threads);
+        if (want > max_tiles) want = max_tiles;
+        if (want < 1) want = 1;
+        n_tiles = (int)want;
+        n_per_block = cdiv(cdiv(N, n_tiles), 64) * 64;
+        n_tiles = cdiv(N, n_per_block);
+    }
+    p->threads = threads;
+    p->n_tiles = n_tiles;
+    p->n_per_block = n_per_block;
+    return p->q_blocks <= 65535 && B <= 65535;
+}
+
 static int check_mr_args(const char* who, const void* a, const void* b, const void* c, int B, int C,
                          int N, int M, int K, int idx_stride, int idx_step) {
     NEXTOU_REQUIRE(a && b && c, "%s: null pointer", who);
@@ -395,6 +539,34 @@ extern "C" int nextou_mr_aggregate_fwd(const float* x, const float* y, const int
     // algorithmic HBM bytes: read x (+y), read idx (int32), write the 2C-channel output (+ arg)
     const double fwd_bytes = 4.0 * B * C * ((double)N + (y ? M : 0)) + 4.0 * B * (double)N * K + 8.0 * B * C * (double)N +
                              (arg_out ? 2.0 * B * C * (double)N : 0.0);
+    Q4Plan qp;
+    if (center_idx == nullptr && K <= 32 && plan_q4(B, C, N, M, &qp)) {
+        dim3 grid(qp.n_tiles, qp.q_blocks, B), block(qp.threads);
+        const int kb = K <= 8 ? 8 : (K <= 16 ? 16 : 32);
+        ProfScope prof(s, kBoundHbm, fwd_bytes, "mr_fwd_q4_kernel<%d,%s,%s>[B%d C%d N%d M%d K%d]", kb,
+                       self ? "self" : "xy", arg_out ? "arg" : "noarg", B, C, N, M, K);
+#define NEXTOU_MR_Q4(KB, SELF, ARG)                                                                          \
+    do {                                                                                                     \
+        if (qp.lds > 64 * 1024)                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_fwd_q4_kernel<KB, SELF, ARG>),       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)qp.lds);              \
+        hipLaunchKernelGGL((mr_fwd_q4_kernel<KB, SELF, ARG>), grid, block, qp.lds, s, x, src, nn_idx, out, arg_out, \
+                           C, N, M, K, idx_stride, idx_step, qp.quads, qp.n_per_block);                      \
+    } while (0)
+#define NEXTOU_MR_Q4_KB(KB)                                                      \
+    do {                                                                         \
+        if (self && arg_out) NEXTOU_MR_Q4(KB, true, true);                       \
+        else if (self) NEXTOU_MR_Q4(KB, true, false);                            \
+        else if (arg_out) NEXTOU_MR_Q4(KB, false, true);                         \
+        else NEXTOU_MR_Q4(KB, false, false);                                     \
+    } while (0)
+        if (kb == 8) NEXTOU_MR_Q4_KB(8);
+        else if (kb == 16) NEXTOU_MR_Q4_KB(16);
+        else NEXTOU_MR_Q4_KB(32);
+#undef NEXTOU_MR_Q4_KB
+#undef NEXTOU_MR_Q4
+        return check_launch("mr_fwd_q4_kernel");
+    }
     MrPlan p;
     if (center_idx == nullptr && K <= 32 && plan_lds(B, C, N, M, M, true, &p)) {
         dim3 grid(p.n_tiles, p.c_chunks, B), block(p.threads);
@@ -429,7 +601,9 @@ extern "C" int nextou_mr_aggregate_fwd(const float* x, const float* y, const int
 // 1 if nextou_mr_aggregate_fwd can fill arg_out for this shape (lets the caller decide what to save)
 extern "C" int nextou_mr_aggregate_has_arg(int B, int C, int N, int M, int K) {
     MrPlan p;
-    return (M <= 65536 && K <= 32 && B > 0 && C > 0 && N > 0 && M > 0 && plan_lds(B, C, N, M, M, true, &p)) ? 1 : 0;
+    Q4Plan q;
+    return (M <= 65536 && K <= 32 && B > 0 && C > 0 && N > 0 && M > 0 &&
+            (plan_q4(B, C, N, M, &q) || plan_lds(B, C, N, M, M, true, &p))) ? 1 : 0;
 }
 
 extern "C" int nextou_mr_aggregate_bwd_arg(const float* gout, const uint16_t* arg, float* dx, float* dy, int B,

@@ -76,6 +76,7 @@ class ConvPad:
     entry: bool = False             # decides whether the padded regime starts here
     exit: bool = False              # always emits the real output channel count
     pad_input: bool = True          # False: the input is never padded (network input, graph-stage features)
+    image_channels_to: int = 0      # entry only: zero-pad the network input itself to this many channels when padding
 
 
 def _pad_axis(t: torch.Tensor, axis: int, new: int, value: float = 0.0) -> torch.Tensor:
@@ -133,6 +134,22 @@ def padded_conv_params(module: nn.Module, x: torch.Tensor, with_bias: bool):
     return w, bias
 
 
+def pad_image_channels(module: nn.Module, x: torch.Tensor, weight: torch.Tensor):
+    """Entry convolution in the padded regime: the network input (1 channel at cfg 2) is itself zero-padded to 4 channels.
+    MIOpen's weight-gradient kernel for a 1-channel input needs 7.8 ms at 64x224x192 (0.3 % of the MFMA peak); the same
+    layer with 4 input channels 1.5 ms, and its forward 0.39 ms instead of 1.07 ms (profiles/r02_conv_evidence_padding_ab.md)."""
+    spec: Optional[ConvPad] = getattr(module, "_pad_spec", None)
+    if spec is None or not spec.entry or not spec.image_channels_to or weight.shape[0] == module.out_channels:
+        return x, weight
+    c, to = x.shape[1], spec.image_channels_to
+    if c >= to:
+        return x, weight
+    mf = torch.channels_last_3d if x.dim() == 5 else torch.channels_last
+    xp = x.new_zeros((x.shape[0], to) + tuple(x.shape[2:])).contiguous(memory_format=mf)
+    xp[:, :c] = x
+    return xp, _pad_axis(weight, 1, to)
+
+
 def padded_norm_params(norm: nn.Module, x: torch.Tensor, pre_bias):
     """-> (weight, bias, running_mean, running_var, pre_bias, write_back) for a fused norm whose input may carry padding
     channels.  ``write_back()`` copies the updated running statistics of the real channels into the module's buffers."""
@@ -186,7 +203,8 @@ def pad_plain_stage_channels(model: nn.Module, multiple: int) -> int:
         blocks = enc.stages[s][0].convs
         for i, blk in enumerate(blocks):
             if s == 0 and i == 0:
-                mark_conv(blk.conv, [blk.conv.in_channels], entry=True, pad_input=False)
+                mark_conv(blk.conv, [blk.conv.in_channels], entry=True, pad_input=False,
+                          image_channels_to=4 if blk.conv.in_channels < 4 else 0)
             else:
                 mark_conv(blk.conv, [c_prev])
             mark_norm(blk)

@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from .. import graph_ops
-from .channel_pad import padded_conv_params, padded_norm_params
+from .channel_pad import pad_image_channels, padded_conv_params, padded_norm_params
 
 __all__ = ["BatchNormAct1d", "BatchNormAct2d", "BatchNormAct3d", "InstanceNormAct1d", "InstanceNormAct2d",
            "InstanceNormAct3d", "ConvBiasFolded1d", "ConvBiasFolded2d", "ConvBiasFolded3d", "ConvOwnBias2d",
@@ -48,6 +48,7 @@ class _ConvBiasFolded:
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         weight, _ = padded_conv_params(self, x, with_bias=False)      # channel_pad.py: zero-padded 33 -> 40 / 66 -> 72
+        x, weight = pad_image_channels(self, x, weight)
         return self._conv_forward(x, weight, None)
 
 

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--kernels", action="store_true")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--cl", action="store_true", help="channels_last_3d inputs: the NDHWC graph-stage path (fused window / pool kernels)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.backends.cudnn.benchmark = True
@@ -64,7 +65,10 @@ def main():
             fuse_norm_act(blk)
             blk = blk.to(dev).train()
             grapher, ffn = blk.blocks[0][0], blk.blocks[0][1]
-            x = torch.randn((args.batch, C) + tuple(shapes[s]), device=dev, requires_grad=True)
+            x = torch.randn((args.batch, C) + tuple(shapes[s]), device=dev)
+            if args.cl:
+                x = x.contiguous(memory_format=torch.channels_last_3d)
+            x.requires_grad_(True)
             gy = torch.randn_like(x)
             for name, m in (("%sGrapher" % kind, grapher), ("FFN", ffn)):
                 label = "s%d %s" % (s, kind)
