@@ -126,6 +126,13 @@ int nextou_mr_aggregate_has_arg(int B, int C, int N, int M, int K);
 int nextou_mr_aggregate_bwd_arg(const float* gout, const uint16_t* arg, float* dx, float* dy,
                                 int B, int C, int N, int M, nextou_stream_t stream);
 
+/* Self graphs of N = M <= 512 points (the Swin windows), given the neighbour ids as well: the same backward as a GATHER over
+ * reverse neighbour lists built per window in LDS — no floating-point atomics, fixed summation order (bit-reproducible
+ * gradients).  nextou_mr_aggregate_bwd_wants_idx() tells the caller whether keeping nn_idx alive for the backward pays. */
+int nextou_mr_aggregate_bwd_wants_idx(int B, int C, int N, int K);
+int nextou_mr_aggregate_bwd_arg_idx(const float* gout, const uint16_t* arg, const int32_t* nn_idx, float* dx,
+                                    int B, int C, int N, int K, int idx_stride, int idx_step, nextou_stream_t stream);
+
 int nextou_mr_aggregate_bwd(const float* gout, const float* x, const float* y,
                             const int32_t* nn_idx, const int32_t* center_idx,
                             float* dx, float* dy,

@@ -42,6 +42,9 @@ _SIGNATURES = {
     "nextou_mr_aggregate_has_arg": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "nextou_mr_aggregate_bwd_arg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                             c_void_p]),
+    "nextou_mr_aggregate_bwd_wants_idx": (c_int, [c_int, c_int, c_int, c_int]),
+    "nextou_mr_aggregate_bwd_arg_idx": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                c_void_p]),
     "nextou_mr_aggregate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p]),

@@ -384,6 +384,120 @@ __global__ __launch_bounds__(256) void mr_bwd_arg_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward of a SELF window graph (N = M <= 512) as a GATHER over reverse neighbour lists — no float atomics.
+//   dx[c, m] = (g_x - g_mr)[c, m] + sum over the queries n that list m among their neighbours of [arg[c, n] == m] * g_mr[c, n]
+// The scatter version above spends 81 % of its wave cycles waiting on ds_add_f32 (rocprofv3 SQ_WAIT_INST_LDS 4.9e8 of 6.05e8,
+// ~118 LDS cycles per wave-instruction, profiles/r01_sq_counters.md).  Here a workgroup (one window, a block of channel
+// quads) first builds the reverse lists of the window in LDS — count (integer LDS atomics, N*K of them instead of C*N float
+// ones), scan, fill, then every lane sorts its own short segment, which makes the summation order fixed: gradients are
+// bit-reproducible run to run — and then lane m walks its list once per channel quad, reading the quad's g_mr (float4) and
+// arg ids (4 x uint16) of each listed query from LDS.  A query that lists m twice (possible for hand-made index tensors,
+// not for kNN output) counts once, as the forward's first-maximum rule does.
+// grid = (quad blocks, B); LDS = quads * N * 24 B + (N + 1) * 4 + N * 4 + N * K * 2.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void mr_bwd_rev_kernel(const float* __restrict__ gout, const uint16_t* __restrict__ arg,
+                                                         const int32_t* __restrict__ idx, float* __restrict__ dx, int C, int N,
+                                                         int K, int idx_stride, int idx_step, int quads) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rev_lds[];
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * quads * 4;
+    int nq = (C - c0 + 3) >> 2;
+    if (nq > quads) nq = quads;
+    float4* g4 = reinterpret_cast<float4*>(rev_lds);                                  // [quads][N]
+    uint2* a4 = reinterpret_cast<uint2*>(rev_lds + (size_t)quads * N * 16);           // [quads][N]  4 x uint16
+    int* off = reinterpret_cast<int*>(rev_lds + (size_t)quads * N * 24);              // [N + 1]
+    int* cur = off + (N + 1);                                                         // [N]
+    uint16_t* ent = reinterpret_cast<uint16_t*>(cur + N);                             // [N * K]
+    const int tid = threadIdx.x;
+    // ---- stage g_mr and arg, quad-interleaved (lanes along n: coalesced row reads, conflict-free 16 / 8-byte writes)
+    const float* gb = gout + ((size_t)b * 2 * C + 2 * c0) * N;
+    const uint16_t* ab = arg + ((size_t)b * C + c0) * N;
+    for (int e = tid; e < nq * N; e += blockDim.x) {
+        const int q = e / N, n = e - q * N;
+        const int c = 4 * q;
+        const bool v1 = c0 + c + 1 < C, v2 = c0 + c + 2 < C, v3 = c0 + c + 3 < C;
+        const float* gp = gb + (size_t)(2 * c + 1) * N + n;
+        const uint16_t* ap = ab + (size_t)c * N + n;
+        float4 g;
+        g.x = gp[0];
+        g.y = v1 ? gp[(size_t)2 * N] : 0.f;
+        g.z = v2 ? gp[(size_t)4 * N] : 0.f;
+        g.w = v3 ? gp[(size_t)6 * N] : 0.f;
+        const unsigned a0 = ap[0], a1 = v1 ? ap[(size_t)N] : 0xffffu, a2 = v2 ? ap[(size_t)2 * N] : 0xffffu,
+                       a3 = v3 ? ap[(size_t)3 * N] : 0xffffu;
+        g4[e] = g;
+        a4[e] = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
+    }
+    // ---- reverse lists of this window
+    for (int m = tid; m <= N; m += blockDim.x) off[m] = 0;
+    for (int m = tid; m < N; m += blockDim.x) cur[m] = 0;
+    __syncthreads();
+    const int32_t* ib = idx + (size_t)b * N * idx_stride;
+    for (int e = tid; e < N * K; e += blockDim.x) {
+        const int n = e / K, j = e - n * K;
+        atomicAdd(&off[ib[(size_t)n * idx_stride + (size_t)j * idx_step] + 1], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {        // inclusive scan of off[1..N] by one wave: N <= 512 -> 8 values per lane
+        const int per = (N + 63) / 64;
+        int local = 0;
+        for (int i = 0; i < per; ++i) { const int m = tid * per + i; if (m < N) local += off[m + 1]; }
+        int run = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(run, d, 64); if (tid >= d) run += t; }
+        int base = run - local;
+        for (int i = 0; i < per; ++i) { const int m = tid * per + i; if (m < N) { base += off[m + 1]; off[m + 1] = base; } }
+    }
+    __syncthreads();
+    for (int e = tid; e < N * K; e += blockDim.x) {
+        const int n = e / K, j = e - n * K;
+        const int m = ib[(size_t)n * idx_stride + (size_t)j * idx_step];
+        ent[off[m] + atomicAdd(&cur[m], 1)] = (uint16_t)n;
+    }
+    __syncthreads();
+    for (int m = tid; m < N; m += blockDim.x) {     // insertion sort of the lane's own segment (a handful of entries)
+        const int lo = off[m], hi = off[m + 1];
+        for (int i = lo + 1; i < hi; ++i) {
+            const uint16_t v = ent[i];
+            int k = i - 1;
+            while (k >= lo && ent[k] > v) { ent[k + 1] = ent[k]; --k; }
+            ent[k + 1] = v;
+        }
+    }
+    __syncthreads();
+    // ---- gather: lane m, every channel quad of the block
+    for (int m = tid; m < N; m += blockDim.x) {
+        const int lo = off[m], hi = off[m + 1];
+        const unsigned um = (unsigned)m;
+        for (int q = 0; q < nq; ++q) {
+            const float4* gq = g4 + q * N;
+            const uint2* aq = a4 + q * N;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int prev = -1;
+            for (int e = lo; e < hi; ++e) {
+                const int n = ent[e];
+                if (n == prev) continue;
+                prev = n;
+                const uint2 a = aq[n];
+                const float4 g = gq[n];
+                s0 += ((a.x & 0xffffu) == um) ? g.x : 0.f;
+                s1 += ((a.x >> 16) == um) ? g.y : 0.f;
+                s2 += ((a.y & 0xffffu) == um) ? g.z : 0.f;
+                s3 += ((a.y >> 16) == um) ? g.w : 0.f;
+            }
+            const int c = c0 + 4 * q;
+            const float4 gm = gq[m];
+            const float* gx = gout + ((size_t)b * 2 * C + 2 * c) * N + m;
+            float* o = dx + ((size_t)b * C + c) * N + m;
+            o[0] = s0 + (gx[0] - gm.x);
+            if (c + 1 < C) o[(size_t)N] = s1 + (gx[(size_t)2 * N] - gm.y);
+            if (c + 2 < C) o[(size_t)2 * N] = s2 + (gx[(size_t)4 * N] - gm.z);
+            if (c + 3 < C) o[(size_t)3 * N] = s3 + (gx[(size_t)6 * N] - gm.w);
+        }
+    }
+}
+
 // generic backward: global atomics, arbitrary centre ids.  dx / dsrc pre-zeroed by the host.
 __global__ __launch_bounds__(256) void mr_bwd_global_kernel(
     const float* __restrict__ gout, const float* __restrict__ x, const float* __restrict__ src,
@@ -604,6 +718,42 @@ extern "C" int nextou_mr_aggregate_has_arg(int B, int C, int N, int M, int K) {
     Q4Plan q;
     return (M <= 65536 && K <= 32 && B > 0 && C > 0 && N > 0 && M > 0 &&
             (plan_q4(B, C, N, M, &q) || plan_lds(B, C, N, M, M, true, &p))) ? 1 : 0;
+}
+
+// 1 if nextou_mr_aggregate_bwd_arg can take the reverse-list gather for a self graph of this shape when given nn_idx
+extern "C" int nextou_mr_aggregate_bwd_wants_idx(int B, int C, int N, int K) {
+    return (getenv("NEXTOU_MR_BWD_V1") == nullptr && B > 0 && C > 0 && N > 0 && N <= 512 && K > 0 && K <= 64) ? 1 : 0;
+}
+
+static int launch_bwd_rev(const float* gout, const uint16_t* arg, const int32_t* nn_idx, float* dx, int B, int C, int N, int K,
+                          int idx_stride, int idx_step, hipStream_t s) {
+    const int total_quads = (C + 3) / 4;
+    const size_t fixed = (size_t)(2 * N + 1) * 4 + (size_t)N * K * 2 + 16;
+    int quads = (int)((28 * 1024) / ((size_t)N * 24));       // ~28 KB of g_mr / arg tiles per workgroup
+    if (quads < 1) quads = 1;
+    if (quads > total_quads) quads = total_quads;
+    quads = cdiv(total_quads, cdiv(total_quads, quads));
+    size_t lds = (size_t)quads * N * 24 + fixed;
+    lds = (lds + 15) & ~(size_t)15;
+    const int threads = ((N < 512 ? N : 512) + 63) / 64 * 64;
+    const double bytes = 8.0 * B * C * (double)N + 2.0 * B * C * (double)N + 4.0 * B * C * (double)N + 4.0 * B * (double)N * K;
+    ProfScope prof(s, kBoundHbm, bytes, "mr_bwd_rev_kernel<self>[B%d C%d N%d K%d]", B, C, N, K);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_rev_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(mr_bwd_rev_kernel, dim3(cdiv(total_quads, quads), B), dim3(threads), lds, s, gout, arg, nn_idx, dx, C, N, K,
+                       idx_stride, idx_step, quads);
+    return check_launch("mr_bwd_rev_kernel");
+}
+
+extern "C" int nextou_mr_aggregate_bwd_arg_idx(const float* gout, const uint16_t* arg, const int32_t* nn_idx, float* dx, int B,
+                                               int C, int N, int K, int idx_stride, int idx_step, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(gout && arg && nn_idx && dx, "mr_aggregate_bwd_arg_idx: null pointer");
+    NEXTOU_REQUIRE(B > 0 && C > 0 && N > 0 && K > 0 && B <= 65535, "mr_aggregate_bwd_arg_idx: bad size B=%d C=%d N=%d K=%d", B, C, N, K);
+    NEXTOU_REQUIRE(idx_step > 0 && idx_stride >= (K - 1) * idx_step + 1, "mr_aggregate_bwd_arg_idx: idx_stride=%d too small for K=%d step=%d",
+                   idx_stride, K, idx_step);
+    if (!nextou_mr_aggregate_bwd_wants_idx(B, C, N, K))
+        return fail(NEXTOU_ENOTSUP, "mr_aggregate_bwd_arg_idx: self graphs of N <= 512 points only (N=%d)", N);
+    return launch_bwd_rev(gout, arg, nn_idx, dx, B, C, N, K, idx_stride, idx_step, (hipStream_t)stream);
 }
 
 extern "C" int nextou_mr_aggregate_bwd_arg(const float* gout, const uint16_t* arg, float* dx, float* dy, int B,

@@ -155,6 +155,22 @@ class _HipBackend:
         return dx, dy
 
     @staticmethod
+    def mr_bwd_wants_idx(B, C, N, K):
+        return bool(_lib.lib().nextou_mr_aggregate_bwd_wants_idx(B, C, N, K))
+
+    @staticmethod
+    def mr_bwd_arg_idx(gout, arg, nn_idx, K, idx_step):
+        """self graph of N <= 512 points: reverse-list gather, no float atomics (bit-reproducible)."""
+        L = _lib.lib()
+        B, C, N = arg.shape
+        dx = torch.empty((B, C, N), dtype=torch.float32, device=gout.device)
+        with torch.cuda.device(gout.device):
+            rc = L.nextou_mr_aggregate_bwd_arg_idx(gout.data_ptr(), arg.data_ptr(), nn_idx.data_ptr(), dx.data_ptr(), B, C, N, K,
+                                                   nn_idx.shape[2], idx_step, _stream_ptr(gout.device))
+        _lib.check(rc, "mr_aggregate_bwd_arg_idx")
+        return dx
+
+    @staticmethod
     def mr_bwd(gout, x, y, nn_idx, center, K, idx_step):
         L = _lib.lib()
         B, C, N = x.shape
@@ -507,7 +523,11 @@ class _MRAggregate(torch.autograd.Function):
         ctx.K, ctx.idx_step = K, idx_step
         ctx.M = x.shape[2] if y is None else y.shape[2]
         ctx.use_arg = arg is not None
-        if ctx.use_arg:
+        ctx.use_idx = bool(ctx.use_arg and y is None and getattr(be, "mr_bwd_wants_idx", lambda *a: False)(
+            x.shape[0], x.shape[1], x.shape[2], K))
+        if ctx.use_idx:         # window graphs: the backward gathers over reverse neighbour lists built from nn_idx
+            ctx.save_for_backward(arg, nn_idx)
+        elif ctx.use_arg:
             ctx.save_for_backward(arg)
         else:
             ctx.save_for_backward(x, y if y is not None else x.new_empty(0), nn_idx,
@@ -517,6 +537,9 @@ class _MRAggregate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         gout = _f32c(gout)
+        if ctx.use_idx:
+            arg, nn_idx = ctx.saved_tensors
+            return _backend_for(gout).mr_bwd_arg_idx(gout, arg, nn_idx, ctx.K, ctx.idx_step), None, None, None, None, None
         if ctx.use_arg:
             (arg,) = ctx.saved_tensors
             dx, dy = _backend_for(gout).mr_bwd_arg(gout, arg, ctx.M, ctx.has_y)
