@@ -593,8 +593,14 @@ struct Q4Plan {
     int quads, q_blocks, n_tiles, n_per_block, threads;
     size_t lds;
 };
-static bool plan_q4(int B, int C, int N, int M, Q4Plan* p) {
-    if (getenv("NEXTOU_MR_FWD_V1")) return false;        // A/B switch: the dword-gather kernel of round 1
+static bool plan_q4(int B, int C, int N, int M, int K, bool self, Q4Plan* p) {
+    // Measured (profiles/r02_kernel_bench_k2.md): the quad kernel wins where the LDS gather is the bound and the id list
+    // is short — self windows, K <= 16 (Swin s2 79.8 -> 67.0 us = 60 % of 8 TB/s) — and loses on the pooled graphs
+    // (K = 28 / 32 ids + 32 float4 in flight = 208 VGPRs, 2 waves per SIMD: Pool s3 73 -> 95 us), which keep the dword kernel.
+    // NEXTOU_MR_FWD=v1 | q4 forces one of them for A/B runs.
+    const char* force = getenv("NEXTOU_MR_FWD");
+    if (force && force[0] == 'v') return false;
+    if (!(force && force[0] == 'q') && !(self && K <= 16 && N <= 512)) return false;
     const size_t per_quad = (size_t)M * 16;
     if (per_quad > 152 * 1024) return false;
     const int total_quads = (C + 3) / 4;
@@ -602,6 +608,7 @@ static bool plan_q4(int B, int C, int N, int M, Q4Plan* p) {
     int quads = (int)(budget / per_quad);
     if (quads < 1) quads = 1;
     if (quads > total_quads) quads = total_quads;
+    while (quads > 1 && (long long)cdiv(total_quads, quads) * B < 512 && N <= 1024) quads = (quads + 1) / 2;   // fill the chip
     quads = cdiv(total_quads, cdiv(total_quads, quads));      // balance the last block
     p->quads = quads;
     p->q_blocks = cdiv(total_quads, quads);
@@ -654,7 +661,7 @@ extern "C" int nextou_mr_aggregate_fwd(const float* x, const float* y, const int
     const double fwd_bytes = 4.0 * B * C * ((double)N + (y ? M : 0)) + 4.0 * B * (double)N * K + 8.0 * B * C * (double)N +
                              (arg_out ? 2.0 * B * C * (double)N : 0.0);
     Q4Plan qp;
-    if (center_idx == nullptr && K <= 32 && plan_q4(B, C, N, M, &qp)) {
+    if (center_idx == nullptr && K <= 32 && plan_q4(B, C, N, M, K, self, &qp)) {
         dim3 grid(qp.n_tiles, qp.q_blocks, B), block(qp.threads);
         const int kb = K <= 8 ? 8 : (K <= 16 ? 16 : 32);
         ProfScope prof(s, kBoundHbm, fwd_bytes, "mr_fwd_q4_kernel<%d,%s,%s>[B%d C%d N%d M%d K%d]", kb,
@@ -717,7 +724,7 @@ extern "C" int nextou_mr_aggregate_has_arg(int B, int C, int N, int M, int K) {
     MrPlan p;
     Q4Plan q;
     return (M <= 65536 && K <= 32 && B > 0 && C > 0 && N > 0 && M > 0 &&
-            (plan_q4(B, C, N, M, &q) || plan_lds(B, C, N, M, M, true, &p))) ? 1 : 0;
+            (plan_q4(B, C, N, M, K, M == N, &q) || plan_lds(B, C, N, M, M, true, &p))) ? 1 : 0;
 }
 
 // 1 if nextou_mr_aggregate_bwd_arg can take the reverse-list gather for a self graph of this shape when given nn_idx

@@ -447,16 +447,8 @@ class SwinGrapher(_GrapherBase):
         shortcut = x
         size_tuple = tuple(x.shape[2:])
         assert size_tuple == tuple(self.img_shape), "input features has wrong size"
-        if is_channels_last_volume(x) and isinstance(self.drop_path, nn.Identity):
-            # shift + partition read the channels-last volume once and emit channel-major windows; reverse + unshift +
-            # the residual add write it once (graph_ops.window_gather / window_scatter)
-            shift = tuple(self.shift_size) if max(self.shift_size) > 0 else (0,) * dim
-            windows = graph_ops.window_gather(x, self.window_size, shift)
-            h = self.fc1(windows.view(windows.shape[0], windows.shape[1], *self.window_size))
-            h = self.graph_conv(h, self._get_relative_pos(self.relative_pos, tuple(h.shape[2:])))
-            h = self.fc2(h)
-            return graph_ops.window_scatter(h.reshape(h.shape[0], h.shape[1], -1), size_tuple, self.window_size, shift,
-                                            residual=shortcut)
+        if is_channels_last_volume(x) and isinstance(self.drop_path, nn.Identity) and self.graph_conv.r == 1:
+            return self._forward_channels_last(x, size_tuple, dim)
         axes = tuple(range(2, 2 + dim))
         shifted = max(self.shift_size) > 0
         if shifted:
@@ -467,6 +459,27 @@ class SwinGrapher(_GrapherBase):
         if shifted:
             x = torch.roll(x, shifts=tuple(self.shift_size), dims=axes)
         return self.drop_path(x) + shortcut
+
+
+def _swin_forward_channels_last(self, x, size_tuple, dim):
+    """SwinGrapher on a channels-last volume.  Only the two graph kernels need the (windows, C, points) rows; fc1, the
+    MRConv's grouped 1x1 conv + norm + activation and fc2 are point-wise (and their batch statistics are sums over all
+    points), so they commute with the window permutation and run on the NDHWC volume — where MIOpen's CK kernels need
+    no layout transposes (they cost 1.34 ms of a 4.3 ms stage-2 block on window-major NCDHW tensors,
+    profiles/r02_gnn_stage_profile.md).  The shift + partition and the reverse + un-shift are index math inside
+    graph_ops.window_gather / window_scatter.  Same function as reference :766-818 up to the summation order of the batch
+    statistics."""
+    shift = tuple(self.shift_size) if max(self.shift_size) > 0 else (0,) * dim
+    gc = self.graph_conv
+    h = self.fc1(x)
+    windows = graph_ops.window_gather(h, self.window_size, shift)                      # (B * nW, C, Nw)
+    nn_idx = gc.dilated_knn_graph.neighbor_ids(windows, None, self._get_relative_pos(self.relative_pos, tuple(self.window_size)))
+    agg = graph_ops.mr_aggregate(windows, nn_idx)                                      # (B * nW, 2C, Nw)
+    vol = graph_ops.window_scatter(agg, size_tuple, self.window_size, shift)           # NDHWC (B, 2C, *size)
+    return self.fc2(gc.gconv.nn(vol)) + x
+
+
+SwinGrapher._forward_channels_last = _swin_forward_channels_last
 
 
 class _GNNBlocks(nn.Module):
