@@ -128,7 +128,8 @@ int nextou_mr_aggregate_bwd_arg(const float* gout, const uint16_t* arg, float* d
 
 /* Self graphs of N = M <= 512 points (the Swin windows), given the neighbour ids as well: the same backward as a GATHER over
  * reverse neighbour lists built per window in LDS — no floating-point atomics, fixed summation order (bit-reproducible
- * gradients).  nextou_mr_aggregate_bwd_wants_idx() tells the caller whether keeping nn_idx alive for the backward pays. */
+ * gradients).  Measured slower than the scatter on MI355X (200 vs 133 us at cfg-2 stage 2), so
+ * nextou_mr_aggregate_bwd_wants_idx() — the policy the autograd glue asks — says 1 only under NEXTOU_MR_BWD=rev. */
 int nextou_mr_aggregate_bwd_wants_idx(int B, int C, int N, int K);
 int nextou_mr_aggregate_bwd_arg_idx(const float* gout, const uint16_t* arg, const int32_t* nn_idx, float* dx,
                                     int B, int C, int N, int K, int idx_stride, int idx_step, nextou_stream_t stream);

@@ -595,12 +595,13 @@ struct Q4Plan {
 };
 static bool plan_q4(int B, int C, int N, int M, int K, bool self, Q4Plan* p) {
     // Measured (profiles/r02_kernel_bench_k2.md): the quad kernel wins where the LDS gather is the bound and the id list
-    // is short — self windows, K <= 16 (Swin s2 79.8 -> 67.0 us = 60 % of 8 TB/s) — and loses on the pooled graphs
-    // (K = 28 / 32 ids + 32 float4 in flight = 208 VGPRs, 2 waves per SIMD: Pool s3 73 -> 95 us), which keep the dword kernel.
+    // is short — the cfg-2 stage-2 windows, K = 7 (79.8 -> 66.2 us = 61 % of 8 TB/s) — is level at K = 14 and loses beyond
+    // (K = 16 windows of 384 points 233 -> 319 us; pooled graphs with K = 28 / 32 ids + 32 float4 in flight = 208 VGPRs,
+    // 2 waves per SIMD: Pool s3 73 -> 95 us), which keep the dword kernel.
     // NEXTOU_MR_FWD=v1 | q4 forces one of them for A/B runs.
     const char* force = getenv("NEXTOU_MR_FWD");
     if (force && force[0] == 'v') return false;
-    if (!(force && force[0] == 'q') && !(self && K <= 16 && N <= 512)) return false;
+    if (!(force && force[0] == 'q') && !(self && K <= 8 && N <= 512)) return false;
     const size_t per_quad = (size_t)M * 16;
     if (per_quad > 152 * 1024) return false;
     const int total_quads = (C + 3) / 4;
@@ -727,9 +728,15 @@ extern "C" int nextou_mr_aggregate_has_arg(int B, int C, int N, int M, int K) {
             (plan_q4(B, C, N, M, K, M == N, &q) || plan_lds(B, C, N, M, M, true, &p))) ? 1 : 0;
 }
 
-// 1 if nextou_mr_aggregate_bwd_arg can take the reverse-list gather for a self graph of this shape when given nn_idx
+// 1 if the caller should keep nn_idx alive and take nextou_mr_aggregate_bwd_arg_idx for a self graph of this shape.
+// Policy, not capability: measured on MI355X (profiles/r02_kernel_bench_k2.md) the reverse-list gather is SLOWER than the
+// LDS-atomic scatter it was meant to replace (Swin s2 200 us vs 133 us; cfg-5 Swin s2 677 vs 282 us — every workgroup of
+// a window rebuilds the lists, and lanes of one wave walk lists of different lengths), so it is opt-in
+// (NEXTOU_MR_BWD=rev) for runs that want bit-reproducible gradients.
+static bool rev_shape_ok(int B, int C, int N, int K) { return B > 0 && C > 0 && N > 0 && N <= 512 && K > 0 && K <= 64; }
 extern "C" int nextou_mr_aggregate_bwd_wants_idx(int B, int C, int N, int K) {
-    return (getenv("NEXTOU_MR_BWD_V1") == nullptr && B > 0 && C > 0 && N > 0 && N <= 512 && K > 0 && K <= 64) ? 1 : 0;
+    const char* e = getenv("NEXTOU_MR_BWD");
+    return (e != nullptr && e[0] == 'r' && rev_shape_ok(B, C, N, K)) ? 1 : 0;
 }
 
 static int launch_bwd_rev(const float* gout, const uint16_t* arg, const int32_t* nn_idx, float* dx, int B, int C, int N, int K,
@@ -758,7 +765,7 @@ extern "C" int nextou_mr_aggregate_bwd_arg_idx(const float* gout, const uint16_t
     NEXTOU_REQUIRE(B > 0 && C > 0 && N > 0 && K > 0 && B <= 65535, "mr_aggregate_bwd_arg_idx: bad size B=%d C=%d N=%d K=%d", B, C, N, K);
     NEXTOU_REQUIRE(idx_step > 0 && idx_stride >= (K - 1) * idx_step + 1, "mr_aggregate_bwd_arg_idx: idx_stride=%d too small for K=%d step=%d",
                    idx_stride, K, idx_step);
-    if (!nextou_mr_aggregate_bwd_wants_idx(B, C, N, K))
+    if (!rev_shape_ok(B, C, N, K))
         return fail(NEXTOU_ENOTSUP, "mr_aggregate_bwd_arg_idx: self graphs of N <= 512 points only (N=%d)", N);
     return launch_bwd_rev(gout, arg, nn_idx, dx, B, C, N, K, idx_stride, idx_step, (hipStream_t)stream);
 }
