@@ -46,48 +46,74 @@ __device__ __forceinline__ long long window_point_row(int win, int p, const Vol&
     return ((long long)d * v.H + h) * v.W + x;
 }
 
-// grid = (windows per sample, channel tiles, B); LDS = Nw * (Cc + 1) floats
+// grid = (windows per sample, channel tiles, B); LDS = Nw * 65 floats (tile) + Nw ints (row of every window point)
 // GATHER:  out_cm[(b * nWin + win), c, p] = x_cl[b, row(win, p), c]
 // !GATHER: out_cl[b, row(win, p), c] = src_cm[(b * nWin + win), c, p] (+ residual_cl[b, row, c])
-template <bool GATHER>
+// VEC: C % 4 == 0 and 16-byte aligned bases — the channels-last side moves float4 (16 lanes cover the 256-byte run of a
+// tile row); the channel-major side is walked one channel row per wave, lanes along the points.  No integer division in
+// the loops: the window-point -> volume-row map is computed once per workgroup into LDS.
+template <bool GATHER, bool VEC>
 __global__ __launch_bounds__(kLayThreads) void window_move_kernel(const float* __restrict__ src, const float* __restrict__ residual,
                                                                   float* __restrict__ dst, Vol v, Win w, int C, int nH, int nW,
                                                                   int n_win, int Nw) {
     extern __shared__ float tile[];
+    int* rows = reinterpret_cast<int*>(tile + (size_t)Nw * (kTileChannels + 1));
     const int win = blockIdx.x, b = blockIdx.z;
     const int c0 = blockIdx.y * kTileChannels;
     const int cc = min(kTileChannels, C - c0);
     const int ld = kTileChannels + 1;
     const long long vol_rows = (long long)v.D * v.H * v.W;
-    const float* cl = (GATHER ? src : residual);
-    float* cm_base = nullptr;
     const size_t cm_off = ((size_t)(b * n_win + win) * C + c0) * Nw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = kLayThreads >> 6;
+    for (int p = threadIdx.x; p < Nw; p += kLayThreads) rows[p] = (int)window_point_row(win, p, v, w, nH, nW);
+    __syncthreads();
+    const float* cl_in = GATHER ? src : residual;
+    const size_t cl_base = (size_t)b * vol_rows * C + c0;
     if (GATHER) {
-        // channels-last rows -> LDS (lanes along the channels)
-        for (int e = threadIdx.x; e < Nw * cc; e += kLayThreads) {
-            const int p = e / cc, c = e - p * cc;
-            const long long r = (long long)b * vol_rows + window_point_row(win, p, v, w, nH, nW);
-            tile[p * ld + c] = cl[r * C + c0 + c];
+        if (VEC) {
+            for (int e = threadIdx.x; e < Nw * 16; e += kLayThreads) {
+                const int p = e >> 4, c4 = (e & 15) << 2;
+                if (c4 < cc) {
+                    const float4 val = *reinterpret_cast<const float4*>(cl_in + cl_base + (size_t)rows[p] * C + c4);
+                    float* t = tile + p * ld + c4;
+                    t[0] = val.x; t[1] = val.y; t[2] = val.z; t[3] = val.w;
+                }
+            }
+        } else {
+            for (int p = wave; p < Nw; p += n_waves)
+                if (lane < cc) tile[p * ld + lane] = cl_in[cl_base + (size_t)rows[p] * C + lane];
         }
         __syncthreads();
-        cm_base = dst + cm_off;
-        for (int e = threadIdx.x; e < cc * Nw; e += kLayThreads) {   // LDS -> channel-major rows (lanes along the points)
-            const int c = e / Nw, p = e - c * Nw;
-            cm_base[(size_t)c * Nw + p] = tile[p * ld + c];
-        }
+        float* cm = dst + cm_off;
+        for (int c = wave; c < cc; c += n_waves)
+            for (int p = lane; p < Nw; p += 64) cm[(size_t)c * Nw + p] = tile[p * ld + c];
     } else {
         const float* cm = src + cm_off;
-        for (int e = threadIdx.x; e < cc * Nw; e += kLayThreads) {
-            const int c = e / Nw, p = e - c * Nw;
-            tile[p * ld + c] = cm[(size_t)c * Nw + p];
-        }
+        for (int c = wave; c < cc; c += n_waves)
+            for (int p = lane; p < Nw; p += 64) tile[p * ld + c] = cm[(size_t)c * Nw + p];
         __syncthreads();
-        for (int e = threadIdx.x; e < Nw * cc; e += kLayThreads) {
-            const int p = e / cc, c = e - p * cc;
-            const long long r = (long long)b * vol_rows + window_point_row(win, p, v, w, nH, nW);
-            float val = tile[p * ld + c];
-            if (residual != nullptr) val += residual[r * C + c0 + c];
-            dst[r * C + c0 + c] = val;
+        if (VEC) {
+            for (int e = threadIdx.x; e < Nw * 16; e += kLayThreads) {
+                const int p = e >> 4, c4 = (e & 15) << 2;
+                if (c4 < cc) {
+                    const float* t = tile + p * ld + c4;
+                    float4 val = make_float4(t[0], t[1], t[2], t[3]);
+                    const size_t off = cl_base + (size_t)rows[p] * C + c4;
+                    if (residual != nullptr) {
+                        const float4 r = *reinterpret_cast<const float4*>(residual + off);
+                        val.x += r.x; val.y += r.y; val.z += r.z; val.w += r.w;
+                    }
+                    *reinterpret_cast<float4*>(dst + off) = val;
+                }
+            }
+        } else {
+            for (int p = wave; p < Nw; p += n_waves)
+                if (lane < cc) {
+                    const size_t off = cl_base + (size_t)rows[p] * C + lane;
+                    float val = tile[p * ld + lane];
+                    if (residual != nullptr) val += residual[off];
+                    dst[off] = val;
+                }
         }
     }
 }
@@ -106,77 +132,134 @@ __device__ __forceinline__ long long cell_row(int n, int k, const Vol& v, const 
     return ((long long)(dz * q.pd + kd) * v.H + (hy * q.ph + kh)) * v.W + (wx * q.pw + kw);
 }
 
+// The three pool kernels share one tile walk: grid = (point tiles, channel tiles, B); the volume row of every
+// (tile point, cell position) is computed once into LDS; VEC (C2 % 4 == 0, C % 4 == 0, aligned bases) moves float4 /
+// uchar4 on the channels-last side with 16 lanes per point, the channel-major side goes one channel row per wave.
+constexpr int kMaxCells = 8;
+
+__device__ __forceinline__ void fill_cell_rows(int* rows, int n0, int tn, int cells, const Vol& v, const Pool& q) {
+    for (int e = threadIdx.x; e < tn * cells; e += kLayThreads) {
+        const int i = e / cells, k = e - i * cells;
+        rows[e] = (int)cell_row(n0 + i, k, v, q);
+    }
+}
+
 // Max pool of channels-last rows -> channel-major values + the winning cell (uint8, points-major (B, N, C)).
 // First maximum in (d, h, w) scan order wins, NaN wins (ATen's max_pool3d_with_indices rule).
-// grid = (point tiles, channel tiles, B); LDS = T * 65 floats
+template <bool VEC>
 __global__ __launch_bounds__(kLayThreads) void pool_rows_kernel(const float* __restrict__ x_cl, float* __restrict__ val_cm,
                                                                 uint8_t* __restrict__ cell, Vol v, Pool q, int C, int N) {
     __shared__ float tile[kTilePoints * (kTileChannels + 1)];
+    __shared__ int rows[kTilePoints * kMaxCells];
     const int b = blockIdx.z, c0 = blockIdx.y * kTileChannels, n0 = blockIdx.x * kTilePoints;
     const int cc = min(kTileChannels, C - c0), tn = min(kTilePoints, N - n0);
     const int ld = kTileChannels + 1, cells = q.pd * q.ph * q.pw;
     const long long vol_rows = (long long)v.D * v.H * v.W;
-    for (int e = threadIdx.x; e < tn * cc; e += kLayThreads) {
-        const int i = e / cc, c = e - i * cc;
-        const float* base = x_cl + (long long)b * vol_rows * C + c0 + c;
-        float best = base[cell_row(n0 + i, 0, v, q) * C];
-        int arg = 0;
-        for (int k = 1; k < cells; ++k) {
-            const float val = base[cell_row(n0 + i, k, v, q) * C];
-            if (val > best || val != val) { best = val; arg = k; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = kLayThreads >> 6;
+    fill_cell_rows(rows, n0, tn, cells, v, q);
+    __syncthreads();
+    const float* base = x_cl + (size_t)b * vol_rows * C + c0;
+    if (VEC) {
+        for (int e = threadIdx.x; e < tn * 16; e += kLayThreads) {
+            const int i = e >> 4, c4 = (e & 15) << 2;
+            if (c4 >= cc) continue;
+            const int* r = rows + i * cells;
+            float4 best = *reinterpret_cast<const float4*>(base + (size_t)r[0] * C + c4);
+            unsigned a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (int k = 1; k < cells; ++k) {
+                const float4 val = *reinterpret_cast<const float4*>(base + (size_t)r[k] * C + c4);
+                if (val.x > best.x || val.x != val.x) { best.x = val.x; a0 = k; }
+                if (val.y > best.y || val.y != val.y) { best.y = val.y; a1 = k; }
+                if (val.z > best.z || val.z != val.z) { best.z = val.z; a2 = k; }
+                if (val.w > best.w || val.w != val.w) { best.w = val.w; a3 = k; }
+            }
+            float* t = tile + i * ld + c4;
+            t[0] = best.x; t[1] = best.y; t[2] = best.z; t[3] = best.w;
+            *reinterpret_cast<unsigned*>(cell + ((size_t)b * N + n0 + i) * C + c0 + c4) = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
         }
-        tile[i * ld + c] = best;
-        cell[((size_t)b * N + n0 + i) * C + c0 + c] = (uint8_t)arg;
+    } else {
+        for (int i = wave; i < tn; i += n_waves) {
+            if (lane >= cc) continue;
+            const int* r = rows + i * cells;
+            float best = base[(size_t)r[0] * C + lane];
+            int arg = 0;
+            for (int k = 1; k < cells; ++k) {
+                const float val = base[(size_t)r[k] * C + lane];
+                if (val > best || val != val) { best = val; arg = k; }
+            }
+            tile[i * ld + lane] = best;
+            cell[((size_t)b * N + n0 + i) * C + c0 + lane] = (uint8_t)arg;
+        }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < cc * tn; e += kLayThreads) {
-        const int c = e / tn, i = e - c * tn;
-        val_cm[((size_t)b * C + c0 + c) * N + n0 + i] = tile[i * ld + c];
-    }
+    for (int c = wave; c < cc; c += n_waves)
+        if (lane < tn) val_cm[((size_t)b * C + c0 + c) * N + n0 + lane] = tile[lane * ld + c];
 }
 
 // out_cm[b, c2, n] = x_cl[b, cell_row(n, cell[b, n, c2 mod C]), c2]      (C2 = C or 2C channels)
 __global__ __launch_bounds__(kLayThreads) void cell_gather_kernel(const float* __restrict__ x_cl, const uint8_t* __restrict__ cell,
                                                                   float* __restrict__ out_cm, Vol v, Pool q, int C2, int C, int N) {
     __shared__ float tile[kTilePoints * (kTileChannels + 1)];
-    const int b = blockIdx.z, c0 = blockIdx.y * kTileChannels, n0 = blockIdx.x * kTilePoints;
-    const int cc = min(kTileChannels, C2 - c0), tn = min(kTilePoints, N - n0);
-    const int ld = kTileChannels + 1;
-    const long long vol_rows = (long long)v.D * v.H * v.W;
-    for (int e = threadIdx.x; e < tn * cc; e += kLayThreads) {
-        const int i = e / cc, c = e - i * cc;
-        const int c2 = c0 + c;
-        const int k = cell[((size_t)b * N + n0 + i) * C + (c2 >= C ? c2 - C : c2)];
-        tile[i * ld + c] = x_cl[((long long)b * vol_rows + cell_row(n0 + i, k, v, q)) * C2 + c2];
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < cc * tn; e += kLayThreads) {
-        const int c = e / tn, i = e - c * tn;
-        out_cm[((size_t)b * C2 + c0 + c) * N + n0 + i] = tile[i * ld + c];
-    }
-}
-
-// out_cl[b, cell_row(n, k), c2] = (cell[b, n, c2 mod C] == k) ? src_cm[b, c2, n] : 0   for every cell k: the full tensor is
-// written exactly once, zeros included (no memset, no index concatenation)
-__global__ __launch_bounds__(kLayThreads) void cell_scatter_kernel(const float* __restrict__ src_cm, const uint8_t* __restrict__ cell,
-                                                                   float* __restrict__ out_cl, Vol v, Pool q, int C2, int C, int N) {
-    __shared__ float tile[kTilePoints * (kTileChannels + 1)];
+    __shared__ int rows[kTilePoints * kMaxCells];
     const int b = blockIdx.z, c0 = blockIdx.y * kTileChannels, n0 = blockIdx.x * kTilePoints;
     const int cc = min(kTileChannels, C2 - c0), tn = min(kTilePoints, N - n0);
     const int ld = kTileChannels + 1, cells = q.pd * q.ph * q.pw;
     const long long vol_rows = (long long)v.D * v.H * v.W;
-    for (int e = threadIdx.x; e < cc * tn; e += kLayThreads) {
-        const int c = e / tn, i = e - c * tn;
-        tile[i * ld + c] = src_cm[((size_t)b * C2 + c0 + c) * N + n0 + i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = kLayThreads >> 6;
+    fill_cell_rows(rows, n0, tn, cells, v, q);
+    __syncthreads();
+    const float* base = x_cl + (size_t)b * vol_rows * C2;
+    for (int i = wave; i < tn; i += n_waves) {          // lanes along the channels: every lane its own cell of the point
+        if (lane >= cc) continue;
+        const int c2 = c0 + lane;
+        const int k = cell[((size_t)b * N + n0 + i) * C + (c2 >= C ? c2 - C : c2)];
+        tile[i * ld + lane] = base[(size_t)rows[i * cells + k] * C2 + c2];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < tn * cc; e += kLayThreads) {
-        const int i = e / cc, c = e - i * cc;
-        const int c2 = c0 + c;
-        const int arg = cell[((size_t)b * N + n0 + i) * C + (c2 >= C ? c2 - C : c2)];
-        const float val = tile[i * ld + c];
-        float* base = out_cl + (long long)b * vol_rows * C2 + c2;
-        for (int k = 0; k < cells; ++k) base[cell_row(n0 + i, k, v, q) * C2] = (k == arg) ? val : 0.f;
+    for (int c = wave; c < cc; c += n_waves)
+        if (lane < tn) out_cm[((size_t)b * C2 + c0 + c) * N + n0 + lane] = tile[lane * ld + c];
+}
+
+// out_cl[b, cell_row(n, k), c2] = (cell[b, n, c2 mod C] == k) ? src_cm[b, c2, n] : 0   for every cell k: the full tensor is
+// written exactly once, zeros included (no memset, no index concatenation)
+template <bool VEC>
+__global__ __launch_bounds__(kLayThreads) void cell_scatter_kernel(const float* __restrict__ src_cm, const uint8_t* __restrict__ cell,
+                                                                   float* __restrict__ out_cl, Vol v, Pool q, int C2, int C, int N) {
+    __shared__ float tile[kTilePoints * (kTileChannels + 1)];
+    __shared__ int rows[kTilePoints * kMaxCells];
+    const int b = blockIdx.z, c0 = blockIdx.y * kTileChannels, n0 = blockIdx.x * kTilePoints;
+    const int cc = min(kTileChannels, C2 - c0), tn = min(kTilePoints, N - n0);
+    const int ld = kTileChannels + 1, cells = q.pd * q.ph * q.pw;
+    const long long vol_rows = (long long)v.D * v.H * v.W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = kLayThreads >> 6;
+    fill_cell_rows(rows, n0, tn, cells, v, q);
+    for (int c = wave; c < cc; c += n_waves)
+        if (lane < tn) tile[lane * ld + c] = src_cm[((size_t)b * C2 + c0 + c) * N + n0 + lane];
+    __syncthreads();
+    float* base = out_cl + (size_t)b * vol_rows * C2 + c0;
+    if (VEC) {      // tile channel blocks never straddle C (C % 64 == 0 is not needed: c2 mod C is taken per 4-channel group)
+        for (int e = threadIdx.x; e < tn * 16; e += kLayThreads) {
+            const int i = e >> 4, c4 = (e & 15) << 2;
+            if (c4 >= cc) continue;
+            const int c2 = c0 + c4;
+            const unsigned packed = *reinterpret_cast<const unsigned*>(cell + ((size_t)b * N + n0 + i) * C + (c2 >= C ? c2 - C : c2));
+            const float* t = tile + i * ld + c4;
+            const float4 val = make_float4(t[0], t[1], t[2], t[3]);
+            const unsigned a0 = packed & 255u, a1 = (packed >> 8) & 255u, a2 = (packed >> 16) & 255u, a3 = packed >> 24;
+            const int* r = rows + i * cells;
+            for (unsigned k = 0; k < (unsigned)cells; ++k)
+                *reinterpret_cast<float4*>(base + (size_t)r[k] * C2 + c4) =
+                    make_float4(k == a0 ? val.x : 0.f, k == a1 ? val.y : 0.f, k == a2 ? val.z : 0.f, k == a3 ? val.w : 0.f);
+        }
+    } else {
+        for (int i = wave; i < tn; i += n_waves) {
+            if (lane >= cc) continue;
+            const int c2 = c0 + lane;
+            const int arg = cell[((size_t)b * N + n0 + i) * C + (c2 >= C ? c2 - C : c2)];
+            const float val = tile[i * ld + lane];
+            const int* r = rows + i * cells;
+            for (int k = 0; k < cells; ++k) base[(size_t)r[k] * C2 + lane] = (k == arg) ? val : 0.f;
+        }
     }
 }
 
@@ -195,29 +278,35 @@ static int launch_window(bool gather, const float* src, const float* residual, f
                    "%s: window (%d,%d,%d) does not tile the volume (%d,%d,%d)", who, wd, wh, ww, D, H, W);
     NEXTOU_REQUIRE(sd >= 0 && sd < D && sh >= 0 && sh < H && sw >= 0 && sw < W, "%s: shift (%d,%d,%d) out of range", who, sd, sh, sw);
     const int Nw = wd * wh * ww;
-    const size_t lds = (size_t)Nw * (kTileChannels + 1) * sizeof(float);
+    const size_t lds = (size_t)Nw * (kTileChannels + 1) * sizeof(float) + (size_t)Nw * sizeof(int);
     if (lds > 160 * 1024) return fail(NEXTOU_ENOTSUP, "%s: a window of %d points does not fit the LDS tile", who, Nw);
     const int nD = D / wd, nH = H / wh, nW = W / ww, n_win = nD * nH * nW;
     const Vol v{D, H, W};
     const Win w{wd, wh, ww, sd, sh, sw};
     const dim3 grid(n_win, cdiv(C, kTileChannels), B);
     const double bytes = (gather || residual == nullptr ? 2.0 : 3.0) * 4.0 * B * (double)C * D * H * W;
+    const bool vec = (C % 4 == 0) && (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) |
+                                        reinterpret_cast<uintptr_t>(residual)) & 15u) == 0);
     ProfScope prof(s, kBoundHbm, bytes, "%s[B%d C%d %dx%dx%d win %dx%dx%d]", gather ? "window_gather_kernel" : "window_scatter_kernel",
                    B, C, D, H, W, wd, wh, ww);
-    if (gather) {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_move_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(window_move_kernel<true>, grid, dim3(kLayThreads), lds, s, src, (const float*)nullptr, dst, v, w, C, nH, nW, n_win, Nw);
-    } else {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_move_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(window_move_kernel<false>, grid, dim3(kLayThreads), lds, s, src, residual, dst, v, w, C, nH, nW, n_win, Nw);
-    }
+#define NEXTOU_WINDOW(G, V)                                                                                              \
+    do {                                                                                                                 \
+        if (lds > 64 * 1024)                                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_move_kernel<G, V>),                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+        hipLaunchKernelGGL((window_move_kernel<G, V>), grid, dim3(kLayThreads), lds, s, src, residual, dst, v, w, C, nH, nW, \
+                           n_win, Nw);                                                                                   \
+    } while (0)
+    if (gather && vec) NEXTOU_WINDOW(true, true);
+    else if (gather) NEXTOU_WINDOW(true, false);
+    else if (vec) NEXTOU_WINDOW(false, true);
+    else NEXTOU_WINDOW(false, false);
+#undef NEXTOU_WINDOW
     return check_launch(who);
 }
 
 static int make_pool(const char* who, int D, int H, int W, int pd, int ph, int pw, Pool* q) {
-    NEXTOU_REQUIRE(pd > 0 && ph > 0 && pw > 0 && pd * ph * pw <= 255 && D % pd == 0 && H % ph == 0 && W % pw == 0,
+    NEXTOU_REQUIRE(pd > 0 && ph > 0 && pw > 0 && pd * ph * pw <= kMaxCells && D % pd == 0 && H % ph == 0 && W % pw == 0,
                    "%s: pool (%d,%d,%d) does not tile the volume (%d,%d,%d)", who, pd, ph, pw, D, H, W);
     *q = Pool{pd, ph, pw, D / pd, H / ph, W / pw};
     return 0;
@@ -247,8 +336,10 @@ extern "C" int nextou_pool_rows(const float* x_cl, float* values_cm, uint8_t* ce
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(s, kBoundHbm, 4.0 * B * (double)C * D * H * W + 5.0 * B * (double)C * N, "pool_rows_kernel[B%d C%d %dx%dx%d pool %dx%dx%d]",
                    B, C, D, H, W, pd, ph, pw);
-    hipLaunchKernelGGL(pool_rows_kernel, dim3(cdiv(N, kTilePoints), cdiv(C, kTileChannels), B), dim3(kLayThreads), 0, s, x_cl, values_cm,
-                       cell, Vol{D, H, W}, q, C, N);
+    const dim3 grid(cdiv(N, kTilePoints), cdiv(C, kTileChannels), B);
+    const bool vec = (C % 4 == 0) && (((reinterpret_cast<uintptr_t>(x_cl) | reinterpret_cast<uintptr_t>(cell)) & 15u) == 0);
+    if (vec) hipLaunchKernelGGL(pool_rows_kernel<true>, grid, dim3(kLayThreads), 0, s, x_cl, values_cm, cell, Vol{D, H, W}, q, C, N);
+    else hipLaunchKernelGGL(pool_rows_kernel<false>, grid, dim3(kLayThreads), 0, s, x_cl, values_cm, cell, Vol{D, H, W}, q, C, N);
     return check_launch("pool_rows_kernel");
 }
 
@@ -279,7 +370,10 @@ extern "C" int nextou_cell_scatter(const float* src_cm, const uint8_t* cell, flo
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(s, kBoundHbm, 4.0 * B * (double)C2 * D * H * W + 4.0 * B * (double)C2 * N + 1.0 * B * (double)C * N,
                    "cell_scatter_kernel[B%d C%d %dx%dx%d pool %dx%dx%d]", B, C2, D, H, W, pd, ph, pw);
-    hipLaunchKernelGGL(cell_scatter_kernel, dim3(cdiv(N, kTilePoints), cdiv(C2, kTileChannels), B), dim3(kLayThreads), 0, s, src_cm, cell, out_cl,
-                       Vol{D, H, W}, q, C2, C, N);
+    const dim3 grid(cdiv(N, kTilePoints), cdiv(C2, kTileChannels), B);
+    // a 4-channel group must not straddle the C boundary of the duplicated index set: C % 4 == 0 covers it
+    const bool vec = (C % 4 == 0) && (C2 % 4 == 0) && (((reinterpret_cast<uintptr_t>(out_cl) | reinterpret_cast<uintptr_t>(cell)) & 15u) == 0);
+    if (vec) hipLaunchKernelGGL(cell_scatter_kernel<true>, grid, dim3(kLayThreads), 0, s, src_cm, cell, out_cl, Vol{D, H, W}, q, C2, C, N);
+    else hipLaunchKernelGGL(cell_scatter_kernel<false>, grid, dim3(kLayThreads), 0, s, src_cm, cell, out_cl, Vol{D, H, W}, q, C2, C, N);
     return check_launch("cell_scatter_kernel");
 }
