@@ -84,6 +84,7 @@ class BucketedGradientAverager:
             self.buckets.append(_Bucket(current))
         self._slot = {}
         self._hooks = []
+        self._produced_cache = {}
         for bi, b in enumerate(self.buckets):
             for pi, p in enumerate(b.params):
                 self._slot[p] = (bi, pi)
@@ -127,7 +128,12 @@ class BucketedGradientAverager:
                 b.views[pi].zero_()
         if dst:
             torch._foreach_copy_(dst, src)
-        b.flags.copy_(torch.tensor([1.0 if f else 0.0 for f in b.filled], dtype=b.flat.dtype), non_blocking=True)
+        # "was produced" flags, written with device-side fills only: a host-to-device copy from pageable memory would
+        # block the host until the stream reaches it — in the middle of backward — and starve the launch queue behind it
+        b.flags.fill_(1.0)
+        for pi, f in enumerate(b.filled):
+            if not f:
+                b.flags[pi:pi + 1].zero_()
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     @torch.no_grad()
@@ -148,10 +154,17 @@ class BucketedGradientAverager:
             if b.work is None:
                 self._launch(b)
         inv = 1.0 / self.world
-        for b in self.buckets:
+        for bi, b in enumerate(self.buckets):
             b.work.wait()
             b.flat[:b.n_grad].mul_(inv)
-            produced = (b.flags > 0).tolist() if not all(b.filled) else None   # host sync only when something was missing
+            produced = None
+            if not all(b.filled):
+                # which of the locally missing gradients did NO rank produce?  Read back once per distinct pattern (a host
+                # sync), then remembered: the pattern is structural (the zero-weighted head), the same every step
+                key = (bi, tuple(b.filled))
+                if key not in self._produced_cache:
+                    self._produced_cache[key] = (b.flags > 0).tolist()
+                produced = self._produced_cache[key]
             for pi, p in enumerate(b.params):
                 p.grad = b.views[pi] if (produced is None or produced[pi]) else None
             b.work = None

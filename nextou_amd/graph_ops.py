@@ -743,6 +743,57 @@ class _ConvOwnBiasGrad(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None, None
 
 
+class _ConvDgradAsForward(torch.autograd.Function):
+    """Stride-1 'same' convolution whose data gradient is computed as a FORWARD convolution of the output gradient with
+    the flipped, transposed filter — the same numbers in another summation order.  MIOpen's CK forward kernels are
+    markedly faster than its backward-data kernels on these shapes (MI355X, NDHWC fp32, tools/conv_probe.py /
+    profiles/r02_conv_evidence_padding_ab.md: 40 -> 40 at 64x224x192 dgrad 3.24 ms vs forward 2.32 ms; 72 -> 72 at
+    64x112x96 7.28 vs 5.18 ms), and the library stays MIOpen either way.  The weight gradient is the library's own."""
+
+    @staticmethod
+    def forward(ctx, x, weight, padding):
+        n = weight.dim() - 2
+        ones, zeros = (1,) * n, (0,) * n
+        y = torch.ops.aten.convolution(x, weight, None, ones, padding, ones, False, zeros, 1)
+        ctx.save_for_backward(x, weight)
+        ctx.padding = padding
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        n = weight.dim() - 2
+        ones, zeros = (1,) * n, (0,) * n
+        cl = _dense_channels_last(x)
+        gy = gy.contiguous(memory_format=cl) if cl is not None else gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.transpose(0, 1).flip(*range(2, 2 + n))
+            wt = wt.contiguous(memory_format=cl) if cl is not None else wt.contiguous()
+            gx = torch.ops.aten.convolution(gy, wt, None, ones, ctx.padding, ones, False, zeros, 1)
+        if ctx.needs_input_grad[1]:
+            _, gw, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, ones, ctx.padding, ones, False, zeros, 1,
+                                                           [False, True, False])
+        return gx, gw, None
+
+
+def dgrad_as_forward_eligible(conv: torch.nn.Module, x: torch.Tensor) -> bool:
+    """Device fp32 tensors outside autocast, un-grouped stride-1 convolutions with odd kernels and 'same' zero padding."""
+    import os
+    if os.environ.get("NEXTOU_DGRAD_AS_FWD", "1") == "0":
+        return False
+    if not x.is_cuda or x.dtype != torch.float32 or conv.weight.dtype != torch.float32 or torch.is_autocast_enabled("cuda"):
+        return False
+    if conv.transposed or conv.groups != 1 or isinstance(conv.padding, str) or getattr(conv, "padding_mode", "zeros") != "zeros":
+        return False
+    return all(s == 1 for s in conv.stride) and all(d == 1 for d in conv.dilation) and \
+        all(k % 2 == 1 and p == k // 2 for k, p in zip(conv.kernel_size, conv.padding))
+
+
+def conv_dgrad_as_forward(x, weight, padding):
+    return _ConvDgradAsForward.apply(x, weight, tuple(int(p) for p in padding))
+
+
 def conv_own_bias_grad(x, weight, bias, stride, padding, dilation, transposed, output_padding, groups):
     """N-d (transposed) convolution with bias on the GPU; see :class:`_ConvOwnBiasGrad`."""
     return _ConvOwnBiasGrad.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation), bool(transposed),
