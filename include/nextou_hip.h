@@ -60,7 +60,7 @@ size_t nextou_profile_report(char* buf, size_t cap);
  * Replaces DenseDilatedKnnGraph.forward + {dense,xy_dense}_knn_matrix + *_pairwise_distance
  *   (reference network_architecture/torch_edge.py:151-163, 58-110, 12-55): F.normalize over
  *   channels, dist = (|x|^2 + (-2 x.y)) + |y|^2 (+ relative_pos), topk(-dist, K).
- * Canonical arithmetic (bit-exact contract with oracle/knn_canonical.c):
+ * Canonical arithmetic (bit-exact contract with oracle/nextou_oracle.c):
  *   den  = max(sqrtf(fma-chain_c x^2), 1e-12);  xn = x / den          (IEEE division)
  *   xs   = fma-chain_c xn^2 ;  inner = fma-chain_c xn*yn  (c ascending, one rounding per step)
  *   dist = ((xs + (-2*inner)) + ys) [+ relpos]

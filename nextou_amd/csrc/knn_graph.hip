@@ -9,7 +9,7 @@
 //   knn_dist_naive / knn_select_naive : the materialising fallback (any K), also the on-GPU
 //                       cross-check of the "MFMA == fmaf chain" claim.
 //
-// Arithmetic contract (must stay bit-identical to oracle/knn_canonical.c):
+// Arithmetic contract (must stay bit-identical to oracle/nextou_oracle.c):
 //   den = max(sqrtf(chain(x*x)), 1e-12f); xn = x / den; xs = chain(xn*xn);
 //   inner = chain(xn*yn) with acc = fmaf(a_c, b_c, acc), c ascending, acc0 = 0;
 //   dist = ((xs + (-2*inner)) + ys) [+ relpos];   order by (dist, index).

@@ -37,7 +37,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
 // differences, the element autograd's max backward routes the gradient to), as uint16, so that the
 // backward pass is a pure scatter (mr_bwd_arg_kernel) instead of a second gather + arg-max.
 template <int KB, bool SELF, bool WITH_ARG>
-__global__ __launch_bounds__(256) void mr_fwd_lds_kernel(
+__global__ __launch_bounds__(512) void mr_fwd_lds_kernel(
     const float* __restrict__ x, const float* __restrict__ src, const int32_t* __restrict__ idx,
     float* __restrict__ out, uint16_t* __restrict__ arg, int C, int N, int M, int K, int idx_stride,
     int idx_step, int chunk, int n_per_block) {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void mr_fwd_global_kernel(
 //         pre-zeroed dy with one global atomic per touched (c, m).
 // ---------------------------------------------------------------------------------------------
 template <int KB, bool SELF>
-__global__ __launch_bounds__(256) void mr_bwd_lds_kernel(
+__global__ __launch_bounds__(512) void mr_bwd_lds_kernel(
     const float* __restrict__ gout, const float* __restrict__ x, const float* __restrict__ src,
     const int32_t* __restrict__ idx, float* __restrict__ dx, float* __restrict__ dsrc, int C, int N,
     int M, int K, int idx_stride, int idx_step, int chunk, int n_per_block) {
@@ -568,6 +568,10 @@ static bool plan_lds(int B, int C, int N, int M, int floats_per_channel, bool ti
     if (tile_n && N > 1024) {
         n_per_block = 1024;
         n_tiles = cdiv(N, n_per_block);
+        // pooled graphs: the 64 KB tile allows two workgroups per CU; 512 threads each give the random LDS gathers
+        // 16 waves per CU to hide behind instead of 8 (NEXTOU_MR_THREADS=256 restores round 1 for A/B)
+        const char* e = getenv("NEXTOU_MR_THREADS");
+        threads = (e && atoi(e) == 256) ? 256 : 512;
     }
     // shrink the channel chunk until the grid has >= 512 workgroups; keep >= 4 channels per
     // workgroup when N is tiled so the idx registers are reused across channels

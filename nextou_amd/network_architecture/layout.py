@@ -68,6 +68,8 @@ def runs_in_fp32(x: torch.Tensor) -> bool:
     channels-last 3-D solvers for 33 / 66 channels are far slower than its bf16 NCDHW ones.  So reduced precision
     keeps NCDHW.
     """
+    if os.environ.get("NEXTOU_CHANNELS_LAST_ANY_DTYPE") == "1":     # experiments only (profiles/r02_bf16_ndhwc_trace.md)
+        return True
     if x.dtype != torch.float32:
         return False
     if x.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") != torch.float32:
