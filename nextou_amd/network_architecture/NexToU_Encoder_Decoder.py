@@ -326,11 +326,11 @@ class PoolDyGraphConv(DyGraphConv):
         zeros included (graph_ops.pool_rows / cell_scatter) — no int64 indices, no cat, no memset, no layout copies."""
         b, c = x.shape[:2]
         full_spatial = tuple(x.shape[2:])
-        if not any(p != 1 for p in self.pool_size):     # small stages: plain layout change around the graph op
-            out = self._graph_forward(x.contiguous(), relative_pos).reshape(b, -1, *full_spatial)
-            return out.contiguous(memory_format=torch.channels_last if x.dim() == 4 else torch.channels_last_3d)
+        pooled = any(p != 1 for p in self.pool_size)
+        # a stage that does not pool (pool size all ones) takes the same two kernels: with one-voxel cells they are the
+        # plain channels-last <-> channel-major tile transposes
         values, cell = graph_ops.pool_rows(x, self.pool_size)
-        if graph_ops.tape_active():                     # test hook: record / replay the reference's MaxPool indices
+        if pooled and graph_ops.tape_active():          # test hook: record / replay the reference's MaxPool indices
             flat = graph_ops.taped(lambda: graph_ops.cells_to_flat_indices(cell, full_spatial, self.pool_size), x.device)
             if graph_ops.tape_replaying():
                 values, cell = graph_ops.pool_rows(
