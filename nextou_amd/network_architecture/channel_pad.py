@@ -14,7 +14,7 @@ the fly (``F.pad`` / ``cat`` of a few KB — autograd slices the gradients back)
 modules carry ``pad`` extra all-zero channels:
 
 * an *entry* module (first convolution of stage 0) decides per call: it pads its output iff its input is a device tensor
-  whose convolutions run in fp32 (the CPU checker path and reduced-precision autocast stay un-padded);
+  the layout policy applies to (``layout.layout_policy_applies``; the CPU checker path stays un-padded);
 * every other padded module looks at the channel count it receives — the real count means "not padded", the padded count
   means "padded" — and follows suit on its output;
 * *exit* modules (segmentation heads, the first convolution of the first graph stage) always emit the real channel count.
@@ -34,7 +34,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .layout import runs_in_fp32
+from .layout import layout_policy_applies
 
 
 _force_entry: Optional[bool] = None     # test hook: True / False overrides the entry modules' per-call decision
@@ -109,7 +109,7 @@ def conv_pad_plan(module: nn.Module, x: torch.Tensor):
     if spec.exit:
         pad_out = False
     elif spec.entry:
-        pad_out = bool(x.is_cuda and runs_in_fp32(x)) if _force_entry is None else _force_entry
+        pad_out = bool(x.is_cuda and layout_policy_applies(x)) if _force_entry is None else _force_entry
     else:
         pad_out = pad_in
     return pad_in, pad_out

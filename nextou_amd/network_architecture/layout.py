@@ -15,8 +15,8 @@ where the data has to move anyway: the window shift / partition / reverse and th
 wider than 256 channels.  So with ``auto`` every stage of a 3-D model is channels-last from the network input to the logits.
 
 ``NEXTOU_CHANNELS_LAST_STAGES``: ``auto`` (default: all stages), ``plain`` (round 1: only the stages without graph blocks),
-``none``, or a comma list of stage indices.  Whatever the set, a stage only goes channels-last when its convolutions run
-in fp32 (:func:`runs_in_fp32`): under bf16 autocast the same policy is a 125 ms *loss* on cfg 2.
+``none``, or a comma list of stage indices.  Under reduced-precision autocast the policy applies only together with the
+internal channel padding (:func:`layout_policy_applies`).
 """
 from __future__ import annotations
 
@@ -39,9 +39,10 @@ def channels_last_stages(conv_op, n_plain_conv_stages: int, n_stages: int = None
 
 
 def is_channels_last_volume(x: torch.Tensor) -> bool:
-    """True for a float32 device tensor (B,C,*spatial), C > 1, stored (B,*spatial,C)-contiguous: what the fused window /
-    pool kernels of the graph blocks take as it is."""
-    if not x.is_cuda or x.dtype != torch.float32 or x.dim() not in (4, 5) or x.shape[1] == 1:
+    """True for a floating-point device tensor (B,C,*spatial), C > 1, stored (B,*spatial,C)-contiguous: what the fused
+    window / pool kernels of the graph blocks take (fp32 as it is; bf16 / fp16 autocast tensors are widened on the way in —
+    the graph kernels always compute in fp32)."""
+    if not x.is_cuda or not x.is_floating_point() or x.dtype == torch.float64 or x.dim() not in (4, 5) or x.shape[1] == 1:
         return False
     mf = torch.channels_last if x.dim() == 4 else torch.channels_last_3d
     return x.is_contiguous(memory_format=mf) and not x.is_contiguous()
@@ -61,15 +62,7 @@ def to_channels_last(x: torch.Tensor) -> torch.Tensor:
 
 
 def runs_in_fp32(x: torch.Tensor) -> bool:
-    """True when the convolutions fed by ``x`` will execute in fp32: an fp32 tensor outside reduced-precision autocast.
-
-    The channels-last policy is an fp32 result.  Measured on MI355X, cfg 2 (profiles/r01_bf16_regression_ab.md):
-    fp32 291.3 ms NCDHW -> 270.7 ms NDHWC, but under bf16 autocast 184.6 ms NCDHW -> 309.3 ms NDHWC — MIOpen's bf16
-    channels-last 3-D solvers for 33 / 66 channels are far slower than its bf16 NCDHW ones.  So reduced precision
-    keeps NCDHW.
-    """
-    if os.environ.get("NEXTOU_CHANNELS_LAST_ANY_DTYPE") == "1":     # experiments only (profiles/r02_bf16_ndhwc_trace.md)
-        return True
+    """True when the convolutions fed by ``x`` will execute in fp32: an fp32 tensor outside reduced-precision autocast."""
     if x.dtype != torch.float32:
         return False
     if x.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") != torch.float32:
@@ -77,9 +70,29 @@ def runs_in_fp32(x: torch.Tensor) -> bool:
     return True
 
 
+def layout_policy_applies(x: torch.Tensor) -> bool:
+    """Whether the channels-last stages and the internal channel padding apply to the convolutions fed by ``x``.
+
+    fp32: always.  Reduced precision (bf16 / fp16 autocast): only together with the channel padding.  Round 1 measured
+    NDHWC under bf16 autocast as a 125 ms *loss* on cfg 2 (309 vs 185 ms, profiles/r01_bf16_regression_ab.md) and fenced the
+    policy off; the round-2 traces say why — at 33 / 66 channels MIOpen's bf16 NDHWC solvers are slow, and in NCDHW it falls
+    back to im2col + GEMM (32 ms of ``Col2Im3dU`` per step) — and that with 40 / 72 channels the same NDHWC path is the fast
+    one: 189.1 ms (NCDHW) -> 111.1 ms per step (profiles/r02_bf16_ndhwc_trace.md).  ``NEXTOU_REDUCED_PRECISION_LAYOUT=ncdhw``
+    restores the round-1 behaviour for A/B runs.
+    """
+    if runs_in_fp32(x):
+        return True
+    if not x.is_floating_point():
+        return False
+    if os.environ.get("NEXTOU_REDUCED_PRECISION_LAYOUT", "auto").strip().lower() == "ncdhw":
+        return False
+    from .channel_pad import pad_multiple
+    return pad_multiple() > 0
+
+
 def set_stage_layout(x: torch.Tensor, channels_last: bool) -> torch.Tensor:
     """Layout conversion at a stage boundary; only device tensors are ever moved (the CPU checker path is NCDHW).
     Encoder and decoder call this with the same stage set in the same forward, so they agree on every skip."""
     if not x.is_cuda:
         return x
-    return to_channels_last(x) if (channels_last and runs_in_fp32(x)) else x.contiguous()
+    return to_channels_last(x) if (channels_last and layout_policy_applies(x)) else x.contiguous()
