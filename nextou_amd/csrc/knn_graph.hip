@@ -18,6 +18,7 @@
 // correctly rounded divide/sqrt.
 #include "common.h"
 #include <cmath>
+#include <cstdlib>
 
 // Experiment switch (tools/ablate_knn.sh builds side libraries with -DNEXTOU_ABLATE=n; the product
 // build leaves it 0):  1 = skip the top-K pushes, 2 = stage only the first slab of every chunk,
@@ -148,6 +149,78 @@ struct TopK {
     }
 };
 
+// --------------------------------------------------------------------------------------------
+// Top-K as sorting networks on packed 64-bit keys (K >= 14).  key = orderable(dist) << 32 | index, so one unsigned
+// 64-bit compare IS the (dist, index) order of the contract, exact ties included.  Per 32x32 tile a lane sorts its 16 new
+// candidates with a bitonic network (80 compare-exchanges), folds them into its sorted list of KP = 16 / 32 keys
+// (T[KP-1-i] = min(T[KP-1-i], N[i]) leaves a bitonic sequence holding the KP smallest of the union) and re-sorts it with a
+// bitonic merge (KP/2 * log2 KP compare-exchanges): ~850 VALU instructions per tile at KP = 32, whatever the candidates
+// are — the shift-insert list above costs 5 * K per candidate ROW as soon as one of the 64 lanes qualifies (always, in
+// practice: 25-45 % of the candidates still beat a lane's running K-th), i.e. 2240 per tile at K = 28.
+// --------------------------------------------------------------------------------------------
+using u64 = unsigned long long;
+constexpr u64 kKeyMax = ~0ull;
+
+__device__ __forceinline__ u64 make_key(float d, int m) {
+    unsigned u = __float_as_uint(d);
+    u = (u == 0x80000000u) ? 0u : u;                                  // -0 == +0
+    u ^= (unsigned)((int)u >> 31) | 0x80000000u;                      // monotone float -> unsigned
+    return ((u64)u << 32) | (unsigned)m;
+}
+__device__ __forceinline__ float key_dist(u64 k) {
+    unsigned u = (unsigned)(k >> 32);
+    u ^= (u & 0x80000000u) ? 0x80000000u : 0xffffffffu;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ void key_ce(u64& a, u64& b) {             // ascending compare-exchange
+    const bool sw = b < a;
+    const u64 lo = sw ? b : a, hi = sw ? a : b;
+    a = lo;
+    b = hi;
+}
+template <int N>
+__device__ __forceinline__ void bitonic_sort_keys(u64 (&a)[N]) {
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    if ((i & k) == 0) key_ce(a[i], a[l]);
+                    else key_ce(a[l], a[i]);
+                }
+            }
+}
+template <int N>
+__device__ __forceinline__ void bitonic_merge_keys(u64 (&a)[N]) {    // a bitonic -> ascending
+#pragma unroll
+    for (int j = N >> 1; j > 0; j >>= 1)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int l = i ^ j;
+            if (l > i) key_ce(a[i], a[l]);
+        }
+}
+template <int KP>
+struct KeyList {
+    u64 k[KP];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < KP; ++j) k[j] = kKeyMax;
+    }
+    __device__ __forceinline__ void absorb16(u64 (&n)[16]) {          // n: any order; on return the list holds the KP best
+        bitonic_sort_keys<16>(n);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = KP - 1 - i;
+            k[j] = (n[i] < k[j]) ? n[i] : k[j];
+        }
+        bitonic_merge_keys<KP>(k);
+    }
+};
+
 // stage ROWS x WIDTH floats of a (rows, ld) matrix into LDS, zero-filling out-of-range rows/cols.
 // `vec` (ld % 4 == 0, col0 % 4 == 0, 16-B aligned base): 16-B loads and ds_write_b128.
 __device__ __forceinline__ void stage_slab(float* __restrict__ dst, const float* __restrict__ src, int ld,
@@ -183,7 +256,7 @@ __device__ __forceinline__ void stage_slab(float* __restrict__ dst, const float*
 // grid = (query tiles, B, S): split s handles candidates [s*m_per_split, (s+1)*m_per_split).
 // S == 1: the final indices go to `out`; S > 1: every split writes its K best (dist, index) pairs
 // to part_d / part_i [(b*N + n)*S + s][K] and knn_merge_kernel picks the overall K best.
-template <int KB, int TILES>
+template <int KB, int TILES, bool BITONIC>
 __global__ __launch_bounds__(512) void knn_fused_kernel(
     const float* __restrict__ xn, const float* __restrict__ yn,
     const float* __restrict__ xs, const float* __restrict__ ys,
@@ -214,8 +287,11 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
     if (m_end > M) m_end = M;
     const bool vec = vec_ok != 0;
 
-    TopK<KB> top;
-    top.init();
+    constexpr int KP = KB <= 8 ? 8 : (KB <= 16 ? 16 : 32);      // padded list length of the network paths
+    TopK<BITONIC ? 1 : KB> top;
+    KeyList<BITONIC ? KP : 1> keys;
+    if (BITONIC) keys.init();
+    else top.init();
 
     // ---- slab staging plan -------------------------------------------------------------------
     // A self window that one workgroup covers completely (queries == candidates, one chunk) stages ONE
@@ -261,6 +337,8 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
             f32x16 v = acc[t];
+            u64 fresh[16];
+#pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int mbase = mc0 + t * 32 + 8 * g + 4 * h;
                 float yv[4], rv[4];
@@ -283,19 +361,23 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
                 for (int r = 0; r < 4; ++r) {
                     const int m = mbase + r;
                     float dist = INFINITY;
-                    if (nvalid && m < m_end) {
-                        dist = (xsv + (-2.0f * v[r])) + yv[r];
+                    const bool valid = nvalid && m < m_end;
+                    if (valid) {
+                        dist = (xsv + (-2.0f * v[4 * g + r])) + yv[r];
                         if (rp_row != nullptr) dist = dist + rv[r];
+                    }
+                    if (BITONIC) {
+                        fresh[4 * g + r] = valid ? make_key(dist, m) : kKeyMax;
+                        continue;
                     }
                     if (NEXTOU_ABLATE & 1) {
                         top.d[0] = fminf(top.d[0], dist);  // keeps the distance alive
                         continue;
                     }
-                    if (__any(dist < top.d[KB - 1])) top.push_ascending(dist, m);
+                    if (__any(dist < top.d[(BITONIC ? 1 : KB) - 1])) top.push_ascending(dist, m);
                 }
-                // rotate the next 4 accumulator rows into v[0..3]
-                v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3);
             }
+            if (BITONIC) keys.absorb16(fresh);
         }
     }
 
@@ -304,48 +386,77 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
     // holding the KP smallest of the union; log2(KP) half-cleaner stages sort it.  ~KP/2*log2(KP)
     // compare-exchanges instead of K rounds of K-slot inserts (which cost 40 % on top of the pushes
     // when a workgroup only sees a few hundred candidates).  Comparisons are on (dist, index).
-    constexpr int KP = KB <= 8 ? 8 : (KB <= 16 ? 16 : 32);
-    float md[KP];
-    int mi[KP];
-#pragma unroll
-    for (int j = 0; j < KP; ++j) {
-        const int pj = KP - 1 - j;
-        const float ad = (j < KB) ? top.d[j < KB ? j : 0] : INFINITY;
-        const int ai = (j < KB) ? top.i[j < KB ? j : 0] : kSentinelIdx;
-        float bd = INFINITY;
-        int bi = kSentinelIdx;
-        if (pj < KB) {
-            bd = __shfl_xor(top.d[pj < KB ? pj : 0], 32);
-            bi = __shfl_xor(top.i[pj < KB ? pj : 0], 32);
-        }
-        const bool take_b = (bd < ad) || (bd == ad && bi < ai);
-        md[j] = take_b ? bd : ad;
-        mi[j] = take_b ? bi : ai;
-    }
-#pragma unroll
-    for (int stride = KP / 2; stride >= 1; stride >>= 1) {
+    if constexpr (BITONIC) {
+        u64 t[KP];
 #pragma unroll
         for (int j = 0; j < KP; ++j) {
-            if ((j & stride) == 0) {
-                const int q = j + stride;
-                const bool sw = (md[q] < md[j]) || (md[q] == md[j] && mi[q] < mi[j]);
-                const float lo = sw ? md[q] : md[j], hi = sw ? md[j] : md[q];
-                const int li = sw ? mi[q] : mi[j], hi_i = sw ? mi[j] : mi[q];
-                md[j] = lo; md[q] = hi; mi[j] = li; mi[q] = hi_i;
+            const u64 mine = keys.k[j], theirs = keys.k[KP - 1 - j];
+            const unsigned lo = __shfl_xor((unsigned)(theirs & 0xffffffffull), 32);
+            const unsigned hi = __shfl_xor((unsigned)(theirs >> 32), 32);
+            const u64 other = ((u64)hi << 32) | lo;
+            t[j] = other < mine ? other : mine;
+        }
+        bitonic_merge_keys<KP>(t);
+        if (nvalid && h == 0) {
+            if (n_splits == 1) {
+                int32_t* o = out + ((size_t)b * N + n) * K;
+#pragma unroll
+                for (int j = 0; j < KB; ++j)
+                    if (j < K) o[j] = (int32_t)(unsigned)(t[j] & 0xffffffffull);
+            } else {
+                const size_t base = (((size_t)b * N + n) * n_splits + split) * K;
+#pragma unroll
+                for (int j = 0; j < KB; ++j)
+                    if (j < K) {
+                        const bool none = t[j] == kKeyMax;
+                        part_d[base + j] = none ? INFINITY : key_dist(t[j]);
+                        part_i[base + j] = none ? kSentinelIdx : (int32_t)(unsigned)(t[j] & 0xffffffffull);
+                    }
             }
         }
-    }
-    if (nvalid && h == 0) {
-        if (n_splits == 1) {
-            int32_t* o = out + ((size_t)b * N + n) * K;
-#pragma unroll
-            for (int j = 0; j < KB; ++j)
-                if (j < K) o[j] = mi[j];
-        } else {
-            const size_t base = (((size_t)b * N + n) * n_splits + split) * K;
-#pragma unroll
-            for (int j = 0; j < KB; ++j)
-                if (j < K) { part_d[base + j] = md[j]; part_i[base + j] = mi[j]; }
+    } else {
+        float md[KP];
+        int mi[KP];
+    #pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const int pj = KP - 1 - j;
+            const float ad = (j < KB) ? top.d[j < KB ? j : 0] : INFINITY;
+            const int ai = (j < KB) ? top.i[j < KB ? j : 0] : kSentinelIdx;
+            float bd = INFINITY;
+            int bi = kSentinelIdx;
+            if (pj < KB) {
+                bd = __shfl_xor(top.d[pj < KB ? pj : 0], 32);
+                bi = __shfl_xor(top.i[pj < KB ? pj : 0], 32);
+            }
+            const bool take_b = (bd < ad) || (bd == ad && bi < ai);
+            md[j] = take_b ? bd : ad;
+            mi[j] = take_b ? bi : ai;
+        }
+    #pragma unroll
+        for (int stride = KP / 2; stride >= 1; stride >>= 1) {
+    #pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                if ((j & stride) == 0) {
+                    const int q = j + stride;
+                    const bool sw = (md[q] < md[j]) || (md[q] == md[j] && mi[q] < mi[j]);
+                    const float lo = sw ? md[q] : md[j], hi = sw ? md[j] : md[q];
+                    const int li = sw ? mi[q] : mi[j], hi_i = sw ? mi[j] : mi[q];
+                    md[j] = lo; md[q] = hi; mi[j] = li; mi[q] = hi_i;
+                }
+            }
+        }
+        if (nvalid && h == 0) {
+            if (n_splits == 1) {
+                int32_t* o = out + ((size_t)b * N + n) * K;
+    #pragma unroll
+                for (int j = 0; j < KB; ++j)
+                    if (j < K) o[j] = mi[j];
+            } else {
+                const size_t base = (((size_t)b * N + n) * n_splits + split) * K;
+    #pragma unroll
+                for (int j = 0; j < KB; ++j)
+                    if (j < K) { part_d[base + j] = md[j]; part_i[base + j] = mi[j]; }
+            }
         }
     }
 }
@@ -476,6 +587,7 @@ static FusedPlan plan_fused(int B, int N, int M) {
     const bool small = waves < 1024;
     const long long ww = (long long)cdiv(M, 192) * 192, w2 = (long long)cdiv(M, 64) * 64;
     p.tiles = (small || w2 * 10 < ww * 9) ? 2 : 6;
+    if (const char* e = getenv("NEXTOU_KNN_TILES")) p.tiles = atoi(e) == 2 ? 2 : (atoi(e) == 6 ? 6 : p.tiles);   // experiments
     const int tm = 32 * p.tiles;
     const int chunks = cdiv(M, tm);
     long long want = cdiv64(2048, waves);
@@ -539,7 +651,16 @@ struct FusedArgs {
     int B, C, N, M, K;
 };
 
-template <int KB, int TILES>
+// Which top-K the fused kernel runs: the sorting networks on packed keys for K >= 14, the shift-insert list below
+// (NEXTOU_KNN_TOPK=insert forces it everywhere, =network forces the networks for K <= 8 too: A/B runs).
+static bool use_networks(int KB) {
+    static const int mode = [] { const char* e = getenv("NEXTOU_KNN_TOPK"); return e == nullptr ? 0 : (e[0] == 'i' ? 1 : 2); }();
+    if (mode == 1) return false;
+    if (mode == 2) return true;
+    return KB >= 14;
+}
+
+template <int KB, int TILES, bool BITONIC>
 static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
     const int QW = 32 * p.nw;
     const size_t lds = (size_t)p.ks * (32 * TILES + QW) * sizeof(float);
@@ -552,7 +673,7 @@ static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
         // algorithmic work of the distance contraction: 2*B*N*M*C flops
         ProfScope prof(s, kBoundMfma, 2.0 * a.B * (double)a.N * a.M * a.C,
                        "knn_fused_kernel<%d,%d>[B%d C%d N%d M%d K%d]", KB, TILES, a.B, a.C, a.N, a.M, a.K);
-        hipLaunchKernelGGL((knn_fused_kernel<KB, TILES>), grid, dim3(64 * p.nw), lds, s, a.xn, a.yn, a.xs, a.ys,
+        hipLaunchKernelGGL((knn_fused_kernel<KB, TILES, BITONIC>), grid, dim3(64 * p.nw), lds, s, a.xn, a.yn, a.xs, a.ys,
                            a.relpos, a.out, a.part_d, a.part_i, a.C, a.N, a.M, a.K, p.m_per_split, vec_ok, p.ks);
     }
     if (int e = check_launch("knn_fused_kernel")) return e;
@@ -569,8 +690,10 @@ static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
 
 template <int KB>
 static int launch_fused_tiles(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
-    if (p.tiles == 2) return launch_fused<KB, 2>(a, p, s);
-    return launch_fused<KB, 6>(a, p, s);
+    // 192-wide chunks keep 96 accumulator registers per lane: beside 64 + 32 key registers that spills (54 VGPRs at
+    // K = 32), so the network path is taken with 64-wide chunks only
+    if (p.tiles == 2) return use_networks(KB) ? launch_fused<KB, 2, true>(a, p, s) : launch_fused<KB, 2, false>(a, p, s);
+    return launch_fused<KB, 6, false>(a, p, s);
 }
 
 }  // namespace nextou
