@@ -579,7 +579,7 @@ struct FusedPlan {
 // the 256 CUs.  Large grids take 192-wide chunks (fewest staging passes per MFMA); grids that
 // cannot fill the chip even so take 64-wide chunks (more splits) and 64-channel slabs (half the
 // barrier / global-load round trips: these launches are latency-bound, LDS is plentiful).
-static FusedPlan plan_fused(int B, int N, int M) {
+static FusedPlan plan_fused(int B, int N, int M, int K) {
     FusedPlan p;
     const int need = cdiv(N, 32);
     p.nw = need <= 6 ? (need < 1 ? 1 : need) : 4;
@@ -587,6 +587,10 @@ static FusedPlan plan_fused(int B, int N, int M) {
     const bool small = waves < 1024;
     const long long ww = (long long)cdiv(M, 192) * 192, w2 = (long long)cdiv(M, 64) * 64;
     p.tiles = (small || w2 * 10 < ww * 9) ? 2 : 6;
+    // long lists: 192-wide chunks (96 accumulator registers) beside a 28 / 32-slot list cost 192-200 VGPRs = 2 waves per
+    // SIMD; 64-wide chunks (133 VGPRs, 3 waves) are faster although they stage three times as often — cfg-5 Pool s3
+    // 1850 -> 1591 us, Swin s3 268 -> 232 us (profiles/r02_knn_topk_ab.md)
+    if (K > 16) p.tiles = 2;
     if (const char* e = getenv("NEXTOU_KNN_TILES")) p.tiles = atoi(e) == 2 ? 2 : (atoi(e) == 6 ? 6 : p.tiles);   // experiments
     const int tm = 32 * p.tiles;
     const int chunks = cdiv(M, tm);
@@ -621,7 +625,7 @@ static KnnWorkspace knn_layout(int B, int C, int N, int M, int K, int has_y, int
     if (algo == NEXTOU_KNN_NAIVE) {
         w.dist = off; off += align256((size_t)B * N * M * sizeof(float));
     } else {
-        const FusedPlan p = plan_fused(B, N, M);
+        const FusedPlan p = plan_fused(B, N, M, K);
         if (p.splits > 1) {
             w.part_d = off; off += align256((size_t)B * N * p.splits * K * sizeof(float));
             w.part_i = off; off += align256((size_t)B * N * p.splits * K * sizeof(int32_t));
@@ -651,13 +655,16 @@ struct FusedArgs {
     int B, C, N, M, K;
 };
 
-// Which top-K the fused kernel runs: the sorting networks on packed keys for K >= 14, the shift-insert list below
-// (NEXTOU_KNN_TOPK=insert forces it everywhere, =network forces the networks for K <= 8 too: A/B runs).
+// Which top-K the fused kernel runs.  The sorting networks on packed keys are bit-exact (same tests) and were meant to cut
+// the VALU work of the exact selection; measured (profiles/r02_knn_topk_ab.md) they are SLOWER where it matters — Pool s3
+// (K = 28) 411 vs 325 us, Swin s3 (K = 14) 109 vs 80 us; level or slightly ahead on two small shapes — because the
+// shift-insert list skips whole candidate rows whenever no lane of the wave qualifies (more often than the 25-45 % per-lane
+// qualification rate suggests once the lists are warm), while a network costs the same for every tile, and 64 + 32 key
+// registers leave 2 waves per SIMD instead of 4.  The shift-insert list stays the default; NEXTOU_KNN_TOPK=network selects
+// the networks (64-wide chunks only) for A/B runs.
 static bool use_networks(int KB) {
-    static const int mode = [] { const char* e = getenv("NEXTOU_KNN_TOPK"); return e == nullptr ? 0 : (e[0] == 'i' ? 1 : 2); }();
-    if (mode == 1) return false;
-    if (mode == 2) return true;
-    return KB >= 14;
+    static const int mode = [] { const char* e = getenv("NEXTOU_KNN_TOPK"); return (e != nullptr && e[0] == 'n') ? 1 : 0; }();
+    return mode == 1 && KB >= 8;
 }
 
 template <int KB, int TILES, bool BITONIC>
@@ -754,7 +761,7 @@ extern "C" int nextou_knn_graph(const float* x, const float* y, const float* rel
         return check_launch("knn_select_naive_kernel");
     }
 
-    const FusedPlan plan = plan_fused(B, N, M);
+    const FusedPlan plan = plan_fused(B, N, M, K);
     FusedArgs a{xn, yn, xs, ys, relpos, nn_idx, (float*)(base + w.part_d), (int32_t*)(base + w.part_i), B, C, N, M, K};
     // list-length buckets: every slot costs 4 VALU ops per candidate per lane, so the cfg-2 values
     // 7 / 14 / 28 get their own instantiation instead of rounding up to 8 / 16 / 32
