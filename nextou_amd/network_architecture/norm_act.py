@@ -51,11 +51,11 @@ class _ConvBiasFolded:
         x, weight = pad_image_channels(self, x, weight)
         if x.requires_grad and graph_ops.dgrad_as_forward_eligible(self, x):
             return graph_ops.conv_dgrad_as_forward(x, weight, self.padding)    # backward-data as a forward convolution
-        if graph_ops.flat_depth_eligible(x, weight, self.stride, self.padding, self.dilation) and self.groups == 1 \
-                and not isinstance(self.padding, str) and self.padding_mode == "zeros":
-            # kernel [1,k,k] on a channels-last volume: the 2-D convolution of the (B*D, C, H, W) view
+        if not isinstance(self.padding, str) and self.padding_mode == "zeros" and \
+                graph_ops.flat_depth_eligible(x, weight, self.stride, self.padding, self.dilation):
+            # kernel [1,k,k] on a channels-last volume: the 2-D convolution of the (B*D, C, H, W) view (grouped or not)
             y = torch.nn.functional.conv2d(graph_ops.flat_depth(x), weight.squeeze(2), None, self.stride[1:], self.padding[1:],
-                                           self.dilation[1:], 1)
+                                           self.dilation[1:], self.groups)
             return graph_ops.unflat_depth(y, x.shape[0], x.shape[2])
         return self._conv_forward(x, weight, None)
 

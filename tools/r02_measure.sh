@@ -27,9 +27,9 @@ for grp in "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTI
 done
 python $R/tools/pmc_table.py /tmp/sq_k2_1 /tmp/sq_k2_2 --match "nextou::" > $OUT/sq_counters_k2_swin_s2.md 2>&1
 # bf16: what MIOpen picks in NDHWC vs NCDHW
-rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_bf16_ncdhw -o kt -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --autocast-bf16 > $OUT/kt_bf16_ncdhw.log 2>&1
-python $R/tools/rocprof_summary.py /tmp/kt_bf16_ncdhw $OUT/bf16_trace_ncdhw.md "cfg 2 under bf16 autocast, default policy (NCDHW, no padding)" --steady "knn_fused_kernel<28" 2
-NEXTOU_CHANNELS_LAST_ANY_DTYPE=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_bf16_ndhwc -o kt -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --autocast-bf16 > $OUT/kt_bf16_ndhwc.log 2>&1
-python $R/tools/rocprof_summary.py /tmp/kt_bf16_ndhwc $OUT/bf16_trace_ndhwc.md "cfg 2 under bf16 autocast, NDHWC + channel padding forced (NEXTOU_CHANNELS_LAST_ANY_DTYPE=1)" --steady "knn_fused_kernel<28" 2
+NEXTOU_REDUCED_PRECISION_LAYOUT=ncdhw rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_bf16_ncdhw -o kt -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --autocast-bf16 > $OUT/kt_bf16_ncdhw.log 2>&1
+python $R/tools/rocprof_summary.py /tmp/kt_bf16_ncdhw $OUT/bf16_trace_ncdhw.md "cfg 2 under bf16 autocast, round-1 policy (NEXTOU_REDUCED_PRECISION_LAYOUT=ncdhw: NCDHW, no padding)" --steady "knn_fused_kernel<28" 2
+rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_bf16_ndhwc -o kt -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --autocast-bf16 > $OUT/kt_bf16_ndhwc.log 2>&1
+python $R/tools/rocprof_summary.py /tmp/kt_bf16_ndhwc $OUT/bf16_trace_ndhwc.md "cfg 2 under bf16 autocast, default policy (every stage NDHWC + channel padding)" --steady "knn_fused_kernel<28" 2
 grep "^{" $OUT/kt_bf16_ncdhw.log | cut -c1-200; grep "^{" $OUT/kt_bf16_ndhwc.log | cut -c1-200
 du -sh $R/gpurun_out
