@@ -70,10 +70,30 @@ static TilePlan plan_tiles(int B, int C, long long S, int vec_full, bool aligned
 }
 
 template <typename T, int VEC> struct Pack;
+// NEXTOU_K6_NT (experiment, tools/k6_nt_ab.sh): 1 = non-temporal stores, 2 = non-temporal loads, 3 = both, for the fp32
+// 16-byte accesses — every K6 tensor is streamed once per kernel, nothing is reused from L2.
+#ifndef NEXTOU_K6_NT
+#define NEXTOU_K6_NT 0
+#endif
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
 template <> struct Pack<float, 4> {
     float v[4];
-    __device__ void load(const float* p) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-    __device__ void store(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    __device__ void load(const float* p) {
+#if NEXTOU_K6_NT & 2
+        const f32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+#else
+        const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+#endif
+    }
+    __device__ void store(float* p) const {
+#if NEXTOU_K6_NT & 1
+        f32x4_t t; t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4_t*>(p));
+#else
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
+    }
 };
 template <> struct Pack<float, 1> {
     float v[1];

@@ -174,10 +174,6 @@ def padded_norm_params(norm: nn.Module, x: torch.Tensor, pre_bias):
     return w, b, rm, rv, pb, write_back
 
 
-def _conv_of(block) -> nn.Module:
-    return block.conv
-
-
 def pad_plain_stage_channels(model: nn.Module, multiple: int) -> int:
     """Attach padding specs to the plain conv stages of a built (and norm-fused) NexToU; returns the number of modules
     marked.  Only 3-D models with at least one plain conv stage whose feature count is not a multiple already."""
