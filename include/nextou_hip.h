@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NEXTOU_ABI_VERSION 3
+#define NEXTOU_ABI_VERSION 4
 
 #define NEXTOU_EINVAL   (-1)  /* bad argument (null pointer, non-positive size, k > M ...) */
 #define NEXTOU_ENOSPACE (-2)  /* workspace too small */
@@ -275,6 +275,27 @@ int nextou_cell_gather(const float* x_cl, const uint8_t* cell, float* out_cm, in
                        int pd, int ph, int pw, nextou_stream_t stream);
 int nextou_cell_scatter(const float* src_cm, const uint8_t* cell, float* out_cl, int B, int C2, int C, int D, int H, int W,
                         int pd, int ph, int pw, nextou_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7  point-wise (kernel 1, stride 1) convolutions on channels-last rows — the 1x1 convolutions of the Grapher / FFN
+ * blocks (reference NexToU_Encoder_Decoder.py:368-390 FFN, :710-720 / :833-842 fc1 / fc2; torch_nn.py:66-92 the MRConv's
+ * grouped BasicConv), which PyTorch-ROCm hands to MIOpen as convolutions.  x is the (P, groups*K) matrix a channels-last
+ * activation already is in memory (P = B*D*H*W points, row stride ldx floats); weights are the reference's
+ * (groups*N, K, 1[,1[,1]]) tensors.  float32 on v_mfma_f32_16x16x4_f32 (exact f32).  MFMA-bound for K, N >= 132,
+ * HBM-bound below.
+ *
+ * nextou_pw_rows     y[p, g*N + n] = sum_k x[p, g*K + k] * w[g*N + n, k] (+ bias[g*N + n]; bias may be NULL).
+ *                    The data gradient of the same convolution is this call on gy with the per-group transposed weight.
+ *                    K and ldx must be multiples of 4, x and w 16-byte aligned.
+ * nextou_pw_wgrad    dw[g*N + n, k] (+)= sum_p gy[p, g*N + n] * x[p, g*K + k]: split over points into `workspace`
+ *                    (nextou_pw_wgrad_workspace bytes), summed in a fixed order — bit-reproducible.  accumulate != 0 adds
+ *                    to dw.  N, K, ldg, ldx multiples of 4, gy and x 16-byte aligned.
+ * ---------------------------------------------------------------------------------------- */
+int nextou_pw_rows(const float* x, const float* w, const float* bias, float* y, int64_t P, int N, int K, int groups,
+                   int64_t ldx, int64_t ldy, nextou_stream_t stream);
+int nextou_pw_wgrad_workspace(int64_t P, int N, int K, int groups, size_t* bytes);
+int nextou_pw_wgrad(const float* gy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int64_t P, int N,
+                    int K, int groups, int64_t ldg, int64_t ldx, int accumulate, nextou_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -70,7 +70,8 @@ static TilePlan plan_tiles(int B, int C, long long S, int vec_full, bool aligned
 }
 
 template <typename T, int VEC> struct Pack;
-// NEXTOU_K6_NT (experiment, tools/k6_nt_ab.sh): 1 = non-temporal stores, 2 = non-temporal loads, 3 = both, for the fp32
+// NEXTOU_K6_NT (A/B: tools/k6_nt_ab.sh, profiles/r02_k6_nontemporal_ab.md — faster stand-alone, SLOWER inside the step, so off): 1 = non-temporal stores,
+// 2 = non-temporal loads, 3 = both, for the fp32
 // 16-byte accesses — every K6 tensor is streamed once per kernel, nothing is reused from L2.
 #ifndef NEXTOU_K6_NT
 #define NEXTOU_K6_NT 0

@@ -1,0 +1,494 @@
+// K7 — point-wise (1x1[x1]) convolutions of the graph stages on channels-last rows (gfx950, f32 MFMA).
+//
+// The Grapher / FFN blocks of the path are chains of point-wise convolutions (reference
+// NexToU_Encoder_Decoder.py:368-390 FFN fc1/fc2, :710-720 / :833-842 the graphers' fc1 / fc2, torch_nn.py:66-92 the
+// MRConv's grouped BasicConv) and the decoder ends in the 1x1 segmentation heads (:298).  On a channels-last volume
+// every one of them is a GEMM over the (points, channels) matrix that is already in memory:
+//
+//   pw_rows    y[p, n]  = sum_k x[p, k] * w[n, k] (+ bias[n])        forward; data gradient with w transposed
+//   pw_wgrad   dw[n, k] = sum_p gy[p, n] * x[p, k]                   weight gradient: reduction over ALL points
+//
+// Channel counts are 44 ... 1296 (multiples of 4, rarely of 32) and the point count is 336 ... 5.5 M, so the library
+// kernels PyTorch-ROCm picks run at 20-50 % (forward, data gradient) and 2-24 % (weight gradient) of the f32 MFMA
+// peak (profiles/r02_conv_evidence_padding_ab.md).  Both kernels here use v_mfma_f32_16x16x4_f32 (exact f32, bitwise
+// an fmaf chain; 16-granular tiles waste <= 9 % on these channel counts), keep the channel dimension in the lane's
+// four accumulator registers so that results leave as 16-byte stores, and map workgroups to XCDs so that the
+// workgroups which share an input tile share an L2.
+//
+// pw_rows:  workgroup = 4 waves stacked over points, each TM point tiles x all TN channel tiles of the workgroup; both
+// operands are K-contiguous in memory, so one ds_read_b128 per lane feeds FOUR MFMAs (lane group g = lane >> 4 takes
+// k = 16 r + 4 g + {0..3}; which k a lane group holds is free as long as A and B agree).  LDS rows are 20 floats
+// (4 * odd): the 16 lanes of one ds_read_b128 phase hit 16 distinct 4-bank groups.
+//
+// pw_wgrad: the reduction index is the memory row, so the MFMA operands are rows of the tiles as they lie in memory:
+// lane (c = lane & 15, g = lane >> 4) reads tile[row + g][col + c] — ds_read_b32, conflict-free with a row stride
+// = 16 (mod 32) floats.  Split over points (deterministic: partial tiles to a workspace, summed in a fixed order by
+// pw_wgrad_reduce_kernel).
+#include "common.h"
+#include <cstdlib>
+
+namespace nextou {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kPwKC = 16;          // k per LDS stage of pw_rows: one MFMA round (4 lane groups x float4)
+constexpr int kPwLd = kPwKC + 4;   // 20 floats = 80 B = 4 * odd
+constexpr int kXcds = 8;
+
+// blockIdx.x -> work item such that consecutive work items run on ONE XCD (hardware deals workgroups round-robin
+// over the 8 XCDs): the items that share an input tile are neighbours in item order, so they share an L2.
+__device__ __forceinline__ int xcd_item(int block, int grid) { return (block % kXcds) * (grid / kXcds) + block / kXcds; }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ------------------------------------------------------------------------------------------------------------
+// y[p, n] = sum_k x[p, k] w[n, k] + bias[n]
+// ------------------------------------------------------------------------------------------------------------
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void pw_rows_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
+                                                      const float* __restrict__ bias, float* __restrict__ Y, int P, int N, int K,
+                                                      long ldx, long ldw, long ldy, int nb_n, int items, int vec_store) {
+    constexpr int BM = 64 * TM, BN = 16 * TN;
+    constexpr int XV = BM * (kPwKC / 4) / 256;                // float4 per thread per stage, X tile
+    constexpr int WV = (BN * (kPwKC / 4) + 255) / 256;        // ... W tile (last one predicated)
+    extern __shared__ float4 pw_smem4[];
+    float* Xs = reinterpret_cast<float*>(pw_smem4);           // [2][BM][kPwLd]
+    float* Ws = Xs + 2 * BM * kPwLd;                          // [2][BN][kPwLd]
+
+    const int item = xcd_item(blockIdx.x, gridDim.x);
+    if (item >= items) return;
+    const int pb = item / nb_n, nb = item - pb * nb_n;
+    const int g = blockIdx.y;
+    X += (long)g * K;
+    Wt += (long)g * N * ldw;
+    Y += (long)g * N;
+    const int p0 = pb * BM, n0 = nb * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+
+    float4 xr[XV], wr[WV];
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int f = tid + i * 256, row = f / (kPwKC / 4), c4 = f % (kPwKC / 4);
+            const int p = p0 + row, k = k0 + c4 * 4;
+            xr[i] = (p < P && k < K) ? ld4(X + (long)p * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int f = tid + i * 256, row = f / (kPwKC / 4), c4 = f % (kPwKC / 4);
+            const int n = n0 + row, k = k0 + c4 * 4;
+            wr[i] = (row < BN && n < N && k < K) ? ld4(Wt + (long)n * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_stage = [&](int buf) {
+        float* xs = Xs + buf * BM * kPwLd;
+        float* ws = Ws + buf * BN * kPwLd;
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int f = tid + i * 256, row = f / (kPwKC / 4), c4 = f % (kPwKC / 4);
+            *reinterpret_cast<float4*>(xs + row * kPwLd + c4 * 4) = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int f = tid + i * 256, row = f / (kPwKC / 4), c4 = f % (kPwKC / 4);
+            if (row < BN) *reinterpret_cast<float4*>(ws + row * kPwLd + c4 * 4) = wr[i];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int stages = (K + kPwKC - 1) / kPwKC;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int s = 0; s < stages; ++s) {
+        if (s + 1 < stages) load_stage((s + 1) * kPwKC);
+        const float* xs = Xs + (s & 1) * BM * kPwLd + (wave * TM * 16 + r16) * kPwLd + kg * 4;
+        const float* ws = Ws + (s & 1) * BN * kPwLd + r16 * kPwLd + kg * 4;
+        float4 b[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) b[i] = ld4(xs + i * 16 * kPwLd);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float4 a = ld4(ws + j * 16 * kPwLd);
+            // the four k sub-steps of one accumulator are a dependent chain (40-cycle latency, 32-cycle issue): alternate
+            // the TM accumulators between them
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[i].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[i].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[i].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[i].w, acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < stages) store_stage((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // D tile: column = lane & 15 = point, row = 4 (lane >> 4) + reg = channel -> one 16-byte store per tile and lane
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 16 + kg * 4;
+        if (n >= N) continue;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) {
+            const float* bp = bias + (long)g * N + n;
+            bv.x = bp[0];
+            if (n + 1 < N) bv.y = bp[1];
+            if (n + 2 < N) bv.z = bp[2];
+            if (n + 3 < N) bv.w = bp[3];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int p = p0 + (wave * TM + i) * 16 + r16;
+            if (p >= P) continue;
+            float* yp = Y + (long)p * ldy + n;
+            const float4 v = make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
+            if (vec_store && n + 3 < N) {
+                *reinterpret_cast<float4*>(yp) = v;
+            } else {
+                yp[0] = v.x;
+                if (n + 1 < N) yp[1] = v.y;
+                if (n + 2 < N) yp[2] = v.z;
+                if (n + 3 < N) yp[3] = v.w;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// part[split, n, k] = sum_{p in split} gy[p, n] x[p, k]
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kWgPC = 16;   // points per LDS stage
+
+constexpr int wgrad_stride(int cols) { return cols + ((16 - cols % 32) + 32) % 32; }   // = 16 (mod 32) floats
+
+// wave tile TN x TK 16x16 tiles; WN x WK waves per workgroup (all compile-time: the staging loops and LDS strides are
+// constants, which keeps the (3,3) kernel at ~100 VGPRs instead of 256 + SGPR spills with run-time shapes)
+template <int TN, int TK, int WN, int WK>
+__global__ __launch_bounds__(64 * WN * WK) void pw_wgrad_kernel(const float* __restrict__ G, const float* __restrict__ X,
+                                                                float* __restrict__ part, int P, int N, int K, long ldg, long ldx,
+                                                                int nb_n, int nb_k, int rows_per_split, int items) {
+    constexpr int NT = 64 * WN * WK;
+    constexpr int BN = WN * TN * 16, BK = WK * TK * 16;
+    constexpr int SG = wgrad_stride(BN), SX = wgrad_stride(BK);
+    constexpr int GQ = BN / 4, XQ = BK / 4;                             // float4 groups per tile row
+    constexpr int GV = (kWgPC * GQ + NT - 1) / NT, XV = (kWgPC * XQ + NT - 1) / NT;
+    extern __shared__ float4 pw_smem4[];
+    float* Gs = reinterpret_cast<float*>(pw_smem4);        // [2][kWgPC][SG]
+    float* Xs = Gs + 2 * kWgPC * SG;                       // [2][kWgPC][SX]
+
+    const int item = xcd_item(blockIdx.x, gridDim.x);
+    if (item >= items) return;
+    const int tiles = nb_n * nb_k;
+    const int split = item / tiles, tile = item - split * tiles;
+    const int bn = tile / nb_k, bk = tile - bn * nb_k;
+    const int g = blockIdx.y;
+    G += (long)g * N;
+    X += (long)g * K;
+    const int n0 = bn * BN, k0 = bk * BK;
+    const int p_begin = split * rows_per_split;
+    const int p_end = min(P, p_begin + rows_per_split);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, pg = lane >> 4;
+    const int wave_n = wave / WK, wave_k = wave - wave_n * WK;
+
+    float4 gr[GV], xr[XV];
+    auto load_stage = [&](int p_row0) {
+#pragma unroll
+        for (int i = 0; i < GV; ++i) {
+            const int f = tid + i * NT, row = f / GQ, c = (f - row * GQ) * 4;
+            const int p = p_row0 + row, col = n0 + c;
+            gr[i] = (row < kWgPC && p < p_end && col < N) ? ld4(G + (long)p * ldg + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int f = tid + i * NT, row = f / XQ, c = (f - row * XQ) * 4;
+            const int p = p_row0 + row, col = k0 + c;
+            xr[i] = (row < kWgPC && p < p_end && col < K) ? ld4(X + (long)p * ldx + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_stage = [&](int buf) {
+        float* gs = Gs + buf * kWgPC * SG;
+        float* xs = Xs + buf * kWgPC * SX;
+#pragma unroll
+        for (int i = 0; i < GV; ++i) {
+            const int f = tid + i * NT, row = f / GQ, c = (f - row * GQ) * 4;
+            if (row < kWgPC) *reinterpret_cast<float4*>(gs + row * SG + c) = gr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int f = tid + i * NT, row = f / XQ, c = (f - row * XQ) * 4;
+            if (row < kWgPC) *reinterpret_cast<float4*>(xs + row * SX + c) = xr[i];
+        }
+    };
+
+    f32x4 acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int stages = (p_end - p_begin + kWgPC - 1) / kWgPC;
+    if (stages > 0) {
+        load_stage(p_begin);
+        store_stage(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < stages; ++s) {
+        if (s + 1 < stages) load_stage(p_begin + (s + 1) * kWgPC);
+        const float* gs = Gs + (s & 1) * kWgPC * SG + pg * SG + wave_n * TN * 16 + c16;
+        const float* xs = Xs + (s & 1) * kWgPC * SX + pg * SX + wave_k * TK * 16 + c16;
+#pragma unroll
+        for (int r = 0; r < kWgPC; r += 4) {
+            float a[TN], b[TK];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) a[i] = gs[r * SG + i * 16];
+#pragma unroll
+            for (int j = 0; j < TK; ++j) b[j] = xs[r * SX + j * 16];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < stages) store_stage((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // D tile: row = 4 (lane >> 4) + reg = n, column = lane & 15 = k
+    float* out = part + ((long)split * gridDim.y + g) * (long)N * K;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+            const int k = k0 + (wave_k * TK + j) * 16 + c16;
+            if (k >= K) continue;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int n = n0 + (wave_n * TN + i) * 16 + pg * 4 + reg;
+                if (n < N) out[(long)n * K + k] = acc[i][j][reg];
+            }
+        }
+}
+
+// dw[e] = (accumulate ? dw[e] : 0) + sum_split part[split][e] in a fixed order (deterministic): 4 threads per element take
+// the splits = slice (mod 4) in ascending order, then (s0 + s1) + (s2 + s3)
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long elems, int splits,
+                                                              int accumulate) {
+    __shared__ float partial[4][64];
+    const int slice = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long e = (long)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (e < elems)
+        for (int i = slice; i < splits; i += 4) s += part[(long)i * elems + e];
+    partial[slice][lane] = s;
+    __syncthreads();
+    if (slice == 0 && e < elems) {
+        const float t = (partial[0][lane] + partial[1][lane]) + (partial[2][lane] + partial[3][lane]);
+        dw[e] = accumulate ? dw[e] + t : t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+struct RowsPlan { int tm, tn, nb_n, nb_p, items, grid; size_t lds; };
+
+inline int tiles16(int c) { return (c + 15) / 16; }
+
+// channel tiles per workgroup: the divisor-like choice that wastes least; ties -> the larger (fewer re-reads of x)
+RowsPlan plan_rows(int P, int N) {
+    static const int kTn[] = {1, 3, 6, 7, 9, 11};
+    const int t = tiles16(N);
+    int best = 1;
+    long best_cost = -1;
+    for (int tn : kTn) {
+        const long padded = (long)((t + tn - 1) / tn) * tn;
+        // cost: padded MFMA work, plus a small penalty per extra pass over x (more workgroup columns)
+        const long cost = padded * 100 + (long)((t + tn - 1) / tn) * 3 * 16;
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && tn > best)) { best_cost = cost; best = tn; }
+    }
+    RowsPlan q{};
+    q.tm = 2;
+    q.tn = best;
+    q.nb_n = (t + best - 1) / best;
+    q.nb_p = (P + 64 * q.tm - 1) / (64 * q.tm);
+    q.items = q.nb_n * q.nb_p;
+    q.grid = (q.items + kXcds - 1) / kXcds * kXcds;
+    q.lds = (size_t)2 * (64 * q.tm + 16 * q.tn) * kPwLd * sizeof(float);
+    return q;
+}
+
+struct WgradPlan { int cfg, tn, tk, wn, wk, nb_n, nb_k, splits, rows_per_split, items, grid; size_t lds; };
+
+// the instantiated (wave tile, wave arrangement) pairs: X(TN, TK, WN, WK)
+#define NEXTOU_WGRAD_CONFIGS(X) \
+    X(3, 9, 4, 1) X(9, 3, 1, 4) X(3, 9, 3, 1) X(9, 3, 1, 3) X(3, 3, 1, 1) X(3, 3, 2, 2) X(6, 6, 2, 2)
+
+// Cost model (seconds, crude): the matrix cores execute the PADDED tile products and need a wave on every SIMD; every
+// workgroup column re-reads gy and every workgroup row re-reads x (through L2); the partial tiles are written and read once
+// more by the reduction.  The split count trades chip fill against that extra traffic.  Measured choices: profiles/r02_pw_gemm.md.
+WgradPlan plan_wgrad(int P, int N, int K, int groups) {
+    static const int kCfg[][4] = {
+#define X(a, b, c, d) {a, b, c, d},
+        NEXTOU_WGRAD_CONFIGS(X)
+#undef X
+    };
+    const int tn_all = tiles16(N), tk_all = tiles16(K);
+    int force[4] = {0, 0, 0, 0};
+    const char* env = getenv("NEXTOU_PW_WGRAD_TILE");      // experiment: "TN,TK,WN,WK"
+    const bool forced = env && sscanf(env, "%d,%d,%d,%d", &force[0], &force[1], &force[2], &force[3]) == 4;
+    const int max_splits = (P + 4 * kWgPC - 1) / (4 * kWgPC);
+    WgradPlan best{};
+    double best_cost = -1.0;
+    int id = 0;
+    for (const auto& c : kCfg) {
+        const int cfg = id++;
+        if (forced && (force[0] != c[0] || force[1] != c[1] || force[2] != c[2] || force[3] != c[3])) continue;
+        const int bn = c[0] * c[2], bk = c[1] * c[3], waves = c[2] * c[3];
+        const int nb_n = (tn_all + bn - 1) / bn, nb_k = (tk_all + bk - 1) / bk;
+        const int tiles = nb_n * nb_k * groups;
+        const int want = (4096 / waves + tiles - 1) / tiles;        // ~16 waves per CU in the grid
+        const double flops = 2.0 * P * (nb_n * bn * 16.0) * (nb_k * bk * 16.0) * groups;
+        const double t_l2 = 4.0 * P * ((double)nb_k * N + (double)nb_n * K) * groups / 8e12;
+        const double t_in = 4.0 * P * (double)(N + K) * groups / 4.5e12;
+        for (int splits = 1; splits <= max_splits && splits <= 2 * want; splits = splits < 8 ? splits + 1 : splits + splits / 4) {
+            const double fill = (double)tiles * splits * waves / 1024.0;
+            const double t_mfma = flops / (157e12 * (fill < 1.0 ? fill : 1.0)) * (1.0 + 0.3 * (c[0] + c[1]) / (double)(c[0] * c[1]));
+            double cost = t_mfma > t_l2 ? t_mfma : t_l2;
+            if (t_in > cost) cost = t_in;
+            cost += 8.0 * splits * (double)N * K * groups / 3e12;      // partial tiles: written, then read by the reduction
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                best = WgradPlan{cfg, c[0], c[1], c[2], c[3], nb_n, nb_k, splits, 0, 0, 0, 0};
+            }
+        }
+    }
+    if (best_cost < 0) best = WgradPlan{5, 3, 3, 2, 2, (tn_all + 5) / 6, (tk_all + 5) / 6, 1, 0, 0, 0, 0};   // forced tile unknown
+    int splits = best.splits;
+    int rows = (P + splits - 1) / splits;
+    rows = (rows + kWgPC - 1) / kWgPC * kWgPC;
+    splits = (P + rows - 1) / rows;
+    best.splits = splits;
+    best.rows_per_split = rows;
+    best.items = best.nb_n * best.nb_k * splits;
+    best.grid = (best.items + kXcds - 1) / kXcds * kXcds;
+    best.lds = (size_t)2 * kWgPC * (wgrad_stride(best.tn * best.wn * 16) + wgrad_stride(best.tk * best.wk * 16)) * sizeof(float);
+    return best;
+}
+
+template <typename Kern>
+int allow_lds(Kern kern, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail((int)e, "pw: hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+    return 0;
+}
+
+template <int TM, int TN>
+int launch_rows(const RowsPlan& q, const float* x, const float* w, const float* bias, float* y, int P, int N, int K, int groups, long ldx,
+                long ldw, long ldy, int vec_store, hipStream_t s) {
+    static size_t allowed = 0;          // per instantiation; the attribute is sticky
+    if (q.lds > allowed) {
+        if (int e = allow_lds(pw_rows_kernel<TM, TN>, q.lds)) return e;
+        allowed = q.lds;
+    }
+    hipLaunchKernelGGL((pw_rows_kernel<TM, TN>), dim3(q.grid, groups), dim3(256), q.lds, s, x, w, bias, y, P, N, K, ldx, ldw, ldy, q.nb_n,
+                       q.items, vec_store);
+    return check_launch("pw_rows_kernel");
+}
+
+template <int TN, int TK, int WN, int WK>
+int launch_wgrad(const WgradPlan& q, const float* gy, const float* x, float* part, int P, int N, int K, int groups, long ldg, long ldx,
+                 hipStream_t s) {
+    static size_t allowed = 0;
+    if (q.lds > allowed) {
+        if (int e = allow_lds(pw_wgrad_kernel<TN, TK, WN, WK>, q.lds)) return e;
+        allowed = q.lds;
+    }
+    hipLaunchKernelGGL((pw_wgrad_kernel<TN, TK, WN, WK>), dim3(q.grid, groups), dim3(64 * WN * WK), q.lds, s, gy, x, part, P, N, K, ldg, ldx,
+                       q.nb_n, q.nb_k, q.rows_per_split, q.items);
+    return check_launch("pw_wgrad_kernel");
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_pw(const char* who, int64_t P, int N, int K, int groups, int64_t lda, int64_t ldb, int cols_a, int cols_b) {
+    NEXTOU_REQUIRE(P > 0 && P < (int64_t(1) << 31) && N > 0 && K > 0 && groups > 0 && groups < 65536,
+                   "%s: bad sizes P=%lld N=%d K=%d groups=%d", who, (long long)P, N, K, groups);
+    NEXTOU_REQUIRE(lda >= (int64_t)groups * cols_a && ldb >= (int64_t)groups * cols_b, "%s: row strides %lld / %lld shorter than the rows",
+                   who, (long long)lda, (long long)ldb);
+    return 0;
+}
+
+}  // namespace
+}  // namespace nextou
+
+using namespace nextou;
+
+extern "C" int nextou_pw_rows(const float* x, const float* w, const float* bias, float* y, int64_t P, int N, int K, int groups, int64_t ldx,
+                              int64_t ldy, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(x && w && y, "pw_rows: null pointer");
+    if (int e = check_pw("pw_rows", P, N, K, groups, ldx, ldy, K, N)) return e;
+    NEXTOU_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && aligned16(x) && aligned16(w),
+                   "pw_rows: K=%d and ldx=%lld must be multiples of 4 and x, w 16-byte aligned", K, (long long)ldx);
+    const RowsPlan q = plan_rows((int)P, N);
+    const int vec_store = (N % 4 == 0 && ldy % 4 == 0 && aligned16(y)) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K * groups, "pw_rows_kernel<%d,%d>[P%lld N%d K%d g%d]", q.tm, q.tn, (long long)P, N, K,
+                   groups);
+#define NEXTOU_PW_ROWS(TN_) \
+    case TN_: return launch_rows<2, TN_>(q, x, w, bias, y, (int)P, N, K, groups, (long)ldx, (long)K, (long)ldy, vec_store, s)
+    switch (q.tn) {
+        NEXTOU_PW_ROWS(1);
+        NEXTOU_PW_ROWS(3);
+        NEXTOU_PW_ROWS(6);
+        NEXTOU_PW_ROWS(7);
+        NEXTOU_PW_ROWS(9);
+        NEXTOU_PW_ROWS(11);
+    }
+#undef NEXTOU_PW_ROWS
+    return fail(NEXTOU_EINVAL, "pw_rows: no kernel for %d channel tiles", q.tn);
+}
+
+extern "C" int nextou_pw_wgrad_workspace(int64_t P, int N, int K, int groups, size_t* bytes) {
+    NEXTOU_REQUIRE(bytes, "pw_wgrad_workspace: null pointer");
+    if (int e = check_pw("pw_wgrad_workspace", P, N, K, groups, (int64_t)groups * N, (int64_t)groups * K, N, K)) return e;
+    const WgradPlan q = plan_wgrad((int)P, N, K, groups);
+    *bytes = (size_t)q.splits * groups * N * K * sizeof(float);
+    return 0;
+}
+
+extern "C" int nextou_pw_wgrad(const float* gy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int64_t P, int N, int K,
+                               int groups, int64_t ldg, int64_t ldx, int accumulate, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(gy && x && dw && workspace, "pw_wgrad: null pointer");
+    if (int e = check_pw("pw_wgrad", P, N, K, groups, ldg, ldx, N, K)) return e;
+    const WgradPlan q = plan_wgrad((int)P, N, K, groups);
+    const size_t need = (size_t)q.splits * groups * N * K * sizeof(float);
+    NEXTOU_REQUIRE(workspace_bytes >= need, "pw_wgrad: workspace %zu B < %zu B (nextou_pw_wgrad_workspace)", workspace_bytes, need);
+    NEXTOU_REQUIRE(N % 4 == 0 && K % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 && aligned16(gy) && aligned16(x),
+                   "pw_wgrad: N=%d, K=%d and the row strides must be multiples of 4 and gy, x 16-byte aligned", N, K);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = NEXTOU_EINVAL;
+    {
+        ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K * groups, "pw_wgrad_kernel<%d,%d|%dx%d>[P%lld N%d K%d g%d S%d]", q.tn, q.tk, q.wn,
+                       q.wk, (long long)P, N, K, groups, q.splits);
+        int id = 0;
+#define X(a, b, c, d) \
+        if (q.cfg == id++) rc = launch_wgrad<a, b, c, d>(q, gy, x, workspace, (int)P, N, K, groups, (long)ldg, (long)ldx, s);
+        NEXTOU_WGRAD_CONFIGS(X)
+#undef X
+    }
+    if (rc) return rc;
+    const long elems = (long)groups * N * K;
+    ProfScope prof(s, kBoundHbm, 4.0 * elems * (q.splits + 1), "pw_wgrad_reduce_kernel[%ld x S%d]", elems, q.splits);
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, s, workspace, dw, elems, q.splits, accumulate);
+    return check_launch("pw_wgrad_reduce_kernel");
+}

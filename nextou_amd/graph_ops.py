@@ -397,6 +397,40 @@ class _HipBackend:
         return out
 
 
+    # ---- K7: point-wise convolutions on channels-last rows ----
+    @staticmethod
+    def pw_rows(x_cl, w2, bias, groups):
+        """x_cl: dense channels-last (B, groups*K, *sp) float32; w2: (groups*N, K) contiguous -> channels-last (B, groups*N, *sp)."""
+        L_ = _lib.lib()
+        cin = x_cl.shape[1]
+        P = x_cl.numel() // cin
+        N, K = w2.shape[0] // groups, w2.shape[1]
+        y = _empty_channels_last((x_cl.shape[0], w2.shape[0]) + tuple(x_cl.shape[2:]), x_cl.device)
+        with torch.cuda.device(x_cl.device):
+            rc = L_.nextou_pw_rows(x_cl.data_ptr(), w2.data_ptr(), _ptr(bias), y.data_ptr(), P, N, K, groups, cin, w2.shape[0],
+                                   _stream_ptr(x_cl.device))
+        _lib.check(rc, "pw_rows")
+        return y
+
+    @staticmethod
+    def pw_wgrad(gy_cl, x_cl, groups):
+        """(groups*N, K) float32 = sum over points of gy (B, groups*N, *sp) x (B, groups*K, *sp), both dense channels-last."""
+        import ctypes
+        L_ = _lib.lib()
+        cout, cin = gy_cl.shape[1], x_cl.shape[1]
+        P = x_cl.numel() // cin
+        N, K = cout // groups, cin // groups
+        need = ctypes.c_size_t(0)
+        _lib.check(L_.nextou_pw_wgrad_workspace(P, N, K, groups, ctypes.byref(need)), "pw_wgrad_workspace")
+        ws = torch.empty((max(int(need.value), 4) // 4,), dtype=torch.float32, device=x_cl.device)
+        dw = torch.empty((cout, K), dtype=torch.float32, device=x_cl.device)
+        with torch.cuda.device(x_cl.device):
+            rc = L_.nextou_pw_wgrad(gy_cl.data_ptr(), x_cl.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel() * 4, P, N, K, groups,
+                                    cout, cin, 0, _stream_ptr(x_cl.device))
+        _lib.check(rc, "pw_wgrad")
+        return dw
+
+
 def _dhw(sizes, fill=1):
     """(H,W) or (D,H,W) -> (D,H,W): 2-D volumes are one slice thick."""
     sizes = [int(v) for v in sizes]
@@ -775,6 +809,64 @@ class _ConvDgradAsForward(torch.autograd.Function):
             _, gw, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, ones, ctx.padding, ones, False, zeros, 1,
                                                            [False, True, False])
         return gx, gw, None
+
+
+PW_GEMM_DEFAULT = "0"
+
+
+class _PointwiseConv(torch.autograd.Function):
+    """Kernel-1 convolution of a dense channels-last fp32 volume on K7 (csrc/pw_gemm.hip): the forward and the data
+    gradient are the same GEMM kernel over the (points, channels) rows (the latter with the per-group transposed weight),
+    the weight gradient the split-over-points kernel; the bias gradient (rare: these convolutions usually run bias-free
+    in front of a fused norm) is K6's channel sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups):
+        w2 = weight.reshape(weight.shape[0], weight.shape[1])
+        y = _HIP.pw_rows(x, w2.contiguous(), bias, groups)
+        ctx.save_for_backward(x, weight)
+        ctx.groups, ctx.has_bias = groups, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        g = ctx.groups
+        n, k = weight.shape[0] // g, weight.shape[1]
+        gy = gy.contiguous(memory_format={4: torch.channels_last, 5: torch.channels_last_3d}[gy.dim()])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.reshape(g, n, k).transpose(1, 2).reshape(g * k, n).contiguous()
+            gx = _HIP.pw_rows(gy, wt, None, g)
+        if ctx.needs_input_grad[1]:
+            gw = _HIP.pw_wgrad(gy, x, g).reshape(weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = _HIP.channel_sum(gy, channels_last=True)
+        return gx, gw, gb, None
+
+
+def pointwise_eligible(conv: torch.nn.Module, x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Kernel-1 / stride-1 / unpadded convolution of a dense channels-last fp32 device volume outside autocast whose
+    per-group channel counts are multiples of 4 (every 1x1 convolution of the Grapher / FFN blocks; not the 14-class
+    heads).  Opt-in with ``NEXTOU_PW_GEMM=1`` while MIOpen's 2-D kernels are as fast on these shapes
+    (profiles/r02_pw_gemm.md)."""
+    import os
+    if os.environ.get("NEXTOU_PW_GEMM", PW_GEMM_DEFAULT) != "1":
+        return False
+    if not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or torch.is_autocast_enabled("cuda"):
+        return False
+    if conv.transposed or isinstance(conv.padding, str) or _dense_channels_last(x) is None:
+        return False
+    if any(k != 1 for k in weight.shape[2:]) or any(s != 1 for s in conv.stride) or any(p != 0 for p in conv.padding) or \
+            any(d != 1 for d in conv.dilation):
+        return False
+    g = conv.groups
+    return weight.shape[0] % g == 0 and (weight.shape[0] // g) % 4 == 0 and weight.shape[1] % 4 == 0 and \
+        x.shape[1] == g * weight.shape[1]
+
+
+def pointwise_conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], groups: int) -> torch.Tensor:
+    return _PointwiseConv.apply(x, weight, bias, int(groups))
 
 
 def dgrad_as_forward_eligible(conv: torch.nn.Module, x: torch.Tensor) -> bool:

@@ -49,6 +49,8 @@ class _ConvBiasFolded:
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         weight, _ = padded_conv_params(self, x, with_bias=False)      # channel_pad.py: zero-padded 33 -> 40 / 66 -> 72
         x, weight = pad_image_channels(self, x, weight)
+        if graph_ops.pointwise_eligible(self, x, weight):
+            return graph_ops.pointwise_conv(x, weight, None, self.groups)      # K7: 1x1 convolutions as own f32-MFMA GEMMs
         if x.requires_grad and graph_ops.dgrad_as_forward_eligible(self, x):
             return graph_ops.conv_dgrad_as_forward(x, weight, self.padding)    # backward-data as a forward convolution
         if not isinstance(self.padding, str) and self.padding_mode == "zeros" and \
