@@ -76,6 +76,9 @@ template <typename T, int VEC> struct Pack;
 #ifndef NEXTOU_K6_NT
 #define NEXTOU_K6_NT 0
 #endif
+#ifndef NEXTOU_K6_NT_REDUCE
+#define NEXTOU_K6_NT_REDUCE 0
+#endif
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
 template <> struct Pack<float, 4> {
     float v[4];
@@ -85,6 +88,16 @@ template <> struct Pack<float, 4> {
         v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
 #else
         const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+#endif
+    }
+    // the reductions (statistics, backward sums) read every element exactly once and write nothing: NEXTOU_K6_NT_REDUCE=1
+    // makes those loads non-temporal (A/B: profiles/r02_k6_nontemporal_ab.md)
+    __device__ void load_stream(const float* p) {
+#if NEXTOU_K6_NT_REDUCE
+        const f32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+#else
+        load(p);
 #endif
     }
     __device__ void store(float* p) const {
@@ -98,6 +111,7 @@ template <> struct Pack<float, 4> {
 };
 template <> struct Pack<float, 1> {
     float v[1];
+    __device__ void load_stream(const float* p) { load(p); }
     __device__ void load(const float* p) { v[0] = *p; }
     __device__ void store(float* p) const { *p = v[0]; }
 };
@@ -110,6 +124,7 @@ __device__ inline unsigned short f32_to_bf16(float f) {  // round to nearest eve
 }
 template <> struct Pack<__hip_bfloat16, 8> {
     float v[8];
+    __device__ void load_stream(const __hip_bfloat16* p) { load(p); }
     __device__ void load(const __hip_bfloat16* p) {
         const uint4 t = *reinterpret_cast<const uint4*>(p);
         const unsigned w[4] = {t.x, t.y, t.z, t.w};
@@ -125,6 +140,7 @@ template <> struct Pack<__hip_bfloat16, 8> {
 };
 template <> struct Pack<__hip_bfloat16, 1> {
     float v[1];
+    __device__ void load_stream(const __hip_bfloat16* p) { load(p); }
     __device__ void load(const __hip_bfloat16* p) { v[0] = bf16_to_f32(*reinterpret_cast<const unsigned short*>(p)); }
     __device__ void store(__hip_bfloat16* p) const { *reinterpret_cast<unsigned short*>(p) = f32_to_bf16(v[0]); }
 };
@@ -132,6 +148,7 @@ template <> struct Pack<__hip_bfloat16, 1> {
 // fp16 (nnU-Net's default autocast dtype): v_cvt_f32_f16 / v_cvt_f16_f32 (round to nearest even)
 template <> struct Pack<__half, 8> {
     float v[8];
+    __device__ void load_stream(const __half* p) { load(p); }
     __device__ void load(const __half* p) {
         const uint4 t = *reinterpret_cast<const uint4*>(p);
         const unsigned w[4] = {t.x, t.y, t.z, t.w};
@@ -151,6 +168,7 @@ template <> struct Pack<__half, 8> {
 };
 template <> struct Pack<__half, 1> {
     float v[1];
+    __device__ void load_stream(const __half* p) { load(p); }
     __device__ void load(const __half* p) { v[0] = __half2float(*p); }
     __device__ void store(__half* p) const { *p = __float2half_rn(v[0]); }
 };
@@ -560,7 +578,7 @@ __global__ __launch_bounds__(kThreads) void bn_cl_stats_kernel(const T* __restri
         for (; e + 3 * stride < end; e += 4 * stride) {
             Pack<T, VEC> p[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) p[u].load(x + e + u * stride);
+            for (int u = 0; u < 4; ++u) p[u].load_stream(x + e + u * stride);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -568,7 +586,7 @@ __global__ __launch_bounds__(kThreads) void bn_cl_stats_kernel(const T* __restri
         }
         for (; e < end; e += stride) {
             Pack<T, VEC> p;
-            p.load(x + e);
+            p.load_stream(x + e);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { const double v = (double)p.v[j]; s[j] += v; q[j] = fma(v, v, q[j]); }
         }
@@ -678,7 +696,7 @@ __global__ __launch_bounds__(kThreads) void bn_cl_bwd_reduce_kernel(const T* __r
         for (; e + stride < end; e += 2 * stride) {
             Pack<T, VEC> p[2], g[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { p[u].load(x + e + u * stride); g[u].load(gy + e + u * stride); }
+            for (int u = 0; u < 2; ++u) { p[u].load_stream(x + e + u * stride); g[u].load_stream(gy + e + u * stride); }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -692,8 +710,8 @@ __global__ __launch_bounds__(kThreads) void bn_cl_bwd_reduce_kernel(const T* __r
         }
         for (; e < end; e += stride) {
             Pack<T, VEC> p, g;
-            p.load(x + e);
-            g.load(gy + e);
+            p.load_stream(x + e);
+            g.load_stream(gy + e);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float z = fmaf(p.v[j], scale[j], shift[j]);

@@ -46,7 +46,7 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 // y[p, n] = sum_k x[p, k] w[n, k] + bias[n]
 // ------------------------------------------------------------------------------------------------------------
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void pw_rows_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
+__global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                       const float* __restrict__ bias, float* __restrict__ Y, int P, int N, int K,
                                                       long ldx, long ldw, long ldy, int nb_n, int items, int vec_store) {
     constexpr int BM = 64 * TM, BN = 16 * TN;
@@ -56,110 +56,154 @@ __global__ __launch_bounds__(256) void pw_rows_kernel(const float* __restrict__ 
     float* Xs = reinterpret_cast<float*>(pw_smem4);           // [2][BM][kPwLd]
     float* Ws = Xs + 2 * BM * kPwLd;                          // [2][BN][kPwLd]
 
-    const int item = xcd_item(blockIdx.x, gridDim.x);
-    if (item >= items) return;
-    const int pb = item / nb_n, nb = item - pb * nb_n;
+    // persistent workgroups: XCD x owns the contiguous item range [x * per_xcd, (x + 1) * per_xcd) — items are ordered
+    // channel block fastest, so the workgroups resident on one XCD at any time share x tiles (and w) in its L2 — and
+    // slot j of the XCD walks it with stride slots.  A workgroup that finishes a tile has the next tile's first two stages
+    // already in flight while it writes its results: neither the load latency nor the store drain leaves the matrix
+    // cores idle (with one tile per workgroup and K = 132 they were busy 53 % of the time, profiles/r02_pw_gemm.md).
+    const int per_xcd = (items + kXcds - 1) / kXcds;
+    const int xcd = blockIdx.x % kXcds, slots = gridDim.x / kXcds;
+    int walk = blockIdx.x / kXcds;
+    auto item_at = [&](int j) { const int it = xcd * per_xcd + j; return (j < per_xcd && it < items) ? it : -1; };
     const int g = blockIdx.y;
     X += (long)g * K;
     Wt += (long)g * N * ldw;
     Y += (long)g * N;
-    const int p0 = pb * BM, n0 = nb * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
 
-    float4 xr[XV], wr[WV];
-    auto load_stage = [&](int k0) {
+    // register staging, prefetch distance 2: while stage s is multiplied out of LDS, stage s + 1 sits in (or is on its way
+    // to) one register set and the loads of stage s + 2 are issued into the other — one stage of MFMAs (~1.2 us) does not
+    // cover the memory latency under load, two do
+    float4 xr[2][XV], wr[2][WV];
+    auto load_stage = [&](int p0, int n0, int k0, float4* xq, float4* wq) {
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int f = tid + i * 256, row = f / (kPwKC / 4), c4 = f % (kPwKC / 4);
             const int p = p0 + row, k = k0 + c4 * 4;
-            xr[i] = (p < P && k < K) ? ld4(X + (long)p * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xq[i] = (p < P && k < K) ? ld4(X + (long)p * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int f = tid + i * 256, row = f / (kPwKC / 4), c4 = f % (kPwKC / 4);
             const int n = n0 + row, k = k0 + c4 * 4;
-            wr[i] = (row < BN && n < N && k < K) ? ld4(Wt + (long)n * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wq[i] = (row < BN && n < N && k < K) ? ld4(Wt + (long)n * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, const float4* xq, const float4* wq) {
         float* xs = Xs + buf * BM * kPwLd;
         float* ws = Ws + buf * BN * kPwLd;
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int f = tid + i * 256, row = f / (kPwKC / 4), c4 = f % (kPwKC / 4);
-            *reinterpret_cast<float4*>(xs + row * kPwLd + c4 * 4) = xr[i];
+            *reinterpret_cast<float4*>(xs + row * kPwLd + c4 * 4) = xq[i];
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int f = tid + i * 256, row = f / (kPwKC / 4), c4 = f % (kPwKC / 4);
-            if (row < BN) *reinterpret_cast<float4*>(ws + row * kPwLd + c4 * 4) = wr[i];
+            if (row < BN) *reinterpret_cast<float4*>(ws + row * kPwLd + c4 * 4) = wq[i];
         }
     };
 
     f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int stages = (K + kPwKC - 1) / kPwKC;
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-    for (int s = 0; s < stages; ++s) {
-        if (s + 1 < stages) load_stage((s + 1) * kPwKC);
-        const float* xs = Xs + (s & 1) * BM * kPwLd + (wave * TM * 16 + r16) * kPwLd + kg * 4;
-        const float* ws = Ws + (s & 1) * BN * kPwLd + r16 * kPwLd + kg * 4;
+    auto compute = [&](int buf) {
+        const float* xs = Xs + buf * BM * kPwLd + (wave * TM * 16 + r16) * kPwLd + kg * 4;
+        const float* ws = Ws + buf * BN * kPwLd + r16 * kPwLd + kg * 4;
         float4 b[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) b[i] = ld4(xs + i * 16 * kPwLd);
+        // the four k sub-steps of one accumulator are a dependent chain (40-cycle latency, 32-cycle issue): run them over
+        // 2 channel tiles x TM point tiles at a time, so that a chain's next link is >= 4 MFMAs away
+#pragma unroll
+        for (int j = 0; j < TN; j += 2) {
+            const float4 a0 = ld4(ws + j * 16 * kPwLd);
+            const float4 a1 = (j + 1 < TN) ? ld4(ws + (j + 1) * 16 * kPwLd) : a0;
+#define NEXTOU_PW_STEP(c)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                       \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.c, b[i].c, acc[i][j], 0, 0, 0);                               \
+        if (j + 1 < TN) acc[i][j + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.c, b[i].c, acc[i][j + 1], 0, 0, 0);       \
+    }
+            NEXTOU_PW_STEP(x)
+            NEXTOU_PW_STEP(y)
+            NEXTOU_PW_STEP(z)
+            NEXTOU_PW_STEP(w)
+#undef NEXTOU_PW_STEP
+        }
+    };
+
+    auto epilogue = [&](int p0, int n0) {
+        // D tile: column = lane & 15 = point, row = 4 (lane >> 4) + reg = channel -> one 16-byte store per tile and lane
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const float4 a = ld4(ws + j * 16 * kPwLd);
-            // the four k sub-steps of one accumulator are a dependent chain (40-cycle latency, 32-cycle issue): alternate
-            // the TM accumulators between them
+            const int n = n0 + j * 16 + kg * 4;
+            if (n >= N) continue;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) {
+                const float* bp = bias + (long)g * N + n;
+                bv.x = bp[0];
+                if (n + 1 < N) bv.y = bp[1];
+                if (n + 2 < N) bv.z = bp[2];
+                if (n + 3 < N) bv.w = bp[3];
+            }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[i].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[i].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[i].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[i].w, acc[i][j], 0, 0, 0);
-        }
-        if (s + 1 < stages) store_stage((s + 1) & 1);
-        __syncthreads();
-    }
-
-    // D tile: column = lane & 15 = point, row = 4 (lane >> 4) + reg = channel -> one 16-byte store per tile and lane
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + j * 16 + kg * 4;
-        if (n >= N) continue;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) {
-            const float* bp = bias + (long)g * N + n;
-            bv.x = bp[0];
-            if (n + 1 < N) bv.y = bp[1];
-            if (n + 2 < N) bv.z = bp[2];
-            if (n + 3 < N) bv.w = bp[3];
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int p = p0 + (wave * TM + i) * 16 + r16;
-            if (p >= P) continue;
-            float* yp = Y + (long)p * ldy + n;
-            const float4 v = make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
-            if (vec_store && n + 3 < N) {
-                *reinterpret_cast<float4*>(yp) = v;
-            } else {
-                yp[0] = v.x;
-                if (n + 1 < N) yp[1] = v.y;
-                if (n + 2 < N) yp[2] = v.z;
-                if (n + 3 < N) yp[3] = v.w;
+            for (int i = 0; i < TM; ++i) {
+                const int p = p0 + (wave * TM + i) * 16 + r16;
+                if (p >= P) continue;
+                float* yp = Y + (long)p * ldy + n;
+                const float4 v = make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
+                if (vec_store && n + 3 < N) {
+                    *reinterpret_cast<float4*>(yp) = v;
+                } else {
+                    yp[0] = v.x;
+                    if (n + 1 < N) yp[1] = v.y;
+                    if (n + 2 < N) yp[2] = v.z;
+                    if (n + 3 < N) yp[3] = v.w;
+                }
             }
         }
+    };
+
+    const int stages = (K + kPwKC - 1) / kPwKC;
+    int item = item_at(walk);
+    int p0 = 0, n0 = 0;
+    if (item >= 0) {
+        p0 = (item / nb_n) * BM;
+        n0 = (item % nb_n) * BN;
+        load_stage(p0, n0, 0, xr[0], wr[0]);
+        if (stages > 1) load_stage(p0, n0, kPwKC, xr[1], wr[1]);
+    }
+    while (item >= 0) {
+        __syncthreads();                       // the previous tile's last LDS reads are done
+        store_stage(0, xr[0], wr[0]);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // stages in pairs (LDS buffer 0, then 1) so that the register sets are indexed statically; no exit inside the pair —
+        // an exit there makes the compiler shuttle every accumulator between AGPRs and VGPRs once per iteration
+        for (int s = 0; s + 1 < stages; s += 2) {
+            if (s + 2 < stages) load_stage(p0, n0, (s + 2) * kPwKC, xr[0], wr[0]);
+            compute(0);
+            store_stage(1, xr[1], wr[1]);
+            __syncthreads();
+            if (s + 3 < stages) load_stage(p0, n0, (s + 3) * kPwKC, xr[1], wr[1]);
+            compute(1);
+            if (s + 2 < stages) store_stage(0, xr[0], wr[0]);
+            __syncthreads();
+        }
+        if (stages & 1) compute(0);
+        walk += slots;
+        const int next = item_at(walk);
+        const int np0 = next >= 0 ? (next / nb_n) * BM : 0, nn0 = next >= 0 ? (next % nb_n) * BN : 0;
+        if (next >= 0) {
+            load_stage(np0, nn0, 0, xr[0], wr[0]);
+            if (stages > 1) load_stage(np0, nn0, kPwKC, xr[1], wr[1]);
+        }
+        epilogue(p0, n0);
+        item = next;
+        p0 = np0;
+        n0 = nn0;
     }
 }
 
@@ -173,7 +217,7 @@ constexpr int wgrad_stride(int cols) { return cols + ((16 - cols % 32) + 32) % 3
 // wave tile TN x TK 16x16 tiles; WN x WK waves per workgroup (all compile-time: the staging loops and LDS strides are
 // constants, which keeps the (3,3) kernel at ~100 VGPRs instead of 256 + SGPR spills with run-time shapes)
 template <int TN, int TK, int WN, int WK>
-__global__ __launch_bounds__(64 * WN * WK) void pw_wgrad_kernel(const float* __restrict__ G, const float* __restrict__ X,
+__global__ __launch_bounds__(64 * WN * WK, 2) void pw_wgrad_kernel(const float* __restrict__ G, const float* __restrict__ X,
                                                                 float* __restrict__ part, int P, int N, int K, long ldg, long ldx,
                                                                 int nb_n, int nb_k, int rows_per_split, int items) {
     constexpr int NT = 64 * WN * WK;
@@ -200,33 +244,34 @@ __global__ __launch_bounds__(64 * WN * WK) void pw_wgrad_kernel(const float* __r
     const int c16 = lane & 15, pg = lane >> 4;
     const int wave_n = wave / WK, wave_k = wave - wave_n * WK;
 
-    float4 gr[GV], xr[XV];
-    auto load_stage = [&](int p_row0) {
+    // register staging with prefetch distance 2 (see pw_rows_kernel)
+    float4 gr[2][GV], xr[2][XV];
+    auto load_stage = [&](int p_row0, float4* gq, float4* xq) {
 #pragma unroll
         for (int i = 0; i < GV; ++i) {
             const int f = tid + i * NT, row = f / GQ, c = (f - row * GQ) * 4;
             const int p = p_row0 + row, col = n0 + c;
-            gr[i] = (row < kWgPC && p < p_end && col < N) ? ld4(G + (long)p * ldg + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            gq[i] = (row < kWgPC && p < p_end && col < N) ? ld4(G + (long)p * ldg + col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int f = tid + i * NT, row = f / XQ, c = (f - row * XQ) * 4;
             const int p = p_row0 + row, col = k0 + c;
-            xr[i] = (row < kWgPC && p < p_end && col < K) ? ld4(X + (long)p * ldx + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xq[i] = (row < kWgPC && p < p_end && col < K) ? ld4(X + (long)p * ldx + col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, const float4* gq, const float4* xq) {
         float* gs = Gs + buf * kWgPC * SG;
         float* xs = Xs + buf * kWgPC * SX;
 #pragma unroll
         for (int i = 0; i < GV; ++i) {
             const int f = tid + i * NT, row = f / GQ, c = (f - row * GQ) * 4;
-            if (row < kWgPC) *reinterpret_cast<float4*>(gs + row * SG + c) = gr[i];
+            if (row < kWgPC) *reinterpret_cast<float4*>(gs + row * SG + c) = gq[i];
         }
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int f = tid + i * NT, row = f / XQ, c = (f - row * XQ) * 4;
-            if (row < kWgPC) *reinterpret_cast<float4*>(xs + row * SX + c) = xr[i];
+            if (row < kWgPC) *reinterpret_cast<float4*>(xs + row * SX + c) = xq[i];
         }
     };
 
@@ -236,16 +281,9 @@ __global__ __launch_bounds__(64 * WN * WK) void pw_wgrad_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < TK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int stages = (p_end - p_begin + kWgPC - 1) / kWgPC;
-    if (stages > 0) {
-        load_stage(p_begin);
-        store_stage(0);
-    }
-    __syncthreads();
-    for (int s = 0; s < stages; ++s) {
-        if (s + 1 < stages) load_stage(p_begin + (s + 1) * kWgPC);
-        const float* gs = Gs + (s & 1) * kWgPC * SG + pg * SG + wave_n * TN * 16 + c16;
-        const float* xs = Xs + (s & 1) * kWgPC * SX + pg * SX + wave_k * TK * 16 + c16;
+    auto compute = [&](int buf) {
+        const float* gs = Gs + buf * kWgPC * SG + pg * SG + wave_n * TN * 16 + c16;
+        const float* xs = Xs + buf * kWgPC * SX + pg * SX + wave_k * TK * 16 + c16;
 #pragma unroll
         for (int r = 0; r < kWgPC; r += 4) {
             float a[TN], b[TK];
@@ -258,9 +296,26 @@ __global__ __launch_bounds__(64 * WN * WK) void pw_wgrad_kernel(const float* __r
 #pragma unroll
                 for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (s + 1 < stages) store_stage((s + 1) & 1);
+    };
+
+    const int stages = (p_end - p_begin + kWgPC - 1) / kWgPC;
+    if (stages > 0) {
+        load_stage(p_begin, gr[0], xr[0]);
+        if (stages > 1) load_stage(p_begin + kWgPC, gr[1], xr[1]);
+        store_stage(0, gr[0], xr[0]);
+    }
+    __syncthreads();
+    for (int s = 0; s + 1 < stages; s += 2) {      // pairs, no exit inside: see pw_rows_kernel
+        if (s + 2 < stages) load_stage(p_begin + (s + 2) * kWgPC, gr[0], xr[0]);
+        compute(0);
+        store_stage(1, gr[1], xr[1]);
+        __syncthreads();
+        if (s + 3 < stages) load_stage(p_begin + (s + 3) * kWgPC, gr[1], xr[1]);
+        compute(1);
+        if (s + 2 < stages) store_stage(0, gr[0], xr[0]);
         __syncthreads();
     }
+    if (stages & 1) compute(0);
 
     // D tile: row = 4 (lane >> 4) + reg = n, column = lane & 15 = k
     float* out = part + ((long)split * gridDim.y + g) * (long)N * K;
@@ -299,12 +354,22 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
+int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
 struct RowsPlan { int tm, tn, nb_n, nb_p, items, grid; size_t lds; };
 
 inline int tiles16(int c) { return (c + 15) / 16; }
 
 // channel tiles per workgroup: the divisor-like choice that wastes least; ties -> the larger (fewer re-reads of x)
-RowsPlan plan_rows(int P, int N) {
+RowsPlan plan_rows(int P, int N, int groups) {
     static const int kTn[] = {1, 3, 6, 7, 9, 11};
     const int t = tiles16(N);
     int best = 1;
@@ -321,20 +386,27 @@ RowsPlan plan_rows(int P, int N) {
     q.nb_n = (t + best - 1) / best;
     q.nb_p = (P + 64 * q.tm - 1) / (64 * q.tm);
     q.items = q.nb_n * q.nb_p;
-    q.grid = (q.items + kXcds - 1) / kXcds * kXcds;
     q.lds = (size_t)2 * (64 * q.tm + 16 * q.tn) * kPwLd * sizeof(float);
+    // persistent grid: what is resident at once (registers: 2 workgroups per CU from 9 channel tiles up, more below)
+    const int per_cu = best >= 9 ? 2 : best >= 6 ? 3 : best >= 3 ? 5 : 8;
+    int grid = cu_count() * per_cu / (groups > 0 ? groups : 1);
+    if (grid > q.items) grid = q.items;
+    q.grid = (grid + kXcds - 1) / kXcds * kXcds;
     return q;
 }
 
 struct WgradPlan { int cfg, tn, tk, wn, wk, nb_n, nb_k, splits, rows_per_split, items, grid; size_t lds; };
 
-// the instantiated (wave tile, wave arrangement) pairs: X(TN, TK, WN, WK)
+// the instantiated (wave tile, wave arrangement) pairs: X(TN, TK, WN, WK); kWgradPerCu: workgroups resident per CU (registers)
 #define NEXTOU_WGRAD_CONFIGS(X) \
-    X(3, 9, 4, 1) X(9, 3, 1, 4) X(3, 9, 3, 1) X(9, 3, 1, 3) X(3, 3, 1, 1) X(3, 3, 2, 2) X(6, 6, 2, 2)
+    X(3, 9, 4, 1) X(9, 3, 1, 4) X(3, 9, 3, 1) X(9, 3, 1, 3) X(3, 3, 1, 1) X(3, 3, 2, 2)
+static const int kWgradPerCu[] = {2, 2, 2, 2, 12, 4};
 
-// Cost model (seconds, crude): the matrix cores execute the PADDED tile products and need a wave on every SIMD; every
-// workgroup column re-reads gy and every workgroup row re-reads x (through L2); the partial tiles are written and read once
-// more by the reduction.  The split count trades chip fill against that extra traffic.  Measured choices: profiles/r02_pw_gemm.md.
+// Cost model (seconds, crude).  Matrix cores: a wave's share is (rows / 4) * TN * TK MFMAs of 32 cycles; a CU runs its
+// resident workgroups' waves on 4 pipes; workgroups beyond what is resident at once run in further rounds — the split count
+// is chosen so that the LAST round is not a nearly empty one (558 workgroups on 512 slots cost two rounds: measured 364 us
+// where one round takes ~200).  Every workgroup column re-reads gy and every row re-reads x (through L2); the partial tiles
+// are written and read once more by the reduction.  Measured choices: profiles/r02_pw_gemm.md.
 WgradPlan plan_wgrad(int P, int N, int K, int groups) {
     static const int kCfg[][4] = {
 #define X(a, b, c, d) {a, b, c, d},
@@ -346,6 +418,7 @@ WgradPlan plan_wgrad(int P, int N, int K, int groups) {
     const char* env = getenv("NEXTOU_PW_WGRAD_TILE");      // experiment: "TN,TK,WN,WK"
     const bool forced = env && sscanf(env, "%d,%d,%d,%d", &force[0], &force[1], &force[2], &force[3]) == 4;
     const int max_splits = (P + 4 * kWgPC - 1) / (4 * kWgPC);
+    const int cus = cu_count();
     WgradPlan best{};
     double best_cost = -1.0;
     int id = 0;
@@ -355,13 +428,23 @@ WgradPlan plan_wgrad(int P, int N, int K, int groups) {
         const int bn = c[0] * c[2], bk = c[1] * c[3], waves = c[2] * c[3];
         const int nb_n = (tn_all + bn - 1) / bn, nb_k = (tk_all + bk - 1) / bk;
         const int tiles = nb_n * nb_k * groups;
-        const int want = (4096 / waves + tiles - 1) / tiles;        // ~16 waves per CU in the grid
-        const double flops = 2.0 * P * (nb_n * bn * 16.0) * (nb_k * bk * 16.0) * groups;
+        const long capacity = (long)cus * kWgradPerCu[cfg];
         const double t_l2 = 4.0 * P * ((double)nb_k * N + (double)nb_n * K) * groups / 8e12;
         const double t_in = 4.0 * P * (double)(N + K) * groups / 4.5e12;
-        for (int splits = 1; splits <= max_splits && splits <= 2 * want; splits = splits < 8 ? splits + 1 : splits + splits / 4) {
-            const double fill = (double)tiles * splits * waves / 1024.0;
-            const double t_mfma = flops / (157e12 * (fill < 1.0 ? fill : 1.0)) * (1.0 + 0.3 * (c[0] + c[1]) / (double)(c[0] * c[1]));
+        for (int splits = 1; splits <= max_splits; splits = splits < 16 ? splits + 1 : splits + splits / 16) {
+            const long blocks = (long)tiles * splits;
+            if (blocks > 8 * capacity) break;
+            const int rows = ((P + splits - 1) / splits + kWgPC - 1) / kWgPC * kWgPC;
+            const double wave_s = (rows / 4.0) * c[0] * c[1] * 32.0 / 2.4e9 * (1.0 + 0.3 * (c[0] + c[1]) / (double)(c[0] * c[1]));
+            const long full = blocks / capacity, rem = blocks - full * capacity;
+            // a SIMD with ONE wave keeps its matrix pipe ~60 % busy (LDS reads, staging and the barrier are not hidden), with
+            // two or more ~95 % (measured: 512 co-resident 4-wave workgroups ran at 126 TFLOP/s, 246 at 79)
+            auto round_time = [&](double waves_per_simd) {
+                return waves_per_simd <= 1.0 ? 1.0 / 0.6 : waves_per_simd / 0.95;
+            };
+            const double share_full = kWgradPerCu[cfg] * waves / 4.0;
+            const double share_rem = (double)((rem + cus - 1) / cus) * waves / 4.0;
+            const double t_mfma = wave_s * (full * round_time(share_full) + (rem > 0 ? round_time(share_rem) : 0.0));
             double cost = t_mfma > t_l2 ? t_mfma : t_l2;
             if (t_in > cost) cost = t_in;
             cost += 8.0 * splits * (double)N * K * groups / 3e12;      // partial tiles: written, then read by the reduction
@@ -439,7 +522,7 @@ extern "C" int nextou_pw_rows(const float* x, const float* w, const float* bias,
     if (int e = check_pw("pw_rows", P, N, K, groups, ldx, ldy, K, N)) return e;
     NEXTOU_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && aligned16(x) && aligned16(w),
                    "pw_rows: K=%d and ldx=%lld must be multiples of 4 and x, w 16-byte aligned", K, (long long)ldx);
-    const RowsPlan q = plan_rows((int)P, N);
+    const RowsPlan q = plan_rows((int)P, N, groups);
     const int vec_store = (N % 4 == 0 && ldy % 4 == 0 && aligned16(y)) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K * groups, "pw_rows_kernel<%d,%d>[P%lld N%d K%d g%d]", q.tm, q.tn, (long long)P, N, K,

@@ -814,6 +814,12 @@ class _ConvDgradAsForward(torch.autograd.Function):
 PW_GEMM_DEFAULT = "0"
 
 
+def _pw_mode() -> str:
+    """NEXTOU_PW_GEMM: "0" MIOpen, "1" K7 for forward / data gradient / weight gradient, "wgrad" K7 for the weight gradient only."""
+    import os
+    return os.environ.get("NEXTOU_PW_GEMM", PW_GEMM_DEFAULT)
+
+
 class _PointwiseConv(torch.autograd.Function):
     """Kernel-1 convolution of a dense channels-last fp32 volume on K7 (csrc/pw_gemm.hip): the forward and the data
     gradient are the same GEMM kernel over the (points, channels) rows (the latter with the per-group transposed weight),
@@ -822,8 +828,13 @@ class _PointwiseConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, groups):
-        w2 = weight.reshape(weight.shape[0], weight.shape[1])
-        y = _HIP.pw_rows(x, w2.contiguous(), bias, groups)
+        ctx.own_rows = _pw_mode() != "wgrad"
+        if ctx.own_rows:
+            w2 = weight.reshape(weight.shape[0], weight.shape[1])
+            y = _HIP.pw_rows(x, w2.contiguous(), bias, groups)
+        else:        # A/B mode: MIOpen forward / data gradient (depth-flat 2-D view), own weight gradient
+            y = unflat_depth(torch.nn.functional.conv2d(flat_depth(x), weight.squeeze(2), bias, groups=groups), x.shape[0], x.shape[2]) \
+                if x.dim() == 5 else torch.nn.functional.conv2d(x, weight, bias, groups=groups)
         ctx.save_for_backward(x, weight)
         ctx.groups, ctx.has_bias = groups, bias is not None
         return y
@@ -835,9 +846,13 @@ class _PointwiseConv(torch.autograd.Function):
         n, k = weight.shape[0] // g, weight.shape[1]
         gy = gy.contiguous(memory_format={4: torch.channels_last, 5: torch.channels_last_3d}[gy.dim()])
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.own_rows:
             wt = weight.reshape(g, n, k).transpose(1, 2).reshape(g * k, n).contiguous()
             gx = _HIP.pw_rows(gy, wt, None, g)
+        elif ctx.needs_input_grad[0]:
+            nd = weight.dim() - 2
+            gx, _, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, (1,) * nd, (0,) * nd, (1,) * nd, False, (0,) * nd, g,
+                                                           [True, False, False])
         if ctx.needs_input_grad[1]:
             gw = _HIP.pw_wgrad(gy, x, g).reshape(weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -850,8 +865,7 @@ def pointwise_eligible(conv: torch.nn.Module, x: torch.Tensor, weight: torch.Ten
     per-group channel counts are multiples of 4 (every 1x1 convolution of the Grapher / FFN blocks; not the 14-class
     heads).  Opt-in with ``NEXTOU_PW_GEMM=1`` while MIOpen's 2-D kernels are as fast on these shapes
     (profiles/r02_pw_gemm.md)."""
-    import os
-    if os.environ.get("NEXTOU_PW_GEMM", PW_GEMM_DEFAULT) != "1":
+    if _pw_mode() == "0":
         return False
     if not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or torch.is_autocast_enabled("cuda"):
         return False

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--stacks", action="store_true", help="group by Python call stack instead of input shapes")
+    ap.add_argument("--ops", default=None, help="comma-separated substrings: list only the ops whose name contains one of them")
     args = ap.parse_args()
     device = torch.device("cuda", 0)
     torch.backends.cudnn.benchmark = True
@@ -61,7 +62,9 @@ def main():
     skip = ("convolution", "nextou", "Conv")
     shown = 0
     for dev, n, key, shapes, stack in rows:
-        if any(s in key for s in skip):
+        if any(s in key for s in skip) or key.startswith(("void ", "_ZN", "igemm", "hipLaunch", "Memcpy", "Memset", "SubTensor")):
+            continue
+        if args.ops and not any(o in key for o in args.ops.split(",")):
             continue
         print("| %.0f | %d | `%s` | %s %s |" % (dev, n, key[:70], shapes, stack))
         shown += 1

@@ -15,5 +15,7 @@ SRCS=$(python -c "from nextou_amd import build as b; import os; print(' '.join(o
 for n in 0 1 2 3; do
   hipcc $FLAGS -DNEXTOU_K6_NT=$n -shared $SRCS -o tools/_ablate/libnextou_hip_nt$n.so &
 done
+# non-temporal loads in the two channels-last reductions only
+hipcc $FLAGS -DNEXTOU_K6_NT_REDUCE=1 -shared $SRCS -o tools/_ablate/libnextou_hip_ntred.so &
 wait
 ls -la tools/_ablate | grep nt

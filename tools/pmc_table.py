@@ -21,7 +21,7 @@ def main():
     for d in args:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
                 if match in name:
                     vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     kernels = sorted(vals)
