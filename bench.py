@@ -45,7 +45,7 @@ sys.path.insert(0, REPO)
 
 from nextou_amd import _lib, graph_ops  # noqa: E402
 from nextou_amd.ddp import BucketedGradientAverager, init_process_group_from_env, init_single_process_group  # noqa: E402
-from nextou_amd.harness import (config_3d_fullres_nextou, deep_supervision_weights, downsample_targets,  # noqa: E402
+from nextou_amd.harness import (GraphedTrainStep, config_3d_fullres_nextou, deep_supervision_weights, downsample_targets,  # noqa: E402
                                 synthetic_batch)
 from nextou_amd.loss.nnunet_losses import DeepSupervisionWrapper, RobustCrossEntropyLoss  # noqa: E402
 from nextou_amd.nnUNetTrainer.nnUNetTrainer_NexToU import nnUNetTrainer_NexToU  # noqa: E402
@@ -245,6 +245,10 @@ def main():
     ap.add_argument("--autocast-bf16", action="store_true",
                     help="informational (cfg-5 regime): conv stages under bf16 autocast, graph ops stay fp32; "
                          "never the headline number")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="replay the training step as one captured hipGraph (harness.GraphedTrainStep).  auto = on for one GPU "
+                         "without the gradient averager (the N > 1 step launches RCCL collectives from autograd hooks and stays "
+                         "eager), fp32 cfg 2 / cfg 5 / tiny; falls back to the eager step if the capture fails")
     ap.add_argument("--channels-last", action="store_true",
                     help="experiment: run the dense stages in channels_last_3d (NDHWC) memory format")
     args = ap.parse_args()
@@ -283,19 +287,40 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    want_graph = args.graph == "on" or (args.graph == "auto" and averager is None and world == 1 and args.workload != "cfg4")
+    graphed = None
+    if want_graph:
+        try:
+            graphed = GraphedTrainStep(step, warmup=1)
+            for _ in range(2):
+                graphed()
+        except Exception as exc:            # capture is an optimisation: the eager step is the same computation
+            print("bench.py: hipGraph capture failed (%s: %s); timing the eager step" % (type(exc).__name__, exc), file=sys.stderr)
+            graphed = None
+            torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    _lib.lib().nextou_profile_enable(64 * max(args.steps, 1) * 8)
+    run = graphed if graphed is not None else step
+    if graphed is None:
+        _lib.lib().nextou_profile_enable(64 * max(args.steps, 1) * 8)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if graphed is not None:
+        # per-kernel HIP-event timing (the roofline objects) cannot live inside a captured graph: three eager steps of the
+        # same computation after the timed region provide it
+        _lib.lib().nextou_profile_enable(64 * 3 * 8)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
     report = profile_report()
     _lib.lib().nextou_profile_enable(0)
+    profiled_steps = 3 if graphed is not None else args.steps
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -307,9 +332,9 @@ def main():
         roof = roofline_from(report)
         graph = roofline_graph_from(report) if report else None
         if roof is not None:
-            roof["own_kernels_ms_per_step"] = round(sum(r["ms"] for r in report) / args.steps, 3)
+            roof["own_kernels_ms_per_step"] = round(sum(r["ms"] for r in report) / profiled_steps, 3)
             graph["graph_kernels_ms_per_step"] = round(sum(r["ms"] for r in report if r["kernel"].startswith(
-                ("knn_", "mr_", "window_", "pool_rows", "cell_"))) / args.steps, 3)
+                ("knn_", "mr_", "window_", "pool_rows", "cell_"))) / profiled_steps, 3)
         line = {
             "metric": "voxels/sec fwd+bwd, 3D %s patch batch=%d" % ("x".join(map(str, cfg.patch_size)), batch),
             "value": round(voxels_per_step / (elapsed / args.steps), 1),
@@ -328,6 +353,7 @@ def main():
                        "layout": "channels-last stages %s" % sorted(trainer.network.encoder.channels_last_stages),
                        "internal_channel_padding_modules": getattr(trainer.network, "padded_modules", 0),
                        "gradient_averager": averager is not None,
+                       "step_replayed_as_hipgraph": graphed is not None,
                        "parallelism": "dp%d" % world, "final_loss": float(loss.detach())},
             "roofline": roof,
             "roofline_graph": graph,

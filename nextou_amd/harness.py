@@ -159,6 +159,36 @@ class StandaloneTrainerBase:
         return loss.detach()
 
 
+class GraphedTrainStep:
+    """One whole training step (zero_grad -> forward -> loss -> backward -> clip -> SGD) captured into a single hipGraph and
+    replayed: the ~1700 kernel launches of a cfg-2 step become one, which takes the host out of the small stages (the s4 / s5
+    graph blocks are a few microseconds of arithmetic behind ~100 launches each) and closes the idle gaps between kernels.
+
+    ``step_fn`` must read its batch from tensors that live across replays (copy each new batch into them with ``copy_``) and
+    must not synchronise with the host: no ``.item()``, no stochastic dilation (``torch.rand`` on the CPU), no BTI target
+    validation.  ``warmup`` eager steps run first on a side stream (MIOpen's find, lazy momentum buffers, the library's
+    one-time attribute calls); then one step is captured.  ``__call__`` replays it and returns the captured loss tensor.
+    Same numbers as the eager step (same kernels, same order)."""
+
+    def __init__(self, step_fn, warmup: int = 3):
+        from . import _lib
+        _lib.lib().nextou_profile_enable(0)        # event records do not belong inside a captured graph
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(int(warmup), 1)):
+                step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = step_fn()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.loss
+
+
 def deep_supervision_weights(n_scales: int) -> np.ndarray:
     """1/2^i, last scale 0, normalised (reference nnUNetTrainer_NexToU_BTI_Synapse.py:23-27)."""
     w = np.array([1 / (2 ** i) for i in range(n_scales)])
