@@ -8,8 +8,6 @@ unpinned** (no reference test or golden vector covers third-party code).
 """
 from __future__ import annotations
 
-import os
-
 import torch
 from torch import nn
 
@@ -89,17 +87,7 @@ except ImportError:
             if target.ndim == input.ndim:
                 assert target.shape[1] == 1
                 target = target[:, 0]
-            target = target.long()
-            if input.dim() in (4, 5) and input.shape[1] > 1 and not input.is_contiguous() and \
-                    input.is_contiguous(memory_format=torch.channels_last if input.dim() == 4 else torch.channels_last_3d) and \
-                    self.weight is None and self.reduction == "mean" and self.label_smoothing == 0.0 and \
-                    os.environ.get("NEXTOU_CE_ROWS", "1") != "0":
-                # channels-last logits (what the heads of a channels-last network emit): the classes of one voxel are
-                # contiguous, so the SAME mean over voxels is a cross-entropy over the rows of the (voxels, classes) view —
-                # without ATen's conversion of the logits (and of their gradient) to NCDHW and back
-                rows = input.permute(0, *range(2, input.dim()), 1).reshape(-1, input.shape[1])
-                return torch.nn.functional.cross_entropy(rows, target.reshape(-1), ignore_index=self.ignore_index)
-            return super().forward(input, target)
+            return super().forward(input, target.long())
 
     class DeepSupervisionWrapper(nn.Module):
         """sum_i w_i * loss(output_i, target_i); zero weights are skipped."""

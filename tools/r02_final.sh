@@ -7,7 +7,6 @@ python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -
 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "MIOpen\|GridwiseOp" | tail -12 > $OUT/pytest_gpu_full.log; tail -3 $OUT/pytest_gpu_full.log
 python bench.py > $OUT/bench_default.log 2>&1; grep "^{" $OUT/bench_default.log > $OUT/bench_default.json; cut -c1-260 $OUT/bench_default.json
 python bench.py --no-cpu-baseline --graph off > $OUT/bench_graph_off.log 2>&1; grep "^{" $OUT/bench_graph_off.log | cut -c100-180
-NEXTOU_CE_ROWS=0 python bench.py --no-cpu-baseline > $OUT/bench_ce_rows_off.log 2>&1; grep "^{" $OUT/bench_ce_rows_off.log | cut -c100-180
 python bench.py --no-cpu-baseline > $OUT/bench_default_again.log 2>&1; grep "^{" $OUT/bench_default_again.log | cut -c100-180
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_final -o kt -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline > $OUT/kt_final_bench.log 2>&1
