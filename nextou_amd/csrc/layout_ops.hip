@@ -263,6 +263,29 @@ __global__ __launch_bounds__(kLayThreads) void cell_scatter_kernel(const float* 
     }
 }
 
+// out[b, d, hw, kd * C + c] = x[b, d + kd - 1, hw, c], zero outside the volume: the three depth taps of a [3,k,k] convolution as
+// input channels, which turns its weight gradient into a 2-D problem (graph_ops._ConvDgradAsForward).  One workgroup per
+// (plane, chunk of rows); a thread moves 16 bytes; 32-bit index arithmetic only.
+constexpr int kUnrollRows = 32;
+__global__ __launch_bounds__(kLayThreads) void depth_unroll_kernel(const float4* __restrict__ x, float4* __restrict__ out, int C4, int D, int HW) {
+    const int plane = blockIdx.y;                    // b * D + d
+    const int d = plane % D;
+    const int row0 = blockIdx.x * kUnrollRows;
+    const int rows = min(kUnrollRows, HW - row0);
+    const int w3 = 3 * C4;
+    const float4* xp = x + ((long)plane * HW + row0) * C4;
+    float4* op = out + ((long)plane * HW + row0) * w3;
+    const long plane_stride = (long)HW * C4;
+    for (int e = threadIdx.x; e < rows * w3; e += kLayThreads) {
+        const int r = e / w3, j = e - r * w3;
+        const int kd = j / C4, c4 = j - kd * C4;
+        const int ds = d + kd - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ds >= 0 && ds < D) v = xp[(long)(kd - 1) * plane_stride + (long)r * C4 + c4];
+        op[e] = v;
+    }
+}
+
 static int check_vol(const char* who, int B, int C, int D, int H, int W) {
     NEXTOU_REQUIRE(B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && B <= 65535, "%s: bad size B=%d C=%d D=%d H=%d W=%d", who, B, C, D, H, W);
     NEXTOU_REQUIRE((long long)D * H * W < (1ll << 31) && cdiv(C, kTileChannels) <= 65535, "%s: volume / channel count out of range", who);
@@ -376,4 +399,18 @@ extern "C" int nextou_cell_scatter(const float* src_cm, const uint8_t* cell, flo
     if (vec) hipLaunchKernelGGL(cell_scatter_kernel<true>, grid, dim3(kLayThreads), 0, s, src_cm, cell, out_cl, Vol{D, H, W}, q, C2, C, N);
     else hipLaunchKernelGGL(cell_scatter_kernel<false>, grid, dim3(kLayThreads), 0, s, src_cm, cell, out_cl, Vol{D, H, W}, q, C2, C, N);
     return check_launch("cell_scatter_kernel");
+}
+
+extern "C" int nextou_depth_unroll(const float* x_cl, float* out_cl, int B, int C, int D, int H, int W, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(x_cl && out_cl, "depth_unroll: null pointer");
+    if (int e = check_vol("depth_unroll", B, C, D, H, W)) return e;
+    NEXTOU_REQUIRE(C % 4 == 0 && (((reinterpret_cast<uintptr_t>(x_cl) | reinterpret_cast<uintptr_t>(out_cl)) & 15u) == 0),
+                   "depth_unroll: C=%d must be a multiple of 4 and the tensors 16-byte aligned", C);
+    NEXTOU_REQUIRE((long long)B * D <= 65535, "depth_unroll: B*D=%lld planes exceed the grid", (long long)B * D);
+    hipStream_t s = (hipStream_t)stream;
+    const double bytes = 4.0 * B * (double)C * D * H * W;
+    ProfScope prof(s, kBoundHbm, 4.0 * bytes, "depth_unroll_kernel[B%d C%d %dx%dx%d]", B, C, D, H, W);     // one read (neighbour planes from L2) + three writes
+    hipLaunchKernelGGL(depth_unroll_kernel, dim3(cdiv(H * W, kUnrollRows), B * D), dim3(kLayThreads), 0, s,
+                       reinterpret_cast<const float4*>(x_cl), reinterpret_cast<float4*>(out_cl), C / 4, D, H * W);
+    return check_launch("depth_unroll_kernel");
 }

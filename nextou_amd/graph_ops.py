@@ -397,6 +397,17 @@ class _HipBackend:
         return out
 
 
+    @staticmethod
+    def depth_unroll(x_cl):
+        """dense channels_last_3d (B,C,D,H,W) -> (B*D, 3C, H, W) channels_last: depth taps -1, 0, +1 stacked over channels."""
+        L_ = _lib.lib()
+        B, C, D, H, W = x_cl.shape
+        out = torch.empty((B * D, H, W, 3 * C), dtype=torch.float32, device=x_cl.device)
+        with torch.cuda.device(x_cl.device):
+            rc = L_.nextou_depth_unroll(x_cl.data_ptr(), out.data_ptr(), B, C, D, H, W, _stream_ptr(x_cl.device))
+        _lib.check(rc, "depth_unroll")
+        return out.permute(0, 3, 1, 2)
+
     # ---- K7: point-wise convolutions on channels-last rows ----
     @staticmethod
     def pw_rows(x_cl, w2, bias, groups):
@@ -805,7 +816,16 @@ class _ConvDgradAsForward(torch.autograd.Function):
             wt = weight.transpose(0, 1).flip(*range(2, 2 + n))
             wt = wt.contiguous(memory_format=cl) if cl is not None else wt.contiguous()
             gx = torch.ops.aten.convolution(gy, wt, None, ones, ctx.padding, ones, False, zeros, 1)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and wgrad_depth_unroll_eligible(x, weight, ctx.padding):
+            # [3,3,3] kernel: the depth taps become input channels and the weight gradient a 2-D problem (MIOpen's 2-D kernels:
+            # 72 -> 72 at 64x112x96 6.25 -> 5.09 ms, 144 -> 72 11.9 -> 10.5 ms, profiles/r02_conv_depth_unroll_probe.md)
+            co, ci = weight.shape[:2]
+            x3 = _HIP.depth_unroll(x)
+            w2 = weight.permute(0, 2, 1, 3, 4).reshape(co, 3 * ci, 3, 3)
+            _, gw2, _ = torch.ops.aten.convolution_backward(flat_depth(gy), x3, w2, None, (1, 1), tuple(ctx.padding[1:]), (1, 1), False,
+                                                            (0, 0), 1, [False, True, False])
+            gw = gw2.reshape(co, 3, ci, 3, 3).permute(0, 2, 1, 3, 4)
+        elif ctx.needs_input_grad[1]:
             _, gw, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, ones, ctx.padding, ones, False, zeros, 1,
                                                            [False, True, False])
         return gx, gw, None
@@ -881,6 +901,80 @@ def pointwise_eligible(conv: torch.nn.Module, x: torch.Tensor, weight: torch.Ten
 
 def pointwise_conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], groups: int) -> torch.Tensor:
     return _PointwiseConv.apply(x, weight, bias, int(groups))
+
+
+class _ConvDepthUnrolledGrads(torch.autograd.Function):
+    """[3,3,3] convolution with depth stride 1 and in-plane stride > 1 (the stage-0 -> stage-1 down-sampling convolution of the
+    3-D plans): MIOpen's forward as it is, both gradients as 2-D problems over depth-unrolled tensors (``nextou_depth_unroll``).
+    Weight gradient: taps of x as input channels (see :class:`_ConvDgradAsForward`).  Data gradient: y[d] reads x[d + kd - 1],
+    so gx[d'] = sum_kd convT2d(gy[d' - kd + 1], w[:, :, kd]) = the 2-D backward-data of the taps of gy (as 3*Cout output
+    channels) through the depth-flipped filter — MIOpen's 2-D kernel instead of CK's 3-D backward-data."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding):
+        y = torch.ops.aten.convolution(x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1)
+        ctx.save_for_backward(x, weight)
+        ctx.conf = (tuple(stride), tuple(padding))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, padding = ctx.conf
+        co, ci = weight.shape[:2]
+        gy = gy.contiguous(memory_format=torch.channels_last_3d)
+        gx = gw = None
+        import os
+        mode = os.environ.get("NEXTOU_STRIDED_UNROLL", "both")          # both | wgrad | dgrad
+        if mode != "both":
+            mask = [ctx.needs_input_grad[0] and mode != "dgrad", ctx.needs_input_grad[1] and mode != "wgrad", False]
+            if mask[0] or mask[1]:
+                gx, gw, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, stride, padding, (1, 1, 1), False, (0, 0, 0), 1, mask)
+        if ctx.needs_input_grad[0] and mode != "wgrad":
+            w3 = weight.flip(2).permute(2, 0, 1, 3, 4).reshape(3 * co, ci, 3, 3)
+            gx2, _, _ = torch.ops.aten.convolution_backward(_HIP.depth_unroll(gy), flat_depth(x), w3, None, stride[1:], padding[1:], (1, 1),
+                                                            False, (0, 0), 1, [True, False, False])
+            gx = unflat_depth(gx2, x.shape[0], x.shape[2])
+        if ctx.needs_input_grad[1] and mode != "dgrad":
+            w2 = weight.permute(0, 2, 1, 3, 4).reshape(co, 3 * ci, 3, 3)
+            _, gw2, _ = torch.ops.aten.convolution_backward(flat_depth(gy), _HIP.depth_unroll(x), w2, None, stride[1:], padding[1:], (1, 1),
+                                                            False, (0, 0), 1, [False, True, False])
+            gw = gw2.reshape(co, 3, ci, 3, 3).permute(0, 2, 1, 3, 4)
+        return gx, gw, None, None
+
+
+def depth_unrolled_grads_eligible(conv: torch.nn.Module, x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Un-grouped [3,3,3] convolutions with depth stride 1, an in-plane stride > 1 and 'same' zero padding whose gradients
+    :class:`_ConvDepthUnrolledGrads` computes as 2-D problems (same size rule as the stride-1 weight gradient); opt-in with
+    ``NEXTOU_STRIDED_UNROLL=both|wgrad|dgrad``."""
+    import os
+    if os.environ.get("NEXTOU_STRIDED_UNROLL", "off") not in ("both", "wgrad", "dgrad"):
+        return False            # opt-in: measured 181.1 vs 180.2 ms / step with it on (DESIGN.md §5)
+    if conv.transposed or conv.groups != 1 or isinstance(conv.padding, str) or getattr(conv, "padding_mode", "zeros") != "zeros":
+        return False
+    if torch.is_autocast_enabled("cuda") or weight.dtype != torch.float32 or weight.shape[0] % 4 != 0:
+        return False
+    stride = tuple(conv.stride)
+    if len(stride) != 3 or stride[0] != 1 or max(stride[1:]) == 1 or any(d != 1 for d in conv.dilation):
+        return False
+    return wgrad_depth_unroll_eligible(x, weight, conv.padding)
+
+
+def conv_depth_unrolled_grads(x, weight, stride, padding):
+    return _ConvDepthUnrolledGrads.apply(x, weight, tuple(int(v) for v in stride), tuple(int(v) for v in padding))
+
+
+def wgrad_depth_unroll_eligible(x: torch.Tensor, weight: torch.Tensor, padding) -> bool:
+    """[3,3,3] kernels with 'same' padding on a dense channels-last fp32 device volume of at least 16 384 points per sample batch
+    (below that the launch of the unroll costs what the 2-D kernel gains).  ``NEXTOU_WGRAD_DEPTH_UNROLL=0`` keeps the 3-D path."""
+    import os
+    if os.environ.get("NEXTOU_WGRAD_DEPTH_UNROLL", "1") == "0":
+        return False
+    if x.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3) or tuple(padding) != (1, 1, 1):
+        return False
+    if not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 4 != 0 or _dense_channels_last(x) is None:
+        return False
+    return x.shape[0] * x.shape[2] <= 65535 and x.numel() // x.shape[1] >= 16384
 
 
 def dgrad_as_forward_eligible(conv: torch.nn.Module, x: torch.Tensor) -> bool:

@@ -59,6 +59,8 @@ class _ConvBiasFolded:
             y = torch.nn.functional.conv2d(graph_ops.flat_depth(x), weight.squeeze(2), None, self.stride[1:], self.padding[1:],
                                            self.dilation[1:], self.groups)
             return graph_ops.unflat_depth(y, x.shape[0], x.shape[2])
+        if (x.requires_grad or weight.requires_grad) and graph_ops.depth_unrolled_grads_eligible(self, x, weight):
+            return graph_ops.conv_depth_unrolled_grads(x, weight, self.stride, self.padding)   # strided [3,3,3]: 2-D gradients
         return self._conv_forward(x, weight, None)
 
 

@@ -332,3 +332,12 @@ def cell_gather_ref(x, cell, pool):
     reps = x.shape[1] // indices.shape[1]
     idx = torch.cat([indices] * reps, 1)
     return x.flatten(2).gather(2, idx.flatten(2)).contiguous()
+
+
+def depth_unroll_ref(x):
+    """(B, C, D, H, W) -> (B*D, 3C, H, W): channel kd*C + c of depth slice d is x[:, c, d + kd - 1] (zero outside) — the three depth
+    taps a [3,k,k] 'same' convolution of the reference's plain stages (NexToU_Encoder_Decoder.py:125-136) reads for output slice d."""
+    b, c, d, h, w = x.shape
+    padded = torch.nn.functional.pad(x, (0, 0, 0, 0, 1, 1))                       # zero slices before and after the depth axis
+    taps = torch.stack([padded[:, :, kd:kd + d] for kd in range(3)], 1)           # (B, 3, C, D, H, W)
+    return taps.permute(0, 3, 1, 2, 4, 5).reshape(b * d, 3 * c, h, w)
