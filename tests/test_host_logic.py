@@ -224,3 +224,39 @@ def test_internal_channel_padding_is_invisible(cpu_checker):
                    cfg["strides"], 2, cfg["classes"], 2, conv_bias=False, norm_op=cfg["norm_op"],
                    norm_op_kwargs={'eps': 1e-5, 'affine': True}, nonlin=torch.nn.LeakyReLU, nonlin_kwargs={'inplace': True})
     assert plain.padded_modules == 0
+
+
+def test_depth_unroll_formulation_of_the_3d_gradients():
+    """The algebra behind graph_ops._ConvDgradAsForward's 2-D weight gradient and _ConvDepthUnrolledGrads, on the CPU with the
+    oracle's depth_unroll_ref in place of the kernel: for a [3,3,3] 'same' convolution with depth stride 1 (in-plane stride 1 or
+    2), (a) the forward, (b) the weight gradient and (c) the data gradient equal the 2-D problems over the depth-unrolled
+    tensors with the filters rearranged the way the product rearranges them."""
+    import torch
+    import torch.nn.functional as F
+    from oracle.ref_ops import depth_unroll_ref
+
+    torch.manual_seed(5)
+    for stride in ((1, 1, 1), (1, 2, 2)):
+        b, ci, co, d, h, w = 2, 4, 6, 5, 8, 10
+        x = torch.randn(b, ci, d, h, w, dtype=torch.float64, requires_grad=True)
+        wt = torch.randn(co, ci, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        y = F.conv3d(x, wt, None, stride=stride, padding=1)
+        gy = torch.randn_like(y)
+        gx, gw = torch.autograd.grad(y, (x, wt), gy)
+
+        def flat(t):                                   # (B, C, D, H, W) -> (B*D, C, H, W)
+            return t.permute(0, 2, 1, 3, 4).reshape(t.shape[0] * t.shape[2], t.shape[1], t.shape[3], t.shape[4])
+
+        # (a) + (b): taps of x as input channels, filter (Cout, kd*Cin + ci, kh, kw)
+        x3 = depth_unroll_ref(x.detach()).requires_grad_(True)
+        w2 = wt.detach().permute(0, 2, 1, 3, 4).reshape(co, 3 * ci, 3, 3).requires_grad_(True)
+        y2 = F.conv2d(x3, w2, None, stride=stride[1:], padding=1)
+        assert torch.allclose(y2, flat(y.detach()), atol=1e-12)
+        gw2, = torch.autograd.grad(y2, w2, flat(gy))
+        assert torch.allclose(gw2.reshape(co, 3, ci, 3, 3).permute(0, 2, 1, 3, 4), gw, atol=1e-10)
+        # (c): taps of gy as 3*Cout output channels, depth-flipped filter ((kd', co), ci, kh, kw) = w[co, ci, 2 - kd']
+        w3 = wt.detach().flip(2).permute(2, 0, 1, 3, 4).reshape(3 * co, ci, 3, 3)
+        x2 = flat(x.detach()).requires_grad_(True)
+        y3 = F.conv2d(x2, w3, None, stride=stride[1:], padding=1)
+        gx2, = torch.autograd.grad(y3, x2, depth_unroll_ref(gy))
+        assert torch.allclose(gx2.reshape(b, d, ci, h, w).permute(0, 2, 1, 3, 4), gx, atol=1e-10)
