@@ -8,9 +8,11 @@
 //   pw_rows    y[p, n]  = sum_k x[p, k] * w[n, k] (+ bias[n])        forward; data gradient with w transposed
 //   pw_wgrad   dw[n, k] = sum_p gy[p, n] * x[p, k]                   weight gradient: reduction over ALL points
 //
-// Channel counts are 44 ... 1296 (multiples of 4, rarely of 32) and the point count is 336 ... 5.5 M, so the library
-// kernels PyTorch-ROCm picks run at 20-50 % (forward, data gradient) and 2-24 % (weight gradient) of the f32 MFMA
-// peak (profiles/r02_conv_evidence_padding_ab.md).  Both kernels here use v_mfma_f32_16x16x4_f32 (exact f32, bitwise
+// Channel counts are 44 ... 1296 (multiples of 4, rarely of 32) and the point count is 336 ... 5.5 M; CK's 3-D kernels
+// run these at 20-50 % (forward, data gradient) and 2-24 % (weight gradient) of the f32 MFMA peak
+// (profiles/r02_conv_evidence_padding_ab.md), MIOpen's 2-D assembly kernels on the depth-flat view at 45-60 % — which is
+// where these kernels are as well (profiles/r02_pw_gemm.md: level stand-alone, not yet ahead in the step, hence opt-in via
+// NEXTOU_PW_GEMM=1).  Both kernels here use v_mfma_f32_16x16x4_f32 (exact f32, bitwise
 // an fmaf chain; 16-granular tiles waste <= 9 % on these channel counts), keep the channel dimension in the lane's
 // four accumulator registers so that results leave as 16-byte stores, and map workgroups to XCDs so that the
 // workgroups which share an input tile share an L2.
