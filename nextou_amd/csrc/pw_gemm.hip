@@ -44,6 +44,12 @@ __device__ __forceinline__ int xcd_item(int block, int grid) { return (block % k
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// v or zeros, component-wise: `ok ? a : b` on two float4 lvalues is a select of ADDRESSES, which parks the register arrays
+// the operands live in on the stack (scratch)
+__device__ __forceinline__ float4 keep_if(bool ok, float4 v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // y[p, n] = sum_k x[p, k] w[n, k] + bias[n]
 // ------------------------------------------------------------------------------------------------------------
@@ -78,37 +84,41 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
     // to) one register set and the loads of stage s + 2 are issued into the other — one stage of MFMAs (~1.2 us) does not
     // cover the memory latency under load, two do
     float4 xr[2][XV], wr[2][WV];
-    auto load_stage = [&](int p0, int n0, int k0, float4* xq, float4* wq) {
+    // loads are UNCONDITIONAL and their results are not touched until the LDS store one stage later (addresses clamped into the
+    // tensor; out-of-range pieces are zeroed by a select in store_stage): a predicated load is a branch, and a select right
+    // behind the load is a use — either way the compiler waits (s_waitcnt vmcnt(0)) for loads it has just issued, which
+    // defeats the prefetch.  Like this it waits with vmcnt(n), n = the loads of the younger stage still in flight.
+    auto load_stage = [&](int p0, int n0, int k0, float4 (&xq)[XV], float4 (&wq)[WV]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int f = tid + i * 256, row = f / (kPwKC / 4), c4 = f % (kPwKC / 4);
-            const int p = p0 + row, k = k0 + c4 * 4;
-            xq[i] = (p < P && k < K) ? ld4(X + (long)p * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xq[i] = ld4(X + (long)min(p0 + row, P - 1) * ldx + min(k0 + c4 * 4, K - 4));
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int f = tid + i * 256, row = f / (kPwKC / 4), c4 = f % (kPwKC / 4);
-            const int n = n0 + row, k = k0 + c4 * 4;
-            wq[i] = (row < BN && n < N && k < K) ? ld4(Wt + (long)n * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wq[i] = ld4(Wt + (long)min(n0 + row, N - 1) * ldw + min(k0 + c4 * 4, K - 4));
         }
     };
-    auto store_stage = [&](int buf, const float4* xq, const float4* wq) {
+    auto store_stage = [&](int buf, int p0, int n0, int k0, const float4 (&xq)[XV], const float4 (&wq)[WV]) __attribute__((always_inline)) {
         float* xs = Xs + buf * BM * kPwLd;
         float* ws = Ws + buf * BN * kPwLd;
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int f = tid + i * 256, row = f / (kPwKC / 4), c4 = f % (kPwKC / 4);
-            *reinterpret_cast<float4*>(xs + row * kPwLd + c4 * 4) = xq[i];
+            const bool ok = p0 + row < P && k0 + c4 * 4 < K;
+            *reinterpret_cast<float4*>(xs + row * kPwLd + c4 * 4) = keep_if(ok, xq[i]);
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int f = tid + i * 256, row = f / (kPwKC / 4), c4 = f % (kPwKC / 4);
-            if (row < BN) *reinterpret_cast<float4*>(ws + row * kPwLd + c4 * 4) = wq[i];
+            const bool ok = n0 + row < N && k0 + c4 * 4 < K;
+            if (row < BN) *reinterpret_cast<float4*>(ws + row * kPwLd + c4 * 4) = keep_if(ok, wq[i]);
         }
     };
 
     f32x4 acc[TM][TN];
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const float* xs = Xs + buf * BM * kPwLd + (wave * TM * 16 + r16) * kPwLd + kg * 4;
         const float* ws = Ws + buf * BN * kPwLd + r16 * kPwLd + kg * 4;
         float4 b[TM];
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
         }
     };
 
-    auto epilogue = [&](int p0, int n0) {
+    auto epilogue = [&](int p0, int n0) __attribute__((always_inline)) {
         // D tile: column = lane & 15 = point, row = 4 (lane >> 4) + reg = channel -> one 16-byte store per tile and lane
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -172,11 +182,11 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
         p0 = (item / nb_n) * BM;
         n0 = (item % nb_n) * BN;
         load_stage(p0, n0, 0, xr[0], wr[0]);
-        if (stages > 1) load_stage(p0, n0, kPwKC, xr[1], wr[1]);
+        load_stage(p0, n0, stages > 1 ? kPwKC : 0, xr[1], wr[1]);
     }
     while (item >= 0) {
         __syncthreads();                       // the previous tile's last LDS reads are done
-        store_stage(0, xr[0], wr[0]);
+        store_stage(0, p0, n0, 0, xr[0], wr[0]);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -185,23 +195,21 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
         // stages in pairs (LDS buffer 0, then 1) so that the register sets are indexed statically; no exit inside the pair —
         // an exit there makes the compiler shuttle every accumulator between AGPRs and VGPRs once per iteration
         for (int s = 0; s + 1 < stages; s += 2) {
-            if (s + 2 < stages) load_stage(p0, n0, (s + 2) * kPwKC, xr[0], wr[0]);
+            load_stage(p0, n0, min(s + 2, stages - 1) * kPwKC, xr[0], wr[0]);     // past the end: a re-read nobody stores
             compute(0);
-            store_stage(1, xr[1], wr[1]);
+            store_stage(1, p0, n0, (s + 1) * kPwKC, xr[1], wr[1]);
             __syncthreads();
-            if (s + 3 < stages) load_stage(p0, n0, (s + 3) * kPwKC, xr[1], wr[1]);
+            load_stage(p0, n0, min(s + 3, stages - 1) * kPwKC, xr[1], wr[1]);
             compute(1);
-            if (s + 2 < stages) store_stage(0, xr[0], wr[0]);
+            store_stage(0, p0, n0, (s + 2) * kPwKC, xr[0], wr[0]);     // past the end: zeros nobody reads (no branch: keeps vmcnt exact)
             __syncthreads();
         }
         if (stages & 1) compute(0);
         walk += slots;
         const int next = item_at(walk);
-        const int np0 = next >= 0 ? (next / nb_n) * BM : 0, nn0 = next >= 0 ? (next % nb_n) * BN : 0;
-        if (next >= 0) {
-            load_stage(np0, nn0, 0, xr[0], wr[0]);
-            if (stages > 1) load_stage(np0, nn0, kPwKC, xr[1], wr[1]);
-        }
+        const int np0 = next >= 0 ? (next / nb_n) * BM : p0, nn0 = next >= 0 ? (next % nb_n) * BN : n0;
+        load_stage(np0, nn0, 0, xr[0], wr[0]);                                    // no next tile: a re-read of this one
+        load_stage(np0, nn0, stages > 1 ? kPwKC : 0, xr[1], wr[1]);
         epilogue(p0, n0);
         item = next;
         p0 = np0;
@@ -248,32 +256,32 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void pw_wgrad_kernel(const float* 
 
     // register staging with prefetch distance 2 (see pw_rows_kernel)
     float4 gr[2][GV], xr[2][XV];
-    auto load_stage = [&](int p_row0, float4* gq, float4* xq) {
+    auto load_stage = [&](int p_row0, float4 (&gq)[GV], float4 (&xq)[XV]) __attribute__((always_inline)) {          // unconditional, clamped, untouched until the store: see pw_rows_kernel
 #pragma unroll
         for (int i = 0; i < GV; ++i) {
             const int f = tid + i * NT, row = f / GQ, c = (f - row * GQ) * 4;
-            const int p = p_row0 + row, col = n0 + c;
-            gq[i] = (row < kWgPC && p < p_end && col < N) ? ld4(G + (long)p * ldg + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            gq[i] = ld4(G + (long)min(p_row0 + row, P - 1) * ldg + min(n0 + c, N - 4));
         }
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int f = tid + i * NT, row = f / XQ, c = (f - row * XQ) * 4;
-            const int p = p_row0 + row, col = k0 + c;
-            xq[i] = (row < kWgPC && p < p_end && col < K) ? ld4(X + (long)p * ldx + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xq[i] = ld4(X + (long)min(p_row0 + row, P - 1) * ldx + min(k0 + c, K - 4));
         }
     };
-    auto store_stage = [&](int buf, const float4* gq, const float4* xq) {
+    auto store_stage = [&](int buf, int p_row0, const float4 (&gq)[GV], const float4 (&xq)[XV]) __attribute__((always_inline)) {
         float* gs = Gs + buf * kWgPC * SG;
         float* xs = Xs + buf * kWgPC * SX;
 #pragma unroll
         for (int i = 0; i < GV; ++i) {
             const int f = tid + i * NT, row = f / GQ, c = (f - row * GQ) * 4;
-            if (row < kWgPC) *reinterpret_cast<float4*>(gs + row * SG + c) = gq[i];
+            const bool ok = p_row0 + row < p_end && n0 + c < N;
+            if (row < kWgPC) *reinterpret_cast<float4*>(gs + row * SG + c) = keep_if(ok, gq[i]);
         }
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int f = tid + i * NT, row = f / XQ, c = (f - row * XQ) * 4;
-            if (row < kWgPC) *reinterpret_cast<float4*>(xs + row * SX + c) = xq[i];
+            const bool ok = p_row0 + row < p_end && k0 + c < K;
+            if (row < kWgPC) *reinterpret_cast<float4*>(xs + row * SX + c) = keep_if(ok, xq[i]);
         }
     };
 
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void pw_wgrad_kernel(const float* 
 #pragma unroll
         for (int j = 0; j < TK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const float* gs = Gs + buf * kWgPC * SG + pg * SG + wave_n * TN * 16 + c16;
         const float* xs = Xs + buf * kWgPC * SX + pg * SX + wave_k * TK * 16 + c16;
 #pragma unroll
@@ -303,18 +311,18 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void pw_wgrad_kernel(const float* 
     const int stages = (p_end - p_begin + kWgPC - 1) / kWgPC;
     if (stages > 0) {
         load_stage(p_begin, gr[0], xr[0]);
-        if (stages > 1) load_stage(p_begin + kWgPC, gr[1], xr[1]);
-        store_stage(0, gr[0], xr[0]);
+        load_stage(p_begin + kWgPC, gr[1], xr[1]);
+        store_stage(0, p_begin, gr[0], xr[0]);
     }
     __syncthreads();
-    for (int s = 0; s + 1 < stages; s += 2) {      // pairs, no exit inside: see pw_rows_kernel
-        if (s + 2 < stages) load_stage(p_begin + (s + 2) * kWgPC, gr[0], xr[0]);
+    for (int s = 0; s + 1 < stages; s += 2) {      // pairs, no exit inside, loads always issued: see pw_rows_kernel
+        load_stage(p_begin + (s + 2) * kWgPC, gr[0], xr[0]);       // past p_end: zeros (addresses clamped)
         compute(0);
-        store_stage(1, gr[1], xr[1]);
+        store_stage(1, p_begin + (s + 1) * kWgPC, gr[1], xr[1]);
         __syncthreads();
-        if (s + 3 < stages) load_stage(p_begin + (s + 3) * kWgPC, gr[1], xr[1]);
+        load_stage(p_begin + (s + 3) * kWgPC, gr[1], xr[1]);
         compute(1);
-        if (s + 2 < stages) store_stage(0, gr[0], xr[0]);
+        store_stage(0, p_begin + (s + 2) * kWgPC, gr[0], xr[0]);          // past p_end: zeros nobody reads
         __syncthreads();
     }
     if (stages & 1) compute(0);
