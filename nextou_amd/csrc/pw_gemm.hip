@@ -125,11 +125,16 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < TM; ++i) b[i] = ld4(xs + i * 16 * kPwLd);
         // the four k sub-steps of one accumulator are a dependent chain (40-cycle latency, 32-cycle issue): run them over
-        // 2 channel tiles x TM point tiles at a time, so that a chain's next link is >= 4 MFMAs away
+        // 2 channel tiles x TM point tiles at a time, so that a chain's next link is >= 4 MFMAs away; the weight fragments of
+        // the NEXT pair are read from LDS before the MFMAs of the current one (the compiler, left alone, reads them right in
+        // front of their first use: ~100 cycles of LDS latency exposed per 16 MFMAs)
+        float4 a0 = ld4(ws), a1 = TN > 1 ? ld4(ws + 16 * kPwLd) : a0;
 #pragma unroll
         for (int j = 0; j < TN; j += 2) {
-            const float4 a0 = ld4(ws + j * 16 * kPwLd);
-            const float4 a1 = (j + 1 < TN) ? ld4(ws + (j + 1) * 16 * kPwLd) : a0;
+            float4 n0f = a0, n1f = a1;
+            if (j + 2 < TN) n0f = ld4(ws + (j + 2) * 16 * kPwLd);
+            if (j + 3 < TN) n1f = ld4(ws + (j + 3) * 16 * kPwLd);
+            __builtin_amdgcn_sched_barrier(0);      // the scheduler would sink the two reads to just before their first use
 #define NEXTOU_PW_STEP(c)                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                       \
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.c, b[i].c, acc[i][j], 0, 0, 0);                               \
@@ -140,6 +145,8 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
             NEXTOU_PW_STEP(z)
             NEXTOU_PW_STEP(w)
 #undef NEXTOU_PW_STEP
+            a0 = n0f;
+            a1 = n1f;
         }
     };
 
