@@ -34,6 +34,14 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// NEXTOU_PW_ABLATE (experiments, tools/pw_ablate.sh — never in the product build): 1 = no MFMAs (LDS reads kept), 2 = global loads and LDS
+// stores only for the first stage of a tile, 4 = no result stores
+#ifndef NEXTOU_PW_ABLATE
+#define NEXTOU_PW_ABLATE 0
+#endif
+#ifndef NEXTOU_PW_STAGGER
+#define NEXTOU_PW_STAGGER 0          // x 8128 cycles of start delay for every second resident generation of workgroups (experiment)
+#endif
 constexpr int kPwKC = 16;          // k per LDS stage of pw_rows: one MFMA round (4 lane groups x float4)
 constexpr int kPwLd = kPwKC + 4;   // 20 floats = 80 B = 4 * odd
 constexpr int kXcds = 8;
@@ -135,11 +143,15 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
             if (j + 2 < TN) n0f = ld4(ws + (j + 2) * 16 * kPwLd);
             if (j + 3 < TN) n1f = ld4(ws + (j + 3) * 16 * kPwLd);
             __builtin_amdgcn_sched_barrier(0);      // the scheduler would sink the two reads to just before their first use
+#if NEXTOU_PW_ABLATE & 1
+#define NEXTOU_PW_STEP(c) _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[i][j][0] += a0.c + a1.c + b[i].c;
+#else
 #define NEXTOU_PW_STEP(c)                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                       \
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.c, b[i].c, acc[i][j], 0, 0, 0);                               \
         if (j + 1 < TN) acc[i][j + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.c, b[i].c, acc[i][j + 1], 0, 0, 0);       \
     }
+#endif
             NEXTOU_PW_STEP(x)
             NEXTOU_PW_STEP(y)
             NEXTOU_PW_STEP(z)
@@ -168,6 +180,9 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
             for (int i = 0; i < TM; ++i) {
                 const int p = p0 + (wave * TM + i) * 16 + r16;
                 if (p >= P) continue;
+#if NEXTOU_PW_ABLATE & 4
+                if (acc[i][j][0] == acc[i][j][0]) continue;      // stores only for NaNs: keeps the accumulators alive
+#endif
                 float* yp = Y + (long)p * ldy + n;
                 const float4 v = make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
                 if (vec_store && n + 3 < N) {
@@ -185,6 +200,14 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
     const int stages = (K + kPwKC - 1) / kPwKC;
     int item = item_at(walk);
     int p0 = 0, n0 = 0;
+#if NEXTOU_PW_STAGGER
+    // the workgroups that share a CU start together and stay in lockstep: they all multiply, then they all store — the matrix
+    // pipes idle while the stores drain and HBM idles while they multiply (ablation: 223 us compute-only + 66 us stores + ~40 us
+    // loads = the 322 us measured, no overlap).  Delaying the second resident generation by about half a tile period puts its
+    // store phase under the first generation's multiply phase.
+    if ((blockIdx.x / (kXcds * 32)) & 1)
+        for (int i = 0; i < NEXTOU_PW_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     if (item >= 0) {
         p0 = (item / nb_n) * BM;
         n0 = (item % nb_n) * BN;
@@ -202,6 +225,12 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
         // stages in pairs (LDS buffer 0, then 1) so that the register sets are indexed statically; no exit inside the pair —
         // an exit there makes the compiler shuttle every accumulator between AGPRs and VGPRs once per iteration
         for (int s = 0; s + 1 < stages; s += 2) {
+#if NEXTOU_PW_ABLATE & 2
+            compute(0);
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+#else
             load_stage(p0, n0, min(s + 2, stages - 1) * kPwKC, xr[0], wr[0]);     // past the end: a re-read nobody stores
             compute(0);
             store_stage(1, p0, n0, (s + 1) * kPwKC, xr[1], wr[1]);
@@ -210,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
             compute(1);
             store_stage(0, p0, n0, (s + 2) * kPwKC, xr[0], wr[0]);     // past the end: zeros nobody reads (no branch: keeps vmcnt exact)
             __syncthreads();
+#endif
         }
         if (stages & 1) compute(0);
         walk += slots;
@@ -396,6 +426,11 @@ RowsPlan plan_rows(int P, int N, int groups) {
         // cost: padded MFMA work, plus a small penalty per extra pass over x (more workgroup columns)
         const long cost = padded * 100 + (long)((t + tn - 1) / tn) * 3 * 16;
         if (best_cost < 0 || cost < best_cost || (cost == best_cost && tn > best)) { best_cost = cost; best = tn; }
+    }
+    if (const char* e = getenv("NEXTOU_PW_ROWS_TN")) {          // experiment: force the channel tiles per workgroup
+        const int v = atoi(e);
+        for (int tn : kTn)
+            if (tn == v) best = v;
     }
     RowsPlan q{};
     q.tm = 2;
