@@ -136,7 +136,15 @@ def roofline_graph_from(report):
     def pick(prefixes):
         rows = [r for r in report if r["kernel"].startswith(prefixes)]
         return _roofline_entry(max(rows, key=lambda r: r["ms"])) if rows else None
-    return {"K1_knn": pick(("knn_fused_kernel",)), "K2_mr_forward": pick(("mr_fwd",)), "K2_mr_backward": pick(("mr_bwd",)),
+    def worst(prefixes):
+        """the launch shape of these kernels that sits furthest below its roofline (the small stage-4 / 5 calls)"""
+        rows = [_roofline_entry(r) for r in report if r["kernel"].startswith(prefixes)]
+        return min(rows, key=lambda e: e["frac"]) if rows else None
+    return {"K1_knn": pick(("knn_fused_kernel", "knn_window_kernel")), "K2_mr_forward": pick(("mr_fwd",)), "K2_mr_backward": pick(("mr_bwd",)),
+            "K1_knn_worst_shape": worst(("knn_fused_kernel", "knn_window_kernel")), "K2_mr_forward_worst_shape": worst(("mr_fwd",)),
+            "K5_argmax_labels": pick(("argmax_labels_kernel",)), "K5_bti_critical": pick(("bti_critical_kernel",)),
+            "K5_bti_ce_forward": pick(("bti_ce_fwd_kernel",)), "K5_bti_ce_backward": pick(("bti_ce_bwd_kernel",)),
+            "K7_pointwise_rows": pick(("pw_rows_kernel", "pw_fused")), "K7_pointwise_wgrad": pick(("pw_wgrad_kernel",)),
             "graph_kernels_ms_per_step": None}
 
 
@@ -155,8 +163,12 @@ def roofline_from(report):
     tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):   # HBM bytes per launch from a committed rocprofv3 --pmc run
         traffic = json.load(open(tpath)).get(top["kernel"])
+    real = _real_channel_fraction(top["kernel"])
     return {"bound": top["bound"], "achieved": round(achieved, 3), "peak": peak, "unit": unit,
             "frac": round(achieved / peak, 4), "traffic": traffic,
+            "frac_on_unpadded_bytes": None if real is None else round(real * achieved / peak, 4),
+            "frac_on_unpadded_bytes_note": "the plain stages carry 33 -> 40 / 66 -> 72 channels inside the network (channel_pad.py); "
+                                           "`achieved` counts the bytes the kernel really moves, this field only the real channels' share",
             "traffic_source": "not measured in this run: looked up in profiles/pmc_traffic.json, the committed rocprofv3 "
                               "--pmc FETCH_SIZE / WRITE_SIZE passes (separate, gfx950-corrected) of this kernel label; "
                               "null when the label has no committed counter run",
@@ -164,7 +176,19 @@ def roofline_from(report):
             "own_kernels_ms_per_step": None}
 
 
-def cpu_baseline(workload, timed_steps=2):
+def _real_channel_fraction(label):
+    """C_real / C_padded when the launch label is a K6 call on an internally padded plain-stage tensor (C = 40 or 72 at cfg 2)."""
+    import re
+    m = re.search(r"\[B\d+ C(\d+) S\d+\]", label)
+    if not m or not label.startswith(("bn_", "channel_sum")):
+        return None
+    return {40: 33.0 / 40.0, 72: 66.0 / 72.0}.get(int(m.group(1)))
+
+
+CPU_BASELINE_THREADS = None     # set from the committed sweep (profiles/r03_cpu_baseline_thread_sweep.md); None = torch's default
+
+
+def cpu_baseline(workload, timed_steps=2, threads=None, sweep=False):
     """oracle/ref_ops.py (the reference's op sequence, PyTorch-CPU fp32) on this host's cores: train steps of the same
     network at batch 1 — 1 warm-up + ``timed_steps`` timed, median reported.
 
@@ -176,7 +200,7 @@ def cpu_baseline(workload, timed_steps=2):
     from oracle.ref_ops import TorchRefBackend   # checker / baseline only — never the product path
     import oracle  # noqa: F401
     patch, base, max_f, _, classes = WORKLOADS[workload]
-    threads = torch.get_num_threads()
+    default_threads = torch.get_num_threads()
     graph_ops.install_cpu_checker(TorchRefBackend)
     try:
         trainer, cfg, _, _ = build_trainer(workload, torch.device("cpu"), False)
@@ -186,20 +210,40 @@ def cpu_baseline(workload, timed_steps=2):
         targets = [target if s == tuple(target.shape[2:]) else
                    torch.nn.functional.interpolate(target, size=s, mode="nearest") for s in shapes]
         step = make_step(trainer, data, targets, None)
-        times = []
-        for i in range(1 + timed_steps):
+
+        def timed():
             t0 = time.perf_counter()
             step()
-            times.append(time.perf_counter() - t0)
+            return time.perf_counter() - t0
+
+        # 128 threads on a 256-logical-core host lost to the reference on 8 cores.  `--cpu-thread-sweep`
+        # times ONE step per thread count after the warm-up (~6 extra steps, ~5 min: not the default run); the default run
+        # uses the thread count that sweep found best on this host type (CPU_BASELINE_THREADS) and says so in `cores`.
+        warm = timed()
+        physical = max(1, (os.cpu_count() or 2) // 2)
+        chosen = min(threads or CPU_BASELINE_THREADS or default_threads, max(physical, 1))
+        sweep_times = {}
+        if sweep:
+            for n in sorted({min(n, physical) for n in (8, 16, 32, 64, 128)} | {chosen}):
+                torch.set_num_threads(n)
+                sweep_times[n] = timed()
+            chosen = min(sweep_times, key=sweep_times.get)
+        torch.set_num_threads(chosen)
+        times = ([sweep_times[chosen]] if sweep else []) + [timed() for _ in range(max(timed_steps - (1 if sweep else 0), 1))]
+        best = chosen
     finally:
         graph_ops.install_cpu_checker(None)
+        torch.set_num_threads(default_threads)
     voxels = int(np.prod(patch))
-    timed = sorted(times[1:])
-    dt = timed[len(timed) // 2] if len(timed) % 2 else 0.5 * (timed[len(timed) // 2 - 1] + timed[len(timed) // 2])
-    return {"value": round(voxels / dt, 1), "unit": "voxels/s", "cores": threads, "kind": "port",
-            "sample": "train steps (fwd+loss+bwd+SGD) at batch 1 of the %s patch, fp32: 1 warm-up (%.1f s) + %d timed (%s s), "
-                      "median %.1f s" % ("x".join(map(str, patch)), times[0], timed_steps,
-                                         ", ".join("%.1f" % t for t in times[1:]), dt),
+    timed_sorted = sorted(times)
+    n = len(timed_sorted)
+    dt = timed_sorted[n // 2] if n % 2 else 0.5 * (timed_sorted[n // 2 - 1] + timed_sorted[n // 2])
+    return {"value": round(voxels / dt, 1), "unit": "voxels/s", "cores": best, "kind": "port",
+            "sample": "train steps (fwd+loss+bwd+SGD) at batch 1 of the %s patch, fp32: 1 warm-up (%.1f s) + %d timed on %d threads "
+                      "(%s s), median %.1f s%s"
+                      % ("x".join(map(str, patch)), warm, len(times), best, ", ".join("%.1f" % t for t in times), dt,
+                         "; thread sweep, one step each: %s" % {k: round(v, 1) for k, v in sweep_times.items()} if sweep else ""),
+            "thread_sweep_s_per_step": {str(k): round(v, 2) for k, v in sweep_times.items()} or None,
             "cpu": _cpu_model()}
 
 
@@ -237,6 +281,9 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps after one warm-up (batch 1)")
+    ap.add_argument("--cpu-threads", type=int, default=None, help="threads of the CPU-baseline leg (default: the committed sweep's best)")
+    ap.add_argument("--cpu-thread-sweep", action="store_true",
+                    help="CPU-baseline leg: after the warm-up, time one step at 8/16/32/64/128 threads and report the best (~5 min extra)")
     ap.add_argument("--no-miopen-find", action="store_true", help="disable MIOpen's find/benchmark mode")
     ap.add_argument("--bucket-mb", type=int, default=32)
     ap.add_argument("--force-averager", action="store_true",
@@ -246,9 +293,9 @@ def main():
                     help="informational (cfg-5 regime): conv stages under bf16 autocast, graph ops stay fp32; "
                          "never the headline number")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="replay the training step as one captured hipGraph (harness.GraphedTrainStep).  auto = on for one GPU "
-                         "without the gradient averager (the N > 1 step launches RCCL collectives from autograd hooks and stays "
-                         "eager), fp32 cfg 2 / cfg 5 / tiny; falls back to the eager step if the capture fails")
+                    help="replay the training step as one captured hipGraph (harness.GraphedTrainStep).  auto = on for every N "
+                         "(the averaged step captures its RCCL collectives) except cfg 4 (host-side target validation); auto "
+                         "falls back to the eager step if the capture fails and reports the error in the JSON line, on raises")
     ap.add_argument("--channels-last", action="store_true",
                     help="experiment: run the dense stages in channels_last_3d (NDHWC) memory format")
     args = ap.parse_args()
@@ -287,15 +334,22 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    want_graph = args.graph == "on" or (args.graph == "auto" and averager is None and world == 1 and args.workload != "cfg4")
-    graphed = None
+    # auto: the whole step as one hipGraph, N = 1 and N > 1 alike (the averaged step is capturable: RCCL collectives on their
+    # own stream, no host synchronisation in the hooks or in finalize() once the warm-up steps have seen the gradient pattern)
+    want_graph = args.graph == "on" or (args.graph == "auto" and args.workload != "cfg4")
+    graphed, capture_error = None, None
     if want_graph:
         try:
-            graphed = GraphedTrainStep(step, warmup=1)
+            graphed = GraphedTrainStep(step, warmup=1, network=trainer.network)
             for _ in range(2):
                 graphed()
-        except Exception as exc:            # capture is an optimisation: the eager step is the same computation
-            print("bench.py: hipGraph capture failed (%s: %s); timing the eager step" % (type(exc).__name__, exc), file=sys.stderr)
+        except Exception as exc:
+            # never silent: `--graph on` fails; `auto` falls back to the eager step — the same computation —
+            # and the JSON line says so (config.step_replayed_as_hipgraph = false, config.graph_capture_error)
+            if args.graph == "on":
+                raise
+            capture_error = "%s: %s" % (type(exc).__name__, exc)
+            print("bench.py: hipGraph capture failed (%s); timing the eager step" % capture_error, file=sys.stderr)
             graphed = None
             torch.cuda.synchronize()
     if world > 1:
@@ -321,6 +375,8 @@ def main():
     report = profile_report()
     _lib.lib().nextou_profile_enable(0)
     profiled_steps = 3 if graphed is not None else args.steps
+    if averager is not None:
+        averager.check_consistency()        # every rank produced gradients for the same parameters on every step
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -353,14 +409,14 @@ def main():
                        "layout": "channels-last stages %s" % sorted(trainer.network.encoder.channels_last_stages),
                        "internal_channel_padding_modules": getattr(trainer.network, "padded_modules", 0),
                        "gradient_averager": averager is not None,
-                       "step_replayed_as_hipgraph": graphed is not None,
+                       "step_replayed_as_hipgraph": graphed is not None, "graph_capture_error": capture_error,
                        "parallelism": "dp%d" % world, "final_loss": float(loss.detach())},
             "roofline": roof,
             "roofline_graph": graph,
         }
         if cpu_copy_ok:
             try:
-                line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_steps)
+                line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_steps, args.cpu_threads, args.cpu_thread_sweep)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "voxels/s", "cores": torch.get_num_threads(),
                                         "kind": "port", "sample": "failed: %r" % (e,)}

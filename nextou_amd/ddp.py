@@ -85,6 +85,8 @@ class BucketedGradientAverager:
         self._slot = {}
         self._hooks = []
         self._produced_cache = {}
+        self._missing_cache = {}
+        self._mismatch = torch.zeros((), dtype=torch.long, device=params[0].device) if params else None
         for bi, b in enumerate(self.buckets):
             for pi, p in enumerate(b.params):
                 self._slot[p] = (bi, pi)
@@ -117,23 +119,36 @@ class BucketedGradientAverager:
                 p.grad = None
 
     @torch.no_grad()
+    def _missing_index(self, b: _Bucket, pattern) -> torch.Tensor:
+        """Device int64 positions of the parameters without a local gradient, one tensor per distinct pattern (built once:
+        the host-to-device copy behind it blocks the host, which must not happen in the middle of every backward — and
+        cannot happen inside a captured step, where the warm-up steps have filled this cache)."""
+        key = (id(b), pattern)
+        idx = self._missing_cache.get(key)
+        if idx is None:
+            idx = torch.tensor([pi for pi, f in enumerate(pattern) if not f], dtype=torch.long).to(b.flat.device)
+            self._missing_cache[key] = idx
+        return idx
+
+    @torch.no_grad()
     def _launch(self, b: _Bucket) -> None:
-        src, dst = [], []
+        src, dst, empty = [], [], []
         for pi, p in enumerate(b.params):
             if b.filled[pi]:
                 if p.grad.data_ptr() != b.views[pi].data_ptr():     # accumulated in place into the view: nothing to move
                     src.append(p.grad.reshape(b.views[pi].shape) if p.grad.shape != b.views[pi].shape else p.grad)
                     dst.append(b.views[pi])
             else:
-                b.views[pi].zero_()
+                empty.append(b.views[pi])
         if dst:
             torch._foreach_copy_(dst, src)
-        # "was produced" flags, written with device-side fills only: a host-to-device copy from pageable memory would
-        # block the host until the stream reaches it — in the middle of backward — and starve the launch queue behind it
+        # "was produced" flags, written with device-side fills only (two launches whatever the pattern): a host-to-device
+        # copy from pageable memory would block the host until the stream reaches it — in the middle of backward — and
+        # starve the launch queue behind it
         b.flags.fill_(1.0)
-        for pi, f in enumerate(b.filled):
-            if not f:
-                b.flags[pi:pi + 1].zero_()
+        if empty:
+            torch._foreach_zero_(empty)                              # one multi-tensor launch, not one per parameter
+            b.flags.index_fill_(0, self._missing_index(b, tuple(b.filled)), 0.0)
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     @torch.no_grad()
@@ -149,27 +164,48 @@ class BucketedGradientAverager:
     @torch.no_grad()
     def finalize(self) -> None:
         """Join the collectives.  Buckets with a parameter that got no gradient on this rank (e.g. the zero-weighted
-        lowest deep-supervision head) are launched here with zeros in its place."""
+        lowest deep-supervision head) are launched here with zeros in its place.
+
+        No host synchronisation after the first step of a given pattern, so a whole averaged step can be captured into one
+        hipGraph (``harness.GraphedTrainStep``; RCCL collectives are capturable): which parameters NO rank produced a
+        gradient for — those keep ``grad = None`` — is read back once per distinct local pattern and remembered.  That is
+        sound only while the pattern is STRUCTURAL, i.e. the same on every rank and every step (the zero-weighted head).
+        The summed flags show a violation on the device (0 < flag < world: some ranks produced the gradient, others did
+        not); every step adds those to a device counter, and :meth:`check_consistency` — one host read, called by the
+        caller wherever it synchronises anyway — raises if the contract was ever broken."""
         for b in self.buckets:
             if b.work is None:
                 self._launch(b)
         inv = 1.0 / self.world
         for bi, b in enumerate(self.buckets):
             b.work.wait()
+            if self.world > 1:
+                self._mismatch.add_(((b.flags > 0) & (b.flags < self.world)).sum())
             b.flat[:b.n_grad].mul_(inv)
             produced = None
             if not all(b.filled):
-                # which of the locally missing gradients did NO rank produce?  Read back once per distinct pattern (a host
-                # sync), then remembered: the pattern is structural (the zero-weighted head), the same every step
                 key = (bi, tuple(b.filled))
                 if key not in self._produced_cache:
-                    self._produced_cache[key] = (b.flags > 0).tolist()
+                    flags = b.flags.tolist()                         # the one host read of this pattern
+                    if any(0 < f < self.world for f in flags):
+                        raise RuntimeError("BucketedGradientAverager: ranks disagree on which parameters of bucket %d received a "
+                                           "gradient (flags %s of world %d); only structurally unused parameters are supported"
+                                           % (bi, [f for f in flags if 0 < f < self.world][:8], self.world))
+                    self._produced_cache[key] = [f > 0 for f in flags]
                 produced = self._produced_cache[key]
             for pi, p in enumerate(b.params):
                 p.grad = b.views[pi] if (produced is None or produced[pi]) else None
             b.work = None
             b.pending = len(b.params)
             b.filled = [False] * len(b.params)
+
+    def check_consistency(self) -> None:
+        """Host read of the device-side mismatch counter (see :meth:`finalize`); raises if, on any step so far, some ranks
+        produced a gradient for a parameter and others did not."""
+        n = int(self._mismatch.item()) if self.world > 1 else 0
+        if n:
+            raise RuntimeError("BucketedGradientAverager: %d (parameter, step) pairs received a gradient on some ranks only; the "
+                               "remembered grad-is-None decisions may be stale" % n)
 
     def remove_hooks(self) -> None:
         for h in self._hooks:

@@ -170,8 +170,10 @@ class GraphedTrainStep:
     one-time attribute calls); then one step is captured.  ``__call__`` replays it and returns the captured loss tensor.
     Same numbers as the eager step (same kernels, same order)."""
 
-    def __init__(self, step_fn, warmup: int = 3):
+    def __init__(self, step_fn, warmup: int = 3, network: Optional[torch.nn.Module] = None):
         from . import _lib
+        if network is not None:
+            assert_capturable(network)
         _lib.lib().nextou_profile_enable(0)        # event records do not belong inside a captured graph
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -187,6 +189,20 @@ class GraphedTrainStep:
     def __call__(self):
         self.graph.replay()
         return self.loss
+
+
+def assert_capturable(network: torch.nn.Module) -> None:
+    """Raise unless ``network``'s forward is the same computation on every replay of a captured step: a graph block whose
+    kNN dilation is > 1 with ``stochastic`` set draws ``torch.rand`` on the host per call (reference torch_edge.py:126-136)
+    — captured once, the draw would be frozen for every replay (and its ``randperm(...).to(device)`` is a pageable
+    host-to-device copy, illegal during capture).  Every constructible NexToU has dilation 1, where the draw cannot change
+    the result and is never made; set ``epsilon = 0`` / ``stochastic = False`` on the blocks to capture anything else."""
+    from .network_architecture.torch_edge import DenseDilatedKnnGraph, reference_rng_stream
+    for name, m in network.named_modules():
+        if isinstance(m, DenseDilatedKnnGraph) and m.stochastic and m.epsilon > 0 and network.training and \
+                (m.dilation > 1 or reference_rng_stream()):
+            raise RuntimeError("GraphedTrainStep: %s draws its stochastic dilation on the host every call (dilation %d, epsilon %g); "
+                               "a captured step would freeze the draw" % (name, m.dilation, m.epsilon))
 
 
 def deep_supervision_weights(n_scales: int) -> np.ndarray:

@@ -65,6 +65,9 @@ class NexToU(nn.Module):
             self.encoder.channels_last_stages = channels_last_stages(conv_op, self.encoder.n_conv_stages, n_stages)
             # 33 -> 40 / 66 -> 72 channels inside the plain conv stages (channel_pad.py): parameters keep their shapes
             self.padded_modules = pad_plain_stage_channels(self, pad_multiple())
+            # reduced-precision autocast keeps NDHWC only when the plain stages really run multiple-of-8 channel counts
+            plain = list(self.encoder.output_channels)[:self.encoder.n_conv_stages]
+            self.encoder.reduced_precision_layout_ok = bool(self.padded_modules) or all(f % 8 == 0 for f in plain)
 
     def forward(self, x):
         return self.decoder(self.encoder(x))

@@ -447,7 +447,8 @@ class SwinGrapher(_GrapherBase):
         shortcut = x
         size_tuple = tuple(x.shape[2:])
         assert size_tuple == tuple(self.img_shape), "input features has wrong size"
-        if is_channels_last_volume(x) and isinstance(self.drop_path, nn.Identity) and self.graph_conv.r == 1:
+        if is_channels_last_volume(x) and isinstance(self.drop_path, nn.Identity) and self.graph_conv.r == 1 and \
+                self._pointwise_ops_commute_with_windows():
             return self._forward_channels_last(x, size_tuple, dim)
         axes = tuple(range(2, 2 + dim))
         shifted = max(self.shift_size) > 0
@@ -459,6 +460,15 @@ class SwinGrapher(_GrapherBase):
         if shifted:
             x = torch.roll(x, shifts=tuple(self.shift_size), dims=axes)
         return self.drop_path(x) + shortcut
+
+
+def _swin_pointwise_ops_commute(self) -> bool:
+    """fc1 / fc2 / the MRConv's norm may run on the whole volume instead of the (B * nW, C, window) tensors only when their
+    statistics are sums over ALL points of the batch (BatchNorm, or running statistics): a per-sample norm (InstanceNorm as
+    ``norm_op``) normalises per WINDOW in the reference, which the volume path would silently turn into per volume
+    (ADVICE r2).  Anything else takes the window-major path."""
+    batch_norm = nn.modules.batchnorm._BatchNorm
+    return all(isinstance(m, batch_norm) for m in (self.fc1[1], self.fc2[1], self.graph_conv.gconv.nn[1]))
 
 
 def _swin_forward_channels_last(self, x, size_tuple, dim):
@@ -480,6 +490,7 @@ def _swin_forward_channels_last(self, x, size_tuple, dim):
 
 
 SwinGrapher._forward_channels_last = _swin_forward_channels_last
+SwinGrapher._pointwise_ops_commute_with_windows = _swin_pointwise_ops_commute
 
 
 class _GNNBlocks(nn.Module):
@@ -620,11 +631,12 @@ class NexToU_Encoder(nn.Module):
         self.kernel_sizes = kernel_sizes
 
     channels_last_stages = frozenset()   # set by NexToU.__init__ (network_architecture/layout.py)
+    reduced_precision_layout_ok = None   # ... as is this: True iff the plain stages really run multiple-of-8 channel counts
 
     def forward(self, x):
         skips = []
         for s, stage in enumerate(self.stages):
-            x = stage(set_stage_layout(x, s in self.channels_last_stages))
+            x = stage(set_stage_layout(x, s in self.channels_last_stages, self.reduced_precision_layout_ok))
             skips.append(x)
         return skips if self.return_skips else skips[-1]
 
@@ -706,7 +718,7 @@ class NexToU_Decoder(nn.Module):
         last = len(self.stages) - 1
         for s, stage in enumerate(self.stages):
             # decoder stage s works at the resolution (and in the memory layout) of encoder stage last - s
-            x = set_stage_layout(x, (last - s) in self.encoder.channels_last_stages)
+            x = set_stage_layout(x, (last - s) in self.encoder.channels_last_stages, self.encoder.reduced_precision_layout_ok)
             x = self.transpconvs[s](x)
             x = stage(torch.cat((x, skips[-(s + 2)]), 1))
             if self.deep_supervision:

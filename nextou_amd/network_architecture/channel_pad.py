@@ -13,10 +13,12 @@ and optimizer state see 33 / 66).  On the forward pass a padded module builds it
 the fly (``F.pad`` / ``cat`` of a few KB — autograd slices the gradients back) and the activations between the padded
 modules carry ``pad`` extra all-zero channels:
 
-* an *entry* module (first convolution of stage 0) decides per call: it pads its output iff its input is a device tensor
-  the layout policy applies to (``layout.layout_policy_applies``; the CPU checker path stays un-padded);
-* every other padded module looks at the channel count it receives — the real count means "not padded", the padded count
-  means "padded" — and follows suit on its output;
+* an *entry* module (first convolution of stage 0; an up-convolution fed by a graph stage) decides per call: it pads its
+  output iff its input is a device tensor the layout policy applies to (``layout.layout_policy_applies``; the CPU checker
+  path stays un-padded), and records the decision in the model's shared :class:`PadRegime`;
+* every other padded module follows the channel count it receives (real count = "not padded", padded count = "padded")
+  when the two differ, and reads the shared regime when they do not: with feature counts like 12 / 24, where one plain
+  stage needs padding and the next is a multiple already, the count alone cannot tell the regimes apart (ADVICE r2);
 * *exit* modules (segmentation heads, the first convolution of the first graph stage) always emit the real channel count.
 
 Zero channels stay exactly zero through conv (zero filters) -> batch norm (mean 0, variance 0, weight 1, bias 0 -> 0) ->
@@ -79,6 +81,16 @@ class ConvPad:
     image_channels_to: int = 0      # entry only: zero-pad the network input itself to this many channels when padding
 
 
+class PadRegime:
+    """Per-forward state shared by the padded modules of ONE model: whether the activations between them currently carry
+    padding channels.  Written by the entry modules on every call, read by everything downstream."""
+
+    __slots__ = ("on",)
+
+    def __init__(self):
+        self.on = False
+
+
 def _pad_axis(t: torch.Tensor, axis: int, new: int, value: float = 0.0) -> torch.Tensor:
     n = new - t.shape[axis]
     if n == 0:
@@ -106,12 +118,15 @@ def conv_pad_plan(module: nn.Module, x: torch.Tensor):
     else:
         raise RuntimeError("channel padding: %s received %d channels, expected %d (real) or %d (padded)"
                            % (type(module).__name__, cin, real_in, padded_in))
-    if spec.exit:
-        pad_out = False
-    elif spec.entry:
-        pad_out = bool(x.is_cuda and layout_policy_applies(x)) if _force_entry is None else _force_entry
-    else:
-        pad_out = pad_in
+    regime: PadRegime = module._pad_regime
+    if spec.entry:
+        # (a module that carries a spec belongs to a model whose padding was applied: reduced precision is fine)
+        on = regime.on = bool(x.is_cuda and layout_policy_applies(x, True)) if _force_entry is None else bool(_force_entry)
+    elif padded_in != real_in:
+        on = pad_in             # the input's channel count is unambiguous (also when a sub-module is run on its own)
+    else:                       # real == padded count for this input (e.g. 24 channels): only the regime can tell
+        on = regime.on if _force_entry is None else bool(_force_entry)
+    pad_out = on and not spec.exit
     return pad_in, pad_out
 
 
@@ -225,6 +240,9 @@ def pad_plain_stage_channels(model: nn.Module, multiple: int) -> int:
     capable = (na.ConvBiasFolded3d, na.ConvOwnBias3d, na.ConvTransposeOwnBias3d, na.BatchNormAct3d)
     if not all(isinstance(m, capable) for m, _, _ in plan):
         return 0        # e.g. conv_bias=False or another norm: those module classes do not know about padding
+    regime = PadRegime()
     for m, attr, value in plan:
         setattr(m, attr, value)
+        if attr == "_pad_spec":
+            m._pad_regime = regime
     return len(plan)

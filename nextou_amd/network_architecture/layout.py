@@ -70,8 +70,10 @@ def runs_in_fp32(x: torch.Tensor) -> bool:
     return True
 
 
-def layout_policy_applies(x: torch.Tensor) -> bool:
+def layout_policy_applies(x: torch.Tensor, reduced_precision_ok=None) -> bool:
     """Whether the channels-last stages and the internal channel padding apply to the convolutions fed by ``x``.
+    ``reduced_precision_ok``: what the MODEL says about itself (``NexToU.__init__``: its plain stages really carry channel
+    counts that are multiples of 8, padded or native) — ``None`` falls back to the environment-level switch.
 
     fp32: always.  Reduced precision (bf16 / fp16 autocast): only together with the channel padding.  Round 1 measured
     NDHWC under bf16 autocast as a 125 ms *loss* on cfg 2 (309 vs 185 ms, profiles/r01_bf16_regression_ab.md) and fenced the
@@ -86,13 +88,17 @@ def layout_policy_applies(x: torch.Tensor) -> bool:
         return False
     if os.environ.get("NEXTOU_REDUCED_PRECISION_LAYOUT", "auto").strip().lower() == "ncdhw":
         return False
+    if reduced_precision_ok is not None:
+        # a model whose padding could not be applied (conv_bias=False, another norm class) runs 33 / 66 channels;
+        # NDHWC under bf16 at those counts is the 309 vs 185 ms regression round 1 fenced off
+        return bool(reduced_precision_ok)
     from .channel_pad import pad_multiple
     return pad_multiple() > 0
 
 
-def set_stage_layout(x: torch.Tensor, channels_last: bool) -> torch.Tensor:
+def set_stage_layout(x: torch.Tensor, channels_last: bool, reduced_precision_ok=None) -> torch.Tensor:
     """Layout conversion at a stage boundary; only device tensors are ever moved (the CPU checker path is NCDHW).
     Encoder and decoder call this with the same stage set in the same forward, so they agree on every skip."""
     if not x.is_cuda:
         return x
-    return to_channels_last(x) if (channels_last and layout_policy_applies(x)) else x.contiguous()
+    return to_channels_last(x) if (channels_last and layout_policy_applies(x, reduced_precision_ok)) else x.contiguous()

@@ -226,6 +226,37 @@ def test_internal_channel_padding_is_invisible(cpu_checker):
     assert plain.padded_modules == 0
 
 
+@pytest.mark.parametrize("base", [12, 4, 20])
+def test_internal_channel_padding_with_mixed_feature_counts(cpu_checker, base):
+    """plans where one plain stage's feature count needs padding and the next is a multiple of 8
+    already (12 / 24, 4 / 8, 20 / 40).  The padded regime is carried by the model's shared PadRegime, not inferred from a
+    channel count that is the same in both regimes; the padded forward used to raise inside the decoder
+    ('received 28 channels, expected 24 (real) or 32 (padded)')."""
+    import copy
+    import model_cases as mc
+    from nextou_amd.network_architecture.channel_pad import force_padding
+    cfg = dict(mc.TINY_3D, features=[base, 2 * base, 48, 48, 48, 48])
+    torch.manual_seed(3)
+    model = mc.build_model(cfg).train()
+    assert model.padded_modules > 0
+    x = torch.randn(1, 1, 32, 128, 128)
+
+    from nextou_amd import graph_ops
+
+    def run(flag, tape):
+        m = copy.deepcopy(model)
+        with force_padding(flag), graph_ops.index_tape(tape):
+            outs = m(x)
+        return [o.detach() for o in outs]
+
+    rec = graph_ops.IndexTape()
+    o0 = run(False, rec)                                   # records the kNN ids / pool arg-max of the un-padded run
+    o1 = run(True, graph_ops.IndexTape(rec.entries))       # ... which the padded run replays (protocol P-B)
+    assert all(a.shape == b.shape for a, b in zip(o0, o1))
+    scale = max(float(o.abs().max()) for o in o0)
+    assert max(float((a - b).abs().max()) for a, b in zip(o0, o1)) <= 1e-4 * scale
+
+
 def test_depth_unroll_formulation_of_the_3d_gradients():
     """The algebra behind graph_ops._ConvDgradAsForward's 2-D weight gradient and _ConvDepthUnrolledGrads, on the CPU with the
     oracle's depth_unroll_ref in place of the kernel: for a [3,3,3] 'same' convolution with depth stride 1 (in-plane stride 1 or

@@ -106,6 +106,56 @@ def bench_norm(args, dev, L):
         json.dump(rows, open(args.json, "w"), indent=1)
 
 
+def bench_bti(args, dev, L):
+    """K5 at the cfg-4 shapes (BASELINE.json configs[3]): the four deep-supervision scales the BTI loss runs on (batch 2,
+    14 classes, Synapse exclusion list, connectivity 26), blob labels and blob-ish logits (the arg-max of the logits is a
+    noisy copy of the labels, so ~5-10 % of the voxels are critical, as in the cfg-4 train step).  Per kernel: HIP-event
+    time inside the library, algorithmic bytes (logits 4L per voxel for the arg-max and again for the
+    CE, labels / critical map 1 byte each) over it, fraction of the 8 TB/s HBM peak."""
+    from nextou_amd.harness import config_3d_fullres_nextou, synthetic_batch
+    from nextou_amd.loss.bti_loss import BTI_Loss
+    from nextou_amd.nnUNetTrainer.nnUNetTrainer_NexToU_BTI_Synapse import nnUNetTrainer_NexToU_BTI_Synapse as Synapse
+    loss = BTI_Loss(3, 26, [], Synapse.exclusion_list, 1)
+    loss.validate_targets = False
+    cfg = config_3d_fullres_nextou(patch_size=(64, 224, 192), base=33, max_features=324, batch_size=2)
+    _, target = synthetic_batch(cfg, 1, 14, 2, dev, blob_labels=True)
+    rows = []
+    print("%-16s %-44s %10s %12s %7s" % ("scale", "kernel", "us/launch", "achieved", "frac"))
+    shape = [64, 224, 192]
+    for scale, pool in enumerate([(1, 1, 1), (1, 2, 2), (2, 2, 2), (2, 2, 2)]):
+        shape = [s // p for s, p in zip(shape, pool)]
+        label = "x".join(map(str, shape))
+        if args.only and args.only not in label:
+            continue
+        t = torch.nn.functional.interpolate(target, size=shape, mode="nearest")
+        g = torch.Generator(device=dev).manual_seed(7)
+        logits = torch.randn((2, 14, *shape), generator=g, device=dev) * 1.5
+        logits.scatter_add_(1, t.long(), torch.full_like(t, 3.0))
+        logits.requires_grad_(True)
+        for it in range(2 + args.iters):
+            if it == 2:
+                torch.cuda.synchronize()
+                L.nextou_profile_enable(16 * args.iters)
+            v = loss(logits, t)
+            torch.autograd.grad(v, logits)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            crit = float(loss.critical_voxels_from_labels(graph_ops.argmax_labels(logits)).float().mean())
+        buf = ctypes.create_string_buffer(1 << 20)
+        L.nextou_profile_report(buf, len(buf))
+        L.nextou_profile_enable(0)
+        for r in json.loads(buf.value.decode()):
+            per_s = r["ms"] / r["launches"] / 1e3
+            ach = r["work"] / r["launches"] / per_s
+            rows.append({"call": label, "kernel": r["kernel"], "bound": r["bound"], "us": per_s * 1e6, "achieved": ach,
+                         "frac": ach / PEAK[r["bound"]], "critical_fraction": crit})
+            print("%-16s %-44s %10.1f %8.0f GB/s %6.1f%%" % (label, r["kernel"][:44], per_s * 1e6, ach / 1e9, 100 * ach / PEAK["hbm"]))
+        print("%-16s critical voxels: %.1f %%" % (label, 100 * crit))
+    print("total K5 kernel time for one loss fwd+bwd over the four scales: %.3f ms" % (sum(r["us"] for r in rows) / 1e3))
+    if args.json:
+        json.dump(rows, open(args.json, "w"), indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg", type=int, default=2)
@@ -114,11 +164,14 @@ def main():
     ap.add_argument("--only", default=None, help="substring filter on the call label")
     ap.add_argument("--norm", action="store_true", help="bench K6 (norm + LeakyReLU) instead of K1/K2")
     ap.add_argument("--cl", action="store_true", help="with --norm: channels-last tensors")
+    ap.add_argument("--bti", action="store_true", help="bench K5 (arg-max labels, critical map, critical-voxel CE) at the cfg-4 scales")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     L = _lib.lib()
     if args.norm:
         return bench_norm(args, dev, L)
+    if args.bti:
+        return bench_bti(args, dev, L)
     calls = CFG2 if args.cfg == 2 else CFG5
     rows = []
     for label, B, C, N, M, k in calls:
