@@ -185,7 +185,7 @@ def _real_channel_fraction(label):
     return {40: 33.0 / 40.0, 72: 66.0 / 72.0}.get(int(m.group(1)))
 
 
-CPU_BASELINE_THREADS = None     # set from the committed sweep (profiles/r03_cpu_baseline_thread_sweep.md); None = torch's default
+CPU_BASELINE_THREADS = 32       # best of the committed sweep on the GPU boxes' EPYC 9575F hosts (profiles/r03_cpu_baseline_thread_sweep.md)
 
 
 def cpu_baseline(workload, timed_steps=2, threads=None, sweep=False):
@@ -302,6 +302,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    # "rank 0 prints ONE JSON line": native libraries write to file descriptor 1 as well (RCCL prints a version banner when its
+    # communicator comes up — it followed the JSON line in the world-size-1 runs of profiles/r03_averaged_step_hipgraph.md), so
+    # descriptor 1 is pointed at stderr for the whole run and the JSON line goes to a private duplicate of the real stdout
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     _lib.lib()  # fail loudly if the HIP extension is missing
     # RCCL ("nccl") is the product backend; NEXTOU_DIST_BACKEND=gloo lets the N > 1 code path be exercised
     # by two ranks sharing the single GPU of a test box (tests/test_gpu_parity.py)
@@ -422,7 +428,8 @@ def main():
                                         "kind": "port", "sample": "failed: %r" % (e,)}
         elif world == 1:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NEXTOU_ABI_VERSION 5
+#define NEXTOU_ABI_VERSION 6
 
 #define NEXTOU_EINVAL   (-1)  /* bad argument (null pointer, non-positive size, k > M ...) */
 #define NEXTOU_ENOSPACE (-2)  /* workspace too small */
@@ -301,6 +301,54 @@ int nextou_pw_rows(const float* x, const float* w, const float* bias, float* y, 
 int nextou_pw_wgrad_workspace(int64_t P, int N, int K, int groups, size_t* bytes);
 int nextou_pw_wgrad(const float* gy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int64_t P, int N,
                     int K, int groups, int64_t ldg, int64_t ldx, int accumulate, nextou_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7 + K6 fused (round 3): the point-wise pipeline of a Grapher / FFN block —
+ *   conv 1x1 -> norm -> LeakyReLU -> conv 1x1 -> norm -> (+ shortcut)
+ * (reference NexToU_Encoder_Decoder.py:368-390 FFN; :710-720, :833-842 fc1 / fc2; torch_nn.py:66-92 BasicConv) —
+ * without the passes over the activation that the op-by-op form needs: the producing GEMM's epilogue delivers the batch
+ * statistics of its output, the consuming GEMM's operand load applies norm + activation, so the activated tensor (363 MB for
+ * the stage-2 FFN of cfg 2) is never written, and the statistics / apply passes of K6 over it never run.
+ *
+ * nextou_pw_rows_fused   y[p, g*N + n] = sum_k A[p, g*K + k] * w[g*N + n, k]  (no bias; N, K, ldx, ldy multiples of 4) with
+ *     A = x, or — operand prologue, pro_scale != NULL — A[p, c] = leaky_relu(fmaf(x[p, c], pro_scale[c], pro_shift[c]), pro_slope)
+ *         (c = g*K + k over all groups*K input channels; exactly K6's apply arithmetic);
+ *     stats_partial != NULL, bwd_h == NULL: statistics epilogue — stats_partial[(c * T + t) * 2 + {0, 1}] = (sum, sum of squares)
+ *         of y[:, c] over point tile t, T = nextou_pw_rows_tiles(P, N, groups), c over groups*N output channels: the `partial`
+ *         input of nextou_norm_finalize;
+ *     bwd_h != NULL: gradient-statistics epilogue of a data-gradient GEMM (y = d loss / d activated): with h = bwd_h[p, c]
+ *         (row stride ldh), z = fmaf(h, scale, shift), dz = y * (z > 0 ? 1 : bwd_slope), xhat = (h - bwd_mean[c]) * bwd_invstd[c]
+ *         (scale = bwd_weight * bwd_invstd, shift = fmaf(-bwd_mean, scale, bwd_bias)):
+ *         stats_partial[...] = (sum dz, sum dz * xhat) — the `partial` input of nextou_norm_bwd_finalize.  y is stored unchanged.
+ *     Partial sums: fp32 over a wave's 32 points (fixed tree), float64 across waves and tiles, fixed order (bit-reproducible).
+ * nextou_pw_wgrad_fused  nextou_pw_wgrad with the same operand prologue on x (the weight gradient of the second convolution).
+ * nextou_norm_finalize   (sum, sum of squares) partials -> save_mean / save_invstd (training: batch statistics, running
+ *     statistics updated, pre_bias as in nextou_norm_act_fwd; inference: from the running statistics) and, when scale / shift
+ *     are given, the affine scale = weight * invstd, shift = fmaf(-mean, scale, bias) that an operand prologue consumes.
+ * nextou_norm_apply_rows y = leaky_relu(fmaf(x, scale, shift), slope) [+ residual] over channels-last fp32 rows (rows, C):
+ *     K6's apply pass alone, with the block's shortcut add folded in.
+ * nextou_norm_bwd_finalize / nextou_norm_bwd_apply_rows   the two halves of K6's backward after the reduce: coeff (2C floats) +
+ *     parameter gradients from (sum dz, sum dz*xhat) partials; gx = scale * ((dz - coeff[2c]) - xhat * coeff[2c+1]).
+ * ---------------------------------------------------------------------------------------- */
+int nextou_pw_rows_tiles(int64_t P, int N, int groups);
+int nextou_pw_rows_fused(const float* x, const float* w, float* y, int64_t P, int N, int K, int groups, int64_t ldx, int64_t ldy,
+                         const float* pro_scale, const float* pro_shift, float pro_slope, double* stats_partial,
+                         const float* bwd_h, int64_t ldh, const float* bwd_weight, const float* bwd_bias, const float* bwd_mean,
+                         const float* bwd_invstd, float bwd_slope, nextou_stream_t stream);
+int nextou_pw_wgrad_fused(const float* gy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int64_t P, int N,
+                          int K, int groups, int64_t ldg, int64_t ldx, int accumulate, const float* pro_scale,
+                          const float* pro_shift, float pro_slope, nextou_stream_t stream);
+int nextou_norm_finalize(const double* partial, int tiles, double count, const float* pre_bias, float* running_mean,
+                         float* running_var, float* save_mean, float* save_invstd, const float* weight, const float* bias,
+                         float* scale, float* shift, int C, int training, float momentum, float eps, nextou_stream_t stream);
+int nextou_norm_apply_rows(const float* x, const float* residual, float* y, const float* weight, const float* bias,
+                           const float* save_mean, const float* save_invstd, int64_t rows, int C, float slope,
+                           nextou_stream_t stream);
+int nextou_norm_bwd_finalize(const double* partial, int tiles, double count, float* coeff, float* gweight, float* gbias, int C,
+                             int training, nextou_stream_t stream);
+int nextou_norm_bwd_apply_rows(const float* x, const float* gy, float* gx, const float* coeff, const float* weight,
+                               const float* bias, const float* save_mean, const float* save_invstd, int64_t rows, int C,
+                               float slope, nextou_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 import torch  # noqa: F401  (must precede the dlopen, see module docstring)
 
@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("NEXTOU_HIP_LIB") or os.path.join(_PKG_DIR, "libnextou
 
 KNN_AUTO, KNN_FUSED, KNN_NAIVE = 0, 1, 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # name -> (restype, argtypes); mirrors include/nextou_hip.h one to one
 _SIGNATURES = {
@@ -78,6 +78,19 @@ _SIGNATURES = {
     "nextou_pw_wgrad_workspace": (c_int, [c_int64, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "nextou_pw_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int64, c_int64,
                                 c_int, c_void_p]),
+    "nextou_pw_rows_tiles": (c_int, [c_int64, c_int, c_int]),
+    "nextou_pw_rows_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64,
+                                     c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_float, c_void_p]),
+    "nextou_pw_wgrad_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int64, c_int64,
+                                      c_int, c_void_p, c_void_p, c_float, c_void_p]),
+    "nextou_norm_finalize": (c_int, [c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p]),
+    "nextou_norm_apply_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float,
+                                       c_void_p]),
+    "nextou_norm_bwd_finalize": (c_int, [c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "nextou_norm_bwd_apply_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                           c_int, c_float, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -599,7 +599,9 @@ __global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(const double2*
                                                          const float* __restrict__ pre_bias, float* running_mean,
                                                          float* running_var, float* __restrict__ save_mean,
                                                          float* __restrict__ save_invstd, int training, float momentum,
-                                                         float eps) {
+                                                         float eps, const float* __restrict__ weight = nullptr,
+                                                         const float* __restrict__ bias = nullptr, float* __restrict__ scale_out = nullptr,
+                                                         float* __restrict__ shift_out = nullptr) {
     const int c = blockIdx.x;
     float mean, invstd;
     double var = 0.0;
@@ -618,6 +620,11 @@ __global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(const double2*
     if (threadIdx.x == 0) {
         save_mean[c] = mean;
         save_invstd[c] = invstd;
+        if (scale_out) {            // the affine K6's apply kernels compute per thread, for consumers that normalise on operand load (K7)
+            const float sc = (weight ? weight[c] : 1.f) * invstd;
+            scale_out[c] = sc;
+            shift_out[c] = fmaf(-mean, sc, bias ? bias[c] : 0.f);
+        }
         if (training && running_mean) {
             const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
             const double batch_mean = (double)mean + (pre_bias ? (double)pre_bias[c] : 0.0);
@@ -632,7 +639,8 @@ __global__ __launch_bounds__(kThreads) void bn_cl_apply_kernel(const T* __restri
                                                                const float* __restrict__ weight, const float* __restrict__ bias,
                                                                const float* __restrict__ save_mean,
                                                                const float* __restrict__ save_invstd, long long total, int C,
-                                                               int tact, long long span, float slope) {
+                                                               int tact, long long span, float slope,
+                                                               const T* __restrict__ residual = nullptr) {
     if ((int)threadIdx.x >= tact) return;
     int ch[VEC];
     cl_channels<VEC>(C, ch);
@@ -647,6 +655,17 @@ __global__ __launch_bounds__(kThreads) void bn_cl_apply_kernel(const T* __restri
     const long long end = min(total, base + span);
     const long long stride = (long long)tact * VEC;
     long long e = base + (long long)threadIdx.x * VEC;
+    if (residual) {        // y = leaky(norm(x)) + residual: the block's shortcut add rides on the pass that writes y anyway
+        for (; e < end; e += stride) {
+            Pack<T, VEC> p, r;
+            p.load(x + e);
+            r.load(residual + e);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) p.v[j] = leaky(fmaf(p.v[j], scale[j], shift[j]), slope) + r.v[j];
+            p.store(y + e);
+        }
+        return;
+    }
     for (; e + 3 * stride < end; e += 4 * stride) {
         Pack<T, VEC> p[4];
 #pragma unroll
@@ -1033,7 +1052,8 @@ __global__ __launch_bounds__(kThreads) void bn_clw_apply_kernel(const T* __restr
                                                                 const float* __restrict__ weight, const float* __restrict__ bias,
                                                                 const float* __restrict__ save_mean,
                                                                 const float* __restrict__ save_invstd, long long rows, int C,
-                                                                int cx_log2, long long rows_per_block, float slope) {
+                                                                int cx_log2, long long rows_per_block, float slope,
+                                                                const T* __restrict__ residual = nullptr) {
     const ClwThread t = clw_decode<VEC>(rows, C, cx_log2, rows_per_block);
     if (!t.active) return;
     float scale[VEC], shift[VEC];
@@ -1045,6 +1065,31 @@ __global__ __launch_bounds__(kThreads) void bn_clw_apply_kernel(const T* __restr
         shift[j] = fmaf(-save_mean[c], scale[j], b);
     }
     long long r = t.r0 + t.ry;
+    if (residual) {        // see bn_cl_apply_kernel
+        for (; r + t.nry < t.r1; r += 2ll * t.nry) {
+            Pack<T, VEC> p[2], q[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                p[u].load(x + (r + (long long)u * t.nry) * C + t.ch0);
+                q[u].load(residual + (r + (long long)u * t.nry) * C + t.ch0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) p[u].v[j] = leaky(fmaf(p[u].v[j], scale[j], shift[j]), slope) + q[u].v[j];
+                p[u].store(y + (r + (long long)u * t.nry) * C + t.ch0);
+            }
+        }
+        for (; r < t.r1; r += t.nry) {
+            Pack<T, VEC> p, q;
+            p.load(x + r * C + t.ch0);
+            q.load(residual + r * C + t.ch0);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) p.v[j] = leaky(fmaf(p.v[j], scale[j], shift[j]), slope) + q.v[j];
+            p.store(y + r * C + t.ch0);
+        }
+        return;
+    }
     for (; r + 3ll * t.nry < t.r1; r += 4ll * t.nry) {
         Pack<T, VEC> p[4];
 #pragma unroll
@@ -1312,6 +1357,94 @@ extern "C" int nextou_norm_act_bwd(const void* x, const void* gy, const float* w
         return fail(NEXTOU_ENOSPACE, "norm_act_bwd: workspace %zu < %zu bytes", ws_bytes, (size_t)C * p.tiles * sizeof(double2));
     norm_dispatch<false>(a, p, dtype, (hipStream_t)stream);
     return check_launch("bn_bwd_apply_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K6 in pieces (round 3): for callers whose producer already delivered the per-tile partial sums — K7's
+// statistics epilogues (csrc/pw_gemm.hip) — or whose consumer normalises on operand load.  Channels-last fp32 rows.
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int nextou_norm_finalize(const double* partial, int tiles, double count, const float* pre_bias, float* running_mean,
+                                    float* running_var, float* save_mean, float* save_invstd, const float* weight, const float* bias,
+                                    float* scale, float* shift, int C, int training, float momentum, float eps, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(save_mean && save_invstd && C > 0 && count > 0.0, "norm_finalize: null pointer or empty problem");
+    NEXTOU_REQUIRE(!training || (partial && tiles > 0), "norm_finalize: training needs the partial sums");
+    NEXTOU_REQUIRE(training || (running_mean && running_var), "norm_finalize: inference needs the running statistics");
+    NEXTOU_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "norm_finalize: running_mean / running_var must come together");
+    NEXTOU_REQUIRE((scale == nullptr) == (shift == nullptr), "norm_finalize: scale / shift must come together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(kFinThreads), 0, (hipStream_t)stream, reinterpret_cast<const double2*>(partial), tiles,
+                       count, pre_bias, running_mean, running_var, save_mean, save_invstd, training, momentum, eps, weight, bias, scale, shift);
+    return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int nextou_norm_apply_rows(const float* x, const float* residual, float* y, const float* weight, const float* bias,
+                                      const float* save_mean, const float* save_invstd, int64_t rows, int C, float slope,
+                                      nextou_stream_t stream) {
+    NEXTOU_REQUIRE(x && y && save_mean && save_invstd && rows > 0 && C > 0, "norm_apply_rows: null pointer or empty problem");
+    hipStream_t s = (hipStream_t)stream;
+    const bool al = aligned16(x) && aligned16(y) && (!residual || aligned16(residual));
+    const double bytes = (double)rows * C * sizeof(float);
+    if (use_clw(C)) {
+        const ClwPlan p = plan_clw(rows, C, 4, al);
+        const dim3 grid(p.nrb, p.ncb);
+        ProfScope prof(s, kBoundHbm, (residual ? 3.0 : 2.0) * bytes, "bn_clw_apply_kernel<f32%s>[R%lld C%d]", residual ? ",+res" : "", (long long)rows, C);
+        if (p.vec == 4)
+            hipLaunchKernelGGL((bn_clw_apply_kernel<float, 4>), grid, dim3(kThreads), 0, s, x, y, weight, bias, save_mean, save_invstd, (long long)rows,
+                               C, p.cx_log2, p.rows_per_block, slope, residual);
+        else
+            hipLaunchKernelGGL((bn_clw_apply_kernel<float, 1>), grid, dim3(kThreads), 0, s, x, y, weight, bias, save_mean, save_invstd, (long long)rows,
+                               C, p.cx_log2, p.rows_per_block, slope, residual);
+        return check_launch("bn_clw_apply_kernel");
+    }
+    const long long total = (long long)rows * C;
+    const ClPlan p = plan_cl(total, C, 4, al);
+    ProfScope prof(s, kBoundHbm, (residual ? 3.0 : 2.0) * bytes, "bn_cl_apply_kernel<f32%s>[R%lld C%d]", residual ? ",+res" : "", (long long)rows, C);
+    if (p.vec == 4)
+        hipLaunchKernelGGL((bn_cl_apply_kernel<float, 4>), dim3(p.blocks), dim3(kThreads), 0, s, x, y, weight, bias, save_mean, save_invstd, total, C,
+                           p.tact, p.span, slope, residual);
+    else
+        hipLaunchKernelGGL((bn_cl_apply_kernel<float, 1>), dim3(p.blocks), dim3(kThreads), 0, s, x, y, weight, bias, save_mean, save_invstd, total, C,
+                           p.tact, p.span, slope, residual);
+    return check_launch("bn_cl_apply_kernel");
+}
+
+extern "C" int nextou_norm_bwd_finalize(const double* partial, int tiles, double count, float* coeff, float* gweight, float* gbias, int C,
+                                        int training, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(partial && coeff && tiles > 0 && C > 0 && count > 0.0, "norm_bwd_finalize: null pointer or empty problem");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kFinThreads), 0, (hipStream_t)stream, reinterpret_cast<const double2*>(partial), tiles,
+                       count, reinterpret_cast<float2*>(coeff), gweight, gbias, training);
+    return check_launch("bn_bwd_finalize_kernel");
+}
+
+extern "C" int nextou_norm_bwd_apply_rows(const float* x, const float* gy, float* gx, const float* coeff, const float* weight,
+                                          const float* bias, const float* save_mean, const float* save_invstd, int64_t rows, int C,
+                                          float slope, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(x && gy && gx && coeff && save_mean && save_invstd && rows > 0 && C > 0, "norm_bwd_apply_rows: null pointer or empty problem");
+    hipStream_t s = (hipStream_t)stream;
+    const bool al = aligned16(x) && aligned16(gy) && aligned16(gx);
+    const double bytes = (double)rows * C * sizeof(float);
+    const float2* k = reinterpret_cast<const float2*>(coeff);
+    if (use_clw(C)) {
+        const ClwPlan p = plan_clw(rows, C, 4, al);
+        const dim3 grid(p.nrb, p.ncb);
+        ProfScope prof(s, kBoundHbm, 3.0 * bytes, "bn_clw_bwd_apply_kernel<f32>[R%lld C%d]", (long long)rows, C);
+        if (p.vec == 4)
+            hipLaunchKernelGGL((bn_clw_bwd_apply_kernel<float, 4>), grid, dim3(kThreads), 0, s, x, gy, gx, k, weight, bias, save_mean, save_invstd,
+                               (long long)rows, C, p.cx_log2, p.rows_per_block, slope);
+        else
+            hipLaunchKernelGGL((bn_clw_bwd_apply_kernel<float, 1>), grid, dim3(kThreads), 0, s, x, gy, gx, k, weight, bias, save_mean, save_invstd,
+                               (long long)rows, C, p.cx_log2, p.rows_per_block, slope);
+        return check_launch("bn_clw_bwd_apply_kernel");
+    }
+    const long long total = (long long)rows * C;
+    const ClPlan p = plan_cl(total, C, 4, al);
+    ProfScope prof(s, kBoundHbm, 3.0 * bytes, "bn_cl_bwd_apply_kernel<f32>[R%lld C%d]", (long long)rows, C);
+    if (p.vec == 4)
+        hipLaunchKernelGGL((bn_cl_bwd_apply_kernel<float, 4>), dim3(p.blocks), dim3(kThreads), 0, s, x, gy, gx, k, weight, bias, save_mean, save_invstd,
+                           total, C, p.tact, p.span, slope);
+    else
+        hipLaunchKernelGGL((bn_cl_bwd_apply_kernel<float, 1>), dim3(p.blocks), dim3(kThreads), 0, s, x, gy, gx, k, weight, bias, save_mean, save_invstd,
+                           total, C, p.tact, p.span, slope);
+    return check_launch("bn_cl_bwd_apply_kernel");
 }
 
 extern "C" int nextou_channel_sum(const void* x, float* out, void* ws, size_t ws_bytes, int B, int C, int64_t S, int dtype,

@@ -58,19 +58,54 @@ __device__ __forceinline__ float4 keep_if(bool ok, float4 v) {
     return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
+// What a fused launch of pw_rows adds to the plain GEMM (the Grapher / FFN blocks' norm + activation inside the
+// 1x1 convolutions; reference torch_nn.py:84-90, NexToU_Encoder_Decoder.py:384-390, :710-720, :833-842):
+//   PRO = 1  operand prologue: the x tile is normalised + activated on its way into LDS,
+//            a[p, k] = leaky(fmaf(x[p, k], scale[k], shift[k]), slope) with scale = w * invstd, shift = fmaf(-mean, scale, b) —
+//            bit for bit K6's apply, so the activated tensor never exists in HBM;
+//   EPI = 1  statistics epilogue: per output channel (sum y, sum y^2) of the tile's points -> `partial` (K6's finalize input);
+//   EPI = 2  gradient-statistics epilogue for a data-gradient GEMM whose output is d(activated) : with h = the forward's
+//            pre-norm tensor at the output's coordinates, z = h * scale + shift, dz = y * (z > 0 ? 1 : slope),
+//            xhat = (h - mean) * invstd: (sum dz, sum dz * xhat) -> `partial` (K6's backward-finalize input).  y itself is
+//            written unchanged (K6's backward apply recomputes dz from it).
+// Partials: a wave reduces its 32 points in fp32 (fixed DPP tree), the workgroup's four waves are combined in float64 in wave
+// order, one double2 per (channel, point tile) goes to partial[channel * tiles + tile] — K6's layout; fixed order throughout
+// (bit-reproducible).
+struct PwFuse {
+    const float *pro_scale, *pro_shift;                     // prologue affine over the K input channels (per group: index g*K + k):
+    float pro_slope;                                        //   scale = weight * invstd, shift = bias - mean * scale (nextou_norm_finalize)
+    double2* partial;                                       // [groups * N][tiles]
+    const float* h;                                         // EPI = 2: (P, groups * N) rows, stride ldh
+    long ldh;
+    const float *epi_w, *epi_b, *epi_mean, *epi_invstd;     // EPI = 2: the norm whose backward statistics are collected
+    float epi_slope;
+};
+
+// sum over the 16 lanes of a DPP row (lanes that share lane >> 4), result in every lane; fixed tree
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
+__device__ __forceinline__ float leaky_f(float z, float slope) { return z > 0.f ? z : z * slope; }
+
 // ------------------------------------------------------------------------------------------------------------
 // y[p, n] = sum_k x[p, k] w[n, k] + bias[n]
 // ------------------------------------------------------------------------------------------------------------
-template <int TM, int TN>
+template <int TM, int TN, int PRO, int EPI>
 __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                       const float* __restrict__ bias, float* __restrict__ Y, int P, int N, int K,
-                                                      long ldx, long ldw, long ldy, int nb_n, int items, int vec_store) {
+                                                      long ldx, long ldw, long ldy, int nb_n, int items, int vec_store, PwFuse fz) {
     constexpr int BM = 64 * TM, BN = 16 * TN;
     constexpr int XV = BM * (kPwKC / 4) / 256;                // float4 per thread per stage, X tile
     constexpr int WV = (BN * (kPwKC / 4) + 255) / 256;        // ... W tile (last one predicated)
     extern __shared__ float4 pw_smem4[];
     float* Xs = reinterpret_cast<float*>(pw_smem4);           // [2][BM][kPwLd]
     float* Ws = Xs + 2 * BM * kPwLd;                          // [2][BN][kPwLd]
+    float2* red = reinterpret_cast<float2*>(Ws + 2 * BN * kPwLd);   // EPI != 0: [4 waves][BN] (sum, sum') of a wave's 32 points
 
     // persistent workgroups: XCD x owns the contiguous item range [x * per_xcd, (x + 1) * per_xcd) — items are ordered
     // channel block fastest, so the workgroups resident on one XCD at any time share x tiles (and w) in its L2 — and
@@ -92,11 +127,22 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
     // to) one register set and the loads of stage s + 2 are issued into the other — one stage of MFMAs (~1.2 us) does not
     // cover the memory latency under load, two do
     float4 xr[2][XV], wr[2][WV];
+    // PRO: the thread's k offset inside a stage is the same for all its X pieces (f % 4 == tid % 4 because 256 % 4 == 0), so one
+    // (scale, shift) float4 pair per stage and register set covers them; they are loaded with the stage (prefetched alike)
+    float4 psc[2], psh[2];
+    auto load_pro = [&](int k0, float4& sc, float4& sh) __attribute__((always_inline)) {
+        if constexpr (PRO == 1) {
+            const long k = (long)g * K + min(k0 + (tid & 3) * 4, K - 4);
+            sc = ld4(fz.pro_scale + k);
+            sh = ld4(fz.pro_shift + k);
+        }
+    };
     // loads are UNCONDITIONAL and their results are not touched until the LDS store one stage later (addresses clamped into the
     // tensor; out-of-range pieces are zeroed by a select in store_stage): a predicated load is a branch, and a select right
     // behind the load is a use — either way the compiler waits (s_waitcnt vmcnt(0)) for loads it has just issued, which
     // defeats the prefetch.  Like this it waits with vmcnt(n), n = the loads of the younger stage still in flight.
-    auto load_stage = [&](int p0, int n0, int k0, float4 (&xq)[XV], float4 (&wq)[WV]) __attribute__((always_inline)) {
+    auto load_stage = [&](int p0, int n0, int k0, float4 (&xq)[XV], float4 (&wq)[WV], float4& sc, float4& sh) __attribute__((always_inline)) {
+        load_pro(k0, sc, sh);
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int f = tid + i * 256, row = f / (kPwKC / 4), c4 = f % (kPwKC / 4);
@@ -108,14 +154,19 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
             wq[i] = ld4(Wt + (long)min(n0 + row, N - 1) * ldw + min(k0 + c4 * 4, K - 4));
         }
     };
-    auto store_stage = [&](int buf, int p0, int n0, int k0, const float4 (&xq)[XV], const float4 (&wq)[WV]) __attribute__((always_inline)) {
+    auto store_stage = [&](int buf, int p0, int n0, int k0, const float4 (&xq)[XV], const float4 (&wq)[WV], const float4& sc,
+                           const float4& sh) __attribute__((always_inline)) {
         float* xs = Xs + buf * BM * kPwLd;
         float* ws = Ws + buf * BN * kPwLd;
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int f = tid + i * 256, row = f / (kPwKC / 4), c4 = f % (kPwKC / 4);
             const bool ok = p0 + row < P && k0 + c4 * 4 < K;
-            *reinterpret_cast<float4*>(xs + row * kPwLd + c4 * 4) = keep_if(ok, xq[i]);
+            float4 v = xq[i];
+            if constexpr (PRO == 1)        // K6's apply, bit for bit: leaky(fmaf(x, scale, shift)); padding stays exactly zero (keep_if below)
+                v = make_float4(leaky_f(fmaf(v.x, sc.x, sh.x), fz.pro_slope), leaky_f(fmaf(v.y, sc.y, sh.y), fz.pro_slope),
+                                leaky_f(fmaf(v.z, sc.z, sh.z), fz.pro_slope), leaky_f(fmaf(v.w, sc.w, sh.w), fz.pro_slope));
+            *reinterpret_cast<float4*>(xs + row * kPwLd + c4 * 4) = keep_if(ok, v);
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
@@ -195,6 +246,73 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
                 }
             }
         }
+        if constexpr (EPI != 0) {
+            // per-channel partial sums of this tile (fused launches: bias == NULL, N % 4 == 0; rows past P are exact zeros and
+            // add nothing).  A lane holds 4 channels x TM points per channel tile, the 16 lanes of its DPP row the other points.
+            constexpr int JB = EPI == 2 ? 3 : 1;       // EPI 2: h loads of JB channel tiles are issued together (latency batches)
+#pragma unroll
+            for (int j0 = 0; j0 < TN; j0 += JB) {
+                float4 hq[JB][TM];
+                if constexpr (EPI == 2) {
+#pragma unroll
+                    for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            const int n = min(n0 + (j0 + jj) * 16 + kg * 4, N - 4);
+                            const int p = min(p0 + (wave * TM + i) * 16 + r16, P - 1);
+                            hq[jj][i] = ld4(fz.h + (long)p * fz.ldh + (long)g * N + n);
+                        }
+                }
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj) {
+                    const int j = j0 + jj;
+                    if (j >= TN) break;
+                    const int n = n0 + j * 16 + kg * 4;
+                    if (n >= N) continue;                       // uniform over the DPP row (same kg)
+                    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (EPI == 1) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s[r] += v; q[r] = fmaf(v, v, q[r]); }
+                    } else {
+                        const long c = (long)g * N + n;
+                        const float4 w = ld4(fz.epi_w + c), b = ld4(fz.epi_b + c), m = ld4(fz.epi_mean + c), is = ld4(fz.epi_invstd + c);
+                        const float wv[4] = {w.x, w.y, w.z, w.w}, bv4[4] = {b.x, b.y, b.z, b.w}, mv[4] = {m.x, m.y, m.z, m.w},
+                                    iv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            const float hv[4] = {hq[jj][i].x, hq[jj][i].y, hq[jj][i].z, hq[jj][i].w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {           // K6's backward reduce, term for term
+                                const float scale = wv[r] * iv[r], shift = fmaf(-mv[r], scale, bv4[r]);
+                                const float z = fmaf(hv[r], scale, shift);
+                                const float gq = acc[i][j][r];
+                                const float dz = z > 0.f ? gq : gq * fz.epi_slope;
+                                const float xh = (hv[r] - mv[r]) * iv[r];
+                                s[r] += dz;
+                                q[r] = fmaf(dz, xh, q[r]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]); }
+                    if (r16 == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) red[wave * BN + j * 16 + kg * 4 + r] = make_float2(s[r], q[r]);
+                    }
+                }
+            }
+            __syncthreads();
+            const int tiles_p = items / nb_n, tile_p = p0 / BM;
+            for (int c = tid; c < BN; c += 256) {
+                if (n0 + c >= N) continue;
+                const double S = (((double)red[c].x + (double)red[BN + c].x) + (double)red[2 * BN + c].x) + (double)red[3 * BN + c].x;
+                const double Q = (((double)red[c].y + (double)red[BN + c].y) + (double)red[2 * BN + c].y) + (double)red[3 * BN + c].y;
+                fz.partial[((long)g * N + n0 + c) * tiles_p + tile_p] = make_double2(S, Q);
+            }
+            // `red` is next written in the next tile's epilogue, behind the barriers of its main loop
+        }
     };
 
     const int stages = (K + kPwKC - 1) / kPwKC;
@@ -211,12 +329,12 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
     if (item >= 0) {
         p0 = (item / nb_n) * BM;
         n0 = (item % nb_n) * BN;
-        load_stage(p0, n0, 0, xr[0], wr[0]);
-        load_stage(p0, n0, stages > 1 ? kPwKC : 0, xr[1], wr[1]);
+        load_stage(p0, n0, 0, xr[0], wr[0], psc[0], psh[0]);
+        load_stage(p0, n0, stages > 1 ? kPwKC : 0, xr[1], wr[1], psc[1], psh[1]);
     }
     while (item >= 0) {
         __syncthreads();                       // the previous tile's last LDS reads are done
-        store_stage(0, p0, n0, 0, xr[0], wr[0]);
+        store_stage(0, p0, n0, 0, xr[0], wr[0], psc[0], psh[0]);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -231,13 +349,13 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
             compute(0);
             __syncthreads();
 #else
-            load_stage(p0, n0, min(s + 2, stages - 1) * kPwKC, xr[0], wr[0]);     // past the end: a re-read nobody stores
+            load_stage(p0, n0, min(s + 2, stages - 1) * kPwKC, xr[0], wr[0], psc[0], psh[0]);     // past the end: a re-read nobody stores
             compute(0);
-            store_stage(1, p0, n0, (s + 1) * kPwKC, xr[1], wr[1]);
+            store_stage(1, p0, n0, (s + 1) * kPwKC, xr[1], wr[1], psc[1], psh[1]);
             __syncthreads();
-            load_stage(p0, n0, min(s + 3, stages - 1) * kPwKC, xr[1], wr[1]);
+            load_stage(p0, n0, min(s + 3, stages - 1) * kPwKC, xr[1], wr[1], psc[1], psh[1]);
             compute(1);
-            store_stage(0, p0, n0, (s + 2) * kPwKC, xr[0], wr[0]);     // past the end: zeros nobody reads (no branch: keeps vmcnt exact)
+            store_stage(0, p0, n0, (s + 2) * kPwKC, xr[0], wr[0], psc[0], psh[0]);     // past the end: zeros nobody reads (no branch: keeps vmcnt exact)
             __syncthreads();
 #endif
         }
@@ -245,8 +363,8 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
         walk += slots;
         const int next = item_at(walk);
         const int np0 = next >= 0 ? (next / nb_n) * BM : p0, nn0 = next >= 0 ? (next % nb_n) * BN : n0;
-        load_stage(np0, nn0, 0, xr[0], wr[0]);                                    // no next tile: a re-read of this one
-        load_stage(np0, nn0, stages > 1 ? kPwKC : 0, xr[1], wr[1]);
+        load_stage(np0, nn0, 0, xr[0], wr[0], psc[0], psh[0]);                                    // no next tile: a re-read of this one
+        load_stage(np0, nn0, stages > 1 ? kPwKC : 0, xr[1], wr[1], psc[1], psh[1]);
         epilogue(p0, n0);
         item = next;
         p0 = np0;
@@ -263,10 +381,12 @@ constexpr int wgrad_stride(int cols) { return cols + ((16 - cols % 32) + 32) % 3
 
 // wave tile TN x TK 16x16 tiles; WN x WK waves per workgroup (all compile-time: the staging loops and LDS strides are
 // constants, which keeps the (3,3) kernel at ~100 VGPRs instead of 256 + SGPR spills with run-time shapes)
-template <int TN, int TK, int WN, int WK>
+// PRO = 1: the x operand is normalised + activated on its way into LDS (see PwFuse / pw_rows_kernel): the weight gradient of a
+// convolution whose input was only ever produced inside the forward GEMM's operand load.
+template <int TN, int TK, int WN, int WK, int PRO>
 __global__ __launch_bounds__(64 * WN * WK, 2) void pw_wgrad_kernel(const float* __restrict__ G, const float* __restrict__ X,
                                                                 float* __restrict__ part, int P, int N, int K, long ldg, long ldx,
-                                                                int nb_n, int nb_k, int rows_per_split, int items) {
+                                                                int nb_n, int nb_k, int rows_per_split, int items, PwFuse fz) {
     constexpr int NT = 64 * WN * WK;
     constexpr int BN = WN * TN * 16, BK = WK * TK * 16;
     constexpr int SG = wgrad_stride(BN), SX = wgrad_stride(BK);
@@ -275,6 +395,8 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void pw_wgrad_kernel(const float* 
     extern __shared__ float4 pw_smem4[];
     float* Gs = reinterpret_cast<float*>(pw_smem4);        // [2][kWgPC][SG]
     float* Xs = Gs + 2 * kWgPC * SG;                       // [2][kWgPC][SX]
+    float* Psc = Xs + 2 * kWgPC * SX;                      // PRO: [BK] scale, then [BK] shift of this workgroup's k block
+    float* Psh = Psc + BK;
 
     const int item = xcd_item(blockIdx.x, gridDim.x);
     if (item >= items) return;
@@ -290,6 +412,13 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void pw_wgrad_kernel(const float* 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, pg = lane >> 4;
     const int wave_n = wave / WK, wave_k = wave - wave_n * WK;
+    if constexpr (PRO == 1) {
+        for (int c = tid; c < BK; c += NT) {
+            const long k = (long)g * K + min(k0 + c, K - 1);
+            Psc[c] = fz.pro_scale[k];
+            Psh[c] = fz.pro_shift[k];
+        }
+    }
 
     // register staging with prefetch distance 2 (see pw_rows_kernel)
     float4 gr[2][GV], xr[2][XV];
@@ -318,7 +447,15 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void pw_wgrad_kernel(const float* 
         for (int i = 0; i < XV; ++i) {
             const int f = tid + i * NT, row = f / XQ, c = (f - row * XQ) * 4;
             const bool ok = p_row0 + row < p_end && k0 + c < K;
-            if (row < kWgPC) *reinterpret_cast<float4*>(xs + row * SX + c) = keep_if(ok, xq[i]);
+            float4 v = xq[i];
+            if constexpr (PRO == 1) {
+                if (row < kWgPC) {
+                    const float4 sc = *reinterpret_cast<const float4*>(Psc + c), sh = *reinterpret_cast<const float4*>(Psh + c);
+                    v = make_float4(leaky_f(fmaf(v.x, sc.x, sh.x), fz.pro_slope), leaky_f(fmaf(v.y, sc.y, sh.y), fz.pro_slope),
+                                    leaky_f(fmaf(v.z, sc.z, sh.z), fz.pro_slope), leaky_f(fmaf(v.w, sc.w, sh.w), fz.pro_slope));
+                }
+            }
+            if (row < kWgPC) *reinterpret_cast<float4*>(xs + row * SX + c) = keep_if(ok, v);
         }
     };
 
@@ -349,8 +486,9 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void pw_wgrad_kernel(const float* 
     if (stages > 0) {
         load_stage(p_begin, gr[0], xr[0]);
         load_stage(p_begin + kWgPC, gr[1], xr[1]);
-        store_stage(0, p_begin, gr[0], xr[0]);
     }
+    if constexpr (PRO == 1) __syncthreads();           // Psc / Psh are read by the first store_stage
+    if (stages > 0) store_stage(0, p_begin, gr[0], xr[0]);
     __syncthreads();
     for (int s = 0; s + 1 < stages; s += 2) {      // pairs, no exit inside, loads always issued: see pw_rows_kernel
         load_stage(p_begin + (s + 2) * kWgPC, gr[0], xr[0]);       // past p_end: zeros (addresses clamped)
@@ -527,29 +665,48 @@ int allow_lds(Kern kern, size_t bytes) {
     return 0;
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int PRO, int EPI>
 int launch_rows(const RowsPlan& q, const float* x, const float* w, const float* bias, float* y, int P, int N, int K, int groups, long ldx,
-                long ldw, long ldy, int vec_store, hipStream_t s) {
+                long ldw, long ldy, int vec_store, const PwFuse& fz, hipStream_t s) {
     static size_t allowed = 0;          // per instantiation; the attribute is sticky
-    if (q.lds > allowed) {
-        if (int e = allow_lds(pw_rows_kernel<TM, TN>, q.lds)) return e;
-        allowed = q.lds;
+    const size_t lds = q.lds + (EPI != 0 ? (size_t)4 * 16 * TN * sizeof(float2) : 0);
+    if (lds > allowed) {
+        if (int e = allow_lds(pw_rows_kernel<TM, TN, PRO, EPI>, lds)) return e;
+        allowed = lds;
     }
-    hipLaunchKernelGGL((pw_rows_kernel<TM, TN>), dim3(q.grid, groups), dim3(256), q.lds, s, x, w, bias, y, P, N, K, ldx, ldw, ldy, q.nb_n,
-                       q.items, vec_store);
+    hipLaunchKernelGGL((pw_rows_kernel<TM, TN, PRO, EPI>), dim3(q.grid, groups), dim3(256), lds, s, x, w, bias, y, P, N, K, ldx, ldw, ldy,
+                       q.nb_n, q.items, vec_store, fz);
     return check_launch("pw_rows_kernel");
 }
 
-template <int TN, int TK, int WN, int WK>
-int launch_wgrad(const WgradPlan& q, const float* gy, const float* x, float* part, int P, int N, int K, int groups, long ldg, long ldx,
-                 hipStream_t s) {
-    static size_t allowed = 0;
-    if (q.lds > allowed) {
-        if (int e = allow_lds(pw_wgrad_kernel<TN, TK, WN, WK>, q.lds)) return e;
-        allowed = q.lds;
+template <int PRO, int EPI>
+int dispatch_rows(const RowsPlan& q, const float* x, const float* w, const float* bias, float* y, int P, int N, int K, int groups, long ldx,
+                  long ldy, int vec_store, const PwFuse& fz, hipStream_t s) {
+#define NEXTOU_PW_ROWS(TN_) \
+    case TN_: return launch_rows<2, TN_, PRO, EPI>(q, x, w, bias, y, P, N, K, groups, ldx, (long)K, ldy, vec_store, fz, s)
+    switch (q.tn) {
+        NEXTOU_PW_ROWS(1);
+        NEXTOU_PW_ROWS(3);
+        NEXTOU_PW_ROWS(6);
+        NEXTOU_PW_ROWS(7);
+        NEXTOU_PW_ROWS(9);
+        NEXTOU_PW_ROWS(11);
     }
-    hipLaunchKernelGGL((pw_wgrad_kernel<TN, TK, WN, WK>), dim3(q.grid, groups), dim3(64 * WN * WK), q.lds, s, gy, x, part, P, N, K, ldg, ldx,
-                       q.nb_n, q.nb_k, q.rows_per_split, q.items);
+#undef NEXTOU_PW_ROWS
+    return fail(NEXTOU_EINVAL, "pw_rows: no kernel for %d channel tiles", q.tn);
+}
+
+template <int TN, int TK, int WN, int WK, int PRO>
+int launch_wgrad(const WgradPlan& q, const float* gy, const float* x, float* part, int P, int N, int K, int groups, long ldg, long ldx,
+                 const PwFuse& fz, hipStream_t s) {
+    static size_t allowed = 0;
+    const size_t lds = q.lds + (PRO ? (size_t)2 * WK * TK * 16 * sizeof(float) : 0);
+    if (lds > allowed) {
+        if (int e = allow_lds(pw_wgrad_kernel<TN, TK, WN, WK, PRO>, lds)) return e;
+        allowed = lds;
+    }
+    hipLaunchKernelGGL((pw_wgrad_kernel<TN, TK, WN, WK, PRO>), dim3(q.grid, groups), dim3(64 * WN * WK), lds, s, gy, x, part, P, N, K, ldg,
+                       ldx, q.nb_n, q.nb_k, q.rows_per_split, q.items, fz);
     return check_launch("pw_wgrad_kernel");
 }
 
@@ -579,18 +736,46 @@ extern "C" int nextou_pw_rows(const float* x, const float* w, const float* bias,
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K * groups, "pw_rows_kernel<%d,%d>[P%lld N%d K%d g%d]", q.tm, q.tn, (long long)P, N, K,
                    groups);
-#define NEXTOU_PW_ROWS(TN_) \
-    case TN_: return launch_rows<2, TN_>(q, x, w, bias, y, (int)P, N, K, groups, (long)ldx, (long)K, (long)ldy, vec_store, s)
-    switch (q.tn) {
-        NEXTOU_PW_ROWS(1);
-        NEXTOU_PW_ROWS(3);
-        NEXTOU_PW_ROWS(6);
-        NEXTOU_PW_ROWS(7);
-        NEXTOU_PW_ROWS(9);
-        NEXTOU_PW_ROWS(11);
-    }
-#undef NEXTOU_PW_ROWS
-    return fail(NEXTOU_EINVAL, "pw_rows: no kernel for %d channel tiles", q.tn);
+    return dispatch_rows<0, 0>(q, x, w, bias, y, (int)P, N, K, groups, (long)ldx, (long)ldy, vec_store, PwFuse{}, s);
+}
+
+extern "C" int nextou_pw_rows_tiles(int64_t P, int N, int groups) {
+    if (P <= 0 || N <= 0 || groups <= 0) return 0;
+    return plan_rows((int)P, N, groups).nb_p;
+}
+
+extern "C" int nextou_pw_rows_fused(const float* x, const float* w, float* y, int64_t P, int N, int K, int groups, int64_t ldx, int64_t ldy,
+                                    const float* pro_scale, const float* pro_shift, float pro_slope, double* stats_partial, const float* bwd_h, int64_t ldh, const float* bwd_weight,
+                                    const float* bwd_bias, const float* bwd_mean, const float* bwd_invstd, float bwd_slope,
+                                    nextou_stream_t stream) {
+    NEXTOU_REQUIRE(x && w && y, "pw_rows_fused: null pointer");
+    if (int e = check_pw("pw_rows_fused", P, N, K, groups, ldx, ldy, K, N)) return e;
+    NEXTOU_REQUIRE(K % 4 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(w) && aligned16(y),
+                   "pw_rows_fused: K=%d, N=%d and the row strides must be multiples of 4 and x, w, y 16-byte aligned", K, N);
+    const bool pro = pro_scale != nullptr;
+    NEXTOU_REQUIRE(!pro || (pro_shift && aligned16(pro_scale) && aligned16(pro_shift)),
+                   "pw_rows_fused: the operand prologue needs scale and shift (16-byte aligned)");
+    const int epi = bwd_h ? 2 : (stats_partial ? 1 : 0);
+    NEXTOU_REQUIRE(epi != 2 || (stats_partial && bwd_weight && bwd_bias && bwd_mean && bwd_invstd && ldh % 4 == 0 && aligned16(bwd_h) &&
+                                ldh >= (int64_t)groups * N && aligned16(bwd_weight) && aligned16(bwd_bias) && aligned16(bwd_mean) &&
+                                aligned16(bwd_invstd)),
+                   "pw_rows_fused: the gradient-statistics epilogue needs partials, h (row stride %lld) and the norm's four vectors", (long long)ldh);
+    NEXTOU_REQUIRE(!(pro && epi == 2), "pw_rows_fused: prologue + gradient-statistics epilogue is not an instantiated combination");
+    const RowsPlan q = plan_rows((int)P, N, groups);
+    PwFuse fz{};
+    fz.pro_scale = pro_scale; fz.pro_shift = pro_shift; fz.pro_slope = pro_slope;
+    fz.partial = reinterpret_cast<double2*>(stats_partial);
+    fz.h = bwd_h; fz.ldh = (long)ldh; fz.epi_w = bwd_weight; fz.epi_b = bwd_bias; fz.epi_mean = bwd_mean; fz.epi_invstd = bwd_invstd;
+    fz.epi_slope = bwd_slope;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K * groups, "pw_rows_kernel<%d,%d|%s%s>[P%lld N%d K%d g%d]", q.tm, q.tn,
+                   pro ? "norm-act," : "", epi == 2 ? "grad-stats" : (epi == 1 ? "stats" : "plain"), (long long)P, N, K, groups);
+    const int Pi = (int)P;
+    if (!pro && epi == 1) return dispatch_rows<0, 1>(q, x, w, nullptr, y, Pi, N, K, groups, (long)ldx, (long)ldy, 1, fz, s);
+    if (pro && epi == 1) return dispatch_rows<1, 1>(q, x, w, nullptr, y, Pi, N, K, groups, (long)ldx, (long)ldy, 1, fz, s);
+    if (pro && epi == 0) return dispatch_rows<1, 0>(q, x, w, nullptr, y, Pi, N, K, groups, (long)ldx, (long)ldy, 1, fz, s);
+    if (!pro && epi == 2) return dispatch_rows<0, 2>(q, x, w, nullptr, y, Pi, N, K, groups, (long)ldx, (long)ldy, 1, fz, s);
+    return dispatch_rows<0, 0>(q, x, w, nullptr, y, Pi, N, K, groups, (long)ldx, (long)ldy, 1, fz, s);
 }
 
 extern "C" int nextou_pw_wgrad_workspace(int64_t P, int N, int K, int groups, size_t* bytes) {
@@ -601,8 +786,8 @@ extern "C" int nextou_pw_wgrad_workspace(int64_t P, int N, int K, int groups, si
     return 0;
 }
 
-extern "C" int nextou_pw_wgrad(const float* gy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int64_t P, int N, int K,
-                               int groups, int64_t ldg, int64_t ldx, int accumulate, nextou_stream_t stream) {
+static int pw_wgrad_impl(const float* gy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int64_t P, int N, int K,
+                         int groups, int64_t ldg, int64_t ldx, int accumulate, const PwFuse* fz, nextou_stream_t stream) {
     NEXTOU_REQUIRE(gy && x && dw && workspace, "pw_wgrad: null pointer");
     if (int e = check_pw("pw_wgrad", P, N, K, groups, ldg, ldx, N, K)) return e;
     const WgradPlan q = plan_wgrad((int)P, N, K, groups);
@@ -613,11 +798,13 @@ extern "C" int nextou_pw_wgrad(const float* gy, const float* x, float* dw, float
     hipStream_t s = (hipStream_t)stream;
     int rc = NEXTOU_EINVAL;
     {
-        ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K * groups, "pw_wgrad_kernel<%d,%d|%dx%d>[P%lld N%d K%d g%d S%d]", q.tn, q.tk, q.wn,
-                       q.wk, (long long)P, N, K, groups, q.splits);
+        ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K * groups, "pw_wgrad_kernel<%d,%d|%dx%d%s>[P%lld N%d K%d g%d S%d]", q.tn, q.tk, q.wn,
+                       q.wk, fz ? "|norm-act" : "", (long long)P, N, K, groups, q.splits);
         int id = 0;
-#define X(a, b, c, d) \
-        if (q.cfg == id++) rc = launch_wgrad<a, b, c, d>(q, gy, x, workspace, (int)P, N, K, groups, (long)ldg, (long)ldx, s);
+#define X(a, b, c, d)                                                                                                              \
+        if (q.cfg == id++)                                                                                                         \
+            rc = fz ? launch_wgrad<a, b, c, d, 1>(q, gy, x, workspace, (int)P, N, K, groups, (long)ldg, (long)ldx, *fz, s)         \
+                    : launch_wgrad<a, b, c, d, 0>(q, gy, x, workspace, (int)P, N, K, groups, (long)ldg, (long)ldx, PwFuse{}, s);
         NEXTOU_WGRAD_CONFIGS(X)
 #undef X
     }
@@ -626,4 +813,18 @@ extern "C" int nextou_pw_wgrad(const float* gy, const float* x, float* dw, float
     ProfScope prof(s, kBoundHbm, 4.0 * elems * (q.splits + 1), "pw_wgrad_reduce_kernel[%ld x S%d]", elems, q.splits);
     hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, s, workspace, dw, elems, q.splits, accumulate);
     return check_launch("pw_wgrad_reduce_kernel");
+}
+
+extern "C" int nextou_pw_wgrad(const float* gy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int64_t P, int N, int K,
+                               int groups, int64_t ldg, int64_t ldx, int accumulate, nextou_stream_t stream) {
+    return pw_wgrad_impl(gy, x, dw, workspace, workspace_bytes, P, N, K, groups, ldg, ldx, accumulate, nullptr, stream);
+}
+
+extern "C" int nextou_pw_wgrad_fused(const float* gy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int64_t P, int N,
+                                     int K, int groups, int64_t ldg, int64_t ldx, int accumulate, const float* pro_scale,
+                                     const float* pro_shift, float pro_slope, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(pro_scale && pro_shift, "pw_wgrad_fused: the operand prologue needs scale and shift");
+    PwFuse fz{};
+    fz.pro_scale = pro_scale; fz.pro_shift = pro_shift; fz.pro_slope = pro_slope;
+    return pw_wgrad_impl(gy, x, dw, workspace, workspace_bytes, P, N, K, groups, ldg, ldx, accumulate, &fz, stream);
 }

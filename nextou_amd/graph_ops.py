@@ -442,6 +442,96 @@ class _HipBackend:
         return dw
 
 
+    # ---- K7 + K6 fused: statistics epilogue / operand prologue GEMMs and K6 in pieces ----
+    @staticmethod
+    def pw_rows_fused(x_cl, w2, groups, pro=None, want_stats=False, bwd=None):
+        """x_cl dense channels-last (B, groups*K, *sp); w2 (groups*N, K).  ``pro`` = (scale, shift, slope): normalise + activate the
+        operand on load.  ``want_stats``: also return the (C, T, 2) float64 (sum, sum of squares) partials of the output.
+        ``bwd`` = (h_cl, weight, bias, mean, invstd, slope): gradient-statistics epilogue, returns the (sum dz, sum dz*xhat) partials."""
+        L_ = _lib.lib()
+        cin = x_cl.shape[1]
+        P = x_cl.numel() // cin
+        N, K = w2.shape[0] // groups, w2.shape[1]
+        y = _empty_channels_last((x_cl.shape[0], w2.shape[0]) + tuple(x_cl.shape[2:]), x_cl.device)
+        partial = None
+        if want_stats or bwd is not None:
+            tiles = int(L_.nextou_pw_rows_tiles(P, N, groups))
+            partial = torch.empty((w2.shape[0], tiles, 2), dtype=torch.float64, device=x_cl.device)
+        ps, psh, pslope = (pro[0], pro[1], float(pro[2])) if pro is not None else (None, None, 1.0)
+        bh, bw, bb, bm, bi, bslope = bwd if bwd is not None else (None, None, None, None, None, 1.0)
+        with torch.cuda.device(x_cl.device):
+            rc = L_.nextou_pw_rows_fused(x_cl.data_ptr(), w2.data_ptr(), y.data_ptr(), P, N, K, groups, cin, w2.shape[0],
+                                         _ptr(ps), _ptr(psh), pslope, _ptr(partial), _ptr(bh), 0 if bh is None else bh.shape[1],
+                                         _ptr(bw), _ptr(bb), _ptr(bm), _ptr(bi), float(bslope), _stream_ptr(x_cl.device))
+        _lib.check(rc, "pw_rows_fused")
+        return y, partial
+
+    @staticmethod
+    def pw_wgrad_fused(gy_cl, x_cl, groups, pro):
+        import ctypes
+        L_ = _lib.lib()
+        cout, cin = gy_cl.shape[1], x_cl.shape[1]
+        P = x_cl.numel() // cin
+        N, K = cout // groups, cin // groups
+        need = ctypes.c_size_t(0)
+        _lib.check(L_.nextou_pw_wgrad_workspace(P, N, K, groups, ctypes.byref(need)), "pw_wgrad_workspace")
+        ws = torch.empty((max(int(need.value), 4) // 4,), dtype=torch.float32, device=x_cl.device)
+        dw = torch.empty((cout, K), dtype=torch.float32, device=x_cl.device)
+        with torch.cuda.device(x_cl.device):
+            rc = L_.nextou_pw_wgrad_fused(gy_cl.data_ptr(), x_cl.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel() * 4, P, N, K, groups,
+                                          cout, cin, 0, pro[0].data_ptr(), pro[1].data_ptr(), float(pro[2]), _stream_ptr(x_cl.device))
+        _lib.check(rc, "pw_wgrad_fused")
+        return dw
+
+    @staticmethod
+    def norm_finalize(partial, count, C, device, weight, bias, pre_bias, running_mean, running_var, training, momentum, eps):
+        """-> (save_mean, save_invstd, scale, shift), each (C,) float32; running statistics updated in place when training."""
+        L_ = _lib.lib()
+        out = torch.empty((4, C), dtype=torch.float32, device=device)
+        tiles = 0 if partial is None else partial.shape[1]
+        with torch.cuda.device(device):
+            rc = L_.nextou_norm_finalize(_ptr(partial), tiles, float(count), _ptr(pre_bias), _ptr(running_mean), _ptr(running_var),
+                                         out[0].data_ptr(), out[1].data_ptr(), _ptr(weight), _ptr(bias), out[2].data_ptr(),
+                                         out[3].data_ptr(), C, int(training), float(momentum), float(eps), _stream_ptr(device))
+        _lib.check(rc, "norm_finalize")
+        return out[0], out[1], out[2], out[3]
+
+    @staticmethod
+    def norm_apply_rows(x_cl, residual_cl, weight, bias, mean, invstd, slope):
+        L_ = _lib.lib()
+        C = x_cl.shape[1]
+        y = torch.empty_like(x_cl)
+        with torch.cuda.device(x_cl.device):
+            rc = L_.nextou_norm_apply_rows(x_cl.data_ptr(), _ptr(residual_cl), y.data_ptr(), _ptr(weight), _ptr(bias), mean.data_ptr(),
+                                           invstd.data_ptr(), x_cl.numel() // C, C, float(slope), _stream_ptr(x_cl.device))
+        _lib.check(rc, "norm_apply_rows")
+        return y
+
+    @staticmethod
+    def norm_bwd_finalize(partial, count, C, device, training):
+        """-> (coeff (C, 2), gweight (C,), gbias (C,))"""
+        L_ = _lib.lib()
+        coeff = torch.empty((C, 2), dtype=torch.float32, device=device)
+        gwb = torch.empty((2, C), dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            rc = L_.nextou_norm_bwd_finalize(partial.data_ptr(), partial.shape[1], float(count), coeff.data_ptr(), gwb[0].data_ptr(),
+                                             gwb[1].data_ptr(), C, int(training), _stream_ptr(device))
+        _lib.check(rc, "norm_bwd_finalize")
+        return coeff, gwb[0], gwb[1]
+
+    @staticmethod
+    def norm_bwd_apply_rows(x_cl, gy_cl, coeff, weight, bias, mean, invstd, slope):
+        L_ = _lib.lib()
+        C = x_cl.shape[1]
+        gx = torch.empty_like(x_cl)
+        with torch.cuda.device(x_cl.device):
+            rc = L_.nextou_norm_bwd_apply_rows(x_cl.data_ptr(), gy_cl.data_ptr(), gx.data_ptr(), coeff.data_ptr(), _ptr(weight), _ptr(bias),
+                                               mean.data_ptr(), invstd.data_ptr(), x_cl.numel() // C, C, float(slope),
+                                               _stream_ptr(x_cl.device))
+        _lib.check(rc, "norm_bwd_apply_rows")
+        return gx
+
+
 def _dhw(sizes, fill=1):
     """(H,W) or (D,H,W) -> (D,H,W): 2-D volumes are one slice thick."""
     sizes = [int(v) for v in sizes]
@@ -901,6 +991,166 @@ def pointwise_eligible(conv: torch.nn.Module, x: torch.Tensor, weight: torch.Ten
 
 def pointwise_conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], groups: int) -> torch.Tensor:
     return _PointwiseConv.apply(x, weight, bias, int(groups))
+
+
+PW_FUSE_DEFAULT = "1"
+
+
+def _pw_fuse_mode() -> str:
+    """NEXTOU_PW_FUSE: "0" op-by-op blocks (MIOpen / K7 convolutions + K6 passes), "1" (default) the fused point-wise pipeline with the
+    gradient statistics in the data-gradient GEMM's epilogue, "fwd" the fused forward with K6's own backward reduce (A/B)."""
+    import os
+    return os.environ.get("NEXTOU_PW_FUSE", PW_FUSE_DEFAULT)
+
+
+class _NormState:
+    """What one fused norm of a point-wise chain needs besides its parameters (plain Python, not a tensor argument)."""
+    __slots__ = ("batch_stats", "momentum", "eps", "slope", "running_mean", "running_var")
+
+    def __init__(self, batch_stats, momentum, eps, slope, running_mean, running_var):
+        self.batch_stats, self.momentum, self.eps, self.slope = bool(batch_stats), float(momentum), float(eps), float(slope)
+        self.running_mean, self.running_var = running_mean, running_var
+
+
+class _PointwiseChain(torch.autograd.Function):
+    """``x -> conv1x1 (groups) -> norm -> LeakyReLU [-> conv1x1 -> norm -> LeakyReLU] [+ residual]`` on a dense channels-last fp32
+    volume as ONE pipeline of K7 GEMMs with K6 folded into them (csrc/pw_gemm.hip, include/nextou_hip.h "K7 + K6 fused"):
+
+    forward   GEMM1 + statistics epilogue -> finalize -> [GEMM2 with norm + activation in the operand load + statistics epilogue ->
+              finalize ->] apply (+ residual).  The activated hidden tensor is never written; K6's statistics passes never run.
+    backward  K6 backward of the last norm -> [data-gradient GEMM with the hidden norm's gradient statistics in its epilogue ->
+              finalize -> apply; weight-gradient GEMM re-creating the activated operand on load ->] data / weight gradient of conv1.
+
+    The reference runs this as conv -> batch_norm -> leaky_relu -> conv -> batch_norm -> add (NexToU_Encoder_Decoder.py:368-390 FFN,
+    :710-720 / :833-842 fc1 / fc2, torch_nn.py:66-92 BasicConv); same arithmetic per element as the op-by-op K7 / K6 path (the
+    normalisation is K6's fmaf, the statistics are float64 sums of the same values in another order)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, w1, g1, b1, cb1, w2, g2, b2, cb2, groups1, n1, n2, fuse_bwd):
+        dev = x.device
+        P = x.numel() // x.shape[1]
+        c1 = w1.shape[0]
+        w1m = w1.reshape(c1, w1.shape[1]).contiguous()
+        h, part1 = _HIP.pw_rows_fused(x, w1m, groups1, want_stats=n1.batch_stats)
+        m1, i1, sc1, sh1 = _HIP.norm_finalize(part1, P, c1, dev, g1, b1, cb1, n1.running_mean, n1.running_var, n1.batch_stats,
+                                              n1.momentum, n1.eps)
+        if w2 is not None:
+            c2 = w2.shape[0]
+            w2m = w2.reshape(c2, w2.shape[1]).contiguous()
+            y, part2 = _HIP.pw_rows_fused(h, w2m, 1, pro=(sc1, sh1, n1.slope), want_stats=n2.batch_stats)
+            m2, i2, _, _ = _HIP.norm_finalize(part2, P, c2, dev, g2, b2, cb2, n2.running_mean, n2.running_var, n2.batch_stats,
+                                              n2.momentum, n2.eps)
+            out = _HIP.norm_apply_rows(y, residual, g2, b2, m2, i2, n2.slope)
+            ctx.save_for_backward(x, h, y, w1, w2, g1, b1, g2, b2, m1, i1, sc1, sh1, m2, i2)
+        else:
+            out = _HIP.norm_apply_rows(h, residual, g1, b1, m1, i1, n1.slope)
+            ctx.save_for_backward(x, h, w1, g1, b1, m1, i1)
+        ctx.conf = (groups1, n1, n2, residual is not None, fuse_bwd, w2 is not None, cb1, cb2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        groups1, n1, n2, has_res, fuse_bwd, two, cb1, cb2 = ctx.conf
+        mf = {4: torch.channels_last, 5: torch.channels_last_3d}[g.dim()]
+        g = g.contiguous(memory_format=mf)
+        gw2 = gg2 = gb2 = gcb2 = None
+        if two:
+            x, h, y, w1, w2, g1, b1, g2, b2, m1, i1, sc1, sh1, m2, i2 = ctx.saved_tensors
+            P = x.numel() // x.shape[1]
+            c1, c2 = w1.shape[0], w2.shape[0]
+            dy, gg2, gb2 = _HIP.norm_act_bwd(y, g, g2, b2, m2, i2, n2.batch_stats, n2.slope, 0, channels_last=True)
+            w2t = w2.reshape(c2, c1).t().contiguous()
+            if fuse_bwd and n1.batch_stats:
+                da, part = _HIP.pw_rows_fused(dy, w2t, 1, bwd=(h, g1, b1, m1, i1, n1.slope))
+                coeff, gg1, gb1 = _HIP.norm_bwd_finalize(part, P, c1, g.device, True)
+                dh = _HIP.norm_bwd_apply_rows(h, da, coeff, g1, b1, m1, i1, n1.slope)
+            else:
+                da = _HIP.pw_rows(dy, w2t, None, 1)
+                dh, gg1, gb1 = _HIP.norm_act_bwd(h, da, g1, b1, m1, i1, n1.batch_stats, n1.slope, 0, channels_last=True)
+            del da
+            if ctx.needs_input_grad[6]:
+                gw2 = _HIP.pw_wgrad_fused(dy, h, 1, (sc1, sh1, n1.slope)).reshape(w2.shape)
+            if cb2 is not None and ctx.needs_input_grad[9]:
+                gcb2 = torch.zeros_like(cb2) if n2.batch_stats else (gb2 * i2 * (g2 if g2 is not None else 1.0))
+        else:
+            x, h, w1, g1, b1, m1, i1 = ctx.saved_tensors
+            c1 = w1.shape[0]
+            dh, gg1, gb1 = _HIP.norm_act_bwd(h, g, g1, b1, m1, i1, n1.batch_stats, n1.slope, 0, channels_last=True)
+        gx = gw1 = gcb1 = None
+        n, k = c1 // groups1, w1.shape[1]
+        if ctx.needs_input_grad[0]:
+            w1t = w1.reshape(groups1, n, k).transpose(1, 2).reshape(groups1 * k, n).contiguous()
+            gx = _HIP.pw_rows(dh, w1t, None, groups1)
+        if ctx.needs_input_grad[2]:
+            gw1 = _HIP.pw_wgrad(dh, x, groups1).reshape(w1.shape)
+        if cb1 is not None and ctx.needs_input_grad[5]:
+            gcb1 = torch.zeros_like(cb1) if n1.batch_stats else (gb1 * i1 * (g1 if g1 is not None else 1.0))
+        return (gx, g if has_res else None, gw1, gg1 if ctx.needs_input_grad[3] else None, gb1 if ctx.needs_input_grad[4] else None, gcb1,
+                gw2, gg2 if ctx.needs_input_grad[7] else None, gb2 if ctx.needs_input_grad[8] else None, gcb2, None, None, None, None)
+
+
+def pointwise_chain(x, residual, conv1, norm1, conv2=None, norm2=None):
+    """Fused ``norm2(conv2(norm1(conv1(x)))) [+ residual]`` (each norm with its absorbed LeakyReLU) when every piece qualifies — see
+    :func:`pointwise_chain_eligible` — else ``None``.  ``conv*``: the 1x1 convolution modules (bias folded into the norm or absent),
+    ``norm*``: the fused ``BatchNormAct`` modules behind them."""
+    mode = _pw_fuse_mode()
+    if mode == "0" or not pointwise_chain_eligible(x, residual, conv1, norm1, conv2, norm2):
+        return None
+    n1 = _norm_state(norm1)
+    n2 = _norm_state(norm2) if norm2 is not None else None
+    cb1 = conv1.bias
+    cb2 = conv2.bias if conv2 is not None else None
+    res = None if residual is None else as_channels_last_rows(residual)
+    return _PointwiseChain.apply(x, res, conv1.weight, norm1.weight, norm1.bias, cb1,
+                                 None if conv2 is None else conv2.weight, None if norm2 is None else norm2.weight,
+                                 None if norm2 is None else norm2.bias, cb2, int(conv1.groups), n1, n2, mode != "fwd")
+
+
+def _norm_state(norm) -> _NormState:
+    """torch.nn.modules.batchnorm._BatchNorm.forward's bookkeeping for one fused norm module (see norm_act._BatchNormAct)."""
+    batch_stats, factor, keep_running = norm._step()
+    return _NormState(batch_stats, factor, norm.eps, norm.negative_slope, norm.running_mean if keep_running else None,
+                      norm.running_var if keep_running else None)
+
+
+def _plain_1x1(conv, cin) -> bool:
+    w = conv.weight
+    if conv.transposed or isinstance(conv.padding, str) or w.dtype != torch.float32:
+        return False
+    if any(k != 1 for k in w.shape[2:]) or any(v != 1 for v in conv.stride) or any(v != 0 for v in conv.padding) or \
+            any(v != 1 for v in conv.dilation):
+        return False
+    g = conv.groups
+    return w.shape[0] % g == 0 and (w.shape[0] // g) % 4 == 0 and w.shape[1] % 4 == 0 and cin == g * w.shape[1] and \
+        getattr(conv, "_pad_spec", None) is None
+
+
+def pointwise_chain_eligible(x, residual, conv1, norm1, conv2=None, norm2=None) -> bool:
+    """Dense channels-last fp32 device volume outside autocast; 1x1 / stride-1 / unpadded convolutions with per-group channel counts
+    that are multiples of 4, the second one un-grouped, each with its bias folded into the norm behind it (norm_act._ConvBiasFolded)
+    or none; fused BatchNorm modules (batch or running statistics) without internal channel padding."""
+    if not x.is_cuda or x.dtype != torch.float32 or torch.is_autocast_enabled("cuda") or _dense_channels_last(x) is None:
+        return False
+    if residual is not None and (residual.dtype != torch.float32 or residual.shape[0] != x.shape[0] or residual.shape[2:] != x.shape[2:]):
+        return False
+    cin = x.shape[1]
+    for conv, norm in ((conv1, norm1), (conv2, norm2)):
+        if conv is None:
+            continue
+        if not _plain_1x1(conv, cin) or not hasattr(norm, "_step") or getattr(norm, "_pad_multiple", 0):
+            return False
+        if conv.bias is not None and getattr(norm, "_pre_bias_src", (None,))[0] is not conv:
+            return False            # a bias that is really added to the conv output: not this pipeline
+        if norm.num_features != conv.weight.shape[0] or (norm.weight is None) != (norm.bias is None):
+            return False
+        batch_stats = norm.training or (norm.running_mean is None and norm.running_var is None)
+        if not batch_stats and norm.running_mean is None:
+            return False
+        cin = conv.weight.shape[0]
+    if conv2 is not None and conv2.groups != 1:
+        return False
+    out_c = (conv2 if conv2 is not None else conv1).weight.shape[0]
+    return residual is None or residual.shape[1] == out_c
 
 
 class _ConvDepthUnrolledGrads(torch.autograd.Function):

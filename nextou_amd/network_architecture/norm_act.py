@@ -128,15 +128,21 @@ _OWN_BIAS = {nn.Conv2d: ConvOwnBias2d, nn.Conv3d: ConvOwnBias3d, nn.ConvTranspos
 class _BatchNormAct:
     negative_slope: float = 1.0
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        self._check_input_dim(x)
-        # same bookkeeping as torch.nn.modules.batchnorm._BatchNorm.forward
+    def _step(self):
+        """``(use_batch_stats, momentum factor, keep_running)`` of this call — the bookkeeping of
+        torch.nn.modules.batchnorm._BatchNorm.forward (advances ``num_batches_tracked``); also called by the fused point-wise
+        pipeline (graph_ops.pointwise_chain), which runs this norm inside its GEMMs."""
         factor = 0.0 if self.momentum is None else self.momentum
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
             factor = 1.0 / float(self.num_batches_tracked) if self.momentum is None else self.momentum
         use_batch_stats = self.training or (self.running_mean is None and self.running_var is None)
         keep_running = (not self.training) or self.track_running_stats
+        return use_batch_stats, factor, keep_running
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._check_input_dim(x)
+        use_batch_stats, factor, keep_running = self._step()
         weight, bias, rm, rv, pre_bias, write_back = padded_norm_params(self, x, _pre_bias(self))
         y = graph_ops.norm_act(x, weight, bias, rm if keep_running else None, rv if keep_running else None,
                                use_batch_stats, factor, self.eps, self.negative_slope, pre_bias=pre_bias)
