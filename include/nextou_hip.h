@@ -314,7 +314,7 @@ int nextou_pw_wgrad(const float* gy, const float* x, float* dw, float* workspace
  *     A = x, or — operand prologue, pro_scale != NULL — A[p, c] = leaky_relu(fmaf(x[p, c], pro_scale[c], pro_shift[c]), pro_slope)
  *         (c = g*K + k over all groups*K input channels; exactly K6's apply arithmetic);
  *     stats_partial != NULL, bwd_h == NULL: statistics epilogue — stats_partial[(c * T + t) * 2 + {0, 1}] = (sum, sum of squares)
- *         of y[:, c] over point tile t, T = nextou_pw_rows_tiles(P, N, groups), c over groups*N output channels: the `partial`
+ *         of y[:, c] over point tile t, T = nextou_pw_rows_tiles(P, N, K, groups), c over groups*N output channels: the `partial`
  *         input of nextou_norm_finalize;
  *     bwd_h != NULL: gradient-statistics epilogue of a data-gradient GEMM (y = d loss / d activated): with h = bwd_h[p, c]
  *         (row stride ldh), z = fmaf(h, scale, shift), dz = y * (z > 0 ? 1 : bwd_slope), xhat = (h - bwd_mean[c]) * bwd_invstd[c]
@@ -330,7 +330,7 @@ int nextou_pw_wgrad(const float* gy, const float* x, float* dw, float* workspace
  * nextou_norm_bwd_finalize / nextou_norm_bwd_apply_rows   the two halves of K6's backward after the reduce: coeff (2C floats) +
  *     parameter gradients from (sum dz, sum dz*xhat) partials; gx = scale * ((dz - coeff[2c]) - xhat * coeff[2c+1]).
  * ---------------------------------------------------------------------------------------- */
-int nextou_pw_rows_tiles(int64_t P, int N, int groups);
+int nextou_pw_rows_tiles(int64_t P, int N, int K, int groups);
 int nextou_pw_rows_fused(const float* x, const float* w, float* y, int64_t P, int N, int K, int groups, int64_t ldx, int64_t ldy,
                          const float* pro_scale, const float* pro_shift, float pro_slope, double* stats_partial,
                          const float* bwd_h, int64_t ldh, const float* bwd_weight, const float* bwd_bias, const float* bwd_mean,

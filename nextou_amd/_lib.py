@@ -78,7 +78,7 @@ _SIGNATURES = {
     "nextou_pw_wgrad_workspace": (c_int, [c_int64, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "nextou_pw_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int64, c_int64,
                                 c_int, c_void_p]),
-    "nextou_pw_rows_tiles": (c_int, [c_int64, c_int, c_int]),
+    "nextou_pw_rows_tiles": (c_int, [c_int64, c_int, c_int, c_int]),
     "nextou_pw_rows_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64,
                                      c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_float, c_void_p]),

@@ -49,10 +49,11 @@ __global__ __launch_bounds__(256) void argmax_labels_kernel(const float* __restr
     }
 }
 
-// One thread per voxel; the two LUTs live in LDS; neighbour labels come through L1/L2 (each label
-// byte is touched by at most 27 threads of neighbouring rows).
+// Round-1 kernel, kept as the fallback for min_thick > 3: one thread per voxel; the two LUTs live in LDS; neighbour labels come
+// through L1/L2 (each label byte is touched by at most 27 threads of neighbouring rows).  81 memory instructions per voxel at
+// connectivity 26: 96 us for the 2 x 64 x 224 x 192 volume of cfg 4 = 1.4 % of the HBM roofline (profiles/r03_kernel_bench_k5_start.md).
 // full_box: box neighbourhood of radius `rad` (connectivity 26 / 8); otherwise the 6 / 4 cross.
-__global__ __launch_bounds__(256) void bti_critical_kernel(
+__global__ __launch_bounds__(256) void bti_critical_naive_kernel(
     const uint8_t* __restrict__ labels, const uint32_t* __restrict__ lut_a,
     const uint32_t* __restrict__ lut_c, int n_labels, uint8_t* __restrict__ critical, int D, int H,
     int W, int full_box, int rad) {
@@ -109,6 +110,139 @@ __global__ __launch_bounds__(256) void bti_critical_kernel(
     critical[(size_t)b * V + v] = ((nc & a) | (na & c)) ? 1 : 0;
 }
 
+// Round 3: the same map as a SEPARABLE bitwise-OR dilation over LDS tiles.  With m = (lut_a[label], lut_c[label]) per voxel,
+// the box neighbourhood's OR factorises into an OR along x, then y, then z; the 6 / 4 cross is (in-plane cross) | centre(z-1) |
+// centre(z+1).  A workgroup owns a 64 x 8 column of voxels and walks the depth: per plane it looks every label of the halo tile
+// up ONCE (one ds_read_b64 of the packed LUT), ORs along x into a second LDS plane and along y out of it, and keeps the last
+// 2R+1 plane values of its voxels in registers — ~10 LDS instructions per voxel instead of 81 L1 / LDS instructions, label bytes
+// read from HBM once per tile (+ halo), critical bytes written once, 64 consecutive bytes per wave.
+constexpr int kCritTX = 64, kCritTY = 8, kCritTZ = 14, kCritG = 4;     // TZ + 2 planes of halo = 4 prefetch groups at R = 1
+
+template <int R, bool BOX>
+__global__ __launch_bounds__(256) void bti_critical_kernel(const uint8_t* __restrict__ labels, const uint32_t* __restrict__ lut_a,
+                                                          const uint32_t* __restrict__ lut_c, int n_labels,
+                                                          uint8_t* __restrict__ critical, int D, int H, int W, int z_chunks) {
+    constexpr int HX = kCritTX + 2 * R, HY = kCritTY + 2 * R;
+    __shared__ uint2 lut[256];
+    __shared__ uint2 M[HY][HX];              // masks of the halo plane
+    __shared__ uint2 P1[HY][kCritTX];        // BOX: OR along x;  cross: unused
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 256; i += 256) lut[i] = i < n_labels ? make_uint2(lut_a[i], lut_c[i]) : make_uint2(0u, 0u);
+    const int b = blockIdx.z / z_chunks, zc = blockIdx.z - b * z_chunks;
+    const int x0 = blockIdx.x * kCritTX, y0 = blockIdx.y * kCritTY, z0 = zc * kCritTZ;
+    const int z1 = min(D, z0 + kCritTZ);
+    const long long HW = (long long)H * W;
+    const uint8_t* lb = labels + (size_t)b * HW * D;
+    uint8_t* cb = critical + (size_t)b * HW * D;
+    const int tx = tid & 63, ty = tid >> 6;                 // the thread's voxels: rows ty and ty + 4 of the tile, column tx
+    // rings over the last 2R+1 planes: BOX: the in-plane OR; cross: [0] / [1] / [2] = centre masks of planes z-2, z-1, z and the
+    // in-plane cross of plane z-1
+    uint2 ring[2][2 * R + 1], centre[2][R + 1], cross_q[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+#pragma unroll
+        for (int k = 0; k < 2 * R + 1; ++k) ring[v][k] = make_uint2(0u, 0u);
+#pragma unroll
+        for (int k = 0; k < R + 1; ++k) centre[v][k] = make_uint2(0u, 0u);
+        cross_q[v] = make_uint2(0u, 0u);
+    }
+    // label bytes of the halo planes, prefetched a GROUP of kCritG planes ahead: a plane's LDS work is ~0.3 us, a global load ~1-2 us,
+    // so un-prefetched the walk over TZ + 2R planes was a chain of exposed load latencies (30 us even for a 16 x 28 x 24 volume)
+    constexpr int NL = (HY * HX + 255) / 256;
+    uint8_t nxt[kCritG][NL], cur[kCritG][NL];
+    auto fetch = [&](int zbase, uint8_t (&dst)[kCritG][NL]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < kCritG; ++g) {
+            const int z = zbase + g;
+            const bool plane_ok = z >= 0 && z < D && z < z1 + R;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int i = tid + k * 256;
+                const int yy = i / HX, xx = i - yy * HX;
+                const int y = y0 + yy - R, x = x0 + xx - R;
+                const bool ok = plane_ok && i < HY * HX && y >= 0 && y < H && x >= 0 && x < W;
+                dst[g][k] = ok ? lb[(size_t)z * HW + (size_t)y * W + x] : (uint8_t)0;
+            }
+        }
+    };
+    fetch(z0 - R, nxt);
+    __syncthreads();
+    for (int zg = z0 - R; zg < z1 + R; zg += kCritG) {
+#pragma unroll
+        for (int g = 0; g < kCritG; ++g)
+#pragma unroll
+            for (int k = 0; k < NL; ++k) cur[g][k] = nxt[g][k];
+        if (zg + kCritG < z1 + R) fetch(zg + kCritG, nxt);
+#pragma unroll
+      for (int g = 0; g < kCritG; ++g) {
+        const int z = zg + g;
+        if (z >= z1 + R) break;
+        const bool plane_ok = z >= 0 && z < D;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = tid + k * 256;
+            if (i >= HY * HX) break;
+            const int yy = i / HX, xx = i - yy * HX;
+            const int y = y0 + yy - R, x = x0 + xx - R;
+            uint2 m = make_uint2(0u, 0u);
+            if (plane_ok && y >= 0 && y < H && x >= 0 && x < W) m = lut[cur[g][k]];
+            M[yy][xx] = m;
+        }
+        __syncthreads();
+        if constexpr (BOX) {
+            for (int i = tid; i < HY * kCritTX; i += 256) {
+                const int yy = i >> 6, xx = i & 63;
+                uint2 o = M[yy][xx];
+#pragma unroll
+                for (int dx = 1; dx <= 2 * R; ++dx) { const uint2 t = M[yy][xx + dx]; o.x |= t.x; o.y |= t.y; }
+                P1[yy][xx] = o;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int row = ty + 4 * v;
+            uint2 o;
+            if constexpr (BOX) {
+                o = P1[row][tx];
+#pragma unroll
+                for (int dy = 1; dy <= 2 * R; ++dy) { const uint2 t = P1[row + dy][tx]; o.x |= t.x; o.y |= t.y; }
+            } else {
+                const uint2 c0 = M[row + 1][tx + 1], l = M[row + 1][tx], r = M[row + 1][tx + 2], u = M[row][tx + 1], d = M[row + 2][tx + 1];
+                o = make_uint2(c0.x | l.x | r.x | u.x | d.x, c0.y | l.y | r.y | u.y | d.y);
+            }
+            // slide the window: after this step ring[.][2R] belongs to plane z, centre[.][R] to plane z
+#pragma unroll
+            for (int k = 0; k < 2 * R; ++k) ring[v][k] = ring[v][k + 1];
+            ring[v][2 * R] = o;
+#pragma unroll
+            for (int k = 0; k < R; ++k) centre[v][k] = centre[v][k + 1];
+            centre[v][R] = M[row + R][tx + R];
+            const int zo = z - R;                           // the plane whose neighbourhood is now complete
+            const int y = y0 + row, x = x0 + tx;
+            if (zo >= z0 && zo < z1 && y < H && x < W) {
+                uint2 n;
+                uint2 self;
+                if constexpr (BOX) {
+                    n = ring[v][0];
+#pragma unroll
+                    for (int k = 1; k < 2 * R + 1; ++k) { n.x |= ring[v][k].x; n.y |= ring[v][k].y; }
+                    self = centre[v][0];
+                } else {
+                    // R == 1: ring[.][1] = in-plane cross of plane zo; centre[.][0] = centre of plane zo; the z taps are the centres
+                    // of planes zo - 1 (kept in cross_q) and zo + 1 (= this plane's centre)
+                    n = make_uint2(ring[v][1].x | cross_q[v].x | centre[v][1].x, ring[v][1].y | cross_q[v].y | centre[v][1].y);
+                    self = centre[v][0];
+                }
+                cb[(size_t)zo * HW + (size_t)y * W + x] = ((n.y & self.x) | (n.x & self.y)) ? 1 : 0;
+            }
+            if constexpr (!BOX) cross_q[v] = centre[v][0];  // becomes "centre of plane zo - 1" for the next output plane
+        }
+        __syncthreads();        // M / P1 are rewritten by the next plane
+      }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // critical-voxel cross-entropy in float64 (reference loss/bti_loss.py:141-143):
 //   ce[b,v] = logsumexp_l(double(x[b,l,v])) - double(x[b,target,v]);  loss[b] = sum_v critical * ce
@@ -129,6 +263,10 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// LMAX > 0: L <= LMAX class planes, held in registers — every logit is read once and every exp evaluated once (the generic
+// LMAX = 0 form re-reads the planes for the max, the sum and, backward, the probabilities, and evaluates exp twice per class
+// in the backward).  Same float64 arithmetic in the same order either way.
+template <int LMAX>
 __global__ __launch_bounds__(256) void bti_ce_fwd_kernel(const float* __restrict__ logits,
                                                          const uint8_t* __restrict__ target,
                                                          const uint8_t* __restrict__ critical,
@@ -146,15 +284,32 @@ __global__ __launch_bounds__(256) void bti_ce_fwd_kernel(const float* __restrict
         if (!__any(crit)) continue;
         if (crit) {
             const int y = tb[v];
-            double m = (double)lb[v], xy = (y == 0) ? m : 0.0;
-            for (int l = 1; l < L; ++l) {
-                const double x = (double)lb[(size_t)l * V + v];
-                if (l == y) xy = x;
-                m = fmax(m, x);
+            if constexpr (LMAX > 0) {
+                float x[LMAX];
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) x[l] = l < L ? lb[(size_t)l * V + v] : -INFINITY;
+                float mf = x[0];
+#pragma unroll
+                for (int l = 1; l < LMAX; ++l) mf = fmaxf(mf, x[l]);          // max of floats == max of their doubles
+                const double m = (double)mf;
+                double s = 0.0, xy = 0.0;
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) {
+                    if (l < L) s += exp((double)x[l] - m);
+                    if (l == y) xy = (double)x[l];
+                }
+                if (y < L) acc += (m + log(s)) - xy;
+            } else {
+                double m = (double)lb[v], xy = (y == 0) ? m : 0.0;
+                for (int l = 1; l < L; ++l) {
+                    const double x = (double)lb[(size_t)l * V + v];
+                    if (l == y) xy = x;
+                    m = fmax(m, x);
+                }
+                double s = 0.0;
+                for (int l = 0; l < L; ++l) s += exp((double)lb[(size_t)l * V + v] - m);
+                if (y < L) acc += (m + log(s)) - xy;
             }
-            double s = 0.0;
-            for (int l = 0; l < L; ++l) s += exp((double)lb[(size_t)l * V + v] - m);
-            if (y < L) acc += (m + log(s)) - xy;
         }
     }
     acc = wave_sum(acc);
@@ -164,6 +319,7 @@ __global__ __launch_bounds__(256) void bti_ce_fwd_kernel(const float* __restrict
 }
 
 // grad[b,l,v] = scale * critical[b,v] * (softmax_l(double x) - [l == target]), written for every voxel.
+template <int LMAX>
 __global__ __launch_bounds__(256) void bti_ce_bwd_kernel(const float* __restrict__ logits,
                                                          const uint8_t* __restrict__ target,
                                                          const uint8_t* __restrict__ critical,
@@ -182,14 +338,37 @@ __global__ __launch_bounds__(256) void bti_ce_bwd_kernel(const float* __restrict
             continue;
         }
         const int y = tb[v];
-        double m = (double)lb[v];
-        for (int l = 1; l < L; ++l) m = fmax(m, (double)lb[(size_t)l * V + v]);
-        double s = 0.0;
-        for (int l = 0; l < L; ++l) s += exp((double)lb[(size_t)l * V + v] - m);
-        const double inv = (y < L) ? scale / s : 0.0;
-        for (int l = 0; l < L; ++l) {
-            const double p = exp((double)lb[(size_t)l * V + v] - m) * inv;
-            gb[(size_t)l * V + v] = (float)(l == y ? p - ((y < L) ? scale : 0.0) : p);
+        if constexpr (LMAX > 0) {
+            float x[LMAX];
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) x[l] = l < L ? lb[(size_t)l * V + v] : -INFINITY;
+            float mf = x[0];
+#pragma unroll
+            for (int l = 1; l < LMAX; ++l) mf = fmaxf(mf, x[l]);
+            const double m = (double)mf;
+            double e[LMAX], s = 0.0;
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                e[l] = l < L ? exp((double)x[l] - m) : 0.0;
+                if (l < L) s += e[l];
+            }
+            const double inv = (y < L) ? scale / s : 0.0;
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                if (l >= L) break;
+                const double p = e[l] * inv;
+                gb[(size_t)l * V + v] = (float)(l == y ? p - ((y < L) ? scale : 0.0) : p);
+            }
+        } else {
+            double m = (double)lb[v];
+            for (int l = 1; l < L; ++l) m = fmax(m, (double)lb[(size_t)l * V + v]);
+            double s = 0.0;
+            for (int l = 0; l < L; ++l) s += exp((double)lb[(size_t)l * V + v] - m);
+            const double inv = (y < L) ? scale / s : 0.0;
+            for (int l = 0; l < L; ++l) {
+                const double p = exp((double)lb[(size_t)l * V + v] - m) * inv;
+                gb[(size_t)l * V + v] = (float)(l == y ? p - ((y < L) ? scale : 0.0) : p);
+            }
         }
     }
 }
@@ -206,8 +385,10 @@ extern "C" int nextou_bti_ce_fwd(const float* logits, const uint8_t* target, con
     NEXTOU_REQUIRE(B > 0 && L > 0 && L <= 256 && V > 0 && B <= 65535, "bti_ce_fwd: bad size B=%d L=%d V=%lld", B, L, (long long)V);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(s, kBoundHbm, (4.0 * L + 2.0) * B * (double)V, "bti_ce_fwd_kernel[B%d L%d V%lld]", B, L, (long long)V);
-    hipLaunchKernelGGL(bti_ce_fwd_kernel, dim3(kCeBlocks, B), dim3(256), 0, s, logits, target, critical, partial, L,
-                       (long long)V);
+    if (L <= 16)
+        hipLaunchKernelGGL(bti_ce_fwd_kernel<16>, dim3(kCeBlocks, B), dim3(256), 0, s, logits, target, critical, partial, L, (long long)V);
+    else
+        hipLaunchKernelGGL(bti_ce_fwd_kernel<0>, dim3(kCeBlocks, B), dim3(256), 0, s, logits, target, critical, partial, L, (long long)V);
     return check_launch("bti_ce_fwd_kernel");
 }
 
@@ -220,8 +401,12 @@ extern "C" int nextou_bti_ce_bwd(const float* logits, const uint8_t* target, con
     ProfScope prof(s, kBoundHbm, (8.0 * L + 2.0) * B * (double)V, "bti_ce_bwd_kernel[B%d L%d V%lld]", B, L, (long long)V);
     long long blocks = cdiv64(V, 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bti_ce_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, s, logits, target, critical, scale_dev,
-                       grad_logits, L, (long long)V);
+    if (L <= 16)
+        hipLaunchKernelGGL(bti_ce_bwd_kernel<16>, dim3((unsigned)blocks, B), dim3(256), 0, s, logits, target, critical, scale_dev, grad_logits, L,
+                           (long long)V);
+    else
+        hipLaunchKernelGGL(bti_ce_bwd_kernel<0>, dim3((unsigned)blocks, B), dim3(256), 0, s, logits, target, critical, scale_dev, grad_logits, L,
+                           (long long)V);
     return check_launch("bti_ce_bwd_kernel");
 }
 
@@ -262,10 +447,22 @@ extern "C" int nextou_bti_critical_map(const uint8_t* labels, const uint32_t* lu
     NEXTOU_REQUIRE(!((connectivity == 8 || connectivity == 4) && D != 1),
                    "bti_critical_map: 2-D connectivity %d needs D == 1 (got %d)", connectivity, D);
     const long long V = (long long)D * H * W;
-    ProfScope prof((hipStream_t)stream, kBoundHbm, 2.0 * B * (double)V, "bti_critical_kernel[B%d %dx%dx%d c%d]", B, D, H, W,
-                   connectivity);
-    hipLaunchKernelGGL(bti_critical_kernel, dim3((unsigned)cdiv64(V, 256), 1, B), dim3(256), 0,
-                       (hipStream_t)stream, labels, lut_a, lut_c, n_labels, critical, D, H, W, full_box,
-                       full_box ? min_thick : 1);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(s, kBoundHbm, 2.0 * B * (double)V, "bti_critical_kernel[B%d %dx%dx%d c%d]", B, D, H, W, connectivity);
+    const int rad = full_box ? min_thick : 1;
+    const int z_chunks = cdiv(D, kCritTZ);
+    const dim3 grid(cdiv(W, kCritTX), cdiv(H, kCritTY), (unsigned)(B * z_chunks));
+    if (rad > 3 || (long long)B * z_chunks > 65535 || cdiv(H, kCritTY) > 65535) {
+        hipLaunchKernelGGL(bti_critical_naive_kernel, dim3((unsigned)cdiv64(V, 256), 1, B), dim3(256), 0, s, labels, lut_a, lut_c, n_labels,
+                           critical, D, H, W, full_box, rad);
+        return check_launch("bti_critical_naive_kernel");
+    }
+#define NEXTOU_CRIT(R_, BOX_)                                                                                                      \
+    hipLaunchKernelGGL((bti_critical_kernel<R_, BOX_>), grid, dim3(256), 0, s, labels, lut_a, lut_c, n_labels, critical, D, H, W, z_chunks)
+    if (!full_box) NEXTOU_CRIT(1, false);
+    else if (rad == 1) NEXTOU_CRIT(1, true);
+    else if (rad == 2) NEXTOU_CRIT(2, true);
+    else NEXTOU_CRIT(3, true);
+#undef NEXTOU_CRIT
     return check_launch("bti_critical_kernel");
 }

@@ -579,7 +579,7 @@ struct FusedPlan {
 // the 256 CUs.  Large grids take 192-wide chunks (fewest staging passes per MFMA); grids that
 // cannot fill the chip even so take 64-wide chunks (more splits) and 64-channel slabs (half the
 // barrier / global-load round trips: these launches are latency-bound, LDS is plentiful).
-static FusedPlan plan_fused(int B, int N, int M, int K) {
+static FusedPlan plan_fused(int B, int N, int M, int K, bool self = false) {
     FusedPlan p;
     const int need = cdiv(N, 32);
     p.nw = need <= 6 ? (need < 1 ? 1 : need) : 4;
@@ -591,18 +591,28 @@ static FusedPlan plan_fused(int B, int N, int M, int K) {
     // SIMD; 64-wide chunks (133 VGPRs, 3 waves) are faster although they stage three times as often — cfg-5 Pool s3
     // 1850 -> 1591 us, Swin s3 268 -> 232 us (profiles/r02_knn_topk_ab.md)
     if (K > 16) p.tiles = 2;
+    // Round 3: windows that ONE workgroup covers (N, M <= 192) on a grid of 512 ... 1023 waves (the stage-3 windows of cfg 2,
+    // B' = 128) took 64-wide chunks, 3 candidate splits and a merge launch: 80 + 16 us; one 192-wide chunk per workgroup, no
+    // split, no merge is 90 us in ONE launch (profiles/r03_kernel_bench_cfg2.md).  Below 512 waves (stage 4 / 5: B' = 16 / 2) the
+    // split stays: there a window's 18 MFLOP on a single CU are the latency (100-130 us un-split against 61-73 + 9 us split).
+    // NEXTOU_KNN_WINDOW=0 restores the round-2 plan for A/B.
+    static const bool window_plan = [] { const char* e = getenv("NEXTOU_KNN_WINDOW"); return !(e && e[0] == '0'); }();
+    const bool window = window_plan && small && waves >= 512 && N <= 192 && M <= 192;
+    if (window) p.tiles = 6;
     if (const char* e = getenv("NEXTOU_KNN_TILES")) p.tiles = atoi(e) == 2 ? 2 : (atoi(e) == 6 ? 6 : p.tiles);   // experiments
     const int tm = 32 * p.tiles;
     const int chunks = cdiv(M, tm);
     long long want = cdiv64(2048, waves);
     if (want > chunks) want = chunks;
     if (want > kMaxSplits) want = kMaxSplits;
-    if (want < 1) want = 1;
+    if (want < 1 || window) want = 1;
     const int chunks_per_split = cdiv(chunks, (int)want);
     p.splits = cdiv(chunks, chunks_per_split);
     p.m_per_split = chunks_per_split * tm;
     p.ks = (waves * p.splits < 2048) ? 64 : 32;
-    if ((size_t)p.ks * (tm + 32 * p.nw) * sizeof(float) > 64 * 1024) p.ks = 32;  // default dynamic-LDS limit
+    // default dynamic-LDS limit; a self window covered by one workgroup stages ONE slab for both MFMA operands (launch_fused)
+    const bool one_slab = self && p.splits == 1 && N <= tm && 32 * p.nw == tm;
+    if ((size_t)p.ks * (one_slab ? tm : tm + 32 * p.nw) * sizeof(float) > 64 * 1024) p.ks = 32;
     return p;
 }
 
@@ -670,7 +680,9 @@ static bool use_networks(int KB) {
 template <int KB, int TILES, bool BITONIC>
 static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
     const int QW = 32 * p.nw;
-    const size_t lds = (size_t)p.ks * (32 * TILES + QW) * sizeof(float);
+    // (the kernel's share_ab condition: queries == candidates, one query tile, one chunk)
+    const bool one_slab = a.yn == a.xn && QW == 32 * TILES && a.N <= QW && p.splits == 1 && a.M <= 32 * TILES;
+    const size_t lds = (size_t)p.ks * (one_slab ? 32 * TILES : 32 * TILES + QW) * sizeof(float);
     dim3 grid(cdiv(a.N, QW), a.B, p.splits);
     // 16-B staging needs row strides and bases that keep every 4-float piece aligned
     const int vec_ok = (a.N % 4 == 0) && (a.M % 4 == 0) &&
@@ -761,7 +773,7 @@ extern "C" int nextou_knn_graph(const float* x, const float* y, const float* rel
         return check_launch("knn_select_naive_kernel");
     }
 
-    const FusedPlan plan = plan_fused(B, N, M, K);
+    const FusedPlan plan = plan_fused(B, N, M, K, !has_y);
     FusedArgs a{xn, yn, xs, ys, relpos, nn_idx, (float*)(base + w.part_d), (int32_t*)(base + w.part_i), B, C, N, M, K};
     // list-length buckets: every slot costs 4 VALU ops per candidate per lane, so the cfg-2 values
     // 7 / 14 / 28 get their own instantiation instead of rounding up to 8 / 16 / 32

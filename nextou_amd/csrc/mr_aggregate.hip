@@ -186,6 +186,149 @@ __global__ __launch_bounds__(512) void mr_fwd_q4_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// forward, channel quads with the NEIGHBOUR LIST split over the four lanes of a DPP quad (round 3).  The pooled graphs
+// (K = 14 ... 32 ids per query) kept the dword kernel in round 2 because 28 ids + their gathered values per lane cost
+// 2 waves per SIMD; its counters (profiles/r03_sq_counters_k2_pool_s3.md) say where the time goes: 70 % of the LDS cycles are
+// bank conflicts of the random ds_read_b32 gathers (6.9 cycles per wave instruction against 2 conflict-free) behind 0.9 waves per
+// SIMD.  Here lane (query, kg) owns the KL = ceil(K / 4) neighbours j = kg * KL .. kg * KL + KL - 1 of its query: KL ids and KL
+// 16-byte gathers in flight (the quad tile of mr_fwd_q4_kernel: one ds_read_b128 moves four channels, ~1.5x fewer LDS cycles per
+// element than the dword gather under random conflicts), ~60 VGPRs, and the four partial (max, arg) pairs meet in two
+// quad_perm steps.  First-maximum-wins is preserved: the lanes' blocks are ascending in j, blocks after the first start from
+// -inf with the strict compare (so they skip what the sequential scan skips), and a pair keeps the lower lane's candidate
+// unless the higher one is strictly greater.
+// grid = (n_tiles, quad blocks, B), 256 threads = 64 queries per pass; LDS = quads * M float4.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+
+constexpr int kKqMaxQuads = 4;       // channel quads per workgroup (the planner never asks for more)
+
+template <int KL, bool SELF, bool WITH_ARG>
+__global__ __launch_bounds__(256) void mr_fwd_kq_kernel(
+    const float* __restrict__ x, const float* __restrict__ src, const int32_t* __restrict__ idx,
+    float* __restrict__ out, uint16_t* __restrict__ arg, int C, int N, int M, int K, int idx_stride,
+    int idx_step, int quads, int n_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float4 tile4[];
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * quads * 4;
+    int nq = (C - c0 + 3) >> 2;
+    if (nq > quads) nq = quads;
+    const float* sb = src + ((size_t)b * C + c0) * M;
+    for (int e = threadIdx.x; e < nq * M; e += blockDim.x) {
+        const int q = e / M, m = e - q * M;
+        const int c = 4 * q;
+        const float* p = sb + (size_t)c * M + m;
+        float4 v;
+        v.x = p[0];
+        v.y = (c0 + c + 1 < C) ? p[(size_t)M] : 0.f;
+        v.z = (c0 + c + 2 < C) ? p[(size_t)2 * M] : 0.f;
+        v.w = (c0 + c + 3 < C) ? p[(size_t)3 * M] : 0.f;
+        tile4[e] = v;
+    }
+    __syncthreads();
+    const int kg = threadIdx.x & 3, ql = threadIdx.x >> 2;          // 64 queries per pass, 4 lanes each
+    const int n_begin = blockIdx.x * n_per_block;
+    int n_end = n_begin + n_per_block;
+    if (n_end > N) n_end = N;
+    const int j_first = kg * KL;
+    // The ids and centre values of pass p + 1 are fetched while pass p computes: un-prefetched, every pass began with a global load
+    // whose latency nothing covered (the first version of this kernel: 74 us on Pool s3 for ~20 us of LDS / VALU work).
+    int idn[KL];
+    float xn[kKqMaxQuads];
+    auto fetch = [&](int nb) __attribute__((always_inline)) {
+        int n = nb + ql;
+        if (n >= n_end) n = n_end - 1;                                // clamped: every lane of a quad takes part in the DPP steps
+        const int32_t* irow = idx + ((size_t)b * N + n) * idx_stride;
+#pragma unroll
+        for (int t = 0; t < KL; ++t) idn[t] = irow[(size_t)((j_first + t < K) ? j_first + t : 0) * idx_step];
+        if (!SELF) {
+#pragma unroll
+            for (int q = 0; q < kKqMaxQuads; ++q) {
+                const int c = c0 + 4 * q + kg;
+                xn[q] = (q < nq && c < C) ? x[((size_t)b * C + c) * N + n] : 0.f;
+            }
+        }
+    };
+    fetch(n_begin);
+    for (int nb = n_begin; nb < n_end; nb += 64) {
+        const int n = nb + ql;
+        const bool live = n < n_end;
+        const int nc = live ? n : n_end - 1;
+        int id[KL];
+        float xc[kKqMaxQuads];
+#pragma unroll
+        for (int t = 0; t < KL; ++t) id[t] = idn[t];
+#pragma unroll
+        for (int q = 0; q < kKqMaxQuads; ++q) xc[q] = xn[q];
+        if (nb + 64 < n_end) fetch(nb + 64);
+#pragma unroll
+        for (int q = 0; q < kKqMaxQuads; ++q) {
+            if (q >= nq) break;
+            const float4* row = tile4 + q * M;
+            const int c = c0 + 4 * q;
+            // the centre values of the quad's four channels: lane kg holds channel c + kg, quad_perm broadcasts spread them
+            float xm;
+            if (SELF) {
+                const float4 r = row[nc];
+                xm = kg == 0 ? r.x : (kg == 1 ? r.y : (kg == 2 ? r.z : r.w));
+            } else {
+                xm = xc[q];
+            }
+            float4 xv;
+            xv.x = dpp_f<0x00>(xm);     // quad_perm [0,0,0,0]
+            xv.y = dpp_f<0x55>(xm);     // [1,1,1,1]
+            xv.z = dpp_f<0xAA>(xm);     // [2,2,2,2]
+            xv.w = dpp_f<0xFF>(xm);     // [3,3,3,3]
+            float4 sv[KL];
+#pragma unroll
+            for (int t = 0; t < KL; ++t) sv[t] = row[id[t]];
+            float4 mx;
+            int a0, a1, a2, a3;
+            if (kg == 0) {              // the scan's first element initialises the maximum (NaN included, as in the sequential form)
+                mx.x = sv[0].x - xv.x; mx.y = sv[0].y - xv.y; mx.z = sv[0].z - xv.z; mx.w = sv[0].w - xv.w;
+            } else {
+                mx.x = mx.y = mx.z = mx.w = -INFINITY;
+            }
+            a0 = a1 = a2 = a3 = id[0];
+#pragma unroll
+            for (int t = 0; t < KL; ++t) {
+                if (j_first + t >= K) continue;          // (uniform per lane; the padded slots hold id[0] of the row)
+                const float d0 = sv[t].x - xv.x, d1 = sv[t].y - xv.y, d2 = sv[t].z - xv.z, d3 = sv[t].w - xv.w;
+                if (d0 > mx.x) { mx.x = d0; a0 = id[t]; }
+                if (d1 > mx.y) { mx.y = d1; a1 = id[t]; }
+                if (d2 > mx.z) { mx.z = d2; a2 = id[t]; }
+                if (d3 > mx.w) { mx.w = d3; a3 = id[t]; }
+            }
+            // pairs (kg ^ 1), then (kg ^ 2): the lower lane's candidate stays unless the higher one is strictly greater
+#define NEXTOU_KQ_MERGE(CTRL, BIT, V, A)                                          \
+            {                                                                     \
+                const float pv = dpp_f<CTRL>(V);                                  \
+                const int pa = dpp_i<CTRL>(A);                                    \
+                const bool take = (kg & BIT) ? !(V > pv) : (pv > V);              \
+                V = take ? pv : V;                                                \
+                A = take ? pa : A;                                                \
+            }
+            NEXTOU_KQ_MERGE(0xB1, 1, mx.x, a0) NEXTOU_KQ_MERGE(0xB1, 1, mx.y, a1) NEXTOU_KQ_MERGE(0xB1, 1, mx.z, a2) NEXTOU_KQ_MERGE(0xB1, 1, mx.w, a3)
+            NEXTOU_KQ_MERGE(0x4E, 2, mx.x, a0) NEXTOU_KQ_MERGE(0x4E, 2, mx.y, a1) NEXTOU_KQ_MERGE(0x4E, 2, mx.z, a2) NEXTOU_KQ_MERGE(0x4E, 2, mx.w, a3)
+#undef NEXTOU_KQ_MERGE
+            // lane kg writes channel c + kg of its query: 16 queries x 4 channel rows per wave instruction
+            const float mv = kg == 0 ? mx.x : (kg == 1 ? mx.y : (kg == 2 ? mx.z : mx.w));
+            const int av = kg == 0 ? a0 : (kg == 1 ? a1 : (kg == 2 ? a2 : a3));
+            if (live && c + kg < C) {
+                float* o = out + ((size_t)b * 2 * C + 2 * (c + kg)) * N + n;
+                o[0] = xm;
+                o[(size_t)N] = mv;
+                if (WITH_ARG) arg[((size_t)b * C + c + kg) * N + n] = (uint16_t)av;
+            }
+        }
+    }
+}
+
 // generic forward: arbitrary centre ids and/or source rows too long for LDS; gathers from
 // global memory (L2-resident rows).  One thread per (b, c, n).
 __global__ __launch_bounds__(256) void mr_fwd_global_kernel(
@@ -636,6 +779,37 @@ static bool plan_q4(int B, int C, int N, int M, int K, bool self, Q4Plan* p) {
     return p->q_blocks <= 65535 && B <= 65535;
 }
 
+// Work decomposition of mr_fwd_kq_kernel: the quad tile of plan_q4 (16 * M bytes per channel quad; ~20 KB tiles for windows, what
+// fits 48 KB for the pooled candidate sets), 256 threads = 64 queries per pass, the query range cut until the grid has ~4
+// workgroups per CU while every workgroup still makes >= 2 passes over its staged tile.
+static bool plan_kq(int B, int C, int N, int M, int K, bool self, Q4Plan* p) {
+    const char* force = getenv("NEXTOU_MR_FWD");
+    if (force && (force[0] == 'v' || force[0] == 'q')) return false;
+    if (!(force && force[0] == 'k') && K <= 8 && self && N <= 512) return false;      // stage-2 windows: mr_fwd_q4_kernel (61 % of HBM)
+    if (M > 65536) return false;
+    const size_t per_quad = (size_t)M * 16;
+    if (per_quad > 152 * 1024) return false;
+    const int total_quads = (C + 3) / 4;
+    size_t budget = M <= 512 ? 20 * 1024 : 48 * 1024;
+    int quads = (int)(budget / per_quad);
+    if (quads < 1) quads = 1;
+    if (quads > kKqMaxQuads) quads = kKqMaxQuads;
+    if (quads > total_quads) quads = total_quads;
+    while (quads > 1 && (long long)cdiv(total_quads, quads) * B * cdiv(N, 128) < 1024) quads = (quads + 1) / 2;     // fill the chip
+    quads = cdiv(total_quads, cdiv(total_quads, quads));      // balance the last block
+    p->quads = quads;
+    p->q_blocks = cdiv(total_quads, quads);
+    p->lds = (size_t)quads * per_quad;
+    long long want = cdiv64(1024, (long long)p->q_blocks * B);
+    const long long max_tiles = N >= 128 ? N / 128 : 1;
+    if (want > max_tiles) want = max_tiles;
+    if (want < 1) want = 1;
+    p->n_per_block = cdiv(cdiv(N, (int)want), 64) * 64;
+    p->n_tiles = cdiv(N, p->n_per_block);
+    p->threads = 256;
+    return p->q_blocks <= 65535 && B <= 65535;
+}
+
 static int check_mr_args(const char* who, const void* a, const void* b, const void* c, int B, int C,
                          int N, int M, int K, int idx_stride, int idx_step) {
     NEXTOU_REQUIRE(a && b && c, "%s: null pointer", who);
@@ -693,6 +867,34 @@ extern "C" int nextou_mr_aggregate_fwd(const float* x, const float* y, const int
 #undef NEXTOU_MR_Q4
         return check_launch("mr_fwd_q4_kernel");
     }
+    if (center_idx == nullptr && K <= 32 && plan_kq(B, C, N, M, K, self, &qp)) {
+        dim3 grid(qp.n_tiles, qp.q_blocks, B), block(qp.threads);
+        const int kl = K <= 8 ? 2 : (K <= 16 ? 4 : (K <= 28 ? 7 : 8));
+        ProfScope prof(s, kBoundHbm, fwd_bytes, "mr_fwd_kq_kernel<%d,%s,%s>[B%d C%d N%d M%d K%d]", kl,
+                       self ? "self" : "xy", arg_out ? "arg" : "noarg", B, C, N, M, K);
+#define NEXTOU_MR_KQ(KL, SELF, ARG)                                                                          \
+    do {                                                                                                     \
+        if (qp.lds > 64 * 1024)                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_fwd_kq_kernel<KL, SELF, ARG>),       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)qp.lds);              \
+        hipLaunchKernelGGL((mr_fwd_kq_kernel<KL, SELF, ARG>), grid, block, qp.lds, s, x, src, nn_idx, out, arg_out, \
+                           C, N, M, K, idx_stride, idx_step, qp.quads, qp.n_per_block);                      \
+    } while (0)
+#define NEXTOU_MR_KQ_KL(KL)                                                      \
+    do {                                                                         \
+        if (self && arg_out) NEXTOU_MR_KQ(KL, true, true);                       \
+        else if (self) NEXTOU_MR_KQ(KL, true, false);                            \
+        else if (arg_out) NEXTOU_MR_KQ(KL, false, true);                         \
+        else NEXTOU_MR_KQ(KL, false, false);                                     \
+    } while (0)
+        if (kl == 2) NEXTOU_MR_KQ_KL(2);
+        else if (kl == 4) NEXTOU_MR_KQ_KL(4);
+        else if (kl == 7) NEXTOU_MR_KQ_KL(7);
+        else NEXTOU_MR_KQ_KL(8);
+#undef NEXTOU_MR_KQ_KL
+#undef NEXTOU_MR_KQ
+        return check_launch("mr_fwd_kq_kernel");
+    }
     MrPlan p;
     if (center_idx == nullptr && K <= 32 && plan_lds(B, C, N, M, M, true, &p)) {
         dim3 grid(p.n_tiles, p.c_chunks, B), block(p.threads);
@@ -729,7 +931,7 @@ extern "C" int nextou_mr_aggregate_has_arg(int B, int C, int N, int M, int K) {
     MrPlan p;
     Q4Plan q;
     return (M <= 65536 && K <= 32 && B > 0 && C > 0 && N > 0 && M > 0 &&
-            (plan_q4(B, C, N, M, K, M == N, &q) || plan_lds(B, C, N, M, M, true, &p))) ? 1 : 0;
+            (plan_q4(B, C, N, M, K, M == N, &q) || plan_kq(B, C, N, M, K, M == N, &q) || plan_lds(B, C, N, M, M, true, &p))) ? 1 : 0;
 }
 
 // 1 if the caller should keep nn_idx alive and take nextou_mr_aggregate_bwd_arg_idx for a self graph of this shape.

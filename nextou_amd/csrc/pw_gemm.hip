@@ -98,7 +98,8 @@ __device__ __forceinline__ float leaky_f(float z, float slope) { return z > 0.f 
 template <int TM, int TN, int PRO, int EPI>
 __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                       const float* __restrict__ bias, float* __restrict__ Y, int P, int N, int K,
-                                                      long ldx, long ldw, long ldy, int nb_n, int items, int vec_store, PwFuse fz) {
+                                                      long ldx, long ldw, long ldy, int nb_n, int items, int vec_store, PwFuse fz,
+                                                      int ktail) {
     constexpr int BM = 64 * TM, BN = 16 * TN;
     constexpr int XV = BM * (kPwKC / 4) / 256;                // float4 per thread per stage, X tile
     constexpr int WV = (BN * (kPwKC / 4) + 255) / 256;        // ... W tile (last one predicated)
@@ -177,7 +178,9 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
     };
 
     f32x4 acc[TM][TN];
-    auto compute = [&](int buf) __attribute__((always_inline)) {
+    // nsub: how many of the stage's four k sub-steps (4 channels each) carry data — 4 except in the last stage of a K that is not a
+    // multiple of 16 (K = 132: the ninth stage holds 4 channels; its other three sub-steps would multiply zeros: 8 % of the MFMAs)
+    auto compute = [&](int buf, int nsub) __attribute__((always_inline)) {
         const float* xs = Xs + buf * BM * kPwLd + (wave * TM * 16 + r16) * kPwLd + kg * 4;
         const float* ws = Ws + buf * BN * kPwLd + r16 * kPwLd + kg * 4;
         float4 b[TM];
@@ -204,9 +207,15 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
     }
 #endif
             NEXTOU_PW_STEP(x)
-            NEXTOU_PW_STEP(y)
-            NEXTOU_PW_STEP(z)
-            NEXTOU_PW_STEP(w)
+            if (nsub > 1) {
+                NEXTOU_PW_STEP(y)
+            }
+            if (nsub > 2) {
+                NEXTOU_PW_STEP(z)
+            }
+            if (nsub > 3) {
+                NEXTOU_PW_STEP(w)
+            }
 #undef NEXTOU_PW_STEP
             a0 = n0f;
             a1 = n1f;
@@ -316,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
     };
 
     const int stages = (K + kPwKC - 1) / kPwKC;
+    const int nsub_last = ktail ? ((K - 1) % kPwKC) / 4 + 1 : 4;
     int item = item_at(walk);
     int p0 = 0, n0 = 0;
 #if NEXTOU_PW_STAGGER
@@ -344,22 +354,22 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
         // an exit there makes the compiler shuttle every accumulator between AGPRs and VGPRs once per iteration
         for (int s = 0; s + 1 < stages; s += 2) {
 #if NEXTOU_PW_ABLATE & 2
-            compute(0);
+            compute(0, 4);
             __syncthreads();
-            compute(0);
+            compute(0, 4);
             __syncthreads();
 #else
             load_stage(p0, n0, min(s + 2, stages - 1) * kPwKC, xr[0], wr[0], psc[0], psh[0]);     // past the end: a re-read nobody stores
-            compute(0);
+            compute(0, 4);
             store_stage(1, p0, n0, (s + 1) * kPwKC, xr[1], wr[1], psc[1], psh[1]);
             __syncthreads();
             load_stage(p0, n0, min(s + 3, stages - 1) * kPwKC, xr[1], wr[1], psc[1], psh[1]);
-            compute(1);
+            compute(1, s + 2 == stages ? nsub_last : 4);
             store_stage(0, p0, n0, (s + 2) * kPwKC, xr[0], wr[0], psc[0], psh[0]);     // past the end: zeros nobody reads (no branch: keeps vmcnt exact)
             __syncthreads();
 #endif
         }
-        if (stages & 1) compute(0);
+        if (stages & 1) compute(0, nsub_last);
         walk += slots;
         const int next = item_at(walk);
         const int np0 = next >= 0 ? (next / nb_n) * BM : p0, nn0 = next >= 0 ? (next % nb_n) * BN : n0;
@@ -369,6 +379,235 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
         item = next;
         p0 = np0;
         n0 = nn0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pw_rows, STATIONARY WEIGHTS (round 3).  y[p, n] = sum_k A[p, k] w[n, k] for the stage-2 shapes of the path, where the point count
+// is long (172 032) and K short (132 ... 528): each wave keeps the weights of its TNW x 16 output channels in REGISTERS for the whole
+// launch and the workgroup — ceil(N / (16 TNW)) waves, all N channels — streams 64-point tiles of x through a double-buffered LDS
+// slab.  Against pw_rows_kernel (weights re-staged through LDS for every tile, K-staged loop with two barriers per 16 k):
+//   * x is read from HBM / MALL ONCE (not once per channel block), the weights never touch LDS, one barrier per 64-point slab;
+//   * the loop body is ONE static instruction sequence per tile (the k loop is unrolled over the register-resident weights), so the
+//     in-order vmcnt counter the compiler waits on is exact: the result stores of tile t stay in flight under the multiply of tile
+//     t + 1 (in pw_rows_kernel the loop-top wait merged the entry path with the back edge and drained the stores before the next
+//     tile could start: its multiply, store and load phases added up — profiles/r02_pw_gemm.md ablation, r03_pw_rows_sw.md);
+//   * statistics epilogue without cross-wave traffic: a channel belongs to exactly one wave.
+// Same MFMA (16x16x4 f32), same k order inside a 16-k chunk (lane group kg holds k = 16 c + 4 kg + {0..3}), k chunks ascending: the
+// results are bit-identical to pw_rows_kernel's.
+// Shape-specialised: <TNW, NW waves, NCH full 16-k chunks per slab, TAIL extra 4-k sub-steps (one slab only), SLABS>,
+// K = SLABS * 16 * NCH + 4 * TAIL; plan_rows_sw() knows the instantiated shapes, everything else takes pw_rows_kernel.
+// ------------------------------------------------------------------------------------------------------------
+// Slabs are 132 channels wide — every K of the path's stage-2 point-wise convolutions is a multiple of 132 (132, 264, 528) —
+// i.e. eight 16-k chunks and one 4-k tail sub-step: K = SLABS * 132.
+constexpr int kSwNch = 8, kSwSk = 16 * kSwNch + 4, kSwSk4 = kSwSk / 4;     // 132 floats = 33 16-byte slots (odd: conflict-light ds_read_b128)
+
+// TNW channel tiles per wave, NW waves; PASSES: the 64-point tile is multiplied in PASSES sequential slices (accumulators:
+// 4 / PASSES point tiles x TNW channel tiles); WSTREAM: the weights of slab s + 1 are re-fetched (L2) into a second register set
+// while slab s multiplies — K = 528 would otherwise hold 132 weight registers per lane (3 waves per SIMD allow 168 in all).
+template <int TNW, int NW, int SLABS, int WSTREAM, int PRO, int EPI>
+__global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __restrict__ X, const float* __restrict__ Wt, float* __restrict__ Y,
+                                                           int P, int N, int K, long ldx, long ldy, int tiles64, PwFuse fz) {
+    constexpr int NT = 64 * NW, SK = kSwSk, SK4 = kSwSk4, LDK = kSwSk, NCH = kSwNch;
+    constexpr int NV = (64 * SK4 + NT - 1) / NT;                           // float4 per thread per slab
+    constexpr int PASSES = SLABS > 1 ? 1 : (TNW >= 3 ? 4 : (TNW == 2 ? 2 : 1));
+    constexpr int PTS = 4 / PASSES;
+    constexpr int WSETS = WSTREAM ? 2 : SLABS;
+    static_assert(SLABS == 1 || TNW == 1, "several slabs keep all four point tiles' accumulators: one channel tile per wave");
+    extern __shared__ float4 pw_smem4[];
+    float* xs = reinterpret_cast<float*>(pw_smem4);                        // [2][64][LDK]
+    float* psc = xs + 2 * 64 * LDK;                                        // PRO: [K] scale, [K] shift
+    float* psh = psc + (PRO ? K : 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+
+    // ---- the wave's weights: w[set][j][c] = W[n0 + 16 j + r16][132 s + 16 c + 4 kg + {0..3}], tail w_t[set][j] = W[..][132 s + 128 + kg]
+    f32x4 wreg[WSETS][TNW][NCH];
+    float wtail[WSETS][TNW];
+    const int n_wave = wave * TNW * 16;
+    auto load_weights = [&](int set, int sl) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+            const int n = n_wave + j * 16 + r16;
+            const float* wp = Wt + (long)min(n, N - 1) * K + sl * SK;
+            const bool ok = n < N;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const float4 v = ld4(wp + 16 * c + 4 * kg);
+                wreg[set][j][c] = ok ? f32x4{v.x, v.y, v.z, v.w} : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            wtail[set][j] = ok ? wp[16 * NCH + kg] : 0.f;
+        }
+    };
+    if constexpr (WSTREAM) {
+        load_weights(0, 0);
+    } else {
+#pragma unroll
+        for (int sl = 0; sl < SLABS; ++sl) load_weights(sl, sl);
+    }
+    if constexpr (PRO == 1) {
+        for (int k = tid; k < K; k += NT) { psc[k] = fz.pro_scale[k]; psh[k] = fz.pro_shift[k]; }
+    }
+
+    // ---- slab staging: global -> registers (in flight during the multiply) -> LDS
+    float4 xr[NV];
+    auto load_slab = [&](int tile, int sl) __attribute__((always_inline)) {
+        const long p0 = (long)tile * 64;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + i * NT, row = f / SK4, c4 = f - row * SK4;
+            const long p = min(p0 + min(row, 63), (long)P - 1);
+            xr[i] = ld4(X + p * ldx + sl * SK + c4 * 4);
+        }
+    };
+    auto store_slab = [&](int buf, int tile, int sl) __attribute__((always_inline)) {
+        float* dst = xs + buf * 64 * LDK;
+        const long p0 = (long)tile * 64;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + i * NT, row = f / SK4, c4 = f - row * SK4;
+            if (f >= 64 * SK4) continue;
+            float4 v = xr[i];
+            if constexpr (PRO == 1) {
+                const float4 sc = *reinterpret_cast<const float4*>(psc + sl * SK + c4 * 4), sh = *reinterpret_cast<const float4*>(psh + sl * SK + c4 * 4);
+                v = make_float4(leaky_f(fmaf(v.x, sc.x, sh.x), fz.pro_slope), leaky_f(fmaf(v.y, sc.y, sh.y), fz.pro_slope),
+                                leaky_f(fmaf(v.z, sc.z, sh.z), fz.pro_slope), leaky_f(fmaf(v.w, sc.w, sh.w), fz.pro_slope));
+            }
+            *reinterpret_cast<float4*>(dst + row * LDK + c4 * 4) = keep_if(p0 + row < P, v);
+        }
+    };
+
+    f32x4 acc[PTS][TNW];
+    auto multiply = [&](int buf, int set, int pass) __attribute__((always_inline)) {
+        const float* base = xs + buf * 64 * LDK + (pass * PTS * 16 + r16) * LDK + 4 * kg;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float4 b[PTS];
+#pragma unroll
+            for (int pt = 0; pt < PTS; ++pt) b[pt] = ld4(base + pt * 16 * LDK + 16 * c);
+#define NEXTOU_SW_STEP(cmp, idx)                                                                                           \
+    _Pragma("unroll") for (int pt = 0; pt < PTS; ++pt) _Pragma("unroll") for (int j = 0; j < TNW; ++j)                    \
+        acc[pt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[set][j][c][idx], b[pt].cmp, acc[pt][j], 0, 0, 0);
+            NEXTOU_SW_STEP(x, 0)
+            NEXTOU_SW_STEP(y, 1)
+            NEXTOU_SW_STEP(z, 2)
+            NEXTOU_SW_STEP(w, 3)
+#undef NEXTOU_SW_STEP
+        }
+        float bt[PTS];
+#pragma unroll
+        for (int pt = 0; pt < PTS; ++pt) bt[pt] = base[pt * 16 * LDK + 16 * NCH - 3 * kg];                   // column 128 + kg
+#pragma unroll
+        for (int pt = 0; pt < PTS; ++pt)
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) acc[pt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wtail[set][j], bt[pt], acc[pt][j], 0, 0, 0);
+    };
+
+    auto epilogue = [&](int tile, int pass) __attribute__((always_inline)) {
+        const long p0 = (long)tile * 64 + pass * PTS * 16;
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+            const int n = n_wave + j * 16 + kg * 4;
+            if (n >= N) continue;                                           // uniform over the DPP row
+            float4 hq[PTS];
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int pt = 0; pt < PTS; ++pt) hq[pt] = ld4(fz.h + min(p0 + pt * 16 + r16, (long)P - 1) * fz.ldh + n);
+            }
+#pragma unroll
+            for (int pt = 0; pt < PTS; ++pt) {
+                const long p = p0 + pt * 16 + r16;
+                if (p < P) *reinterpret_cast<float4*>(Y + p * ldy + n) = make_float4(acc[pt][j][0], acc[pt][j][1], acc[pt][j][2], acc[pt][j][3]);
+            }
+            if constexpr (EPI != 0) {
+                float sm[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (EPI == 1) {
+#pragma unroll
+                    for (int pt = 0; pt < PTS; ++pt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float v = acc[pt][j][r]; sm[r] += v; q[r] = fmaf(v, v, q[r]); }
+                } else {
+                    const float4 w = ld4(fz.epi_w + n), bb = ld4(fz.epi_b + n), m = ld4(fz.epi_mean + n), is = ld4(fz.epi_invstd + n);
+                    const float wv[4] = {w.x, w.y, w.z, w.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w}, mv[4] = {m.x, m.y, m.z, m.w},
+                                iv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+                    for (int pt = 0; pt < PTS; ++pt) {
+                        const float hv[4] = {hq[pt].x, hq[pt].y, hq[pt].z, hq[pt].w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {                   // K6's backward reduce, term for term (rows past P: g = 0)
+                            const float scale = wv[r] * iv[r], shift = fmaf(-mv[r], scale, bv[r]);
+                            const float z = fmaf(hv[r], scale, shift);
+                            const float gq = acc[pt][j][r];
+                            const float dz = z > 0.f ? gq : gq * fz.epi_slope;
+                            const float xh = (hv[r] - mv[r]) * iv[r];
+                            sm[r] += dz;
+                            q[r] = fmaf(dz, xh, q[r]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); q[r] = row16_sum(q[r]); }
+                if (r16 == 0) {
+                    const long t = (long)tile * PASSES + pass;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fz.partial[(long)(n + r) * ((long)tiles64 * PASSES) + t] = make_double2((double)sm[r], (double)q[r]);
+                }
+            }
+        }
+    };
+
+    // ---- persistent loop over the 64-point tiles; ONE static body per tile
+    int tile = blockIdx.x;
+    if (tile < tiles64) load_slab(tile, 0);
+    __syncthreads();                                                        // psc / psh visible
+    if (tile < tiles64) store_slab(0, tile, 0);
+    __syncthreads();
+    int buf = 0;
+    for (; tile < tiles64; tile += gridDim.x) {
+        const int next = tile + gridDim.x < tiles64 ? tile + gridDim.x : tile;          // no next tile: a re-read nobody uses
+        // one slab step: fetch the next slab (and, streaming, its weights), multiply this one, then move the fetched slab into LDS
+        auto step = [&](int sl, int set_now, int set_next) __attribute__((always_inline)) {
+            const int nsl = sl + 1 < SLABS ? sl + 1 : 0;
+            const int ntile = sl + 1 < SLABS ? tile : next;
+            load_slab(ntile, nsl);
+            if constexpr (WSTREAM) load_weights(set_next, nsl);             // in flight during this multiply
+            if constexpr (SLABS == 1) {
+#pragma unroll
+                for (int pass = 0; pass < PASSES; ++pass) {
+#pragma unroll
+                    for (int pt = 0; pt < PTS; ++pt)
+#pragma unroll
+                        for (int j = 0; j < TNW; ++j) acc[pt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    multiply(buf, 0, pass);
+                    epilogue(tile, pass);
+                }
+            } else {
+                if (sl == 0) {
+#pragma unroll
+                    for (int pt = 0; pt < PTS; ++pt)
+#pragma unroll
+                        for (int j = 0; j < TNW; ++j) acc[pt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                multiply(buf, set_now, 0);
+                if (sl == SLABS - 1) epilogue(tile, 0);
+            }
+            store_slab(buf ^ 1, ntile, nsl);
+            __syncthreads();
+            buf ^= 1;
+        };
+        if constexpr (WSTREAM) {
+            // two register sets alternate: the slab loop runs in PAIRS and is not unrolled further (unrolled over four slabs the
+            // scheduler hoisted every slab's LDS reads and weight loads: 87 spilled registers)
+            static_assert(SLABS % 2 == 0, "weight streaming alternates two register sets");
+#pragma unroll 1
+            for (int sl = 0; sl < SLABS; sl += 2) {
+                step(sl, 0, 1);
+                step(sl + 1, 1, 0);
+            }
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < SLABS; ++sl) step(sl, sl, 0);
+        }
     }
 }
 
@@ -554,7 +793,7 @@ struct RowsPlan { int tm, tn, nb_n, nb_p, items, grid; size_t lds; };
 inline int tiles16(int c) { return (c + 15) / 16; }
 
 // channel tiles per workgroup: the divisor-like choice that wastes least; ties -> the larger (fewer re-reads of x)
-RowsPlan plan_rows(int P, int N, int groups) {
+RowsPlan plan_rows(int P, int N, int groups, bool allow_tm1 = false) {
     static const int kTn[] = {1, 3, 6, 7, 9, 11};
     const int t = tiles16(N);
     int best = 1;
@@ -572,13 +811,15 @@ RowsPlan plan_rows(int P, int N, int groups) {
     }
     RowsPlan q{};
     q.tm = 2;
+    if (const char* e = getenv("NEXTOU_PW_ROWS_TM"))                                     // experiment: 64-point workgroup tiles
+        q.tm = (atoi(e) == 1 && allow_tm1 && (best == 9 || best == 11)) ? 1 : 2;
     q.tn = best;
     q.nb_n = (t + best - 1) / best;
     q.nb_p = (P + 64 * q.tm - 1) / (64 * q.tm);
     q.items = q.nb_n * q.nb_p;
     q.lds = (size_t)2 * (64 * q.tm + 16 * q.tn) * kPwLd * sizeof(float);
     // persistent grid: what is resident at once (registers: 2 workgroups per CU from 9 channel tiles up, more below)
-    const int per_cu = best >= 9 ? 2 : best >= 6 ? 3 : best >= 3 ? 5 : 8;
+    const int per_cu = q.tm == 1 ? (best >= 9 ? 3 : 5) : (best >= 9 ? 2 : best >= 6 ? 3 : best >= 3 ? 5 : 8);
     int grid = cu_count() * per_cu / (groups > 0 ? groups : 1);
     if (grid > q.items) grid = q.items;
     q.grid = (grid + kXcds - 1) / kXcds * kXcds;
@@ -674,14 +915,73 @@ int launch_rows(const RowsPlan& q, const float* x, const float* w, const float* 
         if (int e = allow_lds(pw_rows_kernel<TM, TN, PRO, EPI>, lds)) return e;
         allowed = lds;
     }
+    static const int ktail = [] { const char* e = getenv("NEXTOU_PW_KTAIL"); return (e && e[0] == '0') ? 0 : 1; }();
     hipLaunchKernelGGL((pw_rows_kernel<TM, TN, PRO, EPI>), dim3(q.grid, groups), dim3(256), lds, s, x, w, bias, y, P, N, K, ldx, ldw, ldy,
-                       q.nb_n, q.items, vec_store, fz);
+                       q.nb_n, q.items, vec_store, fz, ktail);
     return check_launch("pw_rows_kernel");
+}
+
+// ---- stationary-weights kernel: the instantiated shapes -------------------------------------------------------------
+// X(id, TNW, NW, SLABS, WSTREAM): K = 132 * SLABS, up to 16 * TNW * NW output channels
+#define NEXTOU_SW_CONFIGS(X) \
+    X(0, 3, 11, 1, 0) /* K 132 -> N <= 528: FFN fc1 (132 -> 528) and the data gradient of FFN fc2            */ \
+    X(1, 2, 9, 1, 0)  /* K 132 -> N <= 288: the data gradient of the graphers' fc2 (132 -> 264)               */ \
+    X(2, 1, 9, 1, 0)  /* K 132 -> N <= 144: the graphers' fc1 (132 -> 132) and its data gradient              */ \
+    X(3, 1, 9, 2, 0)  /* K 264 -> N <= 144: the graphers' fc2 (264 -> 132)                                    */ \
+    X(4, 1, 9, 4, 1)  /* K 528 -> N <= 144: FFN fc2 (528 -> 132) and the data gradient of FFN fc1             */
+
+struct SwPlan { int cfg, tnw, nw, tiles64, passes, grid; size_t lds; };
+
+// cfg = -1 unless an instantiated shape fits: one group, enough 64-point tiles to give every CU several (the stage-2 volumes)
+SwPlan plan_rows_sw(int64_t P, int N, int K, int groups, bool pro) {
+    SwPlan q{};
+    q.cfg = -1;
+    static const int mode = [] { const char* e = getenv("NEXTOU_PW_SW"); return e ? atoi(e) : 1; }();
+    if (mode == 0 || groups != 1 || N % 4 != 0 || P < 64 * 4 * (int64_t)cu_count()) return q;
+    const int t = tiles16(N);
+    if (K == 132) q.cfg = t <= 9 ? 2 : (t <= 18 ? 1 : (t <= 33 ? 0 : -1));
+    else if (K == 264 && t <= 9) q.cfg = 3;
+    else if (K == 528 && t <= 9) q.cfg = 4;
+    if (q.cfg < 0) return q;
+    q.tnw = q.cfg == 0 ? 3 : (q.cfg == 1 ? 2 : 1);
+    q.nw = q.cfg == 0 ? 11 : 9;
+    q.passes = q.cfg == 0 ? 4 : (q.cfg == 1 ? 2 : 1);
+    q.tiles64 = (int)((P + 63) / 64);
+    q.grid = q.tiles64 < cu_count() ? q.tiles64 : cu_count();
+    q.lds = (size_t)2 * 64 * kSwSk * sizeof(float) + (pro ? (size_t)2 * K * sizeof(float) : 0);
+    return q;
+}
+
+template <int TNW, int NW, int SLABS, int WSTREAM, int PRO, int EPI>
+int launch_rows_sw(const SwPlan& q, const float* x, const float* w, float* y, int P, int N, int K, long ldx, long ldy, const PwFuse& fz,
+                   hipStream_t s) {
+    static size_t allowed = 0;
+    if (q.lds > allowed) {
+        if (int e = allow_lds(pw_rows_sw_kernel<TNW, NW, SLABS, WSTREAM, PRO, EPI>, q.lds)) return e;
+        allowed = q.lds;
+    }
+    hipLaunchKernelGGL((pw_rows_sw_kernel<TNW, NW, SLABS, WSTREAM, PRO, EPI>), dim3(q.grid), dim3(64 * NW), q.lds, s, x, w, y, P, N, K, ldx, ldy,
+                       q.tiles64, fz);
+    return check_launch("pw_rows_sw_kernel");
+}
+
+template <int PRO, int EPI>
+int dispatch_rows_sw(const SwPlan& q, const float* x, const float* w, float* y, int P, int N, int K, long ldx, long ldy, const PwFuse& fz,
+                     hipStream_t s) {
+#define X(id, tnw, nw, slabs, wstream) \
+    if (q.cfg == id) return launch_rows_sw<tnw, nw, slabs, wstream, PRO, EPI>(q, x, w, y, P, N, K, ldx, ldy, fz, s);
+    NEXTOU_SW_CONFIGS(X)
+#undef X
+    return fail(NEXTOU_EINVAL, "pw_rows_sw: no kernel for plan %d", q.cfg);
 }
 
 template <int PRO, int EPI>
 int dispatch_rows(const RowsPlan& q, const float* x, const float* w, const float* bias, float* y, int P, int N, int K, int groups, long ldx,
                   long ldy, int vec_store, const PwFuse& fz, hipStream_t s) {
+    if constexpr (PRO == 0 && EPI == 0) {
+        if (q.tm == 1 && q.tn == 9) return launch_rows<1, 9, 0, 0>(q, x, w, bias, y, P, N, K, groups, ldx, (long)K, ldy, vec_store, fz, s);
+        if (q.tm == 1 && q.tn == 11) return launch_rows<1, 11, 0, 0>(q, x, w, bias, y, P, N, K, groups, ldx, (long)K, ldy, vec_store, fz, s);
+    }
 #define NEXTOU_PW_ROWS(TN_) \
     case TN_: return launch_rows<2, TN_, PRO, EPI>(q, x, w, bias, y, P, N, K, groups, ldx, (long)K, ldy, vec_store, fz, s)
     switch (q.tn) {
@@ -731,16 +1031,25 @@ extern "C" int nextou_pw_rows(const float* x, const float* w, const float* bias,
     if (int e = check_pw("pw_rows", P, N, K, groups, ldx, ldy, K, N)) return e;
     NEXTOU_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && aligned16(x) && aligned16(w),
                    "pw_rows: K=%d and ldx=%lld must be multiples of 4 and x, w 16-byte aligned", K, (long long)ldx);
-    const RowsPlan q = plan_rows((int)P, N, groups);
+    const RowsPlan q = plan_rows((int)P, N, groups, true);
     const int vec_store = (N % 4 == 0 && ldy % 4 == 0 && aligned16(y)) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
+    if (bias == nullptr && vec_store && ldx == K) {
+        const SwPlan sw = plan_rows_sw(P, N, K, groups, false);
+        if (sw.cfg >= 0) {
+            ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K, "pw_rows_sw_kernel<%d,%d|plain>[P%lld N%d K%d]", sw.tnw, sw.nw, (long long)P, N, K);
+            return dispatch_rows_sw<0, 0>(sw, x, w, y, (int)P, N, K, (long)ldx, (long)ldy, PwFuse{}, s);
+        }
+    }
     ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K * groups, "pw_rows_kernel<%d,%d>[P%lld N%d K%d g%d]", q.tm, q.tn, (long long)P, N, K,
                    groups);
     return dispatch_rows<0, 0>(q, x, w, bias, y, (int)P, N, K, groups, (long)ldx, (long)ldy, vec_store, PwFuse{}, s);
 }
 
-extern "C" int nextou_pw_rows_tiles(int64_t P, int N, int groups) {
-    if (P <= 0 || N <= 0 || groups <= 0) return 0;
+extern "C" int nextou_pw_rows_tiles(int64_t P, int N, int K, int groups) {
+    if (P <= 0 || N <= 0 || K <= 0 || groups <= 0) return 0;
+    const SwPlan sw = plan_rows_sw(P, N, K, groups, false);
+    if (sw.cfg >= 0) return sw.tiles64 * sw.passes;
     return plan_rows((int)P, N, groups).nb_p;
 }
 
@@ -768,9 +1077,19 @@ extern "C" int nextou_pw_rows_fused(const float* x, const float* w, float* y, in
     fz.h = bwd_h; fz.ldh = (long)ldh; fz.epi_w = bwd_weight; fz.epi_b = bwd_bias; fz.epi_mean = bwd_mean; fz.epi_invstd = bwd_invstd;
     fz.epi_slope = bwd_slope;
     hipStream_t s = (hipStream_t)stream;
+    const int Pi = (int)P;
+    const SwPlan sw = ldx == (int64_t)groups * K ? plan_rows_sw(P, N, K, groups, pro) : SwPlan{-1, 0, 0, 0, 0, 0, 0};
+    if (sw.cfg >= 0) {
+        ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K, "pw_rows_sw_kernel<%d,%d|%s%s>[P%lld N%d K%d]", sw.tnw, sw.nw, pro ? "norm-act," : "",
+                       epi == 2 ? "grad-stats" : (epi == 1 ? "stats" : "plain"), (long long)P, N, K);
+        if (!pro && epi == 1) return dispatch_rows_sw<0, 1>(sw, x, w, y, Pi, N, K, (long)ldx, (long)ldy, fz, s);
+        if (pro && epi == 1) return dispatch_rows_sw<1, 1>(sw, x, w, y, Pi, N, K, (long)ldx, (long)ldy, fz, s);
+        if (pro && epi == 0) return dispatch_rows_sw<1, 0>(sw, x, w, y, Pi, N, K, (long)ldx, (long)ldy, fz, s);
+        if (!pro && epi == 2) return dispatch_rows_sw<0, 2>(sw, x, w, y, Pi, N, K, (long)ldx, (long)ldy, fz, s);
+        return dispatch_rows_sw<0, 0>(sw, x, w, y, Pi, N, K, (long)ldx, (long)ldy, fz, s);
+    }
     ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K * groups, "pw_rows_kernel<%d,%d|%s%s>[P%lld N%d K%d g%d]", q.tm, q.tn,
                    pro ? "norm-act," : "", epi == 2 ? "grad-stats" : (epi == 1 ? "stats" : "plain"), (long long)P, N, K, groups);
-    const int Pi = (int)P;
     if (!pro && epi == 1) return dispatch_rows<0, 1>(q, x, w, nullptr, y, Pi, N, K, groups, (long)ldx, (long)ldy, 1, fz, s);
     if (pro && epi == 1) return dispatch_rows<1, 1>(q, x, w, nullptr, y, Pi, N, K, groups, (long)ldx, (long)ldy, 1, fz, s);
     if (pro && epi == 0) return dispatch_rows<1, 0>(q, x, w, nullptr, y, Pi, N, K, groups, (long)ldx, (long)ldy, 1, fz, s);

@@ -455,7 +455,7 @@ class _HipBackend:
         y = _empty_channels_last((x_cl.shape[0], w2.shape[0]) + tuple(x_cl.shape[2:]), x_cl.device)
         partial = None
         if want_stats or bwd is not None:
-            tiles = int(L_.nextou_pw_rows_tiles(P, N, groups))
+            tiles = int(L_.nextou_pw_rows_tiles(P, N, K, groups))
             partial = torch.empty((w2.shape[0], tiles, 2), dtype=torch.float64, device=x_cl.device)
         ps, psh, pslope = (pro[0], pro[1], float(pro[2])) if pro is not None else (None, None, 1.0)
         bh, bw, bb, bm, bi, bslope = bwd if bwd is not None else (None, None, None, None, None, 1.0)

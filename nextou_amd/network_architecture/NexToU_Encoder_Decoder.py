@@ -210,6 +210,11 @@ class FFN(nn.Module):
         self.drop_path = _drop_path(drop_path)
 
     def forward(self, x):
+        if isinstance(self.act, nn.Identity) and isinstance(self.drop_path, nn.Identity) and len(self.fc1) == 2 and len(self.fc2) == 2:
+            # channels-last fp32 volume on the GPU: conv -> norm -> act -> conv -> norm -> + x as one K7 / K6 pipeline
+            y = graph_ops.pointwise_chain(x, x, self.fc1[0], self.fc1[1], self.fc2[0], self.fc2[1])
+            if y is not None:
+                return y
         return self.drop_path(self.fc2(self.act(self.fc1(x)))) + x
 
     def _absorb_activation(self):
@@ -381,11 +386,23 @@ class PoolGrapher(_GrapherBase):
     def forward(self, x):
         _conv_dim(self.conv_op)
         shortcut = x
-        x = self.fc1(x)
+        x = _conv_norm(self.fc1, x)
         pooled_shape = tuple(s // p for s, p in zip(x.shape[2:], self.pool_size))
         x = self.graph_conv(x, self._get_relative_pos(self.relative_pos, pooled_shape))
-        x = self.fc2(x)
-        return self.drop_path(x) + shortcut
+        if isinstance(self.drop_path, nn.Identity):
+            return _conv_norm(self.fc2, x, shortcut)
+        return self.drop_path(self.fc2(x)) + shortcut
+
+
+def _conv_norm(seq, x, residual=None):
+    """``seq`` = Sequential(1x1 conv, norm): the fused statistics-epilogue GEMM + apply (+ residual) when it qualifies
+    (graph_ops.pointwise_chain), else the modules one by one."""
+    if len(seq) == 2:
+        y = graph_ops.pointwise_chain(x, residual, seq[0], seq[1])
+        if y is not None:
+            return y
+    y = seq(x)
+    return y if residual is None else y + residual
 
 
 def window_partition(x, window_size):
@@ -481,12 +498,17 @@ def _swin_forward_channels_last(self, x, size_tuple, dim):
     statistics."""
     shift = tuple(self.shift_size) if max(self.shift_size) > 0 else (0,) * dim
     gc = self.graph_conv
-    h = self.fc1(x)
+    h = _conv_norm(self.fc1, x)
     windows = graph_ops.window_gather(h, self.window_size, shift)                      # (B * nW, C, Nw)
     nn_idx = gc.dilated_knn_graph.neighbor_ids(windows, None, self._get_relative_pos(self.relative_pos, tuple(self.window_size)))
     agg = graph_ops.mr_aggregate(windows, nn_idx)                                      # (B * nW, 2C, Nw)
     vol = graph_ops.window_scatter(agg, size_tuple, self.window_size, shift)           # NDHWC (B, 2C, *size)
-    return self.fc2(gc.gconv.nn(vol)) + x
+    basic = gc.gconv.nn                                                                # grouped 1x1 conv -> norm (-> absorbed LeakyReLU)
+    if len(basic) == 3 and isinstance(basic[2], nn.Identity) and len(self.fc2) == 2:
+        y = graph_ops.pointwise_chain(vol, x, basic[0], basic[1], self.fc2[0], self.fc2[1])
+        if y is not None:
+            return y
+    return self.fc2(basic(vol)) + x
 
 
 SwinGrapher._forward_channels_last = _swin_forward_channels_last

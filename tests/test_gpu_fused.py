@@ -1,0 +1,244 @@
+"""Round-3 parity tests on the MI355X for the fused point-wise pipeline: K7 GEMMs with K6's statistics in
+their epilogues and K6's normalisation + activation in their operand loads (csrc/pw_gemm.hip, include/nextou_hip.h "K7 + K6
+fused"), against (i) the plain K7 / K6 kernels they replace — bit for bit where the arithmetic is the same —, (ii) float64
+restatements of the reference's op sequence conv -> batch_norm -> leaky_relu -> conv -> batch_norm -> add (reference
+NexToU_Encoder_Decoder.py:368-390, :710-720, :833-842; torch_nn.py:66-92), (iii) the op-by-op module path."""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+CL = torch.channels_last_3d
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nextou_amd import _lib, graph_ops
+    _lib.lib()
+    assert "libnextou_hip.so" in open("/proc/self/maps").read(), "HIP extension not loaded into this process"
+    return graph_ops
+
+
+def _cl(t):
+    return t.to(DEV).contiguous(memory_format=CL)
+
+
+def _rows(t):                       # (B, C, D, H, W) channels-last -> (P, C) float64
+    return t.permute(0, 2, 3, 4, 1).reshape(-1, t.shape[1]).double()
+
+
+_SHAPES = [
+    # (B, spatial, Cin, Cmid, groups of the first conv): cfg-2 graph-stage channel counts, ragged point counts (P % 128 != 0) included
+    (2, (4, 7, 6), 132, 528, 1), (1, (3, 5, 7), 264, 264, 6), (2, (8, 14, 12), 264, 1056, 1), (1, (2, 7, 6), 324, 1296, 1),
+    (3, (5, 9, 11), 44, 36, 1), (1, (1, 1, 3), 16, 8, 2), (1, (4, 7, 6), 648, 648, 6),
+]
+
+
+@pytest.mark.parametrize("B,sp,ci,cm,g", _SHAPES)
+def test_fused_gemm_epilogues_and_prologues(ops, B, sp, ci, cm, g):
+    """(a) statistics epilogue: same y as the plain GEMM bit for bit, partial sums == float64 sums of y and y^2;
+    (b) finalize: mean / invstd / affine == float64 statistics, running statistics updated as F.batch_norm does;
+    (c) operand prologue: GEMM(norm + act on load) == GEMM(K6 apply output) bit for bit;
+    (d) gradient-statistics epilogue == the float64 sums K6's backward reduce defines; backward finalize + apply == K6's backward;
+    (e) weight gradient with the operand prologue == the plain weight gradient of the materialised activation, bit for bit."""
+    hip = ops._HIP
+    gen = torch.Generator().manual_seed(ci * 3 + cm)
+    x = _cl(torch.randn((B, ci) + sp, generator=gen) * 1.5 + 0.3)
+    w1 = (torch.randn((cm, ci // g), generator=gen) * 0.1).to(DEV)
+    P = x.numel() // ci
+    # (a)
+    h_plain = hip.pw_rows(x, w1, None, g)
+    h, part = hip.pw_rows_fused(x, w1, g, want_stats=True)
+    assert torch.equal(h, h_plain)
+    h64 = _rows(h)
+    sums = part.sum(1)                                              # (C, 2) float64
+    assert torch.allclose(sums[:, 0], h64.sum(0), rtol=1e-6, atol=1e-6 * float(h64.abs().sum(0).max()))
+    assert torch.allclose(sums[:, 1], h64.square().sum(0), rtol=1e-6)
+    assert torch.equal(part, hip.pw_rows_fused(x, w1, g, want_stats=True)[1])          # fixed order: bit-reproducible
+    # (b)
+    gamma = (torch.rand((cm,), generator=gen) + 0.5).to(DEV)
+    beta = (torch.randn((cm,), generator=gen) * 0.2).to(DEV)
+    cbias = (torch.randn((cm,), generator=gen) * 0.1).to(DEV)
+    rm, rv = torch.zeros(cm, device=DEV), torch.ones(cm, device=DEV)
+    mean, invstd, scale, shift = hip.norm_finalize(part, P, cm, DEV, gamma, beta, cbias, rm, rv, True, 0.1, 1e-5)
+    m64, v64 = h64.mean(0), h64.var(0, unbiased=False)
+    assert torch.allclose(mean.double(), m64, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(invstd.double(), (v64 + 1e-5).rsqrt(), rtol=2e-6)
+    assert torch.equal(scale, gamma * invstd)
+    assert torch.allclose(shift, beta - mean * scale, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(rm.double(), 0.1 * (m64 + cbias.double()), rtol=1e-5, atol=1e-6)     # the folded conv bias enters here only
+    assert torch.allclose(rv.double(), 0.9 + 0.1 * h64.var(0, unbiased=P > 1), rtol=1e-5)
+    # (c)
+    slope = 0.01
+    a = hip.norm_apply_rows(h, None, gamma, beta, mean, invstd, slope)
+    a_ref, mean_ref, invstd_ref = hip.norm_act_fwd(h, gamma, beta, None, None, True, 0.0, 1e-5, slope, 0, None, channels_last=True)
+    # K6's own statistics pass sums every value in float64, the GEMM epilogue 32 points at a time in fp32: same statistics to a few
+    # ulp, and given the SAME statistics K6 in pieces is K6 bit for bit
+    assert torch.allclose(mean, mean_ref, rtol=1e-5, atol=1e-6) and torch.allclose(invstd, invstd_ref, rtol=2e-6)
+    assert torch.equal(hip.norm_apply_rows(h, None, gamma, beta, mean_ref, invstd_ref, slope), a_ref)
+    assert float((a - a_ref).abs().max()) <= 1e-5 * float(a_ref.abs().max())
+    co = ci
+    w2 = (torch.randn((co, cm), generator=gen) * 0.1).to(DEV)
+    y_ref = hip.pw_rows(a, w2, None, 1)
+    y, part2 = hip.pw_rows_fused(h, w2, 1, pro=(scale, shift, slope), want_stats=True)
+    assert torch.equal(y, y_ref)
+    y_nostats, none = hip.pw_rows_fused(h, w2, 1, pro=(scale, shift, slope))
+    assert none is None and torch.equal(y_nostats, y_ref)
+    res = _cl(torch.randn((B, co) + sp, generator=gen))
+    mean2, invstd2, _, _ = hip.norm_finalize(part2, P, co, DEV, None, None, None, None, None, True, 0.0, 1e-5)
+    out = hip.norm_apply_rows(y, res, None, None, mean2, invstd2, 1.0)
+    y64 = _rows(y)
+    ref = (y64 - y64.mean(0)) / (y64.var(0, unbiased=False) + 1e-5).sqrt() + _rows(res)
+    assert float((_rows(out) - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # (d)
+    dy = _cl(torch.randn((B, co) + sp, generator=gen))
+    w2t = w2.t().contiguous()
+    da_plain = hip.pw_rows(dy, w2t, None, 1)
+    da, partb = hip.pw_rows_fused(dy, w2t, 1, bwd=(h, gamma, beta, mean, invstd, slope))
+    assert torch.equal(da, da_plain)
+    z64 = h64 * scale.double() + shift.double()
+    dz64 = _rows(da) * torch.where(z64 > 0, 1.0, slope)
+    xh64 = (h64 - mean.double()) * invstd.double()
+    sb = partb.sum(1)
+    mag = dz64.abs().sum(0)
+    assert bool(((sb[:, 0] - dz64.sum(0)).abs() <= 1e-6 * mag + 1e-9).all())
+    assert bool(((sb[:, 1] - (dz64 * xh64).sum(0)).abs() <= 1e-6 * (dz64 * xh64).abs().sum(0) + 1e-9).all())
+    coeff, gw, gb = hip.norm_bwd_finalize(partb, P, cm, DEV, True)
+    dh = hip.norm_bwd_apply_rows(h, da, coeff, gamma, beta, mean, invstd, slope)
+    dh_ref, gw_ref, gb_ref = hip.norm_act_bwd(h, da, gamma, beta, mean, invstd, True, slope, 0, channels_last=True)
+    tol = 2e-5 * float(dh_ref.abs().max())
+    assert float((dh - dh_ref).abs().max()) <= tol
+    assert torch.allclose(gw, gw_ref, rtol=1e-5, atol=1e-5 * float(gw_ref.abs().max()))
+    assert torch.allclose(gb, gb_ref, rtol=1e-5, atol=1e-5 * float(gb_ref.abs().max()))
+    # (e)
+    assert torch.equal(hip.pw_wgrad_fused(dy, h, 1, (scale, shift, slope)), hip.pw_wgrad(dy, a, 1))
+
+
+def _reference_chain(x, res, w1, g, bn1, slope1, w2, bn2, slope2, training):
+    """conv -> batch_norm -> leaky_relu [-> conv -> batch_norm -> leaky_relu] [+ res]: ATen ops in float64 (the reference's op sequence)."""
+    dd = torch.float64
+
+    def bn(t, p):
+        gamma, beta, rm, rv, cb = p
+        if training:
+            return F.batch_norm(t, None, None, gamma.to(dd), beta.to(dd), True, 0.0, 1e-5)
+        return F.batch_norm(t + cb.to(dd).view(1, -1, 1, 1, 1), rm.to(dd), rv.to(dd), gamma.to(dd), beta.to(dd), False, 0.0, 1e-5)
+    t = F.conv3d(x.to(dd), w1.to(dd)[:, :, None, None, None], None, groups=g)
+    t = F.leaky_relu(bn(t, bn1), slope1)
+    if w2 is not None:
+        t = F.conv3d(t, w2.to(dd)[:, :, None, None, None], None)
+        t = F.leaky_relu(bn(t, bn2), slope2)
+    return t if res is None else t + res.to(dd)
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("B,sp,ci,cm,g,two,with_res", [
+    (2, (4, 7, 6), 132, 528, 1, True, True),          # FFN
+    (2, (4, 7, 6), 264, 264, 6, True, True),          # SwinGrapher tail: grouped BasicConv -> fc2 -> + shortcut (out 132)
+    (1, (3, 5, 7), 132, 132, 1, False, False),        # fc1
+    (1, (3, 5, 7), 264, 132, 1, False, True),         # PoolGrapher fc2 + shortcut
+    (1, (2, 7, 6), 324, 1296, 1, True, True),
+])
+@pytest.mark.parametrize("mode", ["1", "fwd"])
+def test_pointwise_chain_autograd_vs_float64_reference(ops, monkeypatch, training, B, sp, ci, cm, g, two, with_res, mode):
+    """graph_ops._PointwiseChain (forward values, input / weight / norm-parameter / residual gradients) against the float64 ATen
+    restatement of the reference's op sequence, in training (batch statistics) and inference (running statistics + the folded conv
+    bias), with the gradient statistics fused into the data-gradient GEMM ("1") and with K6's own backward reduce ("fwd")."""
+    monkeypatch.setenv("NEXTOU_PW_FUSE", mode)
+    gen = torch.Generator().manual_seed(ci + cm + g + int(two))
+    co = (132 if (two and g == 6) else ci) if two else cm
+    x = _cl(torch.randn((B, ci) + sp, generator=gen)).requires_grad_(True)
+    res = _cl(torch.randn((B, co) + sp, generator=gen)).requires_grad_(True) if with_res else None
+
+    def params(c):
+        return [(torch.rand((c,), generator=gen) + 0.5).to(DEV).requires_grad_(True), (torch.randn((c,), generator=gen) * 0.2).to(DEV).requires_grad_(True),
+                (torch.randn((c,), generator=gen) * 0.1).to(DEV), (torch.rand((c,), generator=gen) + 0.5).to(DEV),
+                (torch.randn((c,), generator=gen) * 0.1).to(DEV).requires_grad_(True)]
+    w1 = (torch.randn((cm, ci // g), generator=gen) * 0.1).to(DEV).requires_grad_(True)
+    bn1 = params(cm)
+    w2 = (torch.randn((co, cm), generator=gen) * 0.1).to(DEV).requires_grad_(True) if two else None
+    bn2 = params(co) if two else None
+    slope1, slope2 = 0.01, 1.0
+
+    def state(p, slope):
+        return ops._NormState(training, 0.1, 1e-5, slope, p[2].clone(), p[3].clone())
+    args = (x, res, w1.view(cm, ci // g, 1, 1, 1), bn1[0], bn1[1], bn1[4], None if w2 is None else w2.view(co, cm, 1, 1, 1),
+            None if bn2 is None else bn2[0], None if bn2 is None else bn2[1], None if bn2 is None else bn2[4], g, state(bn1, slope1),
+            None if bn2 is None else state(bn2, slope2), mode != "fwd")
+    out = ops._PointwiseChain.apply(*args)
+    ref = _reference_chain(x, res, w1, g, bn1, slope1, w2, bn2, slope2, training)
+    scale = float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) <= 3e-5 * scale
+    gout = _cl(torch.randn(out.shape, generator=gen))
+    leaves = [t for t in [x, res, w1, bn1[0], bn1[1], w2] + ([bn2[0], bn2[1]] if two else []) if t is not None]
+    got = torch.autograd.grad(out, leaves, gout, allow_unused=True)
+    want = torch.autograd.grad(ref, leaves, gout.double(), allow_unused=True)
+    for a, b, t in zip(got, want, leaves):
+        assert a is not None and b is not None
+        assert float((a.double() - b.double()).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-6), (tuple(t.shape),)
+    # the folded conv biases: exactly zero gradient under batch statistics, the analytic one with running statistics
+    gcb = torch.autograd.grad(ops._PointwiseChain.apply(*args), [bn1[4]], gout, allow_unused=True)[0]
+    if training:
+        assert gcb is not None and float(gcb.abs().max()) == 0.0
+    else:
+        want_cb = torch.autograd.grad(_reference_chain(x, res, w1, g, bn1, slope1, w2, bn2, slope2, False), [bn1[4]], gout.double())[0]
+        assert float((gcb.double() - want_cb).abs().max()) <= 2e-4 * max(float(want_cb.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_graph_blocks_fused_vs_op_by_op(ops, monkeypatch, mode):
+    """The FFN / SwinGrapher / PoolGrapher modules on a channels-last volume: the fused pipeline (default) against the same
+    modules run op by op (NEXTOU_PW_FUSE=0: MIOpen convolutions + K6 passes) — outputs, input gradient, parameter gradients and
+    running statistics; the launch labels prove which path ran."""
+    import ctypes
+    import json
+    from nextou_amd import _lib, graph_ops
+    from nextou_amd.network_architecture import NexToU_Encoder_Decoder as encdec
+    from nextou_amd.network_architecture.norm_act import fuse_norm_act
+    kw = dict(conv_op=nn.Conv3d, norm_op=nn.BatchNorm3d, norm_op_kwargs={'eps': 1e-5, 'affine': True})
+    torch.manual_seed(4)
+    blocks = {
+        "ffn": (encdec.FFN(132, 528, act="leakyrelu", drop_path=0.0, **kw), (2, 132, 4, 7, 6)),
+        "swin": (encdec.SwinGrapher(12, (4, 8, 8), 4, 1, 'mr', 'leakyrelu', 'instance', True, True, 0.2, 1, n=32, relative_pos=True,
+                                    window_size=(2, 4, 4), shift_size=[1, 2, 2], dropout_op=None, **kw), (2, 12, 4, 8, 8)),
+        "pool": (encdec.PoolGrapher(12, (8, 16, 32), 4, 1, 'mr', 'leakyrelu', 'instance', True, True, 0.2, 2, n=4096, relative_pos=True,
+                                    img_min_shape=(2, 4, 4), dropout_op=None, **kw), (2, 12, 8, 16, 32)),
+    }
+    L_ = _lib.lib()
+    for name, (blk, shape) in blocks.items():
+        fuse_norm_act(blk)
+        blk = blk.to(DEV).train(mode == "train")
+        x0 = torch.randn(shape, device=DEV).contiguous(memory_format=CL)
+        gy = torch.randn(shape, device=DEV).contiguous(memory_format=CL)
+        results = {}
+        tape = graph_ops.IndexTape()
+        for setting in ("1", "0"):
+            monkeypatch.setenv("NEXTOU_PW_FUSE", setting)
+            m = copy.deepcopy(blk)
+            x = x0.clone().requires_grad_(True)
+            L_.nextou_profile_enable(512)
+            # the kNN / arg-max decisions of the first run are replayed in the second (the two paths differ by round-off)
+            with graph_ops.index_tape(tape if setting == "1" else graph_ops.IndexTape(tape.entries)):
+                y = m(x)
+            grads = torch.autograd.grad(y, [x] + [p for p in m.parameters() if p.requires_grad], gy, allow_unused=True)
+            torch.cuda.synchronize()
+            buf = ctypes.create_string_buffer(1 << 16)
+            n = L_.nextou_profile_report(buf, len(buf))
+            L_.nextou_profile_enable(0)
+            names = [r["kernel"] for r in json.loads(buf.value[:n].decode())]
+            results[setting] = (y.detach(), grads, {k: v.clone() for k, v in m.state_dict().items() if "running" in k}, names)
+        fused_names, plain_names = results["1"][3], results["0"][3]
+        assert any("stats" in k for k in fused_names) == (mode == "train"), fused_names
+        assert any(k.startswith("pw_rows_kernel") for k in fused_names) and not any(k.startswith("pw_rows_kernel") for k in plain_names)
+        (y1, g1, r1, _), (y0, g0, r0, _) = results["1"], results["0"]
+        assert float((y1 - y0).abs().max()) <= 5e-5 * float(y0.abs().max()), name
+        for a, b in zip(g1, g0):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert float((a - b).abs().max()) <= 1e-3 * max(float(b.abs().max()), 1e-6), name
+        for k in r0:
+            assert torch.allclose(r1[k], r0[k], rtol=1e-5, atol=1e-6), (name, k)
