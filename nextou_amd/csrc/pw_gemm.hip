@@ -98,8 +98,7 @@ __device__ __forceinline__ float leaky_f(float z, float slope) { return z > 0.f 
 template <int TM, int TN, int PRO, int EPI>
 __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                       const float* __restrict__ bias, float* __restrict__ Y, int P, int N, int K,
-                                                      long ldx, long ldw, long ldy, int nb_n, int items, int vec_store, PwFuse fz,
-                                                      int ktail) {
+                                                      long ldx, long ldw, long ldy, int nb_n, int items, int vec_store, PwFuse fz) {
     constexpr int BM = 64 * TM, BN = 16 * TN;
     constexpr int XV = BM * (kPwKC / 4) / 256;                // float4 per thread per stage, X tile
     constexpr int WV = (BN * (kPwKC / 4) + 255) / 256;        // ... W tile (last one predicated)
@@ -178,9 +177,9 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
     };
 
     f32x4 acc[TM][TN];
-    // nsub: how many of the stage's four k sub-steps (4 channels each) carry data — 4 except in the last stage of a K that is not a
-    // multiple of 16 (K = 132: the ninth stage holds 4 channels; its other three sub-steps would multiply zeros: 8 % of the MFMAs)
-    auto compute = [&](int buf, int nsub) __attribute__((always_inline)) {
+    // (a K that is not a multiple of 16 still runs all four k sub-steps of its last stage: lane group kg holds k = 16 r + 4 kg +
+    // {0..3}, so a 4-channel tail sits in lane group 0 of EVERY sub-step; pw_rows_sw_kernel gives the tail its own lane mapping)
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const float* xs = Xs + buf * BM * kPwLd + (wave * TM * 16 + r16) * kPwLd + kg * 4;
         const float* ws = Ws + buf * BN * kPwLd + r16 * kPwLd + kg * 4;
         float4 b[TM];
@@ -207,15 +206,9 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
     }
 #endif
             NEXTOU_PW_STEP(x)
-            if (nsub > 1) {
-                NEXTOU_PW_STEP(y)
-            }
-            if (nsub > 2) {
-                NEXTOU_PW_STEP(z)
-            }
-            if (nsub > 3) {
-                NEXTOU_PW_STEP(w)
-            }
+            NEXTOU_PW_STEP(y)
+            NEXTOU_PW_STEP(z)
+            NEXTOU_PW_STEP(w)
 #undef NEXTOU_PW_STEP
             a0 = n0f;
             a1 = n1f;
@@ -325,7 +318,6 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
     };
 
     const int stages = (K + kPwKC - 1) / kPwKC;
-    const int nsub_last = ktail ? ((K - 1) % kPwKC) / 4 + 1 : 4;
     int item = item_at(walk);
     int p0 = 0, n0 = 0;
 #if NEXTOU_PW_STAGGER
@@ -354,22 +346,22 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
         // an exit there makes the compiler shuttle every accumulator between AGPRs and VGPRs once per iteration
         for (int s = 0; s + 1 < stages; s += 2) {
 #if NEXTOU_PW_ABLATE & 2
-            compute(0, 4);
+            compute(0);
             __syncthreads();
-            compute(0, 4);
+            compute(0);
             __syncthreads();
 #else
             load_stage(p0, n0, min(s + 2, stages - 1) * kPwKC, xr[0], wr[0], psc[0], psh[0]);     // past the end: a re-read nobody stores
-            compute(0, 4);
+            compute(0);
             store_stage(1, p0, n0, (s + 1) * kPwKC, xr[1], wr[1], psc[1], psh[1]);
             __syncthreads();
             load_stage(p0, n0, min(s + 3, stages - 1) * kPwKC, xr[1], wr[1], psc[1], psh[1]);
-            compute(1, s + 2 == stages ? nsub_last : 4);
+            compute(1);
             store_stage(0, p0, n0, (s + 2) * kPwKC, xr[0], wr[0], psc[0], psh[0]);     // past the end: zeros nobody reads (no branch: keeps vmcnt exact)
             __syncthreads();
 #endif
         }
-        if (stages & 1) compute(0, nsub_last);
+        if (stages & 1) compute(0);
         walk += slots;
         const int next = item_at(walk);
         const int np0 = next >= 0 ? (next / nb_n) * BM : p0, nn0 = next >= 0 ? (next % nb_n) * BN : n0;
@@ -410,14 +402,20 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
                                                            int P, int N, int K, long ldx, long ldy, int tiles64, PwFuse fz) {
     constexpr int NT = 64 * NW, SK = kSwSk, SK4 = kSwSk4, LDK = kSwSk, NCH = kSwNch;
     constexpr int NV = (64 * SK4 + NT - 1) / NT;                           // float4 per thread per slab
+    constexpr int ROWS = (NV * NT + SK4 - 1) / SK4;                        // LDS rows incl. the ones only the staging's overhang touches:
+                                                                           // every thread loads and stores NV pieces UNCONDITIONALLY (a
+                                                                           // predicated piece is sunk into its branch, behind the multiply)
     constexpr int PASSES = SLABS > 1 ? 1 : (TNW >= 3 ? 4 : (TNW == 2 ? 2 : 1));
     constexpr int PTS = 4 / PASSES;
     constexpr int WSETS = WSTREAM ? 2 : SLABS;
     static_assert(SLABS == 1 || TNW == 1, "several slabs keep all four point tiles' accumulators: one channel tile per wave");
     extern __shared__ float4 pw_smem4[];
-    float* xs = reinterpret_cast<float*>(pw_smem4);                        // [2][64][LDK]
-    float* psc = xs + 2 * 64 * LDK;                                        // PRO: [K] scale, [K] shift
+    float* xs = reinterpret_cast<float*>(pw_smem4);                        // [2][ROWS][LDK], rows 0..63 are the tile
+    float* psc = xs + 2 * ROWS * LDK;                                      // PRO: [K] scale, [K] shift
     float* psh = psc + (PRO ? K : 0);
+    // EPI: per-channel (sum, sum') of everything this workgroup has multiplied so far, float64, one private slot per channel (a
+    // channel belongs to one wave): ONE partial per channel and workgroup leaves the kernel instead of one per tile and pass
+    double2* wg_stats = reinterpret_cast<double2*>(psc + (PRO ? 2 * K : 0));         // 16-byte aligned: every piece before it is
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
 
@@ -448,6 +446,9 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
     if constexpr (PRO == 1) {
         for (int k = tid; k < K; k += NT) { psc[k] = fz.pro_scale[k]; psh[k] = fz.pro_shift[k]; }
     }
+    if constexpr (EPI != 0) {
+        for (int c = tid; c < NW * TNW * 16; c += NT) wg_stats[c] = make_double2(0.0, 0.0);
+    }
 
     // ---- slab staging: global -> registers (in flight during the multiply) -> LDS
     float4 xr[NV];
@@ -461,12 +462,11 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
         }
     };
     auto store_slab = [&](int buf, int tile, int sl) __attribute__((always_inline)) {
-        float* dst = xs + buf * 64 * LDK;
+        float* dst = xs + buf * ROWS * LDK;
         const long p0 = (long)tile * 64;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int f = tid + i * NT, row = f / SK4, c4 = f - row * SK4;
-            if (f >= 64 * SK4) continue;
             float4 v = xr[i];
             if constexpr (PRO == 1) {
                 const float4 sc = *reinterpret_cast<const float4*>(psc + sl * SK + c4 * 4), sh = *reinterpret_cast<const float4*>(psh + sl * SK + c4 * 4);
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
 
     f32x4 acc[PTS][TNW];
     auto multiply = [&](int buf, int set, int pass) __attribute__((always_inline)) {
-        const float* base = xs + buf * 64 * LDK + (pass * PTS * 16 + r16) * LDK + 4 * kg;
+        const float* base = xs + buf * ROWS * LDK + (pass * PTS * 16 + r16) * LDK + 4 * kg;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             float4 b[PTS];
@@ -547,10 +547,14 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); q[r] = row16_sum(q[r]); }
-                if (r16 == 0) {
-                    const long t = (long)tile * PASSES + pass;
+                if (r16 == 0) {         // 32 (or 64) points summed in fp32 by the fixed DPP tree, float64 from here on, fixed order
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) fz.partial[(long)(n + r) * ((long)tiles64 * PASSES) + t] = make_double2((double)sm[r], (double)q[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        double2 t = wg_stats[n + r];
+                        t.x += (double)sm[r];
+                        t.y += (double)q[r];
+                        wg_stats[n + r] = t;
+                    }
                 }
             }
         }
@@ -566,22 +570,37 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
     for (; tile < tiles64; tile += gridDim.x) {
         const int next = tile + gridDim.x < tiles64 ? tile + gridDim.x : tile;          // no next tile: a re-read nobody uses
         // one slab step: fetch the next slab (and, streaming, its weights), multiply this one, then move the fetched slab into LDS
+        // The in-order vmcnt counter and where the waits fall (the compiler's waits count the LOADS it tracks; the hardware
+        // counter also holds every store issued before them): the next slab's loads are issued BEHIND the result stores of all
+        // passes but the last, multiply under the last pass (one pass ~ 5 us: more than the load latency), and are consumed —
+        // the wait — before the last pass's stores go out.  So a wait only ever covers stores that are at least a pass old, and
+        // the last pass's stores have the whole next tile to complete.  (First version: loads first, one wait behind twelve fresh
+        // stores per tile — 63 % of the MFMA peak with the matrix pipe idle in every tile's store drain.)
         auto step = [&](int sl, int set_now, int set_next) __attribute__((always_inline)) {
             const int nsl = sl + 1 < SLABS ? sl + 1 : 0;
             const int ntile = sl + 1 < SLABS ? tile : next;
-            load_slab(ntile, nsl);
-            if constexpr (WSTREAM) load_weights(set_next, nsl);             // in flight during this multiply
             if constexpr (SLABS == 1) {
 #pragma unroll
                 for (int pass = 0; pass < PASSES; ++pass) {
+                    if (pass == PASSES - 1) {
+                        load_slab(ntile, nsl);
+                        __builtin_amdgcn_sched_barrier(0);          // ... and the loads in front of it (the scheduler sinks them otherwise)
+                    }
 #pragma unroll
                     for (int pt = 0; pt < PTS; ++pt)
 #pragma unroll
                         for (int j = 0; j < TNW; ++j) acc[pt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     multiply(buf, 0, pass);
+                    if (pass == PASSES - 1) {
+                        __builtin_amdgcn_sched_barrier(0);          // keep the wait for the slab behind the multiply
+                        store_slab(buf ^ 1, ntile, nsl);
+                    }
                     epilogue(tile, pass);
                 }
             } else {
+                load_slab(ntile, nsl);
+                if constexpr (WSTREAM) load_weights(set_next, nsl);             // in flight during this multiply
+                __builtin_amdgcn_sched_barrier(0);
                 if (sl == 0) {
 #pragma unroll
                     for (int pt = 0; pt < PTS; ++pt)
@@ -589,9 +608,10 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
                         for (int j = 0; j < TNW; ++j) acc[pt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 multiply(buf, set_now, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                store_slab(buf ^ 1, ntile, nsl);
                 if (sl == SLABS - 1) epilogue(tile, 0);
             }
-            store_slab(buf ^ 1, ntile, nsl);
             __syncthreads();
             buf ^= 1;
         };
@@ -608,6 +628,10 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
 #pragma unroll
             for (int sl = 0; sl < SLABS; ++sl) step(sl, sl, 0);
         }
+    }
+    if constexpr (EPI != 0) {
+        __syncthreads();
+        for (int c = tid; c < N; c += NT) fz.partial[(long)c * gridDim.x + blockIdx.x] = wg_stats[c];
     }
 }
 
@@ -915,9 +939,8 @@ int launch_rows(const RowsPlan& q, const float* x, const float* w, const float* 
         if (int e = allow_lds(pw_rows_kernel<TM, TN, PRO, EPI>, lds)) return e;
         allowed = lds;
     }
-    static const int ktail = [] { const char* e = getenv("NEXTOU_PW_KTAIL"); return (e && e[0] == '0') ? 0 : 1; }();
     hipLaunchKernelGGL((pw_rows_kernel<TM, TN, PRO, EPI>), dim3(q.grid, groups), dim3(256), lds, s, x, w, bias, y, P, N, K, ldx, ldw, ldy,
-                       q.nb_n, q.items, vec_store, fz, ktail);
+                       q.nb_n, q.items, vec_store, fz);
     return check_launch("pw_rows_kernel");
 }
 
@@ -936,19 +959,21 @@ struct SwPlan { int cfg, tnw, nw, tiles64, passes, grid; size_t lds; };
 SwPlan plan_rows_sw(int64_t P, int N, int K, int groups, bool pro) {
     SwPlan q{};
     q.cfg = -1;
-    static const int mode = [] { const char* e = getenv("NEXTOU_PW_SW"); return e ? atoi(e) : 1; }();
+    const char* env = getenv("NEXTOU_PW_SW");          // read per call: tests and A/B runs flip it inside one process
+    const int mode = env ? atoi(env) : 1;
     if (mode == 0 || groups != 1 || N % 4 != 0 || P < 64 * 4 * (int64_t)cu_count()) return q;
     const int t = tiles16(N);
     if (K == 132) q.cfg = t <= 9 ? 2 : (t <= 18 ? 1 : (t <= 33 ? 0 : -1));
     else if (K == 264 && t <= 9) q.cfg = 3;
-    else if (K == 528 && t <= 9) q.cfg = 4;
+    else if (K == 528 && t <= 9 && mode >= 2) q.cfg = 4;      // streamed weights: 346 us against pw_rows_kernel's 292 (r03_pw_rows_sw.md): opt-in
     if (q.cfg < 0) return q;
     q.tnw = q.cfg == 0 ? 3 : (q.cfg == 1 ? 2 : 1);
     q.nw = q.cfg == 0 ? 11 : 9;
     q.passes = q.cfg == 0 ? 4 : (q.cfg == 1 ? 2 : 1);
     q.tiles64 = (int)((P + 63) / 64);
     q.grid = q.tiles64 < cu_count() ? q.tiles64 : cu_count();
-    q.lds = (size_t)2 * 64 * kSwSk * sizeof(float) + (pro ? (size_t)2 * K * sizeof(float) : 0);
+    const int nt = 64 * q.nw, nv = (64 * kSwSk4 + nt - 1) / nt, rows = (nv * nt + kSwSk4 - 1) / kSwSk4;      // as in the kernel
+    q.lds = (size_t)2 * rows * kSwSk * sizeof(float) + (pro ? (size_t)2 * K * sizeof(float) : 0) + (size_t)q.nw * q.tnw * 16 * sizeof(double2);
     return q;
 }
 
@@ -1049,7 +1074,7 @@ extern "C" int nextou_pw_rows(const float* x, const float* w, const float* bias,
 extern "C" int nextou_pw_rows_tiles(int64_t P, int N, int K, int groups) {
     if (P <= 0 || N <= 0 || K <= 0 || groups <= 0) return 0;
     const SwPlan sw = plan_rows_sw(P, N, K, groups, false);
-    if (sw.cfg >= 0) return sw.tiles64 * sw.passes;
+    if (sw.cfg >= 0) return sw.grid;
     return plan_rows((int)P, N, groups).nb_p;
 }
 

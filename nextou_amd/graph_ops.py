@@ -1003,6 +1003,15 @@ def _pw_fuse_mode() -> str:
     return os.environ.get("NEXTOU_PW_FUSE", PW_FUSE_DEFAULT)
 
 
+def _pw_fuse_min_points() -> int:
+    """Point count from which the fused pipeline replaces the op-by-op block.  Measured on MI355X, cfg 2 (profiles/r03_pw_fused.md):
+    at stage 2 (172 032 points) the fused FFN is 2.44 ms forward + backward against 2.75 ms op by op; at stages 3-5 (21 504 ... 336
+    points) K7's GEMMs run far from full (a 128-point workgroup tile per CU or less) and MIOpen's kernels + K6 win.
+    ``NEXTOU_PW_FUSE_MIN_POINTS`` overrides the threshold (tests set 0)."""
+    import os
+    return int(os.environ.get("NEXTOU_PW_FUSE_MIN_POINTS", "65536"))
+
+
 class _NormState:
     """What one fused norm of a point-wise chain needs besides its parameters (plain Python, not a tensor argument)."""
     __slots__ = ("batch_stats", "momentum", "eps", "slope", "running_mean", "running_var")
@@ -1130,6 +1139,8 @@ def pointwise_chain_eligible(x, residual, conv1, norm1, conv2=None, norm2=None) 
     that are multiples of 4, the second one un-grouped, each with its bias folded into the norm behind it (norm_act._ConvBiasFolded)
     or none; fused BatchNorm modules (batch or running statistics) without internal channel padding."""
     if not x.is_cuda or x.dtype != torch.float32 or torch.is_autocast_enabled("cuda") or _dense_channels_last(x) is None:
+        return False
+    if x.numel() // x.shape[1] < _pw_fuse_min_points():
         return False
     if residual is not None and (residual.dtype != torch.float32 or residual.shape[0] != x.shape[0] or residual.shape[2:] != x.shape[2:]):
         return False

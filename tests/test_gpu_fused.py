@@ -199,6 +199,7 @@ def test_graph_blocks_fused_vs_op_by_op(ops, monkeypatch, mode):
     from nextou_amd import _lib, graph_ops
     from nextou_amd.network_architecture import NexToU_Encoder_Decoder as encdec
     from nextou_amd.network_architecture.norm_act import fuse_norm_act
+    monkeypatch.setenv("NEXTOU_PW_FUSE_MIN_POINTS", "0")        # the test volumes are small: take the fused path whatever the size
     kw = dict(conv_op=nn.Conv3d, norm_op=nn.BatchNorm3d, norm_op_kwargs={'eps': 1e-5, 'affine': True})
     torch.manual_seed(4)
     blocks = {
@@ -232,13 +233,68 @@ def test_graph_blocks_fused_vs_op_by_op(ops, monkeypatch, mode):
             names = [r["kernel"] for r in json.loads(buf.value[:n].decode())]
             results[setting] = (y.detach(), grads, {k: v.clone() for k, v in m.state_dict().items() if "running" in k}, names)
         fused_names, plain_names = results["1"][3], results["0"][3]
-        assert any("stats" in k for k in fused_names) == (mode == "train"), fused_names
+        assert any(k.startswith("pw_rows") and "stats" in k for k in fused_names) == (mode == "train"), fused_names
         assert any(k.startswith("pw_rows_kernel") for k in fused_names) and not any(k.startswith("pw_rows_kernel") for k in plain_names)
         (y1, g1, r1, _), (y0, g0, r0, _) = results["1"], results["0"]
         assert float((y1 - y0).abs().max()) <= 5e-5 * float(y0.abs().max()), name
+        gscale = max(float(b.abs().max()) for b in g0 if b is not None)
         for a, b in zip(g1, g0):
             assert (a is None) == (b is None)
-            if a is not None:
-                assert float((a - b).abs().max()) <= 1e-3 * max(float(b.abs().max()), 1e-6), name
+            if a is not None:   # (gradients that are analytically zero — a norm bias in front of the max-relative aggregate — are noise on both sides)
+                assert float((a - b).abs().max()) <= 1e-3 * max(float(b.abs().max()), 1e-3 * gscale), name
         for k in r0:
             assert torch.allclose(r1[k], r0[k], rtol=1e-5, atol=1e-6), (name, k)
+
+
+@pytest.mark.parametrize("ci,co", [(132, 528), (132, 264), (132, 132), (264, 132), (528, 132)])
+def test_stationary_weights_rows_kernel(ops, monkeypatch, ci, co):
+    """pw_rows_sw_kernel (weights in registers, x streamed once; the stage-2 shapes, >= 65 536 points) against pw_rows_kernel:
+    bit-identical results (same MFMA, same k order), plain and with every fused epilogue / prologue, on a ragged point count; the
+    statistics partials of the two kernels describe the same sums."""
+    hip = ops._HIP
+    gen = torch.Generator().manual_seed(ci + co)
+    sp = (33, 45, 45)                                              # 66 825 points per sample: not a multiple of 64
+    x = _cl(torch.randn((1, ci) + sp, generator=gen))
+    w = (torch.randn((co, ci), generator=gen) * 0.1).to(DEV)
+    gamma = (torch.rand((ci,), generator=gen) + 0.5).to(DEV)
+    beta = (torch.randn((ci,), generator=gen) * 0.2).to(DEV)
+    mean = (torch.randn((ci,), generator=gen) * 0.1).to(DEV)
+    invstd = (torch.rand((ci,), generator=gen) + 0.5).to(DEV)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    h = _cl(torch.randn((1, co) + sp, generator=gen))
+    g2, b2 = (torch.rand((co,), generator=gen) + 0.5).to(DEV), (torch.randn((co,), generator=gen) * 0.2).to(DEV)
+    m2, i2 = (torch.randn((co,), generator=gen) * 0.1).to(DEV), (torch.rand((co,), generator=gen) + 0.5).to(DEV)
+    import json
+    import ctypes
+    from nextou_amd import _lib
+    L_ = _lib.lib()
+
+    def run(mode):
+        monkeypatch.setenv("NEXTOU_PW_SW", mode)
+        L_.nextou_profile_enable(64)
+        out = {"plain": hip.pw_rows(x, w, None, 1), "stats": hip.pw_rows_fused(x, w, 1, want_stats=True),
+               "pro": hip.pw_rows_fused(x, w, 1, pro=(scale, shift, 0.01)),
+               "pro_stats": hip.pw_rows_fused(x, w, 1, pro=(scale, shift, 0.01), want_stats=True),
+               "bwd": hip.pw_rows_fused(x, w, 1, bwd=(h, g2, b2, m2, i2, 0.01))}
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = L_.nextou_profile_report(buf, len(buf))
+        L_.nextou_profile_enable(0)
+        return out, [r["kernel"] for r in json.loads(buf.value[:n].decode())]
+
+    new, names_new = run("2")
+    old, names_old = run("0")
+    assert all(k.startswith("pw_rows_sw_kernel") for k in names_new), names_new
+    assert all(k.startswith("pw_rows_kernel") for k in names_old), names_old
+    assert torch.equal(new["plain"], old["plain"])
+    for key in ("stats", "pro", "pro_stats", "bwd"):
+        assert torch.equal(new[key][0], old[key][0]), key
+    assert torch.equal(new["pro"][0], new["pro_stats"][0])
+    for key in ("stats", "pro_stats", "bwd"):
+        a, b = new[key][1].sum(1), old[key][1].sum(1)              # (C, 2) float64 each; different tilings of the same sums
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6 * float(b.abs().max())), key
+    y64 = new["plain"].permute(0, 2, 3, 4, 1).reshape(-1, co).double()
+    s = new["stats"][1].sum(1)
+    assert torch.allclose(s[:, 0], y64.sum(0), rtol=1e-6, atol=1e-6 * float(y64.abs().sum(0).max()))
+    assert torch.allclose(s[:, 1], y64.square().sum(0), rtol=1e-6)
