@@ -962,12 +962,23 @@ struct ClwPlan {
 static ClwPlan plan_clw(long long rows, int C, int vec_full, bool aligned) {
     ClwPlan p;
     p.vec = (aligned && C % vec_full == 0) ? vec_full : 1;
+    // lanes across the channels: 8 .. 64.  Score = lane utilisation x (contiguous bytes per row and workgroup, saturating at 512 B).
+    // Round 2 maximised the utilisation alone and took 8-lane (128-byte) runs for C = 132: 37-42 % of the HBM peak.  Measured sweep
+    // (profiles/r03_k6_clw_lane_split.md): C = 132 is fastest with 64 lanes (one 528-byte run per row, half the lanes idle):
+    // apply 53 -> 33 us (70 %), backward apply 82 -> 51 us (67 %); C = 264 / 528 with 32 lanes (512-byte runs).  Ties -> wider.
     double best = -1.0;
     p.cx_log2 = 3;
-    for (int lg = 3; lg <= 6; ++lg) {       // 8 .. 64 lanes across the channels; ties go to the wider run
+    for (int lg = 3; lg <= 6; ++lg) {
         const int cw = (1 << lg) * p.vec;
         const double util = (double)C / ((double)cdiv(C, cw) * cw);
-        if (util >= best - 0.03) { if (util > best) best = util; p.cx_log2 = lg; }
+        const double bytes = (1 << lg) * (p.vec > 1 ? 16.0 : 4.0);          // a lane moves 16 bytes on the vector paths of every dtype
+        const double run = bytes >= 512.0 ? 1.0 : bytes / 512.0;
+        const double score = util * run;
+        if (score >= best - 1e-9) { best = score; p.cx_log2 = lg; }
+    }
+    if (const char* e = getenv("NEXTOU_CLW_LG")) {          // experiment: force the lanes-across-channels split (3 .. 6)
+        const int lg = atoi(e);
+        if (lg >= 3 && lg <= 6) p.cx_log2 = lg;
     }
     p.ncb = cdiv(C, (1 << p.cx_log2) * p.vec);
     const int ry = kThreads >> p.cx_log2;

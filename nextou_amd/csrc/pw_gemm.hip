@@ -385,8 +385,9 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
 //     t + 1 (in pw_rows_kernel the loop-top wait merged the entry path with the back edge and drained the stores before the next
 //     tile could start: its multiply, store and load phases added up — profiles/r02_pw_gemm.md ablation, r03_pw_rows_sw.md);
 //   * statistics epilogue without cross-wave traffic: a channel belongs to exactly one wave.
-// Same MFMA (16x16x4 f32), same k order inside a 16-k chunk (lane group kg holds k = 16 c + 4 kg + {0..3}), k chunks ascending: the
-// results are bit-identical to pw_rows_kernel's.
+// Same MFMA (16x16x4 f32), same k order inside a 16-k chunk (lane group kg holds k = 16 c + 4 kg + {0..3}), k chunks ascending: for
+// K = 132 the results are bit-identical to pw_rows_kernel's; for K = 264 / 528 the slabs cut the chain at multiples of 132
+// instead of 16 (another order of the same fp32 fma chain).
 // Shape-specialised: <TNW, NW waves, NCH full 16-k chunks per slab, TAIL extra 4-k sub-steps (one slab only), SLABS>,
 // K = SLABS * 16 * NCH + 4 * TAIL; plan_rows_sw() knows the instantiated shapes, everything else takes pw_rows_kernel.
 // ------------------------------------------------------------------------------------------------------------
@@ -416,6 +417,9 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
     // EPI: per-channel (sum, sum') of everything this workgroup has multiplied so far, float64, one private slot per channel (a
     // channel belongs to one wave): ONE partial per channel and workgroup leaves the kernel instead of one per tile and pass
     double2* wg_stats = reinterpret_cast<double2*>(psc + (PRO ? 2 * K : 0));         // 16-byte aligned: every piece before it is
+    // EPI 2: scale / shift / mean / invstd of the norm whose backward statistics are collected, for this workgroup's channels — read
+    // from LDS in the epilogue (as global loads they were 12 exposed L2 round trips per pass: 381 us against 245 without them)
+    float* ecoef = reinterpret_cast<float*>(wg_stats + (EPI ? NW * TNW * 16 : 0));     // [4][NW * TNW * 16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
 
@@ -448,6 +452,17 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
     }
     if constexpr (EPI != 0) {
         for (int c = tid; c < NW * TNW * 16; c += NT) wg_stats[c] = make_double2(0.0, 0.0);
+    }
+    if constexpr (EPI == 2) {
+        constexpr int NC = NW * TNW * 16;
+        for (int c = tid; c < NC; c += NT) {
+            const int cc = min(c, N - 1);
+            const float is = fz.epi_invstd[cc], m = fz.epi_mean[cc], sc = fz.epi_w[cc] * is;
+            ecoef[c] = sc;
+            ecoef[NC + c] = fmaf(-m, sc, fz.epi_b[cc]);
+            ecoef[2 * NC + c] = m;
+            ecoef[3 * NC + c] = is;
+        }
     }
 
     // ---- slab staging: global -> registers (in flight during the multiply) -> LDS
@@ -503,17 +518,24 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
             for (int j = 0; j < TNW; ++j) acc[pt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wtail[set][j], bt[pt], acc[pt][j], 0, 0, 0);
     };
 
+    // EPI 2: the h values of a pass's output positions, fetched BEFORE the pass multiplies (in flight under ~100 MFMAs per wave)
+    float4 hq[EPI == 2 ? PTS : 1][EPI == 2 ? TNW : 1];
+    auto prefetch_h = [&](int tile, int pass) __attribute__((always_inline)) {
+        if constexpr (EPI == 2) {
+            const long p0 = (long)tile * 64 + pass * PTS * 16;
+#pragma unroll
+            for (int pt = 0; pt < PTS; ++pt)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j)
+                    hq[pt][j] = ld4(fz.h + min(p0 + pt * 16 + r16, (long)P - 1) * fz.ldh + min(n_wave + j * 16 + kg * 4, N - 4));
+        }
+    };
     auto epilogue = [&](int tile, int pass) __attribute__((always_inline)) {
         const long p0 = (long)tile * 64 + pass * PTS * 16;
 #pragma unroll
         for (int j = 0; j < TNW; ++j) {
             const int n = n_wave + j * 16 + kg * 4;
             if (n >= N) continue;                                           // uniform over the DPP row
-            float4 hq[PTS];
-            if constexpr (EPI == 2) {
-#pragma unroll
-                for (int pt = 0; pt < PTS; ++pt) hq[pt] = ld4(fz.h + min(p0 + pt * 16 + r16, (long)P - 1) * fz.ldh + n);
-            }
 #pragma unroll
             for (int pt = 0; pt < PTS; ++pt) {
                 const long p = p0 + pt * 16 + r16;
@@ -527,16 +549,17 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float v = acc[pt][j][r]; sm[r] += v; q[r] = fmaf(v, v, q[r]); }
                 } else {
-                    const float4 w = ld4(fz.epi_w + n), bb = ld4(fz.epi_b + n), m = ld4(fz.epi_mean + n), is = ld4(fz.epi_invstd + n);
-                    const float wv[4] = {w.x, w.y, w.z, w.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w}, mv[4] = {m.x, m.y, m.z, m.w},
-                                iv[4] = {is.x, is.y, is.z, is.w};
+                    constexpr int NC = NW * TNW * 16;
+                    const float4 sc4 = *reinterpret_cast<const float4*>(ecoef + n), sh4 = *reinterpret_cast<const float4*>(ecoef + NC + n),
+                                 m4 = *reinterpret_cast<const float4*>(ecoef + 2 * NC + n), is4 = *reinterpret_cast<const float4*>(ecoef + 3 * NC + n);
+                    const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w},
+                                iv[4] = {is4.x, is4.y, is4.z, is4.w};
 #pragma unroll
                     for (int pt = 0; pt < PTS; ++pt) {
-                        const float hv[4] = {hq[pt].x, hq[pt].y, hq[pt].z, hq[pt].w};
+                        const float hv[4] = {hq[pt][j].x, hq[pt][j].y, hq[pt][j].z, hq[pt][j].w};
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {                   // K6's backward reduce, term for term (rows past P: g = 0)
-                            const float scale = wv[r] * iv[r], shift = fmaf(-mv[r], scale, bv[r]);
-                            const float z = fmaf(hv[r], scale, shift);
+                            const float z = fmaf(hv[r], scv[r], shv[r]);
                             const float gq = acc[pt][j][r];
                             const float dz = z > 0.f ? gq : gq * fz.epi_slope;
                             const float xh = (hv[r] - mv[r]) * iv[r];
@@ -590,6 +613,7 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
                     for (int pt = 0; pt < PTS; ++pt)
 #pragma unroll
                         for (int j = 0; j < TNW; ++j) acc[pt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    prefetch_h(tile, pass);
                     multiply(buf, 0, pass);
                     if (pass == PASSES - 1) {
                         __builtin_amdgcn_sched_barrier(0);          // keep the wait for the slab behind the multiply
@@ -607,6 +631,7 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
 #pragma unroll
                         for (int j = 0; j < TNW; ++j) acc[pt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+                if (sl == SLABS - 1) prefetch_h(tile, 0);
                 multiply(buf, set_now, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 store_slab(buf ^ 1, ntile, nsl);
@@ -776,6 +801,125 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void pw_wgrad_kernel(const float* 
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int n = n0 + (wave_n * TN + i) * 16 + pg * 4 + reg;
+                if (n < N) out[(long)n * K + k] = acc[i][j][reg];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pw_wgrad, STATIONARY OUTPUT (round 3): dw[n, k] = sum_p gy[p, n] x[p, k] for the stage-2 shapes.  One workgroup per CU holds the WHOLE
+// (N x K) product in its waves' accumulators (wave (wn, wk): A x BT tiles of 16 x 16) and streams a contiguous range of 16-point
+// slabs of gy and x through a double-buffered LDS tile: both operands are read from HBM exactly once, nothing is stored inside the
+// loop, one barrier per slab.  pw_wgrad_kernel cuts the product into (tile, point-split) work items instead: every item re-reads
+// its gy / x columns through L2 and the 121-245 splits leave partial tiles for the reduction.  Here the partials are one (N x K)
+// block per workgroup, summed by the same fixed-order pw_wgrad_reduce_kernel (bit-reproducible).  Shape-specialised; the MFMA
+// operands are rows of the slabs as they lie in memory (lane (c16, pg): tile[4 step + pg][col + c16], row stride = 16 mod 32).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kSoPS = 16;        // points per slab
+
+template <int N, int K, int A, int BT, int WN, int WK, int PRO>
+__global__ __launch_bounds__(64 * WN * WK) void pw_wgrad_so_kernel(const float* __restrict__ G, const float* __restrict__ X, float* __restrict__ part,
+                                                                 int P, long ldg, long ldx, int slabs, int slabs_per_wg, PwFuse fz) {
+    constexpr int NT = 64 * WN * WK;
+    constexpr int SG = wgrad_stride(WN * A * 16), SX = wgrad_stride(WK * BT * 16);
+    constexpr int N4 = N / 4, K4 = K / 4;
+    constexpr int NVG = (kSoPS * N4 + NT - 1) / NT, NVX = (kSoPS * K4 + NT - 1) / NT;
+    constexpr int RG = (NVG * NT + N4 - 1) / N4, RX = (NVX * NT + K4 - 1) / K4;       // LDS rows incl. the staging overhang (see pw_rows_sw_kernel)
+    static_assert(N % 4 == 0 && K % 4 == 0 && WN * A * 16 >= N && WK * BT * 16 >= K, "tile cover");
+    extern __shared__ float4 pw_smem4[];
+    float* Gs = reinterpret_cast<float*>(pw_smem4);        // [2][RG][SG]
+    float* Xs = Gs + 2 * RG * SG;                          // [2][RX][SX]
+    float* psc = Xs + 2 * RX * SX;                         // PRO: [K] scale, [K] shift
+    float* psh = psc + (PRO ? K : 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, pg = lane >> 4;
+    const int wn = wave / WK, wk = wave - wn * WK;
+    if constexpr (PRO == 1) {
+        for (int k = tid; k < K; k += NT) { psc[k] = fz.pro_scale[k]; psh[k] = fz.pro_shift[k]; }
+    }
+    const int s_begin = blockIdx.x * slabs_per_wg;
+    const int s_end = min(slabs, s_begin + slabs_per_wg);
+
+    float4 gr[NVG], xr[NVX];
+    auto load_slab = [&](int sl) __attribute__((always_inline)) {
+        const long p0 = (long)sl * kSoPS;
+#pragma unroll
+        for (int i = 0; i < NVG; ++i) {
+            const int f = tid + i * NT, row = f / N4, c4 = f - row * N4;
+            gr[i] = ld4(G + min(p0 + min(row, kSoPS - 1), (long)P - 1) * ldg + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NVX; ++i) {
+            const int f = tid + i * NT, row = f / K4, c4 = f - row * K4;
+            xr[i] = ld4(X + min(p0 + min(row, kSoPS - 1), (long)P - 1) * ldx + c4 * 4);
+        }
+    };
+    auto store_slab = [&](int buf, int sl) __attribute__((always_inline)) {
+        const long p0 = (long)sl * kSoPS;
+        float* gs = Gs + buf * RG * SG;
+        float* xs = Xs + buf * RX * SX;
+#pragma unroll
+        for (int i = 0; i < NVG; ++i) {
+            const int f = tid + i * NT, row = f / N4, c4 = f - row * N4;
+            *reinterpret_cast<float4*>(gs + row * SG + c4 * 4) = keep_if(p0 + row < P, gr[i]);      // points past P add nothing
+        }
+#pragma unroll
+        for (int i = 0; i < NVX; ++i) {
+            const int f = tid + i * NT, row = f / K4, c4 = f - row * K4;
+            float4 v = xr[i];
+            if constexpr (PRO == 1) {
+                const float4 sc = *reinterpret_cast<const float4*>(psc + c4 * 4), sh = *reinterpret_cast<const float4*>(psh + c4 * 4);
+                v = make_float4(leaky_f(fmaf(v.x, sc.x, sh.x), fz.pro_slope), leaky_f(fmaf(v.y, sc.y, sh.y), fz.pro_slope),
+                                leaky_f(fmaf(v.z, sc.z, sh.z), fz.pro_slope), leaky_f(fmaf(v.w, sc.w, sh.w), fz.pro_slope));
+            }
+            *reinterpret_cast<float4*>(xs + row * SX + c4 * 4) = v;      // (gy's rows past P are zero: the products vanish)
+        }
+    };
+
+    f32x4 acc[A][BT];
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+        for (int j = 0; j < BT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (s_begin < s_end) load_slab(s_begin);
+    __syncthreads();                                       // psc / psh visible
+    if (s_begin < s_end) store_slab(0, s_begin);
+    __syncthreads();
+    int buf = 0;
+    for (int sl = s_begin; sl < s_end; ++sl) {
+        load_slab(sl + 1 < s_end ? sl + 1 : sl);           // last slab: a re-read nobody uses
+        __builtin_amdgcn_sched_barrier(0);
+        const float* gs = Gs + buf * RG * SG + pg * SG + wn * A * 16 + c16;
+        const float* xs = Xs + buf * RX * SX + pg * SX + wk * BT * 16 + c16;
+#pragma unroll
+        for (int st = 0; st < kSoPS / 4; ++st) {
+            float a[A], b[BT];
+#pragma unroll
+            for (int i = 0; i < A; ++i) a[i] = gs[st * 4 * SG + i * 16];
+#pragma unroll
+            for (int j = 0; j < BT; ++j) b[j] = xs[st * 4 * SX + j * 16];
+#pragma unroll
+            for (int i = 0; i < A; ++i)
+#pragma unroll
+                for (int j = 0; j < BT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_slab(buf ^ 1, sl + 1 < s_end ? sl + 1 : sl);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // D tile: row = 4 (lane >> 4) + reg = n, column = lane & 15 = k
+    float* out = part + (long)blockIdx.x * N * K;
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+        for (int j = 0; j < BT; ++j) {
+            const int k = (wk * BT + j) * 16 + c16;
+            if (k >= K) continue;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int n = (wn * A + i) * 16 + pg * 4 + reg;
                 if (n < N) out[(long)n * K + k] = acc[i][j][reg];
             }
         }
@@ -973,7 +1117,7 @@ SwPlan plan_rows_sw(int64_t P, int N, int K, int groups, bool pro) {
     q.tiles64 = (int)((P + 63) / 64);
     q.grid = q.tiles64 < cu_count() ? q.tiles64 : cu_count();
     const int nt = 64 * q.nw, nv = (64 * kSwSk4 + nt - 1) / nt, rows = (nv * nt + kSwSk4 - 1) / kSwSk4;      // as in the kernel
-    q.lds = (size_t)2 * rows * kSwSk * sizeof(float) + (pro ? (size_t)2 * K * sizeof(float) : 0) + (size_t)q.nw * q.tnw * 16 * sizeof(double2);
+    q.lds = (size_t)2 * rows * kSwSk * sizeof(float) + (pro ? (size_t)2 * K * sizeof(float) : 0) + (size_t)q.nw * q.tnw * 16 * (sizeof(double2) + 4 * sizeof(float));
     return q;
 }
 
@@ -1122,11 +1266,55 @@ extern "C" int nextou_pw_rows_fused(const float* x, const float* w, float* y, in
     return dispatch_rows<0, 0>(q, x, w, nullptr, y, Pi, N, K, groups, (long)ldx, (long)ldy, 1, fz, s);
 }
 
+// ---- stationary-output weight gradient: the instantiated shapes: X(id, N, K, A, BT, WN, WK)
+#define NEXTOU_SO_CONFIGS(X) \
+    X(0, 528, 132, 3, 9, 11, 1) /* FFN fc1: gy 528 wide, x 132                       */ \
+    X(1, 132, 528, 9, 3, 1, 11) /* FFN fc2: gy 132 wide, x (hidden, prologue) 528    */ \
+    X(2, 132, 132, 1, 9, 9, 1)  /* the graphers' fc1                                  */ \
+    X(3, 132, 264, 1, 17, 9, 1) /* the graphers' fc2: gy 132 wide, x 264              */
+
+struct SoPlan { int cfg, grid, slabs, slabs_per_wg; size_t lds; };
+
+SoPlan plan_wgrad_so(int64_t P, int N, int K, int groups, int64_t ldg, int64_t ldx, bool pro) {
+    SoPlan q{};
+    q.cfg = -1;
+    const char* env = getenv("NEXTOU_PW_SO");
+    if ((env && atoi(env) == 0) || groups != 1 || ldg != N || ldx != K || P < 64 * 4 * (int64_t)cu_count()) return q;
+    int a = 0, bt = 0, wn = 0, wk = 0;
+#define X(id, n, k, A_, BT_, WN_, WK_) if (N == n && K == k) { q.cfg = id; a = A_; bt = BT_; wn = WN_; wk = WK_; }
+    NEXTOU_SO_CONFIGS(X)
+#undef X
+    if (q.cfg < 0) return q;
+    q.slabs = (int)((P + kSoPS - 1) / kSoPS);
+    q.grid = q.slabs < cu_count() ? q.slabs : cu_count();
+    q.slabs_per_wg = (q.slabs + q.grid - 1) / q.grid;
+    q.grid = (q.slabs + q.slabs_per_wg - 1) / q.slabs_per_wg;
+    const int nt = 64 * wn * wk, n4 = N / 4, k4 = K / 4;
+    const int nvg = (kSoPS * n4 + nt - 1) / nt, nvx = (kSoPS * k4 + nt - 1) / nt;
+    const int rg = (nvg * nt + n4 - 1) / n4, rx = (nvx * nt + k4 - 1) / k4;
+    q.lds = (size_t)2 * (rg * wgrad_stride(wn * a * 16) + rx * wgrad_stride(wk * bt * 16)) * sizeof(float) + (pro ? (size_t)2 * K * sizeof(float) : 0);
+    return q;
+}
+
+template <int N, int K, int A, int BT, int WN, int WK, int PRO>
+int launch_wgrad_so(const SoPlan& q, const float* gy, const float* x, float* part, int P, long ldg, long ldx, const PwFuse& fz, hipStream_t s) {
+    static size_t allowed = 0;
+    if (q.lds > allowed) {
+        if (int e = allow_lds(pw_wgrad_so_kernel<N, K, A, BT, WN, WK, PRO>, q.lds)) return e;
+        allowed = q.lds;
+    }
+    hipLaunchKernelGGL((pw_wgrad_so_kernel<N, K, A, BT, WN, WK, PRO>), dim3(q.grid), dim3(64 * WN * WK), q.lds, s, gy, x, part, P, ldg, ldx, q.slabs,
+                       q.slabs_per_wg, fz);
+    return check_launch("pw_wgrad_so_kernel");
+}
+
 extern "C" int nextou_pw_wgrad_workspace(int64_t P, int N, int K, int groups, size_t* bytes) {
     NEXTOU_REQUIRE(bytes, "pw_wgrad_workspace: null pointer");
     if (int e = check_pw("pw_wgrad_workspace", P, N, K, groups, (int64_t)groups * N, (int64_t)groups * K, N, K)) return e;
     const WgradPlan q = plan_wgrad((int)P, N, K, groups);
     *bytes = (size_t)q.splits * groups * N * K * sizeof(float);
+    const SoPlan so = plan_wgrad_so(P, N, K, groups, (int64_t)groups * N, (int64_t)groups * K, false);      // either kernel may take the call
+    if (so.cfg >= 0 && (size_t)so.grid * N * K * sizeof(float) > *bytes) *bytes = (size_t)so.grid * N * K * sizeof(float);
     return 0;
 }
 
@@ -1134,6 +1322,28 @@ static int pw_wgrad_impl(const float* gy, const float* x, float* dw, float* work
                          int groups, int64_t ldg, int64_t ldx, int accumulate, const PwFuse* fz, nextou_stream_t stream) {
     NEXTOU_REQUIRE(gy && x && dw && workspace, "pw_wgrad: null pointer");
     if (int e = check_pw("pw_wgrad", P, N, K, groups, ldg, ldx, N, K)) return e;
+    const SoPlan so = plan_wgrad_so(P, N, K, groups, ldg, ldx, fz != nullptr);
+    if (so.cfg >= 0 && aligned16(gy) && aligned16(x)) {
+        const size_t need_so = (size_t)so.grid * N * K * sizeof(float);
+        NEXTOU_REQUIRE(workspace_bytes >= need_so, "pw_wgrad: workspace %zu B < %zu B (nextou_pw_wgrad_workspace)", workspace_bytes, need_so);
+        hipStream_t s = (hipStream_t)stream;
+        int rc = NEXTOU_EINVAL;
+        {
+            ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K, "pw_wgrad_so_kernel[P%lld N%d K%d%s WG%d]", (long long)P, N, K, fz ? "|norm-act" : "",
+                           so.grid);
+#define X(id, n, k, A_, BT_, WN_, WK_)                                                                                                     \
+            if (so.cfg == id)                                                                                                              \
+                rc = fz ? launch_wgrad_so<n, k, A_, BT_, WN_, WK_, 1>(so, gy, x, workspace, (int)P, (long)ldg, (long)ldx, *fz, s)          \
+                        : launch_wgrad_so<n, k, A_, BT_, WN_, WK_, 0>(so, gy, x, workspace, (int)P, (long)ldg, (long)ldx, PwFuse{}, s);
+            NEXTOU_SO_CONFIGS(X)
+#undef X
+        }
+        if (rc) return rc;
+        const long elems = (long)N * K;
+        ProfScope prof(s, kBoundHbm, 4.0 * elems * (so.grid + 1), "pw_wgrad_reduce_kernel[%ld x S%d]", elems, so.grid);
+        hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, s, workspace, dw, elems, so.grid, accumulate);
+        return check_launch("pw_wgrad_reduce_kernel");
+    }
     const WgradPlan q = plan_wgrad((int)P, N, K, groups);
     const size_t need = (size_t)q.splits * groups * N * K * sizeof(float);
     NEXTOU_REQUIRE(workspace_bytes >= need, "pw_wgrad: workspace %zu B < %zu B (nextou_pw_wgrad_workspace)", workspace_bytes, need);

@@ -248,9 +248,9 @@ def test_graph_blocks_fused_vs_op_by_op(ops, monkeypatch, mode):
 
 @pytest.mark.parametrize("ci,co", [(132, 528), (132, 264), (132, 132), (264, 132), (528, 132)])
 def test_stationary_weights_rows_kernel(ops, monkeypatch, ci, co):
-    """pw_rows_sw_kernel (weights in registers, x streamed once; the stage-2 shapes, >= 65 536 points) against pw_rows_kernel:
-    bit-identical results (same MFMA, same k order), plain and with every fused epilogue / prologue, on a ragged point count; the
-    statistics partials of the two kernels describe the same sums."""
+    """pw_rows_sw_kernel (weights in registers, x streamed once; the stage-2 shapes, >= 65 536 points) against pw_rows_kernel and the
+    float64 product: bit-identical for K = 132 (same MFMA, same k order), fp32 round-off for K = 264 / 528; plain and with every fused
+    epilogue / prologue, on a ragged point count; the statistics partials of the two kernels describe the same sums."""
     hip = ops._HIP
     gen = torch.Generator().manual_seed(ci + co)
     sp = (33, 45, 45)                                              # 66 825 points per sample: not a multiple of 64
@@ -287,9 +287,21 @@ def test_stationary_weights_rows_kernel(ops, monkeypatch, ci, co):
     old, names_old = run("0")
     assert all(k.startswith("pw_rows_sw_kernel") for k in names_new), names_new
     assert all(k.startswith("pw_rows_kernel") for k in names_old), names_old
-    assert torch.equal(new["plain"], old["plain"])
+    # one 132-channel slab: the same MFMA chain as pw_rows_kernel, bit for bit; several slabs (K = 264, 528) cut the k range at
+    # multiples of 132 instead of 16 — another order of the same fp32 chain, equal to round-off
+    x64, w64 = x.permute(0, 2, 3, 4, 1).reshape(-1, ci)[::97].double(), w.double()
+    mag = x64.abs() @ w64.abs().t()
+
+    def same(a, b, key):
+        if ci == 132:
+            assert torch.equal(a, b), key
+        else:
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), key
+    same(new["plain"], old["plain"], "plain")
+    got = new["plain"].permute(0, 2, 3, 4, 1).reshape(-1, co)[::97].double()
+    assert bool(((got - x64 @ w64.t()).abs() <= 6e-7 * mag + 1e-30).all())
     for key in ("stats", "pro", "pro_stats", "bwd"):
-        assert torch.equal(new[key][0], old[key][0]), key
+        same(new[key][0], old[key][0], key)
     assert torch.equal(new["pro"][0], new["pro_stats"][0])
     for key in ("stats", "pro_stats", "bwd"):
         a, b = new[key][1].sum(1), old[key][1].sum(1)              # (C, 2) float64 each; different tilings of the same sums
@@ -298,3 +310,44 @@ def test_stationary_weights_rows_kernel(ops, monkeypatch, ci, co):
     s = new["stats"][1].sum(1)
     assert torch.allclose(s[:, 0], y64.sum(0), rtol=1e-6, atol=1e-6 * float(y64.abs().sum(0).max()))
     assert torch.allclose(s[:, 1], y64.square().sum(0), rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,k", [(528, 132), (132, 528), (132, 132), (132, 264)])
+def test_stationary_output_wgrad_kernel(ops, monkeypatch, n, k):
+    """pw_wgrad_so_kernel (the whole N x K product in one workgroup's accumulators, gy / x streamed once) against the float64 product
+    and against pw_wgrad_kernel — two summation orders of the same products: agreement to fp32 round-off of the 66 825-term sums —,
+    with and without the normalise + activate operand prologue, on a ragged point count; bit-reproducible."""
+    hip = ops._HIP
+    gen = torch.Generator().manual_seed(n * 3 + k)
+    sp = (33, 45, 45)
+    x = _cl(torch.randn((1, k) + sp, generator=gen))
+    gy = _cl(torch.randn((1, n) + sp, generator=gen))
+    scale = (torch.rand((k,), generator=gen) + 0.5).to(DEV)
+    shift = (torch.randn((k,), generator=gen) * 0.2).to(DEV)
+    x64, g64 = _rows(x), _rows(gy)
+    a64 = F.leaky_relu(x64 * scale.double() + shift.double(), 0.01)
+    import ctypes
+    import json
+    from nextou_amd import _lib
+    L_ = _lib.lib()
+
+    def run(mode):
+        monkeypatch.setenv("NEXTOU_PW_SO", mode)
+        L_.nextou_profile_enable(16)
+        out = (hip.pw_wgrad(gy, x, 1), hip.pw_wgrad_fused(gy, x, 1, (scale, shift, 0.01)))
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 16)
+        m = L_.nextou_profile_report(buf, len(buf))
+        L_.nextou_profile_enable(0)
+        return out, [r["kernel"] for r in json.loads(buf.value[:m].decode())]
+
+    (new, new_pro), names_new = run("1")
+    (old, old_pro), names_old = run("0")
+    assert any(s_.startswith("pw_wgrad_so_kernel") for s_ in names_new), names_new
+    assert not any(s_.startswith("pw_wgrad_so_kernel") for s_ in names_old), names_old
+    for got, other, ref, mag in ((new, old, g64.t() @ x64, g64.abs().t() @ x64.abs()), (new_pro, old_pro, g64.t() @ a64, g64.abs().t() @ a64.abs())):
+        bound = 6e-7 * mag * (x64.shape[0] / 2048.0) ** 0.5
+        assert bool(((got.double() - ref).abs() <= bound).all()), float(((got.double() - ref).abs() / bound).max())
+        assert bool(((got.double() - other.double()).abs() <= 2 * bound).all())
+    monkeypatch.setenv("NEXTOU_PW_SO", "1")
+    assert torch.equal(new, hip.pw_wgrad(gy, x, 1))
