@@ -342,7 +342,8 @@ def main():
         step()
     # auto: the whole step as one hipGraph, N = 1 and N > 1 alike (the averaged step is capturable: RCCL collectives on their
     # own stream, no host synchronisation in the hooks or in finalize() once the warm-up steps have seen the gradient pattern)
-    want_graph = args.graph == "on" or (args.graph == "auto" and args.workload != "cfg4")
+    # (gloo — the two-ranks-on-one-GPU test backend — synchronises with the host inside its collectives and cannot be captured)
+    want_graph = args.graph == "on" or (args.graph == "auto" and args.workload != "cfg4" and (averager is None or backend == "nccl"))
     graphed, capture_error = None, None
     if want_graph:
         try:

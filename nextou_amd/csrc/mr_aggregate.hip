@@ -785,7 +785,9 @@ static bool plan_q4(int B, int C, int N, int M, int K, bool self, Q4Plan* p) {
 static bool plan_kq(int B, int C, int N, int M, int K, bool self, Q4Plan* p) {
     const char* force = getenv("NEXTOU_MR_FWD");
     if (force && (force[0] == 'v' || force[0] == 'q')) return false;
-    if (!(force && force[0] == 'k') && K <= 8 && self && N <= 512) return false;      // stage-2 windows: mr_fwd_q4_kernel (61 % of HBM)
+    if (!(force && force[0] == 'k') && K <= 16) return false;      // measured (profiles/r03_kernel_bench_cfg2.md): short lists keep the
+                                                                   // quad kernel (K <= 8 windows, 61 % of HBM) / the dword kernel (K = 14:
+                                                                   // 22.3 vs 23.8 us pooled, 32.2 vs 39.2 us windows); K = 28 / 32 take this one
     if (M > 65536) return false;
     const size_t per_quad = (size_t)M * 16;
     if (per_quad > 152 * 1024) return false;
