@@ -144,7 +144,9 @@ def roofline_graph_from(report):
             "K1_knn_worst_shape": worst(("knn_fused_kernel", "knn_window_kernel")), "K2_mr_forward_worst_shape": worst(("mr_fwd",)),
             "K5_argmax_labels": pick(("argmax_labels_kernel",)), "K5_bti_critical": pick(("bti_critical_kernel",)),
             "K5_bti_ce_forward": pick(("bti_ce_fwd_kernel",)), "K5_bti_ce_backward": pick(("bti_ce_bwd_kernel",)),
-            "K7_pointwise_rows": pick(("pw_rows_kernel", "pw_fused")), "K7_pointwise_wgrad": pick(("pw_wgrad_kernel",)),
+            "K7_pointwise_rows": pick(("pw_rows_kernel", "pw_rows_sw_kernel")),
+            "K7_pointwise_wgrad": pick(("pw_wgrad_kernel", "pw_wgrad_so_kernel")),
+            "K7_pointwise_rows_worst_shape": worst(("pw_rows_kernel", "pw_rows_sw_kernel")),
             "graph_kernels_ms_per_step": None}
 
 

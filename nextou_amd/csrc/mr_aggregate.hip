@@ -4,8 +4,8 @@
 // Reference op sequence replaced (network_architecture/NexToU_Encoder_Decoder.py:401-409,
 // torch_nn.py:94-115): two batched_index_select calls that materialise (B,C,N,K) tensors,
 // a subtraction, a max over K and a cat/reshape channel interleave.  Here a workgroup stages a
-// chunk of source channel rows in LDS once and every lane gathers its K neighbours from LDS;
-// the (B,C,N,K) tensors never exist.  HBM traffic is the algorithmic minimum:
+// chunk of source channel rows in LDS once (four channels of a point interleaved as one float4 in
+// mr_fwd_qb_kernel) and every lane gathers its K neighbours from LDS; the (B,C,N,K) tensors never exist.  HBM traffic is the algorithmic minimum:
 //   fwd  4*B*C*(N+M_y) + 4*B*N*K(idx) + 4*B*2C*N        bwd  fwd + 4*B*C*(N+M_y)
 //
 // Layout: features (B,C,N) channel-major, idx (B,N,idx_stride) int32, out (B,2C,N) with
@@ -82,56 +82,136 @@ __global__ __launch_bounds__(512) void mr_fwd_lds_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward, channel quads.  Same decomposition as above, but the LDS tile interleaves FOUR channels per source point:
-// tile[q][m] is a float4 holding channels c0+4q .. c0+4q+3 of point m, so one ds_read_b128 gathers four channels of a
-// neighbour (the random gather is the cost of this op: 16-B gathers spread 16 lanes over 16 bank groups — measured
-// SQ_LDS_BANK_CONFLICT of the dword version: 1.4e7 of 2e7 LDS cycles on Pool s3) and the index arithmetic is shared by the
-// four.  Staging stays coalesced (lanes along m, four row loads, one conflict-free ds_write_b128), the stores stay
-// coalesced (lanes along n).  grid = (n_tiles, quad blocks, B); LDS = quads * M float4.
+// forward, channel quads: the kernel every K <= 32 graph whose candidate set fits LDS takes (round 3).
+// The LDS tile interleaves FOUR channels per source point (a float4), so one ds_read_b128 gathers four channels of a neighbour
+// and the index arithmetic is shared by the four; a lane owns (query, channel quad) for ALL K neighbours and walks the list in
+// batches of KB gathers in flight.  What it replaced, at the pooled stage-3 shape (B 2, C 264, N 10 752, M 1 344, K 28;
+// profiles/r03_k2_pooled_forward.md):
+//   * the dword kernel above, 76 us: 70 % of its LDS cycles are bank conflicts of the random ds_read_b32 gathers (6.9 cycles
+//     per wave instruction against 2 conflict-free) behind 0.9 waves per SIMD (28 ids + arg-max state per lane);
+//   * a quad kernel with the whole list's gathers in flight, 95 us (208 VGPRs, 2 waves per SIMD);
+//   * a quad kernel with the LIST split over the four lanes of a DPP quad, 64 us: 2.33e7 VALU wave-instructions = 38 us of issue
+//     time on 1024 SIMDs — VALU-bound, and only 4 of its ~9 instructions per gathered element were the arithmetic (subtract,
+//     compare, two selects); the rest was what the split costs (broadcasts, two merge rounds, lane selects, address arithmetic of
+//     64-byte stores); with stores, bank conflicts, arg tracking and staging all switched off it still needed 43 us.
+// Here: no cross-lane step at all; the ids of a query are loaded once (dwordx4) and kept as LDS byte addresses (id << shift, the
+// workgroup's QUADS = 1, 2 or 4 quads of a point are adjacent: tile4[m * QUADS + q], so the quad is an immediate of the ds_read);
+// two v_pk_add_f32 form the four differences of a gather; the (max, arg) update is one 12-instruction block (mr_update4);
+// every global access is a 256-byte row segment (64 consecutive queries of one channel).  1.03e7 VALU wave-instructions, 36 us
+// = 0.30 of 8 TB/s at that shape; what remains is 17 us of VALU issue and 18 us of LDS time (74 % bank-conflict cycles: 16 lanes
+// of a ds_read_b128 pick among 16 bank groups at random) that overlap only partly.
+// grid = (n_tiles, quad blocks, B); LDS = QUADS * M float4; K <= KB * NB.
 // ---------------------------------------------------------------------------------------------
-template <int KB, bool SELF, bool WITH_ARG>
-__global__ __launch_bounds__(512) void mr_fwd_q4_kernel(
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef const f32x4 __attribute__((address_space(3)))* lds_float4_ptr;
+
+// (max, arg) update of four channels against one gathered neighbour: m = d > m ? d : m; a = d > m ? o : a (NaN never replaces).
+// Written as one instruction block: left to the compiler, the four compares of every neighbour are hoisted in front of the
+// selects on `a` and their 64-bit masks — 4 x 27 SGPR pairs per quad — are spilled lane by lane into VGPRs (v_writelane, two per
+// compare, each behind an s_nop).  Three independent instructions sit between a compare and the first select that reads its mask
+// (the VALU-writes-SGPR -> VALU-reads-it-as-mask hazard needs two wait states).
+template <bool WITH_ARG>
+__device__ __forceinline__ void mr_update4(float& m0, float& m1, float& m2, float& m3, unsigned& a0, unsigned& a1, unsigned& a2,
+                                           unsigned& a3, float d0, float d1, float d2, float d3, unsigned o) {
+    unsigned long long c0, c1, c2, c3;
+    if (WITH_ARG) {
+        asm volatile(
+            "v_cmp_gt_f32_e64 %[c0], %[d0], %[m0]\n\t"
+            "v_cmp_gt_f32_e64 %[c1], %[d1], %[m1]\n\t"
+            "v_cmp_gt_f32_e64 %[c2], %[d2], %[m2]\n\t"
+            "v_cmp_gt_f32_e64 %[c3], %[d3], %[m3]\n\t"
+            "v_cndmask_b32_e64 %[m0], %[m0], %[d0], %[c0]\n\t"
+            "v_cndmask_b32_e64 %[a0], %[a0], %[o], %[c0]\n\t"
+            "v_cndmask_b32_e64 %[m1], %[m1], %[d1], %[c1]\n\t"
+            "v_cndmask_b32_e64 %[a1], %[a1], %[o], %[c1]\n\t"
+            "v_cndmask_b32_e64 %[m2], %[m2], %[d2], %[c2]\n\t"
+            "v_cndmask_b32_e64 %[a2], %[a2], %[o], %[c2]\n\t"
+            "v_cndmask_b32_e64 %[m3], %[m3], %[d3], %[c3]\n\t"
+            "v_cndmask_b32_e64 %[a3], %[a3], %[o], %[c3]"
+            : [m0] "+v"(m0), [m1] "+v"(m1), [m2] "+v"(m2), [m3] "+v"(m3), [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2),
+              [a3] "+v"(a3), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3)
+            : [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [o] "v"(o));
+    } else {
+        asm volatile(
+            "v_cmp_gt_f32_e64 %[c0], %[d0], %[m0]\n\t"
+            "v_cmp_gt_f32_e64 %[c1], %[d1], %[m1]\n\t"
+            "v_cmp_gt_f32_e64 %[c2], %[d2], %[m2]\n\t"
+            "v_cmp_gt_f32_e64 %[c3], %[d3], %[m3]\n\t"
+            "v_cndmask_b32_e64 %[m0], %[m0], %[d0], %[c0]\n\t"
+            "v_cndmask_b32_e64 %[m1], %[m1], %[d1], %[c1]\n\t"
+            "v_cndmask_b32_e64 %[m2], %[m2], %[d2], %[c2]\n\t"
+            "v_cndmask_b32_e64 %[m3], %[m3], %[d3], %[c3]"
+            : [m0] "+v"(m0), [m1] "+v"(m1), [m2] "+v"(m2), [m3] "+v"(m3), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2),
+              [c3] "=&s"(c3)
+            : [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3));
+    }
+}
+
+
+
+// EXACT: K == KB * NB (the cfg-2 / cfg-5 list lengths 7, 8, 14, 16, 28, 32 have their own instances; no per-neighbour bound checks)
+template <int KB, int NB, int QUADS, bool EXACT, bool SELF, bool WITH_ARG>
+__global__ __launch_bounds__(512) void mr_fwd_qb_kernel(
     const float* __restrict__ x, const float* __restrict__ src, const int32_t* __restrict__ idx,
     float* __restrict__ out, uint16_t* __restrict__ arg, int C, int N, int M, int K, int idx_stride,
-    int idx_step, int quads, int n_per_block) {
+    int idx_step, int n_per_block) {
+    static_assert(QUADS == 1 || QUADS == 2 || QUADS == 4, "a point's quads are addressed with a shift");
     extern __shared__ __attribute__((aligned(16))) float4 tile4[];
+    constexpr int KT = KB * NB;
+    constexpr int kPointShift = QUADS == 1 ? 4 : (QUADS == 2 ? 5 : 6);     // log2 of the bytes one source point takes in the tile
     const int b = blockIdx.z;
-    const int c0 = blockIdx.y * quads * 4;
+    const int c0 = blockIdx.y * QUADS * 4;
     int nq = (C - c0 + 3) >> 2;
-    if (nq > quads) nq = quads;
+    if (nq > QUADS) nq = QUADS;
     const float* sb = src + ((size_t)b * C + c0) * M;
-    for (int e = threadIdx.x; e < nq * M; e += blockDim.x) {
-        const int q = e / M, m = e - q * M;
-        const int c = 4 * q;
-        const float* p = sb + (size_t)c * M + m;
-        float4 v;
-        v.x = p[0];
-        v.y = (c0 + c + 1 < C) ? p[(size_t)M] : 0.f;
-        v.z = (c0 + c + 2 < C) ? p[(size_t)2 * M] : 0.f;
-        v.w = (c0 + c + 3 < C) ? p[(size_t)3 * M] : 0.f;
-        tile4[e] = v;
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        if (q >= nq) break;
+        const int c = c0 + 4 * q;
+        const float* p = sb + (size_t)4 * q * M;
+        const bool v1 = c + 1 < C, v2 = c + 2 < C, v3 = c + 3 < C;
+        for (int m = threadIdx.x; m < M; m += blockDim.x) {
+            float4 v;
+            v.x = p[m];
+            v.y = v1 ? p[(size_t)M + m] : 0.f;
+            v.z = v2 ? p[(size_t)2 * M + m] : 0.f;
+            v.w = v3 ? p[(size_t)3 * M + m] : 0.f;
+            tile4[m * QUADS + q] = v;
+        }
     }
     __syncthreads();
     const int n_begin = blockIdx.x * n_per_block;
     int n_end = n_begin + n_per_block;
     if (n_end > N) n_end = N;
+    // LDS addresses as plain integers: the base of the dynamic LDS block is a link-time symbol the compiler does not fold into
+    // the ds_read offset field, so it is added once per neighbour id instead of once per gather
+    const unsigned tile_base = (unsigned)(uintptr_t)(lds_float4_ptr)(const void*)tile4;
     for (int n = n_begin + threadIdx.x; n < n_end; n += blockDim.x) {
-        int id[KB];
+        unsigned off[KT];          // LDS byte addresses of the query's neighbours (quad 0): tile_base + (id << kPointShift)
         const int32_t* irow = idx + ((size_t)b * N + n) * idx_stride;
-        if (idx_step == 1) {    // immediate offsets: 32 scalar offset registers would otherwise stay live across the loop
+        if (EXACT && idx_step == 1 && (idx_stride & 3) == 0 && (KT & 3) == 0 && (reinterpret_cast<uintptr_t>(idx) & 15u) == 0) {
+            const int4* r4 = reinterpret_cast<const int4*>(irow);
 #pragma unroll
-            for (int j = 0; j < KB; ++j) id[j] = irow[j < K ? j : 0];
+            for (int j = 0; j < KT / 4; ++j) {
+                const int4 v = r4[j];
+                off[4 * j] = tile_base + ((unsigned)v.x << kPointShift); off[4 * j + 1] = tile_base + ((unsigned)v.y << kPointShift);
+                off[4 * j + 2] = tile_base + ((unsigned)v.z << kPointShift); off[4 * j + 3] = tile_base + ((unsigned)v.w << kPointShift);
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < KB; ++j) id[j] = irow[(j < K ? j : 0) * idx_step];
+            for (int j = 0; j < KT; ++j)
+                off[j] = tile_base + ((unsigned)irow[(size_t)((EXACT || j < K) ? j : 0) * idx_step] << kPointShift);
         }
-        for (int q = 0; q < nq; ++q) {
-            const float4* row = tile4 + q * M;
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q) {
+            if (q >= nq) break;
             const int c = c0 + 4 * q;
             const bool v1 = c + 1 < C, v2 = c + 2 < C, v3 = c + 3 < C;
-            float4 xv;
+            f32x4 xv;
             if (SELF) {
-                xv = row[n];
+                xv = *(lds_float4_ptr)(uintptr_t)(tile_base + ((unsigned)n << kPointShift) + q * 16);
             } else {
                 const float* xp = x + ((size_t)b * C + c) * N + n;
                 xv.x = xp[0];
@@ -139,191 +219,41 @@ __global__ __launch_bounds__(512) void mr_fwd_q4_kernel(
                 xv.z = v2 ? xp[(size_t)2 * N] : 0.f;
                 xv.w = v3 ? xp[(size_t)3 * N] : 0.f;
             }
-            float4 mx;
-            int a0, a1, a2, a3;
-            {
-                const float4 s = row[id[0]];
-                mx.x = s.x - xv.x; mx.y = s.y - xv.y; mx.z = s.z - xv.z; mx.w = s.w - xv.w;
-                a0 = a1 = a2 = a3 = id[0];
-            }
-            // groups of four gathers in flight: 16 VGPRs of payload and 16 compare masks at a time (the fully unrolled
-            // K = 32 loop kept 128 payload VGPRs and spilled 269 SGPRs of masks)
+            const f32x2 xlo = xv.lo, xhi = xv.hi;
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+            unsigned a0 = 0, a1 = 0, a2 = 0, a3 = 0;         // LDS addresses of the winners
 #pragma unroll
-            for (int j0 = 1; j0 < KB; j0 += 4) {
-                float4 sv[4];
+            for (int g = 0; g < NB; ++g) {
+                if (!EXACT && g * KB >= K) break;       // (uniform)
+                f32x4 sv[KB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) sv[u] = row[id[(j0 + u < KB) ? j0 + u : 0]];
+                for (int u = 0; u < KB; ++u) sv[u] = *(lds_float4_ptr)(uintptr_t)(off[g * KB + u] + q * 16);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (j0 + u >= KB) continue;
-                    const int idj = id[(j0 + u < KB) ? j0 + u : 0];
-                    const float d0 = sv[u].x - xv.x, d1 = sv[u].y - xv.y, d2 = sv[u].z - xv.z, d3 = sv[u].w - xv.w;
-                    if (WITH_ARG) {     // strict >: the first maximum of the rounded differences wins (autograd's max)
-                        if (d0 > mx.x) { mx.x = d0; a0 = idj; }
-                        if (d1 > mx.y) { mx.y = d1; a1 = idj; }
-                        if (d2 > mx.z) { mx.z = d2; a2 = idj; }
-                        if (d3 > mx.w) { mx.w = d3; a3 = idj; }
-                    } else {
-                        mx.x = fmaxf(mx.x, d0); mx.y = fmaxf(mx.y, d1); mx.z = fmaxf(mx.z, d2); mx.w = fmaxf(mx.w, d3);
+                for (int u = 0; u < KB; ++u) {
+                    const int j = g * KB + u;
+                    if (!EXACT && j >= K) break;        // (uniform)
+                    const f32x2 dlo = sv[u].lo - xlo, dhi = sv[u].hi - xhi;
+                    if (j == 0) {                       // the first neighbour initialises the maximum (NaN included)
+                        m0 = dlo.x; m1 = dlo.y; m2 = dhi.x; m3 = dhi.y;
+                        a0 = a1 = a2 = a3 = off[0];
+                    } else {                            // strict >: the first maximum of the rounded differences wins
+                        mr_update4<WITH_ARG>(m0, m1, m2, m3, a0, a1, a2, a3, dlo.x, dlo.y, dhi.x, dhi.y, off[j]);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);     // keep the groups apart: do not hoist the next group's gathers
+                __builtin_amdgcn_sched_barrier(0);     // keep the batches apart: the next batch's gathers stay behind this one's selects
             }
             float* o = out + ((size_t)b * 2 * C + 2 * c) * N + n;
             o[0] = xv.x;
-            o[(size_t)N] = mx.x;
-            if (v1) { o[(size_t)2 * N] = xv.y; o[(size_t)3 * N] = mx.y; }
-            if (v2) { o[(size_t)4 * N] = xv.z; o[(size_t)5 * N] = mx.z; }
-            if (v3) { o[(size_t)6 * N] = xv.w; o[(size_t)7 * N] = mx.w; }
+            o[(size_t)N] = m0;
+            if (v1) { o[(size_t)2 * N] = xv.y; o[(size_t)3 * N] = m1; }
+            if (v2) { o[(size_t)4 * N] = xv.z; o[(size_t)5 * N] = m2; }
+            if (v3) { o[(size_t)6 * N] = xv.w; o[(size_t)7 * N] = m3; }
             if (WITH_ARG) {
                 uint16_t* ap = arg + ((size_t)b * C + c) * N + n;
-                ap[0] = (uint16_t)a0;
-                if (v1) ap[(size_t)N] = (uint16_t)a1;
-                if (v2) ap[(size_t)2 * N] = (uint16_t)a2;
-                if (v3) ap[(size_t)3 * N] = (uint16_t)a3;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// forward, channel quads with the NEIGHBOUR LIST split over the four lanes of a DPP quad (round 3).  The pooled graphs
-// (K = 14 ... 32 ids per query) kept the dword kernel in round 2 because 28 ids + their gathered values per lane cost
-// 2 waves per SIMD; its counters (profiles/r03_sq_counters_k2_pool_s3.md) say where the time goes: 70 % of the LDS cycles are
-// bank conflicts of the random ds_read_b32 gathers (6.9 cycles per wave instruction against 2 conflict-free) behind 0.9 waves per
-// SIMD.  Here lane (query, kg) owns the KL = ceil(K / 4) neighbours j = kg * KL .. kg * KL + KL - 1 of its query: KL ids and KL
-// 16-byte gathers in flight (the quad tile of mr_fwd_q4_kernel: one ds_read_b128 moves four channels, ~1.5x fewer LDS cycles per
-// element than the dword gather under random conflicts), ~60 VGPRs, and the four partial (max, arg) pairs meet in two
-// quad_perm steps.  First-maximum-wins is preserved: the lanes' blocks are ascending in j, blocks after the first start from
-// -inf with the strict compare (so they skip what the sequential scan skips), and a pair keeps the lower lane's candidate
-// unless the higher one is strictly greater.
-// grid = (n_tiles, quad blocks, B), 256 threads = 64 queries per pass; LDS = quads * M float4.
-// ---------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
-
-constexpr int kKqMaxQuads = 4;       // channel quads per workgroup (the planner never asks for more)
-
-template <int KL, bool SELF, bool WITH_ARG>
-__global__ __launch_bounds__(256) void mr_fwd_kq_kernel(
-    const float* __restrict__ x, const float* __restrict__ src, const int32_t* __restrict__ idx,
-    float* __restrict__ out, uint16_t* __restrict__ arg, int C, int N, int M, int K, int idx_stride,
-    int idx_step, int quads, int n_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float4 tile4[];
-    const int b = blockIdx.z;
-    const int c0 = blockIdx.y * quads * 4;
-    int nq = (C - c0 + 3) >> 2;
-    if (nq > quads) nq = quads;
-    const float* sb = src + ((size_t)b * C + c0) * M;
-    for (int e = threadIdx.x; e < nq * M; e += blockDim.x) {
-        const int q = e / M, m = e - q * M;
-        const int c = 4 * q;
-        const float* p = sb + (size_t)c * M + m;
-        float4 v;
-        v.x = p[0];
-        v.y = (c0 + c + 1 < C) ? p[(size_t)M] : 0.f;
-        v.z = (c0 + c + 2 < C) ? p[(size_t)2 * M] : 0.f;
-        v.w = (c0 + c + 3 < C) ? p[(size_t)3 * M] : 0.f;
-        tile4[e] = v;
-    }
-    __syncthreads();
-    const int kg = threadIdx.x & 3, ql = threadIdx.x >> 2;          // 64 queries per pass, 4 lanes each
-    const int n_begin = blockIdx.x * n_per_block;
-    int n_end = n_begin + n_per_block;
-    if (n_end > N) n_end = N;
-    const int j_first = kg * KL;
-    // The ids and centre values of pass p + 1 are fetched while pass p computes: un-prefetched, every pass began with a global load
-    // whose latency nothing covered (the first version of this kernel: 74 us on Pool s3 for ~20 us of LDS / VALU work).
-    int idn[KL];
-    float xn[kKqMaxQuads];
-    auto fetch = [&](int nb) __attribute__((always_inline)) {
-        int n = nb + ql;
-        if (n >= n_end) n = n_end - 1;                                // clamped: every lane of a quad takes part in the DPP steps
-        const int32_t* irow = idx + ((size_t)b * N + n) * idx_stride;
-#pragma unroll
-        for (int t = 0; t < KL; ++t) idn[t] = irow[(size_t)((j_first + t < K) ? j_first + t : 0) * idx_step];
-        if (!SELF) {
-#pragma unroll
-            for (int q = 0; q < kKqMaxQuads; ++q) {
-                const int c = c0 + 4 * q + kg;
-                xn[q] = (q < nq && c < C) ? x[((size_t)b * C + c) * N + n] : 0.f;
-            }
-        }
-    };
-    fetch(n_begin);
-    for (int nb = n_begin; nb < n_end; nb += 64) {
-        const int n = nb + ql;
-        const bool live = n < n_end;
-        const int nc = live ? n : n_end - 1;
-        int id[KL];
-        float xc[kKqMaxQuads];
-#pragma unroll
-        for (int t = 0; t < KL; ++t) id[t] = idn[t];
-#pragma unroll
-        for (int q = 0; q < kKqMaxQuads; ++q) xc[q] = xn[q];
-        if (nb + 64 < n_end) fetch(nb + 64);
-#pragma unroll
-        for (int q = 0; q < kKqMaxQuads; ++q) {
-            if (q >= nq) break;
-            const float4* row = tile4 + q * M;
-            const int c = c0 + 4 * q;
-            // the centre values of the quad's four channels: lane kg holds channel c + kg, quad_perm broadcasts spread them
-            float xm;
-            if (SELF) {
-                const float4 r = row[nc];
-                xm = kg == 0 ? r.x : (kg == 1 ? r.y : (kg == 2 ? r.z : r.w));
-            } else {
-                xm = xc[q];
-            }
-            float4 xv;
-            xv.x = dpp_f<0x00>(xm);     // quad_perm [0,0,0,0]
-            xv.y = dpp_f<0x55>(xm);     // [1,1,1,1]
-            xv.z = dpp_f<0xAA>(xm);     // [2,2,2,2]
-            xv.w = dpp_f<0xFF>(xm);     // [3,3,3,3]
-            float4 sv[KL];
-#pragma unroll
-            for (int t = 0; t < KL; ++t) sv[t] = row[id[t]];
-            float4 mx;
-            int a0, a1, a2, a3;
-            if (kg == 0) {              // the scan's first element initialises the maximum (NaN included, as in the sequential form)
-                mx.x = sv[0].x - xv.x; mx.y = sv[0].y - xv.y; mx.z = sv[0].z - xv.z; mx.w = sv[0].w - xv.w;
-            } else {
-                mx.x = mx.y = mx.z = mx.w = -INFINITY;
-            }
-            a0 = a1 = a2 = a3 = id[0];
-#pragma unroll
-            for (int t = 0; t < KL; ++t) {
-                if (j_first + t >= K) continue;          // (uniform per lane; the padded slots hold id[0] of the row)
-                const float d0 = sv[t].x - xv.x, d1 = sv[t].y - xv.y, d2 = sv[t].z - xv.z, d3 = sv[t].w - xv.w;
-                if (d0 > mx.x) { mx.x = d0; a0 = id[t]; }
-                if (d1 > mx.y) { mx.y = d1; a1 = id[t]; }
-                if (d2 > mx.z) { mx.z = d2; a2 = id[t]; }
-                if (d3 > mx.w) { mx.w = d3; a3 = id[t]; }
-            }
-            // pairs (kg ^ 1), then (kg ^ 2): the lower lane's candidate stays unless the higher one is strictly greater
-#define NEXTOU_KQ_MERGE(CTRL, BIT, V, A)                                          \
-            {                                                                     \
-                const float pv = dpp_f<CTRL>(V);                                  \
-                const int pa = dpp_i<CTRL>(A);                                    \
-                const bool take = (kg & BIT) ? !(V > pv) : (pv > V);              \
-                V = take ? pv : V;                                                \
-                A = take ? pa : A;                                                \
-            }
-            NEXTOU_KQ_MERGE(0xB1, 1, mx.x, a0) NEXTOU_KQ_MERGE(0xB1, 1, mx.y, a1) NEXTOU_KQ_MERGE(0xB1, 1, mx.z, a2) NEXTOU_KQ_MERGE(0xB1, 1, mx.w, a3)
-            NEXTOU_KQ_MERGE(0x4E, 2, mx.x, a0) NEXTOU_KQ_MERGE(0x4E, 2, mx.y, a1) NEXTOU_KQ_MERGE(0x4E, 2, mx.z, a2) NEXTOU_KQ_MERGE(0x4E, 2, mx.w, a3)
-#undef NEXTOU_KQ_MERGE
-            // lane kg writes channel c + kg of its query: 16 queries x 4 channel rows per wave instruction
-            const float mv = kg == 0 ? mx.x : (kg == 1 ? mx.y : (kg == 2 ? mx.z : mx.w));
-            const int av = kg == 0 ? a0 : (kg == 1 ? a1 : (kg == 2 ? a2 : a3));
-            if (live && c + kg < C) {
-                float* o = out + ((size_t)b * 2 * C + 2 * (c + kg)) * N + n;
-                o[0] = xm;
-                o[(size_t)N] = mv;
-                if (WITH_ARG) arg[((size_t)b * C + c + kg) * N + n] = (uint16_t)av;
+                ap[0] = (uint16_t)((a0 - tile_base) >> kPointShift);
+                if (v1) ap[(size_t)N] = (uint16_t)((a1 - tile_base) >> kPointShift);
+                if (v2) ap[(size_t)2 * N] = (uint16_t)((a2 - tile_base) >> kPointShift);
+                if (v3) ap[(size_t)3 * N] = (uint16_t)((a3 - tile_base) >> kPointShift);
             }
         }
     }
@@ -733,82 +663,49 @@ static bool plan_lds(int B, int C, int N, int M, int floats_per_channel, bool ti
     return p->c_chunks <= 65535 && B <= 65535;
 }
 
-// Work decomposition of mr_fwd_q4_kernel.  One channel quad costs 16 * M bytes of LDS.  Small source sets (windows) take
-// ~20 KB tiles so that many workgroups share a CU; long ones (pooled candidate sets of 1344 / 3072 points) take what fits
-// 48 KB, and the query range is cut into tiles until the grid has a few workgroups per CU.
 struct Q4Plan {
     int quads, q_blocks, n_tiles, n_per_block, threads;
     size_t lds;
 };
-static bool plan_q4(int B, int C, int N, int M, int K, bool self, Q4Plan* p) {
-    // Measured (profiles/r02_kernel_bench_k2.md): the quad kernel wins where the LDS gather is the bound and the id list
-    // is short — the cfg-2 stage-2 windows, K = 7 (79.8 -> 66.2 us = 61 % of 8 TB/s) — is level at K = 14 and loses beyond
-    // (K = 16 windows of 384 points 233 -> 319 us; pooled graphs with K = 28 / 32 ids + 32 float4 in flight = 208 VGPRs,
-    // 2 waves per SIMD: Pool s3 73 -> 95 us), which keep the dword kernel.
-    // NEXTOU_MR_FWD=v1 | q4 forces one of them for A/B runs.
+// Work decomposition of mr_fwd_qb_kernel: 1, 2 or 4 channel quads per workgroup (16 * M bytes of LDS each), one lane per
+// query, the query range cut until the grid has ~6 workgroups per CU.  Measured over quads x threads x grid size at the cfg-2
+// call shapes (profiles/r03_k2_pooled_forward.md): long candidate sets (M = 1344) are fastest with ONE quad per workgroup
+// (21 KB tiles, 7 workgroups per CU: 36 us against 38-47 with two quads, 59-97 with four) and 512 threads; windows and short
+// pooled sets (M = 168) with two quads and 256 threads (Pool s2 16.2 us against 18.4-21 / 18-22, Swin s3 25.4 against 31 / 27).
+// NEXTOU_MR_FWD=v keeps the dword kernel; NEXTOU_QB_QUADS / NEXTOU_QB_THREADS / NEXTOU_QB_WGS override the three choices for
+// A/B runs (tools/r03_k2_sweep.sh).
+static bool plan_qb(int B, int C, int N, int M, int K, bool self, Q4Plan* p) {
     const char* force = getenv("NEXTOU_MR_FWD");
     if (force && force[0] == 'v') return false;
-    if (!(force && force[0] == 'q') && !(self && K <= 8 && N <= 512)) return false;
-    const size_t per_quad = (size_t)M * 16;
-    if (per_quad > 152 * 1024) return false;
-    const int total_quads = (C + 3) / 4;
-    size_t budget = M <= 512 ? 20 * 1024 : 48 * 1024;
-    int quads = (int)(budget / per_quad);
-    if (quads < 1) quads = 1;
-    if (quads > total_quads) quads = total_quads;
-    while (quads > 1 && (long long)cdiv(total_quads, quads) * B < 512 && N <= 1024) quads = (quads + 1) / 2;   // fill the chip
-    quads = cdiv(total_quads, cdiv(total_quads, quads));      // balance the last block
-    p->quads = quads;
-    p->q_blocks = cdiv(total_quads, quads);
-    p->lds = (size_t)quads * per_quad;
-    int threads = N >= 512 ? 512 : ((N + 63) / 64) * 64;
-    int n_per_block = N, n_tiles = 1;
-    if (N > 1024) {
-        // >= ~3 workgroups per CU, at least 2 queries per lane so that the staged tile is reused
-        long long want = cdiv64(768, (long long)p->q_blocks * B);
-        long long max_tiles = N / (2 * threads);
-        if (want > max_tiles) want = max_tiles;
-        if (want < 1) want = 1;
-        n_tiles = (int)want;
-        n_per_block = cdiv(cdiv(N, n_tiles), 64) * 64;
-        n_tiles = cdiv(N, n_per_block);
-    }
-    p->threads = threads;
-    p->n_tiles = n_tiles;
-    p->n_per_block = n_per_block;
-    return p->q_blocks <= 65535 && B <= 65535;
-}
-
-// Work decomposition of mr_fwd_kq_kernel: the quad tile of plan_q4 (16 * M bytes per channel quad; ~20 KB tiles for windows, what
-// fits 48 KB for the pooled candidate sets), 256 threads = 64 queries per pass, the query range cut until the grid has ~4
-// workgroups per CU while every workgroup still makes >= 2 passes over its staged tile.
-static bool plan_kq(int B, int C, int N, int M, int K, bool self, Q4Plan* p) {
-    const char* force = getenv("NEXTOU_MR_FWD");
-    if (force && (force[0] == 'v' || force[0] == 'q')) return false;
-    if (!(force && force[0] == 'k') && K <= 16) return false;      // measured (profiles/r03_kernel_bench_cfg2.md): short lists keep the
-                                                                   // quad kernel (K <= 8 windows, 61 % of HBM) / the dword kernel (K = 14:
-                                                                   // 22.3 vs 23.8 us pooled, 32.2 vs 39.2 us windows); K = 28 / 32 take this one
     if (M > 65536) return false;
     const size_t per_quad = (size_t)M * 16;
     if (per_quad > 152 * 1024) return false;
     const int total_quads = (C + 3) / 4;
-    size_t budget = M <= 512 ? 20 * 1024 : 48 * 1024;
-    int quads = (int)(budget / per_quad);
-    if (quads < 1) quads = 1;
-    if (quads > kKqMaxQuads) quads = kKqMaxQuads;
-    if (quads > total_quads) quads = total_quads;
-    while (quads > 1 && (long long)cdiv(total_quads, quads) * B * cdiv(N, 128) < 1024) quads = (quads + 1) / 2;     // fill the chip
-    quads = cdiv(total_quads, cdiv(total_quads, quads));      // balance the last block
+    int quads = M > 512 ? 1 : 2;
+    while (quads > 1 && quads > total_quads) quads >>= 1;
+    while (quads > 1 && (long long)cdiv(total_quads, quads) * B * cdiv(N, 256) < 1024) quads >>= 1;      // fill the chip
+    if (const char* e = getenv("NEXTOU_QB_QUADS")) {
+        const int v = atoi(e);
+        if ((v == 1 || v == 2 || v == 4) && (size_t)v * per_quad <= 152 * 1024) quads = v;
+    }
+    int threads = M > 512 ? 512 : 256;
+    if (const char* e = getenv("NEXTOU_QB_THREADS")) {
+        const int v = atoi(e);
+        if (v == 64 || v == 128 || v == 256 || v == 512) threads = v;
+    }
     p->quads = quads;
     p->q_blocks = cdiv(total_quads, quads);
     p->lds = (size_t)quads * per_quad;
-    long long want = cdiv64(1024, (long long)p->q_blocks * B);
-    const long long max_tiles = N >= 128 ? N / 128 : 1;
+    long long target = 1536;
+    if (const char* e = getenv("NEXTOU_QB_WGS")) target = atoll(e) > 0 ? atoll(e) : target;
+    long long want = cdiv64(target, (long long)p->q_blocks * B);
+    const long long max_tiles = cdiv(N, threads);
     if (want > max_tiles) want = max_tiles;
     if (want < 1) want = 1;
     p->n_per_block = cdiv(cdiv(N, (int)want), 64) * 64;
     p->n_tiles = cdiv(N, p->n_per_block);
-    p->threads = 256;
+    p->threads = threads;
+    (void)self; (void)K;
     return p->q_blocks <= 65535 && B <= 65535;
 }
 
@@ -842,60 +739,46 @@ extern "C" int nextou_mr_aggregate_fwd(const float* x, const float* y, const int
     const double fwd_bytes = 4.0 * B * C * ((double)N + (y ? M : 0)) + 4.0 * B * (double)N * K + 8.0 * B * C * (double)N +
                              (arg_out ? 2.0 * B * C * (double)N : 0.0);
     Q4Plan qp;
-    if (center_idx == nullptr && K <= 32 && plan_q4(B, C, N, M, K, self, &qp)) {
+    if (center_idx == nullptr && K <= 32 && plan_qb(B, C, N, M, K, self, &qp)) {
         dim3 grid(qp.n_tiles, qp.q_blocks, B), block(qp.threads);
-        const int kb = K <= 8 ? 8 : (K <= 16 ? 16 : 32);
-        ProfScope prof(s, kBoundHbm, fwd_bytes, "mr_fwd_q4_kernel<%d,%s,%s>[B%d C%d N%d M%d K%d]", kb,
+        // list lengths with their own bound-check-free instance; every other K <= 32 takes the generic 8 x 4 one
+        const bool exact = K == 7 || K == 8 || K == 14 || K == 16 || K == 28 || K == 32;
+        const int kb = exact ? ((K % 7 == 0) ? 7 : 8) : 8;
+        const int nb = exact ? K / kb : 4;
+        ProfScope prof(s, kBoundHbm, fwd_bytes, "mr_fwd_qb_kernel<%dx%d,q%d,%s,%s>[B%d C%d N%d M%d K%d]", kb, nb, qp.quads,
                        self ? "self" : "xy", arg_out ? "arg" : "noarg", B, C, N, M, K);
-#define NEXTOU_MR_Q4(KB, SELF, ARG)                                                                          \
-    do {                                                                                                     \
-        if (qp.lds > 64 * 1024)                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_fwd_q4_kernel<KB, SELF, ARG>),       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)qp.lds);              \
-        hipLaunchKernelGGL((mr_fwd_q4_kernel<KB, SELF, ARG>), grid, block, qp.lds, s, x, src, nn_idx, out, arg_out, \
-                           C, N, M, K, idx_stride, idx_step, qp.quads, qp.n_per_block);                      \
+#define NEXTOU_MR_QB(KB, NB, Q, EX, SELF, ARG)                                                                        \
+    do {                                                                                                              \
+        if (qp.lds > 64 * 1024)                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_fwd_qb_kernel<KB, NB, Q, EX, SELF, ARG>),     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)qp.lds);                       \
+        hipLaunchKernelGGL((mr_fwd_qb_kernel<KB, NB, Q, EX, SELF, ARG>), grid, block, qp.lds, s, x, src, nn_idx, out, \
+                           arg_out, C, N, M, K, idx_stride, idx_step, qp.n_per_block);                                \
     } while (0)
-#define NEXTOU_MR_Q4_KB(KB)                                                      \
+#define NEXTOU_MR_QB_SA(KB, NB, Q, EX)                                           \
     do {                                                                         \
-        if (self && arg_out) NEXTOU_MR_Q4(KB, true, true);                       \
-        else if (self) NEXTOU_MR_Q4(KB, true, false);                            \
-        else if (arg_out) NEXTOU_MR_Q4(KB, false, true);                         \
-        else NEXTOU_MR_Q4(KB, false, false);                                     \
+        if (self && arg_out) NEXTOU_MR_QB(KB, NB, Q, EX, true, true);            \
+        else if (self) NEXTOU_MR_QB(KB, NB, Q, EX, true, false);                 \
+        else if (arg_out) NEXTOU_MR_QB(KB, NB, Q, EX, false, true);              \
+        else NEXTOU_MR_QB(KB, NB, Q, EX, false, false);                          \
     } while (0)
-        if (kb == 8) NEXTOU_MR_Q4_KB(8);
-        else if (kb == 16) NEXTOU_MR_Q4_KB(16);
-        else NEXTOU_MR_Q4_KB(32);
-#undef NEXTOU_MR_Q4_KB
-#undef NEXTOU_MR_Q4
-        return check_launch("mr_fwd_q4_kernel");
-    }
-    if (center_idx == nullptr && K <= 32 && plan_kq(B, C, N, M, K, self, &qp)) {
-        dim3 grid(qp.n_tiles, qp.q_blocks, B), block(qp.threads);
-        const int kl = K <= 8 ? 2 : (K <= 16 ? 4 : (K <= 28 ? 7 : 8));
-        ProfScope prof(s, kBoundHbm, fwd_bytes, "mr_fwd_kq_kernel<%d,%s,%s>[B%d C%d N%d M%d K%d]", kl,
-                       self ? "self" : "xy", arg_out ? "arg" : "noarg", B, C, N, M, K);
-#define NEXTOU_MR_KQ(KL, SELF, ARG)                                                                          \
-    do {                                                                                                     \
-        if (qp.lds > 64 * 1024)                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_fwd_kq_kernel<KL, SELF, ARG>),       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)qp.lds);              \
-        hipLaunchKernelGGL((mr_fwd_kq_kernel<KL, SELF, ARG>), grid, block, qp.lds, s, x, src, nn_idx, out, arg_out, \
-                           C, N, M, K, idx_stride, idx_step, qp.quads, qp.n_per_block);                      \
-    } while (0)
-#define NEXTOU_MR_KQ_KL(KL)                                                      \
+#define NEXTOU_MR_QB_Q(KB, NB, EX)                                               \
     do {                                                                         \
-        if (self && arg_out) NEXTOU_MR_KQ(KL, true, true);                       \
-        else if (self) NEXTOU_MR_KQ(KL, true, false);                            \
-        else if (arg_out) NEXTOU_MR_KQ(KL, false, true);                         \
-        else NEXTOU_MR_KQ(KL, false, false);                                     \
+        if (qp.quads == 1) NEXTOU_MR_QB_SA(KB, NB, 1, EX);                       \
+        else if (qp.quads == 2) NEXTOU_MR_QB_SA(KB, NB, 2, EX);                  \
+        else NEXTOU_MR_QB_SA(KB, NB, 4, EX);                                     \
     } while (0)
-        if (kl == 2) NEXTOU_MR_KQ_KL(2);
-        else if (kl == 4) NEXTOU_MR_KQ_KL(4);
-        else if (kl == 7) NEXTOU_MR_KQ_KL(7);
-        else NEXTOU_MR_KQ_KL(8);
-#undef NEXTOU_MR_KQ_KL
-#undef NEXTOU_MR_KQ
-        return check_launch("mr_fwd_kq_kernel");
+        if (!exact) NEXTOU_MR_QB_Q(8, 4, false);
+        else if (K == 7) NEXTOU_MR_QB_Q(7, 1, true);
+        else if (K == 8) NEXTOU_MR_QB_Q(8, 1, true);
+        else if (K == 14) NEXTOU_MR_QB_Q(7, 2, true);
+        else if (K == 16) NEXTOU_MR_QB_Q(8, 2, true);
+        else if (K == 28) NEXTOU_MR_QB_Q(7, 4, true);
+        else NEXTOU_MR_QB_Q(8, 4, true);
+#undef NEXTOU_MR_QB_Q
+#undef NEXTOU_MR_QB_SA
+#undef NEXTOU_MR_QB
+        return check_launch("mr_fwd_qb_kernel");
     }
     MrPlan p;
     if (center_idx == nullptr && K <= 32 && plan_lds(B, C, N, M, M, true, &p)) {
@@ -933,7 +816,7 @@ extern "C" int nextou_mr_aggregate_has_arg(int B, int C, int N, int M, int K) {
     MrPlan p;
     Q4Plan q;
     return (M <= 65536 && K <= 32 && B > 0 && C > 0 && N > 0 && M > 0 &&
-            (plan_q4(B, C, N, M, K, M == N, &q) || plan_kq(B, C, N, M, K, M == N, &q) || plan_lds(B, C, N, M, M, true, &p))) ? 1 : 0;
+            (plan_qb(B, C, N, M, K, M == N, &q) || plan_lds(B, C, N, M, M, true, &p))) ? 1 : 0;
 }
 
 // 1 if the caller should keep nn_idx alive and take nextou_mr_aggregate_bwd_arg_idx for a self graph of this shape.

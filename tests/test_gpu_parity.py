@@ -213,6 +213,45 @@ def test_mr_aggregate_vs_oracle(ops, ora, B, C, N, M, K, stride_extra, step):
         assert float((grads[1].cpu() - dy).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("force,quads,threads", [(None, None, None), (None, "1", "256"), (None, "2", "512"), (None, "4", "128"),
+                                                  ("v", None, None)])
+@pytest.mark.parametrize("B,C,N,M,K,stride_extra,step", [
+    (2, 33, 168, None, 7, 0, 1),          # window, exact 7 x 1 instance, C not a multiple of 4
+    (2, 12, 300, 96, 8, 0, 1),
+    (2, 24, 3000, 300, 14, 0, 1),
+    (1, 20, 700, 128, 16, 0, 1),
+    (2, 30, 2500, 1344, 28, 0, 1),        # the pooled stage-3 list length
+    (1, 10, 1500, None, 32, 0, 1),
+    (2, 9, 500, 200, 19, 0, 1),           # no exact instance: bound-checked 8 x 4
+    (2, 8, 100, 40, 4, 4, 2),             # dilated view (idx_step 2): scalar id loads
+    (1, 6, 257, 64, 28, 3, 1),            # id rows not 16-byte aligned
+])
+def test_mr_forward_kernel_variants(ops, ora, monkeypatch, force, quads, threads, B, C, N, M, K, stride_extra, step):
+    """Both LDS forward kernels of K2 (the channel-quad kernel in its default plan and with 1 / 2 / 4 quads per workgroup; the
+    dword kernel, NEXTOU_MR_FWD=v) against the oracle: values and recorded arg-max ids bit for bit, with duplicated feature
+    values so that exact ties of the rounded differences occur and the first-maximum rule is exercised."""
+    if force is not None:
+        monkeypatch.setenv("NEXTOU_MR_FWD", force)
+    if quads is not None:
+        monkeypatch.setenv("NEXTOU_QB_QUADS", quads)
+        monkeypatch.setenv("NEXTOU_QB_THREADS", threads)
+        monkeypatch.setenv("NEXTOU_QB_WGS", "64")
+    x = _rand((B, C, N), 41)
+    y = None if M is None else _rand((B, C, M), 42)
+    src = x if y is None else y
+    src[:, :, 1::3] = src[:, :, 0:-1:3][:, :, : src[:, :, 1::3].shape[2]]          # equal neighbours -> ties
+    src.mul_(4).round_().div_(4)                                                      # coarse values: more ties
+    idx = _idx(B, N, M or N, K * step + stride_extra, 43)
+    want, want_arg = ora.mr_fwd(x, y, idx, None, K, step, want_arg=True)
+    xd, yd, idd = x.to(DEV), None if y is None else y.to(DEV), idx.to(DEV)
+    assert ops._HIP.mr_has_arg(B, C, N, M or N, K)
+    got, arg = ops._HIP.mr_fwd(xd, yd, idd, None, K, step, want_arg=True)
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(arg.cpu(), want_arg)
+    plain, none = ops._HIP.mr_fwd(xd, yd, idd, None, K, step, want_arg=False)
+    assert none is None and torch.equal(plain.cpu(), want)
+
+
 def test_mr_aggregate_center_index_and_golden(ops, ora):
     x = _rand((2, 7, 60), 41)
     idx, ctr = _idx(2, 60, 60, 5, 42), _idx(2, 60, 60, 5, 43)

@@ -69,7 +69,8 @@ def main():
         own = [(n, v) for n, v in ranked if "nextou" in n]
         out.write("\n## own kernels (libnextou_hip.so)\n\n| kernel | calls | total ms | mean us |\n|---|---:|---:|---:|\n")
         for name, (calls, us) in own:
-            out.write("| `%s` | %d | %.3f | %.2f |\n" % (name.split("(")[0].replace("|", "\\|"), calls, us / 1e3, us / calls))
+            short = name.replace("(anonymous namespace)::", "").split("(")[0]
+            out.write("| `%s` | %d | %.3f | %.2f |\n" % (short.replace("|", "\\|"), calls, us / 1e3, us / calls))
         own_us = sum(v[1] for _, v in own)
         out.write("\nown kernels: %.3f ms = %.1f%% of GPU kernel time\n" % (own_us / 1e3, 100 * own_us / max(total, 1e-9)))
     print("wrote", dst)
