@@ -88,6 +88,84 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__
 }
 
 // --------------------------------------------------------------------------------------------
+// prep, tiled (round 3): the kernel above keeps 16 loads in flight per point and nothing else, so a 168-point stage
+// (B' = 2: 336 threads on the whole chip) spends 2 x C / 16 dependent round trips to memory — 21-26 us for 0.4 MB, and the pooled
+// graphs pay it twice (queries and candidates, two launches).  Here a workgroup owns 64 points: all 256 threads pull the
+// (C, 64) slab into LDS with every load in flight, ONE wave runs the two strictly c-ordered fmaf chains out of LDS (the
+// arithmetic contract is unchanged: chain(x*x) -> max(sqrt, eps) -> x / den -> chain(xn*xn)), the divides are spread over
+// all four waves, and the normalised slab goes back coalesced.  Queries and candidates share one launch (tiles_x + tiles_y).
+// LDS = C * 64 floats (83 KB at C = 324); C > 384 keeps the kernel above.
+// --------------------------------------------------------------------------------------------
+constexpr int kPrepPts = 64;
+constexpr int kPrepMaxC = 384;
+
+template <bool NORMALIZE>
+__global__ __launch_bounds__(256) void knn_prep_tile_kernel(const float* __restrict__ x, float* __restrict__ xn,
+                                                            float* __restrict__ xs, int N, int tiles_x,
+                                                            const float* __restrict__ y, float* __restrict__ yn,
+                                                            float* __restrict__ ys, int M, int C) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [C][64]
+    __shared__ float den_s[kPrepPts];
+    int t = blockIdx.x;
+    const float* src = x;
+    float* dstn = xn;
+    float* dsts = xs;
+    int P = N;
+    if (t >= tiles_x) { t -= tiles_x; src = y; dstn = yn; dsts = ys; P = M; }
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, cw = threadIdx.x >> 6;
+    const int n = t * kPrepPts + lane;
+    const bool ok = n < P;
+    const float* sb = src + (size_t)b * C * P + (ok ? n : 0);
+    constexpr int U = 16;
+    for (int c0 = cw; c0 < C; c0 += 4 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + 4 * u;
+            v[u] = (ok && c < C) ? sb[(size_t)c * P] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + 4 * u;
+            if (c < C) tile[c * kPrepPts + lane] = v[u];
+        }
+    }
+    __syncthreads();
+    if (cw == 0) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) {
+            const float v = tile[c * kPrepPts + lane];
+            s = fmaf(v, v, s);
+        }
+        if (!NORMALIZE) {
+            if (ok) dsts[(size_t)b * P + n] = s;
+        } else {
+            den_s[lane] = fmaxf(sqrtf(s), kNormEps);
+        }
+    }
+    if (!NORMALIZE) return;
+    __syncthreads();
+    const float den = den_s[lane];
+    for (int c = cw; c < C; c += 4) tile[c * kPrepPts + lane] = tile[c * kPrepPts + lane] / den;
+    __syncthreads();
+    if (cw == 0) {
+        float q = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) {
+            const float v = tile[c * kPrepPts + lane];
+            q = fmaf(v, v, q);
+        }
+        if (ok) dsts[(size_t)b * P + n] = q;
+    }
+    if (ok) {
+        float* ob = dstn + (size_t)b * C * P + n;
+        for (int c = cw; c < C; c += 4) ob[(size_t)c * P] = tile[c * kPrepPts + lane];
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // fused distance + top-K.
 //   grid  = (ceil(N / (32*nw)), B), block = 64*nw threads (nw waves, 32 queries per wave).
 //   MFMA orientation: A operand = candidates (row i = m), B operand = queries (col j = n), so a
@@ -494,6 +572,52 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
     if (rank < K) out[(size_t)row * K + rank] = i;
 }
 
+// Same merge with a workgroup's rows staged in LDS first: the binary searches above are chains of dependent GLOBAL loads
+// (S lists x log2 K probes: 64 us for the 2 688 rows of the stage-4 pooled graph at S = 11, K = 32, i.e. pure latency).
+// grid = ceil(rows / rows_per_wg); LDS = rows_per_wg * S * K * 8 bytes.
+__global__ __launch_bounds__(256) void knn_merge_lds_kernel(const float* __restrict__ part_d,
+                                                            const int32_t* __restrict__ part_i,
+                                                            int32_t* __restrict__ out, long long rows, int S, int K,
+                                                            int rows_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float merge_lds[];
+    const int per_row = S * K;
+    float* sd = merge_lds;
+    int32_t* si = reinterpret_cast<int32_t*>(merge_lds + (size_t)rows_per_wg * per_row);
+    const long long row0 = (long long)blockIdx.x * rows_per_wg;
+    long long left = rows - row0;
+    const int nrows = left < rows_per_wg ? (int)left : rows_per_wg;
+    const int total = nrows * per_row;
+    const size_t base = (size_t)row0 * per_row;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        sd[e] = part_d[base + e];
+        si[e] = part_i[base + e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int r = e / per_row;
+        const int rem = e - r * per_row;
+        const int sp = rem / K, j = rem - sp * K;
+        const float d = sd[e];
+        const int i = si[e];
+        if (i == kSentinelIdx) continue;  // list shorter than K: not a candidate
+        const float* pd = sd + r * per_row;
+        const int32_t* pi = si + r * per_row;
+        int rank = j;
+        for (int o = 0; o < S && rank < K; ++o) {
+            if (o == sp) continue;
+            int lo = 0, hi = K;  // first position in list o that does NOT sort before (d, i)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const float dm = pd[o * K + mid];
+                const int im = pi[o * K + mid];
+                if (dm < d || (dm == d && im < i)) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < K) out[(size_t)(row0 + r) * K + rank] = i;
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // naive pair: materialised distances + one wave per row (any K <= M).
 // --------------------------------------------------------------------------------------------
@@ -657,6 +781,38 @@ static int launch_prep(const float* x, float* xn, float* sq, int B, int C, int N
     return check_launch("knn_prep_kernel");
 }
 
+// queries (and, for a pooled graph, candidates) in one launch of the tiled kernel; NEXTOU_KNN_PREP=v1 keeps the per-point
+// kernel (one launch per operand) for A/B runs
+static int launch_prep_pair(const float* x, float* xn, float* xs, int N, const float* y, float* yn, float* ys, int M, int B,
+                            int C, bool normalize, hipStream_t s) {
+    // Measured (profiles/r03_k1_prep_merge.md): one launch for both operands of a pooled graph beats two of the per-point
+    // kernel (cfg-2 Pool s3 28.3 + 24.1 -> 24.0 us, Pool s2 16.0 + 13.3 -> 16.5 us; cfg-5 Pool s3 36.7 + 29.3 -> 49.8 us); for a
+    // single operand the two are level (the phases of one 64-point tile are as serial as the per-point loop), so self graphs
+    // keep the per-point kernel.  NEXTOU_KNN_PREP=v1 / tile forces one of them.
+    static const int mode = [] { const char* e = getenv("NEXTOU_KNN_PREP"); return !e ? 0 : (e[0] == 'v' ? 1 : 2); }();
+    if (mode == 1 || C > kPrepMaxC || (mode == 0 && y == nullptr)) {
+        if (int e = launch_prep(x, xn, xs, B, C, N, normalize, s)) return e;
+        return y ? launch_prep(y, yn, ys, B, C, M, normalize, s) : 0;
+    }
+    const int tx = cdiv(N, kPrepPts), ty = y ? cdiv(M, kPrepPts) : 0;
+    const size_t lds = (size_t)C * kPrepPts * sizeof(float);
+    const double pts = (double)N + (y ? M : 0);
+    ProfScope prof(s, kBoundHbm, 4.0 * B * pts * ((normalize ? 2.0 : 1.0) * C + 1), "knn_prep_tile_kernel[B%d C%d N%d M%d]", B, C,
+                   N, y ? M : 0);
+    if (normalize) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_prep_tile_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(knn_prep_tile_kernel<true>, dim3(tx + ty, B), dim3(256), lds, s, x, xn, xs, N, tx, y, yn, ys, M, C);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_prep_tile_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(knn_prep_tile_kernel<false>, dim3(tx + ty, B), dim3(256), lds, s, x, xn, xs, N, tx, y, yn, ys, M, C);
+    }
+    return check_launch("knn_prep_tile_kernel");
+}
+
 struct FusedArgs {
     const float *xn, *yn, *xs, *ys, *relpos;
     int32_t* out;
@@ -699,10 +855,24 @@ static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
     if (p.splits > 1) {
         const long long rows = (long long)a.B * a.N;
         ProfScope prof(s, kBoundHbm, 8.0 * rows * p.splits * a.K + 4.0 * rows * a.K, "knn_merge_kernel[B%d N%d S%d K%d]",
-                       a.B, a.N, p.splits, a.K);
-        hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)cdiv64(rows * p.splits * a.K, 256)), dim3(256), 0, s,
-                           a.part_d, a.part_i, a.out, rows, p.splits, a.K);
-        return check_launch("knn_merge_kernel");
+                       a.B, a.N, p.splits, a.K);       // (both merge kernels report under this label)
+        // LDS-staged merge for up to 4 partial lists (cfg-2 Pool s3 53.9 -> 41.9 us, Swin / Pool s4-s5 9 -> 7 us, cfg-5 S = 2
+        // 37 -> 32 us); with 6-11 lists it is level or behind the global one (64 -> 81 us at S = 11 on 2 688 rows, 108 -> 88 us
+        // on 6 144): profiles/r03_k1_prep_merge.md.  NEXTOU_KNN_MERGE=v1 / lds forces one of them.
+        static const int merge_mode = [] { const char* e = getenv("NEXTOU_KNN_MERGE"); return !e ? 0 : (e[0] == 'v' ? 1 : 2); }();
+        if (merge_mode == 1 || (merge_mode == 0 && p.splits > 4)) {
+            hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)cdiv64(rows * p.splits * a.K, 256)), dim3(256), 0, s,
+                               a.part_d, a.part_i, a.out, rows, p.splits, a.K);
+            return check_launch("knn_merge_kernel");
+        }
+        const int per_row = p.splits * a.K;
+        int rows_per_wg = 2048 / per_row;          // <= 16 KB of LDS; at least 4 entries per thread
+        if (rows_per_wg < 1) rows_per_wg = 1;
+        // small problems: fewer rows per workgroup until ~2 workgroups sit on every CU
+        while (rows_per_wg > 1 && cdiv64(rows, rows_per_wg) < 512) rows_per_wg = (rows_per_wg + 1) / 2;
+        hipLaunchKernelGGL(knn_merge_lds_kernel, dim3((unsigned)cdiv64(rows, rows_per_wg)), dim3(256),
+                           (size_t)rows_per_wg * per_row * 8, s, a.part_d, a.part_i, a.out, rows, p.splits, a.K, rows_per_wg);
+        return check_launch("knn_merge_lds_kernel");
     }
     return 0;
 }
@@ -752,10 +922,7 @@ extern "C" int nextou_knn_graph(const float* x, const float* y, const float* rel
     float* yn = (float*)(base + w.yn);
     float* ys = (float*)(base + w.ys);
 
-    if (int e = launch_prep(x, xn, xs, B, C, N, normalize != 0, s)) return e;
-    if (has_y) {
-        if (int e = launch_prep(y, yn, ys, B, C, M, normalize != 0, s)) return e;
-    }
+    if (int e = launch_prep_pair(x, xn, xs, N, has_y ? y : nullptr, yn, ys, M, B, C, normalize != 0, s)) return e;
     if (!normalize) {  // the un-normalised copies are the inputs themselves
         xn = const_cast<float*>(x);
         yn = has_y ? const_cast<float*>(y) : xn;

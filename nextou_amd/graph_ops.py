@@ -752,31 +752,60 @@ class _NormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, instance,
-                pre_bias):
+                pre_bias, pad_holder=None):
         shape = x.shape
         B, C = shape[0], shape[1]
         period = C if instance else 0
         be = _backend_for(x)
+        # zero-padded input channels (channel_pad.py): the parameters keep their real length; they are staged into a persistent
+        # (5, C) buffer of the norm module — rows weight / bias / pre_bias / running mean / running var, padding lanes 1 / 0 / 0 /
+        # 0 / 1 — with ONE multi-tensor copy, and the running statistics come back with one more (F.pad per vector cost ten
+        # launches per call and two for the write-back: ~170 of the step's ~1 700 launches)
+        c_real = C
+        stage = None
+        if pad_holder is not None:
+            c_real = pad_holder.num_features
+            stage = _pad_stage(pad_holder, C, c_real, x.device)
+            dst, src = [], []
+            for row, t in enumerate((weight, bias, pre_bias, running_mean, running_var)):
+                if t is not None:
+                    dst.append(stage[row, :c_real])
+                    src.append(t.detach())
+            if dst:
+                torch._foreach_copy_(dst, src)
+            k_weight = stage[0] if weight is not None else None
+            k_bias = stage[1] if bias is not None else None
+            k_pre = stage[2] if pre_bias is not None else None
+            k_rm = stage[3] if running_mean is not None else None
+            k_rv = stage[4] if running_var is not None else None
+        else:
+            k_weight, k_bias, k_pre, k_rm, k_rv = weight, bias, pre_bias, running_mean, running_var
         cl = _dense_channels_last(x) if (x.is_cuda and not instance) else None
         if cl is not None:      # NDHWC / NHWC memory goes to the channels-last kernels as it is
-            y, mean, invstd = be.norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps,
-                                              slope, 0, pre_bias, channels_last=True)
-            ctx.save_for_backward(x, weight, bias, mean, invstd)
+            y, mean, invstd = be.norm_act_fwd(x, k_weight, k_bias, k_rm, k_rv, training, momentum, eps,
+                                              slope, 0, k_pre, channels_last=True)
+            x3 = x
         else:
             x3 = x.contiguous()
             x3 = x3.view(1, B * C, -1) if instance else x3.view(B, C, -1)
-            y, mean, invstd = be.norm_act_fwd(x3, weight, bias, running_mean, running_var, training, momentum, eps,
-                                              slope, period, pre_bias)
+            y, mean, invstd = be.norm_act_fwd(x3, k_weight, k_bias, k_rm, k_rv, training, momentum, eps,
+                                              slope, period, k_pre)
             y = y.view(shape)
-            ctx.save_for_backward(x3, weight, bias, mean, invstd)
+        if stage is not None:
+            if training and running_mean is not None and running_var is not None:
+                torch._foreach_copy_([running_mean, running_var], [stage[3, :c_real], stage[4, :c_real]])
+            wb = stage[0:2].clone()         # the stage is rewritten by the next call; backward reads its own copy
+            k_weight = wb[0] if weight is not None else None
+            k_bias = wb[1] if bias is not None else None
+        ctx.save_for_backward(x3, k_weight, k_bias, mean, invstd)
         ctx.pre_bias_like = pre_bias
-        ctx.cfg = (bool(training), float(slope), period, shape, B, C, float(eps), cl)
+        ctx.cfg = (bool(training), float(slope), period, shape, B, C, float(eps), cl, c_real)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x3, weight, bias, mean, invstd = ctx.saved_tensors
-        training, slope, period, shape, B, C, eps, cl = ctx.cfg
+        training, slope, period, shape, B, C, eps, cl, c_real = ctx.cfg
         if gy.dtype != x3.dtype:
             gy = gy.to(x3.dtype)
         if cl is not None:
@@ -795,16 +824,27 @@ class _NormAct(torch.autograd.Function):
             if training:
                 gpre = torch.zeros_like(ctx.pre_bias_like)
             else:
-                gpre = (gb * invstd * (weight if weight is not None else 1.0)).to(ctx.pre_bias_like.dtype)
-        gw = gw.to(weight.dtype) if weight is not None and ctx.needs_input_grad[1] else None
-        gb = gb.to(bias.dtype) if bias is not None and ctx.needs_input_grad[2] else None
-        return gx, gw, gb, None, None, None, None, None, None, None, gpre
+                gpre = (gb * invstd * (weight if weight is not None else 1.0))[:c_real].to(ctx.pre_bias_like.dtype)
+        gw = gw[:c_real].to(weight.dtype) if weight is not None and ctx.needs_input_grad[1] else None
+        gb = gb[:c_real].to(bias.dtype) if bias is not None and ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None, None, None, None, None, None, None, gpre, None
+
+
+def _pad_stage(holder, C: int, c_real: int, device) -> torch.Tensor:
+    """The persistent (5, C) parameter stage of a norm module whose input carries ``C - c_real`` zero channels."""
+    stage = getattr(holder, "_pad_stage", None)
+    if stage is None or stage.shape[1] != C or stage.device != device:
+        stage = torch.zeros((5, C), dtype=torch.float32, device=device)
+        stage[0].fill_(1.0)       # weight 1, bias 0 -> a zero channel stays exactly zero (mean 0, variance 0)
+        stage[4].fill_(1.0)       # running variance of a padding lane (never read back)
+        holder._pad_stage = stage
+    return stage
 
 
 def norm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
              running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], training: bool,
              momentum: float, eps: float, negative_slope: float = 1.0, instance: bool = False,
-             pre_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+             pre_bias: Optional[torch.Tensor] = None, pad_holder=None) -> torch.Tensor:
     """``leaky_relu(batch_norm(x [+ pre_bias]) | instance_norm(x), negative_slope)`` on (B,C,*spatial) fp32 / bf16 / fp16
     (statistics and the normalisation itself are always computed in fp32 / fp64; only loads and stores are narrow).
 
@@ -816,6 +856,9 @@ def norm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[tor
     (NexToU_Encoder_Decoder.py:384-390, 710-720, 833-842) and the conv stages' ConvDropoutNormReLU.
     ``negative_slope=1`` is the bare normalisation.  Running statistics are updated in place as
     ``F.batch_norm`` does (unbiased variance, ``momentum``); ``training=False`` uses them.
+
+    ``pad_holder``: the norm module, when ``x`` carries more channels than its ``num_features`` — the extra ones being the
+    all-zero padding channels of network_architecture/channel_pad.py; parameters and statistics keep their real length.
     """
     if x.dtype not in _NORM_DTYPES:
         raise TypeError("norm_act: dtype %s not in (float32, bfloat16, float16)" % x.dtype)
@@ -827,8 +870,10 @@ def norm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[tor
         bias = bias.float()
     if pre_bias is not None and pre_bias.dtype != torch.float32:
         pre_bias = pre_bias.float()
+    if pad_holder is not None and instance:
+        raise ValueError("norm_act: channel padding is only defined for batch statistics")
     return _NormAct.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum),
-                          float(eps), float(negative_slope), bool(instance), pre_bias)
+                          float(eps), float(negative_slope), bool(instance), pre_bias, pad_holder)
 
 
 def _dense_channels_last(x: torch.Tensor):

@@ -10,7 +10,8 @@ they are handed.
 
 Mechanics.  Parameters and buffers keep the reference's shapes (``state_dict`` interchange, ``InitWeights_He``, DDP buckets
 and optimizer state see 33 / 66).  On the forward pass a padded module builds its padded weight / bias / norm parameters on
-the fly (``F.pad`` / ``cat`` of a few KB — autograd slices the gradients back) and the activations between the padded
+the fly (``F.pad`` / ``cat`` of a few KB — autograd slices the gradients back; norm parameters are staged into a persistent
+padded buffer by graph_ops.norm_act) and the activations between the padded
 modules carry ``pad`` extra all-zero channels:
 
 * an *entry* module (first convolution of stage 0; an up-convolution fed by a graph stage) decides per call: it pads its
@@ -165,28 +166,17 @@ def pad_image_channels(module: nn.Module, x: torch.Tensor, weight: torch.Tensor)
     return xp, _pad_axis(weight, 1, to)
 
 
-def padded_norm_params(norm: nn.Module, x: torch.Tensor, pre_bias):
-    """-> (weight, bias, running_mean, running_var, pre_bias, write_back) for a fused norm whose input may carry padding
-    channels.  ``write_back()`` copies the updated running statistics of the real channels into the module's buffers."""
+def norm_input_is_padded(norm: nn.Module, x: torch.Tensor) -> bool:
+    """True when ``x`` reaches a fused norm with its padding channels (then graph_ops.norm_act stages the module's real-length
+    parameters and running statistics into the padded width, ``pad_holder=norm``)."""
     multiple = getattr(norm, "_pad_multiple", 0)
     c_real = norm.num_features
     if not multiple or x.shape[1] == c_real:
-        return norm.weight, norm.bias, norm.running_mean, norm.running_var, pre_bias, None
+        return False
     c_pad = padded(c_real, multiple)
     if x.shape[1] != c_pad:
         raise RuntimeError("channel padding: norm over %d channels received %d (padded count is %d)" % (c_real, x.shape[1], c_pad))
-    w = None if norm.weight is None else _pad_axis(norm.weight, 0, c_pad, 1.0)
-    b = None if norm.bias is None else _pad_axis(norm.bias, 0, c_pad)
-    pb = None if pre_bias is None else _pad_axis(pre_bias, 0, c_pad)
-    rm = rv = None
-    write_back = None
-    if norm.running_mean is not None:
-        rm, rv = _pad_axis(norm.running_mean, 0, c_pad), _pad_axis(norm.running_var, 0, c_pad, 1.0)
-
-        def write_back():
-            norm.running_mean.copy_(rm[:c_real])
-            norm.running_var.copy_(rv[:c_real])
-    return w, b, rm, rv, pb, write_back
+    return True
 
 
 def pad_plain_stage_channels(model: nn.Module, multiple: int) -> int:

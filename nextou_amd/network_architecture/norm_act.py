@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from .. import graph_ops
-from .channel_pad import pad_image_channels, padded_conv_params, padded_norm_params
+from .channel_pad import norm_input_is_padded, pad_image_channels, padded_conv_params
 
 __all__ = ["BatchNormAct1d", "BatchNormAct2d", "BatchNormAct3d", "InstanceNormAct1d", "InstanceNormAct2d",
            "InstanceNormAct3d", "ConvBiasFolded1d", "ConvBiasFolded2d", "ConvBiasFolded3d", "ConvOwnBias2d",
@@ -143,12 +143,10 @@ class _BatchNormAct:
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._check_input_dim(x)
         use_batch_stats, factor, keep_running = self._step()
-        weight, bias, rm, rv, pre_bias, write_back = padded_norm_params(self, x, _pre_bias(self))
-        y = graph_ops.norm_act(x, weight, bias, rm if keep_running else None, rv if keep_running else None,
-                               use_batch_stats, factor, self.eps, self.negative_slope, pre_bias=pre_bias)
-        if write_back is not None and keep_running and use_batch_stats:
-            write_back()
-        return y
+        return graph_ops.norm_act(x, self.weight, self.bias, self.running_mean if keep_running else None,
+                                  self.running_var if keep_running else None, use_batch_stats, factor, self.eps,
+                                  self.negative_slope, pre_bias=_pre_bias(self),
+                                  pad_holder=self if norm_input_is_padded(self, x) else None)
 
     def extra_repr(self) -> str:
         return super().extra_repr() + ", negative_slope=%g" % self.negative_slope
