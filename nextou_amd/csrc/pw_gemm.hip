@@ -1189,6 +1189,178 @@ int check_pw(const char* who, int64_t P, int N, int K, int groups, int64_t lda, 
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Grouped 1x1 convolution with SMALL groups (MRConv's BasicConv on a channels-last volume: 264 -> 264 in 6 groups of 44 at
+// stage 2 of cfg 2; reference torch_nn.py:66-92, groups 4 | 6).  pw_rows_kernel hands every (row tile, group) to its own
+// workgroup: 176-byte row segments in and out, a 128 x 48 x 44 product per workgroup — 170 us for 363 MB of traffic and
+// 4 GFLOP (a quarter of what HBM allows; profiles/r03_pw_rows_grouped.md).  Here a workgroup has ONE WAVE PER GROUP and walks
+// 64-row slabs: the slab's full rows come in and go out as contiguous 16-byte pieces (all groups * K channels of a point), the
+// group's N x K weights sit in the wave's registers for the whole kernel (NT x KSTEPS B operands of v_mfma_f32_16x16x4_f32), the
+// A operand is read from the LDS slab (row stride = 4 mod 8 floats: conflict-free), and — N == K — the result is written over
+// the wave's own columns of the slab, so the store is the mirror image of the load.  EPI = 1: (sum, sum of squares) of every
+// output column, fp32 over a slab's 64 rows, float64 across the workgroup's slabs, one partial per workgroup (the `partial`
+// input of nextou_norm_finalize with tiles = gridDim.x).  Arithmetic: one k-ordered fp32 MFMA chain per output element.
+// Measured (profiles/r03_pw_rows_grouped.md): 170 -> 128 us plain, 168 -> 144 us with the statistics epilogue.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kGrpRows = 64;
+constexpr int kGrpMaxV = 12;          // 16-byte pieces of a slab per thread
+
+template <int NT, int KSTEPS, bool EXACT, int EPI>
+__global__ __launch_bounds__(512) void pw_rows_grp_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                          int P, int N, int K, int groups, long ldx, long ldy, int ld_lds, int slabs,
+                                                          double2* __restrict__ partial) {
+    // EXACT: N == K == 4 * KSTEPS (no bound checks on the operand reads / result writes)
+    extern __shared__ __attribute__((aligned(16))) float grp_lds[];        // [64][ld_lds]
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;             // wave g owns group g
+    const int C = groups * K;                                               // == groups * N
+    const int ln = lane & 15, lk = lane >> 4;
+    // the group's weights: B operand of tile (nt, ks) = w[g * N + nt * 16 + ln][4 * ks + lk]
+    float wreg[NT][KSTEPS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int n = nt * 16 + ln, k = 4 * ks + lk;
+            const int nc = n < N ? n : N - 1, kc = k < K ? k : K - 1;
+            const float t = w[(size_t)(g * N + nc) * K + kc];
+            wreg[nt][ks] = (n < N && k < K) ? t : 0.f;
+        }
+    double s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.0;
+    // a slab = 64 rows of C / 4 16-byte pieces; thread t moves pieces t, t + T, ... (at most kGrpMaxV per thread: plan_rows_grp).
+    // Piece e sits at (row e / c4, quad e % c4); the thread's first one is divided out once, the others follow by addition.
+    const int c4 = C >> 2, T = blockDim.x, total = kGrpRows * c4;
+    const int r0 = tid / c4, q0 = tid - r0 * c4, dr = T / c4, dq = T - dr * c4;
+    for (int slab = blockIdx.x; slab < slabs; slab += gridDim.x) {
+        const int p0 = slab * kGrpRows;
+        __syncthreads();                                                    // the previous slab has left the LDS
+        {
+            // in two batches: half of the thread's loads in flight, then their LDS writes.  Branch-free: rows past the end (and
+            // the pieces past `total`, never stored) re-read row P - 1; such a row's product is computed and dropped
+            int r = r0, q = q0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 v[kGrpMaxV / 2];
+                int rl = r, ql = q;
+#pragma unroll
+                for (int i = 0; i < kGrpMaxV / 2; ++i) {
+                    const int rr = (tid + (h * (kGrpMaxV / 2) + i) * T < total) ? rl : 0;
+                    const int row = p0 + rr < P ? p0 + rr : P - 1;
+                    v[i] = *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + 4 * ql);
+                    rl += dr; ql += dq;
+                    if (ql >= c4) { ql -= c4; ++rl; }
+                }
+#pragma unroll
+                for (int i = 0; i < kGrpMaxV / 2; ++i) {
+                    if (tid + (h * (kGrpMaxV / 2) + i) * T < total) *reinterpret_cast<f32x4*>(grp_lds + r * ld_lds + 4 * q) = v[i];
+                    r += dr; q += dq;
+                    if (q >= c4) { q -= c4; ++r; }
+                }
+            }
+        }
+        __syncthreads();
+        const bool full = p0 + kGrpRows <= P;
+#pragma unroll 1
+        for (int mt = 0; mt < kGrpRows / 16; ++mt) {
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* arow = grp_lds + (mt * 16 + ln) * ld_lds + g * K + lk;
+            float a[KSTEPS];
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) a[ks] = arow[(EXACT || 4 * ks + lk < K) ? 4 * ks : 0];    // (a clamped read meets a zero weight)
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], wreg[nt][ks], acc[nt], 0, 0, 0);
+            // C layout: lane holds rows 4 * lk + {0..3} of column nt * 16 + ln; written over the wave's own input columns
+            float* orow = grp_lds + (mt * 16 + 4 * lk) * ld_lds + g * N + ln;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (nt * 16 + ln < N) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) orow[r * ld_lds + nt * 16] = acc[nt][r];
+                }
+                if (EPI == 1) {                                             // four rows in fp32, then float64 per lane
+                    f32x4 t = acc[nt];
+                    if (!full) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) t[r] = (p0 + mt * 16 + 4 * lk + r < P) ? t[r] : 0.f;
+                    }
+                    const float u = (t[0] + t[1]) + (t[2] + t[3]);
+                    const float q2 = fmaf(t[3], t[3], fmaf(t[2], t[2], fmaf(t[1], t[1], t[0] * t[0])));
+                    s1[nt] += (double)u;
+                    s2[nt] += (double)q2;
+                }
+            }
+        }
+        __syncthreads();                                                    // every group's columns are in place
+        {
+            int r = r0, q = q0;
+#pragma unroll
+            for (int i = 0; i < kGrpMaxV; ++i) {
+                if (tid + i * T < total && p0 + r < P)
+                    *reinterpret_cast<f32x4*>(y + (size_t)(p0 + r) * ldy + 4 * q) = *reinterpret_cast<const f32x4*>(grp_lds + r * ld_lds + 4 * q);
+                r += dr; q += dq;
+                if (q >= c4) { q -= c4; ++r; }
+            }
+        }
+    }
+    if (EPI == 1) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {                                   // the rows held by the other three lane groups
+            double u = s1[nt], q2 = s2[nt];
+            u += __shfl_xor(u, 16); q2 += __shfl_xor(q2, 16);
+            u += __shfl_xor(u, 32); q2 += __shfl_xor(q2, 32);
+            if (lk == 0 && nt * 16 + ln < N) partial[(size_t)(g * N + nt * 16 + ln) * gridDim.x + blockIdx.x] = make_double2(u, q2);
+        }
+    }
+}
+
+struct GrpPlan { int ok, nt, ksteps, grid, slabs, ld; size_t lds; };
+
+// groups of N == K <= 64 channels, 2 ... 8 groups (one wave each), enough rows to give every CU several slabs
+GrpPlan plan_rows_grp(int64_t P, int N, int K, int groups, int64_t ldx, int64_t ldy) {
+    GrpPlan q{};
+    const char* env = getenv("NEXTOU_PW_GRP");          // read per call (tests / A-B)
+    if (env && atoi(env) == 0) return q;
+    const int C = groups * K;
+    if (groups < 2 || groups > 8 || N != K || K % 4 != 0 || K > 64 || ldx < C || ldy < C || P < 64 * 2 * (int64_t)cu_count() ||
+        P > 0x7fffffff)
+        return q;
+    q.nt = K == 44 ? 3 : 4;
+    q.ksteps = K == 44 ? 11 : 16;
+    q.ld = C + ((C % 8 == 4) ? 0 : 4);                  // row stride = 4 mod 8 floats
+    q.lds = (size_t)kGrpRows * q.ld * sizeof(float);
+    if (q.lds > 150 * 1024) return q;
+    if ((kGrpRows * (C / 4) + 64 * groups - 1) / (64 * groups) > kGrpMaxV) return q;      // pieces of a slab per thread
+    q.slabs = (int)((P + kGrpRows - 1) / kGrpRows);
+    const int per_cu = (int)(160 * 1024 / q.lds) < 2 ? 1 : 2;
+    const int max_grid = cu_count() * per_cu;
+    q.grid = q.slabs <= max_grid ? q.slabs : (q.slabs + (q.slabs + max_grid - 1) / max_grid - 1) / ((q.slabs + max_grid - 1) / max_grid);
+    q.ok = 1;
+    return q;
+}
+
+template <int EPI>
+int dispatch_rows_grp(const GrpPlan& q, const float* x, const float* w, float* y, int P, int N, int K, int groups, long ldx, long ldy,
+                      double2* partial, hipStream_t s) {
+#define NEXTOU_GRP_LAUNCH(NT, KS, EX)                                                                                                \
+    do {                                                                                                                           \
+        if (q.lds > 64 * 1024)                                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_rows_grp_kernel<NT, KS, EX, EPI>),                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds);                                     \
+        hipLaunchKernelGGL((pw_rows_grp_kernel<NT, KS, EX, EPI>), dim3(q.grid), dim3(64 * groups), q.lds, s, x, w, y, P, N, K, groups, \
+                           ldx, ldy, q.ld, q.slabs, partial);                                                                      \
+    } while (0)
+    if (q.nt == 3 && q.ksteps == 11) NEXTOU_GRP_LAUNCH(3, 11, true);
+    else NEXTOU_GRP_LAUNCH(4, 16, false);
+#undef NEXTOU_GRP_LAUNCH
+    return check_launch("pw_rows_grp_kernel");
+}
+
 }  // namespace
 }  // namespace nextou
 
@@ -1203,6 +1375,14 @@ extern "C" int nextou_pw_rows(const float* x, const float* w, const float* bias,
     const RowsPlan q = plan_rows((int)P, N, groups, true);
     const int vec_store = (N % 4 == 0 && ldy % 4 == 0 && aligned16(y)) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
+    if (bias == nullptr && vec_store && groups > 1) {
+        const GrpPlan gp = plan_rows_grp(P, N, K, groups, ldx, ldy);
+        if (gp.ok) {
+            ProfScope prof(s, kBoundHbm, 8.0 * (double)P * groups * K, "pw_rows_grp_kernel<%d,%d|plain>[P%lld N%d K%d g%d]", gp.nt, gp.ksteps,
+                           (long long)P, N, K, groups);
+            return dispatch_rows_grp<0>(gp, x, w, y, (int)P, N, K, groups, (long)ldx, (long)ldy, nullptr, s);
+        }
+    }
     if (bias == nullptr && vec_store && ldx == K) {
         const SwPlan sw = plan_rows_sw(P, N, K, groups, false);
         if (sw.cfg >= 0) {
@@ -1217,6 +1397,8 @@ extern "C" int nextou_pw_rows(const float* x, const float* w, const float* bias,
 
 extern "C" int nextou_pw_rows_tiles(int64_t P, int N, int K, int groups) {
     if (P <= 0 || N <= 0 || K <= 0 || groups <= 0) return 0;
+    const GrpPlan gp = plan_rows_grp(P, N, K, groups, (int64_t)groups * K, (int64_t)groups * N);
+    if (gp.ok) return gp.grid;
     const SwPlan sw = plan_rows_sw(P, N, K, groups, false);
     if (sw.cfg >= 0) return sw.grid;
     return plan_rows((int)P, N, groups).nb_p;
@@ -1247,6 +1429,16 @@ extern "C" int nextou_pw_rows_fused(const float* x, const float* w, float* y, in
     fz.epi_slope = bwd_slope;
     hipStream_t s = (hipStream_t)stream;
     const int Pi = (int)P;
+    if (!pro && epi != 2 && groups > 1) {
+        // (nextou_pw_rows_tiles assumes dense rows; a strided caller gets the same plan as long as the strides cover the row)
+        const GrpPlan gp = plan_rows_grp(P, N, K, groups, ldx, ldy);
+        if (gp.ok) {
+            ProfScope prof(s, kBoundHbm, 8.0 * (double)P * groups * K, "pw_rows_grp_kernel<%d,%d|%s>[P%lld N%d K%d g%d]", gp.nt, gp.ksteps,
+                           epi == 1 ? "stats" : "plain", (long long)P, N, K, groups);
+            if (epi == 1) return dispatch_rows_grp<1>(gp, x, w, y, Pi, N, K, groups, (long)ldx, (long)ldy, fz.partial, s);
+            return dispatch_rows_grp<0>(gp, x, w, y, Pi, N, K, groups, (long)ldx, (long)ldy, nullptr, s);
+        }
+    }
     const SwPlan sw = ldx == (int64_t)groups * K ? plan_rows_sw(P, N, K, groups, pro) : SwPlan{-1, 0, 0, 0, 0, 0, 0};
     if (sw.cfg >= 0) {
         ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K, "pw_rows_sw_kernel<%d,%d|%s%s>[P%lld N%d K%d]", sw.tnw, sw.nw, pro ? "norm-act," : "",

@@ -351,3 +351,50 @@ def test_stationary_output_wgrad_kernel(ops, monkeypatch, n, k):
         assert bool(((got.double() - other.double()).abs() <= 2 * bound).all())
     monkeypatch.setenv("NEXTOU_PW_SO", "1")
     assert torch.equal(new, hip.pw_wgrad(gy, x, 1))
+
+
+@pytest.mark.parametrize("groups,k", [(6, 44), (4, 32), (8, 32), (2, 20)])
+def test_small_group_rows_kernel(ops, monkeypatch, groups, k):
+    """pw_rows_grp_kernel (one wave per group, full rows through LDS; MRConv's grouped 1x1 convolution at >= 32 768 points) against
+    pw_rows_kernel (fp32 round-off apart) and the float64 product, plain and with the statistics epilogue, on a ragged point
+    count."""
+    hip = ops._HIP
+    c = groups * k
+    gen = torch.Generator().manual_seed(groups * 100 + k)
+    sp = (21, 45, 45)                                              # 42 525 points: not a multiple of 64
+    x = _cl(torch.randn((1, c) + sp, generator=gen))
+    w = (torch.randn((c, k), generator=gen) * 0.2).to(DEV)
+    import json
+    import ctypes
+    from nextou_amd import _lib
+    L_ = _lib.lib()
+
+    def run(mode):
+        monkeypatch.setenv("NEXTOU_PW_GRP", mode)
+        L_.nextou_profile_enable(64)
+        out = {"plain": hip.pw_rows(x, w, None, groups), "stats": hip.pw_rows_fused(x, w, groups, want_stats=True)}
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = L_.nextou_profile_report(buf, len(buf))
+        L_.nextou_profile_enable(0)
+        return out, [r["kernel"] for r in json.loads(buf.value[:n].decode())]
+
+    new, names_new = run("1")
+    old, names_old = run("0")
+    assert all(n.startswith("pw_rows_grp_kernel") for n in names_new), names_new
+    assert all(n.startswith("pw_rows_kernel") for n in names_old), names_old
+    # (another assignment of k to the four slots of an MFMA step than pw_rows_kernel's: the same fp32 chain in another order)
+    assert float((new["plain"] - old["plain"]).abs().max()) <= 2e-6 * float(old["plain"].abs().max())
+    assert torch.equal(new["stats"][0], new["plain"])
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, groups, k)[::53].double()
+    w64 = w.double().reshape(groups, k, k)
+    want = torch.einsum("pgk,gnk->pgn", rows, w64).reshape(rows.shape[0], c)
+    mag = torch.einsum("pgk,gnk->pgn", rows.abs(), w64.abs()).reshape(rows.shape[0], c)
+    got = new["plain"].permute(0, 2, 3, 4, 1).reshape(-1, c)[::53].double()
+    assert bool(((got - want).abs() <= 6e-7 * mag + 1e-30).all())
+    y64 = new["plain"].permute(0, 2, 3, 4, 1).reshape(-1, c).double()
+    s = new["stats"][1].sum(1)                                     # (C, T, 2) -> (C, 2)
+    assert torch.allclose(s[:, 0], y64.sum(0), rtol=1e-6, atol=1e-6 * float(y64.abs().sum(0).max()))
+    assert torch.allclose(s[:, 1], y64.square().sum(0), rtol=1e-6)
+    so = old["stats"][1].sum(1)
+    assert torch.allclose(s, so, rtol=1e-6, atol=1e-6 * float(so.abs().max()))
