@@ -88,11 +88,12 @@ def layout_policy_applies(x: torch.Tensor, reduced_precision_ok=None) -> bool:
         return False
     if os.environ.get("NEXTOU_REDUCED_PRECISION_LAYOUT", "auto").strip().lower() == "ncdhw":
         return False
+    from .channel_pad import pad_multiple
     if reduced_precision_ok is not None:
         # a model whose padding could not be applied (conv_bias=False, another norm class) runs 33 / 66 channels;
-        # NDHWC under bf16 at those counts is the 309 vs 185 ms regression round 1 fenced off
-        return bool(reduced_precision_ok)
-    from .channel_pad import pad_multiple
+        # NDHWC under bf16 at those counts is the 309 vs 185 ms regression round 1 fenced off.  NEXTOU_PAD_CHANNELS=0 at call
+        # time still switches padding + NDHWC off for a built model (A/B runs).
+        return bool(reduced_precision_ok) and pad_multiple() > 0
     return pad_multiple() > 0
 
 
