@@ -1296,6 +1296,37 @@ def dgrad_as_forward_eligible(conv: torch.nn.Module, x: torch.Tensor) -> bool:
         all(k % 2 == 1 and p == k // 2 for k, p in zip(conv.kernel_size, conv.padding))
 
 
+def rows_gemm_eligible(conv: torch.nn.Module, x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """An un-grouped 1x1 / stride-1 / unpadded convolution of a SMALL dense channels-last device volume (the graph stages 4 / 5 of
+    cfg 2: 2 688 and 336 points): a plain GEMM over the (points, channels) view of the same memory.  MIOpen's convolution kernels
+    need 33-72 us per call at these sizes whatever the problem (and its find step picks between them run by run: the stage-4 / 5
+    FFN measured between 0.55 and 1.07 ms forward + backward from one process to the next); the BLAS GEMM needs 20-47 us —
+    324 -> 1296 at 2 688 points: 33 / 72 / 67 us (forward / data gradient / weight gradient) against 47 / 29 / 29 us, at 336 points
+    44 / 70 / 66 against 20 / 20 / 20 us (profiles/r02_pw_gemm.md, columns conv2d and mm).  From 21 504 points (stage 3) MIOpen's 2-D
+    kernels are the faster ones.  ``NEXTOU_PW_MM_MAX_POINTS`` (default 8192, 0 = off) is the switch."""
+    import os
+    limit = int(os.environ.get("NEXTOU_PW_MM_MAX_POINTS", "8192"))
+    if limit <= 0 or not x.is_cuda or conv.transposed or conv.groups != 1 or isinstance(conv.padding, str):
+        return False
+    if any(k != 1 for k in weight.shape[2:]) or any(v != 1 for v in conv.stride) or any(v != 0 for v in conv.padding) or \
+            any(v != 1 for v in conv.dilation):
+        return False
+    if x.shape[1] != weight.shape[1] or _dense_channels_last(x) is None:
+        return False
+    return x.numel() // x.shape[1] <= limit
+
+
+def rows_gemm(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """``conv1x1(x, weight)`` (no bias) of a dense channels-last volume as ``rows @ weight.T``; input and output rows are views of the
+    channels-last memory, autograd's two gradient GEMMs come with ``linear``."""
+    b, c = x.shape[:2]
+    spatial = tuple(x.shape[2:])
+    nd = x.dim()
+    rows = x.permute(0, *range(2, nd), 1).reshape(-1, c)
+    y = torch.nn.functional.linear(rows, weight.reshape(weight.shape[0], c))
+    return y.view(b, *spatial, weight.shape[0]).permute(0, nd - 1, *range(1, nd - 1))
+
+
 def flat_depth_eligible(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, output_padding=None) -> bool:
     """A 3-D convolution whose kernel has no extent along the depth axis (NexToU's stage 0: [1,3,3]; the (1,2,2)
     up-convolution; every 1x1x1 head) on a dense channels-last volume IS a 2-D convolution of the (B*D, C, H, W) view of

@@ -398,3 +398,32 @@ def test_small_group_rows_kernel(ops, monkeypatch, groups, k):
     assert torch.allclose(s[:, 1], y64.square().sum(0), rtol=1e-6)
     so = old["stats"][1].sum(1)
     assert torch.allclose(s, so, rtol=1e-6, atol=1e-6 * float(so.abs().max()))
+
+
+@pytest.mark.parametrize("shape,cin,cout", [((8, 14, 12), 324, 1296), ((4, 7, 6), 1296, 324), ((16, 16), 32, 48)])
+def test_small_volume_pointwise_conv_as_rows_gemm(ops, monkeypatch, shape, cin, cout):
+    """graph_ops.rows_gemm (the 1x1 convolutions of volumes of <= 8192 points as a BLAS GEMM over the channels-last rows) against
+    ATen's convolution: forward, data and weight gradient to fp32 round-off, channels-last in and out; the module picks it by size."""
+    import torch.nn.functional as F
+    from nextou_amd.network_architecture.norm_act import ConvBiasFolded2d, ConvBiasFolded3d
+    gen = torch.Generator().manual_seed(cin + cout)
+    mf = torch.channels_last_3d if len(shape) == 3 else torch.channels_last
+    conv_f = F.conv3d if len(shape) == 3 else F.conv2d
+    x = torch.randn((2, cin) + shape, generator=gen).to(DEV).contiguous(memory_format=mf).requires_grad_(True)
+    cls = ConvBiasFolded3d if len(shape) == 3 else ConvBiasFolded2d
+    conv = cls(cin, cout, 1, bias=True).to(DEV)
+    assert ops.rows_gemm_eligible(conv, x, conv.weight)
+    y = conv(x)                                                    # bias is folded away: the module returns conv(x) without it
+    assert ops._dense_channels_last(y) is mf and y.shape == (2, cout) + shape
+    g = torch.randn(y.shape, generator=gen).to(DEV).contiguous(memory_format=mf)
+    gx, gw = torch.autograd.grad(y, [x, conv.weight], g)
+    x64, w64 = x.detach().double().requires_grad_(True), conv.weight.detach().double().requires_grad_(True)
+    y64 = conv_f(x64, w64)
+    gx64, gw64 = torch.autograd.grad(y64, [x64, w64], g.double())
+    for a, b in ((y, y64), (gx, gx64), (gw, gw64)):
+        assert float((a.double() - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    monkeypatch.setenv("NEXTOU_PW_MM_MAX_POINTS", "0")
+    assert not ops.rows_gemm_eligible(conv, x, conv.weight)
+    big = torch.randn((2, cin, 32, 32, 32) if len(shape) == 3 else (2, cin, 128, 128), device=DEV).contiguous(memory_format=mf)
+    monkeypatch.delenv("NEXTOU_PW_MM_MAX_POINTS")
+    assert not ops.rows_gemm_eligible(conv, big, conv.weight)      # 65 536 / 32 768 points: MIOpen's kernels
