@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NEXTOU_ABI_VERSION 6
+#define NEXTOU_ABI_VERSION 7
 
 #define NEXTOU_EINVAL   (-1)  /* bad argument (null pointer, non-positive size, k > M ...) */
 #define NEXTOU_ENOSPACE (-2)  /* workspace too small */
@@ -186,6 +186,21 @@ int nextou_bti_ce_fwd(const float* logits, const uint8_t* target, const uint8_t*
 int nextou_bti_ce_bwd(const float* logits, const uint8_t* target, const uint8_t* critical,
                       const double* scale_dev, float* grad_logits, int B, int L, int64_t V,
                       nextou_stream_t stream);
+
+/* K5c  mean cross-entropy of the segmentation logits, fp32 (ABI v7) — the deep-supervision CE inside every NexToU trainer's loss
+ * (nnUNetTrainer_NexToU.py / *_BTI_*.py -> nnU-Net's RobustCrossEntropyLoss = torch.nn.CrossEntropyLoss(reduction='mean')), which ATen runs as
+ * log_softmax -> nll_loss over NCDHW tensors (with channels-last logits: a layout copy in, two passes each way, a copy of the gradient back).
+ *   logits: element (b, l, v) at b * L * V + l * stride_l + v * stride_v; (stride_l, stride_v) = (1, L) — channels-last rows, what the network
+ *           emits — or (V, 1) — NCDHW planes.  L <= 32.  target: int64 (B * V); voxels whose target is ignore_index or outside [0, L) do not count.
+ *   fwd: partial[2 i + {0, 1}], i < nextou_ce_mean_partials(): (sum of -log softmax(x)[target], number of counted voxels) of block i as doubles;
+ *        the caller adds them (fixed order) and divides.
+ *   bwd: grad_logits (same layout as logits) = scale * (softmax(x) - onehot(target)) for counted voxels, 0 for the others; scale_dev: ONE device
+ *        float = upstream gradient / count (no host synchronisation). */
+int nextou_ce_mean_partials(void);
+int nextou_ce_mean_fwd(const float* logits, const int64_t* target, double* partial, int B, int L, int64_t V,
+                       int64_t stride_l, int64_t stride_v, int64_t ignore_index, nextou_stream_t stream);
+int nextou_ce_mean_bwd(const float* logits, const int64_t* target, const float* scale_dev, float* grad_logits, int B, int L, int64_t V,
+                       int64_t stride_l, int64_t stride_v, int64_t ignore_index, nextou_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K6  normalisation fused with LeakyReLU (batch norm and, with B = 1 and C = B*C, instance norm) —

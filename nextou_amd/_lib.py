@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("NEXTOU_HIP_LIB") or os.path.join(_PKG_DIR, "libnextou
 
 KNN_AUTO, KNN_FUSED, KNN_NAIVE = 0, 1, 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # name -> (restype, argtypes); mirrors include/nextou_hip.h one to one
 _SIGNATURES = {
@@ -57,6 +57,9 @@ _SIGNATURES = {
     "nextou_bti_ce_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "nextou_bti_ce_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
                                   c_void_p]),
+    "nextou_ce_mean_partials": (c_int, []),
+    "nextou_ce_mean_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "nextou_ce_mean_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "nextou_bti_critical_map": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                         c_int, c_int, c_int, c_int, c_void_p]),
     "nextou_norm_act_workspace_bytes": (c_size_t, [c_int, c_int, c_int64, c_int]),

@@ -377,6 +377,141 @@ __global__ __launch_bounds__(256) void bti_ce_bwd_kernel(const float* __restrict
 
 using namespace nextou;
 
+namespace nextou {
+
+// --------------------------------------------------------------------------------------------
+// Mean cross-entropy of the segmentation logits (the deep-supervision CE every NexToU trainer's loss contains:
+// nnUNetTrainer_NexToU*.py -> nnU-Net's RobustCrossEntropyLoss = torch.nn.CrossEntropyLoss, mean over the voxels whose target
+// is not `ignore_index`), fp32 arithmetic as ATen's (max-subtracted log-sum-exp), float64 partial sums in a fixed order.
+// ATen runs it as log_softmax -> nll_loss on NCDHW tensors: with the network's logits channels-last that is a layout copy in, two
+// passes forward, two backward and a copy of the gradient back (~3 ms of the cfg-2 step for 99 M logits).  Here: one pass each way
+// over the logits where they lie — element (b, l, v) at b * L * V + l * sl + v * sv, i.e. (sl, sv) = (1, L) for channels-last rows,
+// (V, 1) for NCDHW planes — and the gradient is written in the same layout.
+//   fwd: partial[block] = (sum of -log p[target], number of counted voxels)
+//   bwd: grad[b, l, v] = scale * (p[l] - [l == target]) for counted voxels, 0 otherwise; scale = upstream gradient / count (device)
+// --------------------------------------------------------------------------------------------
+constexpr int kCeMeanBlocks = 2048;
+
+template <int LMAX, bool ROWS>
+__global__ __launch_bounds__(256) void ce_mean_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                                                          double2* __restrict__ partial, int L, long long total, long long V,
+                                                          long long sl, long long sv, long long ignore_index) {
+    // (forward, ROWS: every lane reads its own row as 8-byte pairs — the rows of a wave are one contiguous 64 * L * 4-byte run that the
+    // L / 2 loads cover between them out of L1: 117 us for cfg 2's four heads against 153 us with the LDS staging the backward uses)
+    __shared__ double2 wsum[4];
+    double acc = 0.0, cnt = 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
+        const long long y = target[p];
+        if (y == ignore_index || y < 0 || y >= L) continue;
+        float x[LMAX];
+        if constexpr (ROWS) {
+            const float* base = logits + (size_t)p * L;
+#pragma unroll
+            for (int l = 0; l < LMAX; l += 2) {
+                float2 t = make_float2(-INFINITY, -INFINITY);
+                if (l + 1 < L) t = *reinterpret_cast<const float2*>(base + l);
+                x[l] = t.x;
+                if (l + 1 < LMAX) x[l + 1] = t.y;
+            }
+        } else {
+            const long long b = p / V, v = p - b * V;
+            const float* base = logits + (size_t)b * L * V + (size_t)v * sv;
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) x[l] = l < L ? base[(size_t)l * sl] : -INFINITY;
+        }
+        float m = x[0];
+#pragma unroll
+        for (int l = 1; l < LMAX; ++l) m = fmaxf(m, x[l]);
+        float ssum = 0.f, xy = 0.f;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            if (l < L) ssum += expf(x[l] - m);
+            if (l == (int)y) xy = x[l];
+        }
+        acc += (double)((m + logf(ssum)) - xy);
+        cnt += 1.0;
+    }
+    acc = wave_sum(acc);
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = make_double2(acc, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[blockIdx.x] = make_double2((wsum[0].x + wsum[1].x) + (wsum[2].x + wsum[3].x), (wsum[0].y + wsum[1].y) + (wsum[2].y + wsum[3].y));
+}
+
+// backward, ROWS: a workgroup's 256 voxels are one contiguous run of 256 * L floats that moves through LDS with 16-byte accesses both
+// ways (every lane writing its own 56-byte row: 410 us for cfg 2's four heads = 2 TB/s; staged: 189 us).
+template <int LMAX, bool ROWS>
+__global__ __launch_bounds__(256) void ce_mean_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                                                          const float* __restrict__ scale_dev, float* __restrict__ grad, int L,
+                                                          long long total, long long V, long long sl, long long sv,
+                                                          long long ignore_index) {
+    __shared__ __attribute__((aligned(16))) float tile[ROWS ? 256 * LMAX : 4];
+    const float scale = scale_dev[0];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long p_end = (total + 255) / 256 * 256;
+    for (long long p0 = (long long)blockIdx.x * 256; p0 < p_end; p0 += stride) {
+        const long long p = p0 + threadIdx.x;
+        const bool live = p < total;
+        const long long y = live ? target[p] : ignore_index;
+        const bool counted = live && !(y == ignore_index || y < 0 || y >= L);
+        float x[LMAX];
+        int floats = 0;
+        size_t off = 0;
+        if constexpr (ROWS) {
+            const long long n = total - p0 < 256 ? total - p0 : 256;
+            floats = (int)n * L;
+            const float* src = logits + (size_t)p0 * L;
+            __syncthreads();
+            for (int i = threadIdx.x * 4; i < floats; i += 1024) {
+                if (i + 3 < floats) *reinterpret_cast<float4*>(tile + i) = *reinterpret_cast<const float4*>(src + i);
+                else for (int k = i; k < floats; ++k) tile[k] = src[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) x[l] = (l < L && live) ? tile[threadIdx.x * L + l] : -INFINITY;
+        } else {
+            const long long b = live ? p / V : 0, v = live ? p - b * V : 0;
+            off = (size_t)b * L * V + (size_t)v * sv;
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) x[l] = (l < L && live) ? logits[off + (size_t)l * sl] : -INFINITY;
+        }
+        float m = x[0];
+#pragma unroll
+        for (int l = 1; l < LMAX; ++l) m = fmaxf(m, x[l]);
+        float e[LMAX], ssum = 0.f;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            e[l] = (l < L && live) ? expf(x[l] - m) : 0.f;
+            ssum += e[l];
+        }
+        const float inv = counted ? scale / ssum : 0.f;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) e[l] = e[l] * inv - ((counted && l == (int)y) ? scale : 0.f);
+        if constexpr (ROWS) {
+            __syncthreads();                                             // everyone has read its row
+            if (live) {
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l)
+                    if (l < L) tile[threadIdx.x * L + l] = e[l];
+            }
+            __syncthreads();
+            float* dst = grad + (size_t)p0 * L;
+            for (int i = threadIdx.x * 4; i < floats; i += 1024) {
+                if (i + 3 < floats) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(tile + i);
+                else for (int k = i; k < floats; ++k) dst[k] = tile[k];
+            }
+        } else if (live) {
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l)
+                if (l < L) grad[off + (size_t)l * sl] = e[l];
+        }
+    }
+}
+
+}  // namespace nextou
+
 extern "C" int nextou_bti_ce_partials(void) { return kCeBlocks; }
 
 extern "C" int nextou_bti_ce_fwd(const float* logits, const uint8_t* target, const uint8_t* critical,
@@ -465,4 +600,53 @@ extern "C" int nextou_bti_critical_map(const uint8_t* labels, const uint32_t* lu
     else NEXTOU_CRIT(3, true);
 #undef NEXTOU_CRIT
     return check_launch("bti_critical_kernel");
+}
+
+extern "C" int nextou_ce_mean_partials(void) { return kCeMeanBlocks; }
+
+static int check_ce_mean(const char* who, const void* a, const void* b, const void* c, int B, int L, long long V, long long sl, long long sv) {
+    NEXTOU_REQUIRE(a && b && c, "%s: null pointer", who);
+    NEXTOU_REQUIRE(B > 0 && L > 0 && L <= 32 && V > 0, "%s: bad size B=%d L=%d V=%lld (L <= 32)", who, B, L, V);
+    NEXTOU_REQUIRE((sl == 1 && sv == L) || (sl == V && sv == 1), "%s: strides (%lld, %lld) are neither channels-last rows (1, L) nor planes (V, 1)",
+                   who, sl, sv);
+    return 0;
+}
+
+extern "C" int nextou_ce_mean_fwd(const float* logits, const int64_t* target, double* partial, int B, int L, int64_t V,
+                                  int64_t stride_l, int64_t stride_v, int64_t ignore_index, nextou_stream_t stream) {
+    if (int e = check_ce_mean("ce_mean_fwd", logits, target, partial, B, L, V, stride_l, stride_v)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)B * V;
+    const bool rows = stride_l == 1 && L % 2 == 0 && (reinterpret_cast<uintptr_t>(logits) & 15u) == 0;
+    ProfScope prof(s, kBoundHbm, (4.0 * L + 8.0) * (double)total, "ce_mean_fwd_kernel[B%d L%d V%lld %s]", B, L, (long long)V,
+                   stride_l == 1 ? "rows" : "planes");
+    const dim3 grid(kCeMeanBlocks), block(256);
+#define NEXTOU_CE_FWD(LM, R)                                                                                                       \
+    hipLaunchKernelGGL((ce_mean_fwd_kernel<LM, R>), grid, block, 0, s, logits, (const long long*)target, (double2*)partial, L, total, \
+                       (long long)V, (long long)stride_l, (long long)stride_v, (long long)ignore_index)
+    if (L <= 16) { if (rows) NEXTOU_CE_FWD(16, true); else NEXTOU_CE_FWD(16, false); }
+    else { if (rows) NEXTOU_CE_FWD(32, true); else NEXTOU_CE_FWD(32, false); }
+#undef NEXTOU_CE_FWD
+    return check_launch("ce_mean_fwd_kernel");
+}
+
+extern "C" int nextou_ce_mean_bwd(const float* logits, const int64_t* target, const float* scale_dev, float* grad_logits, int B, int L,
+                                  int64_t V, int64_t stride_l, int64_t stride_v, int64_t ignore_index, nextou_stream_t stream) {
+    if (int e = check_ce_mean("ce_mean_bwd", logits, target, grad_logits, B, L, V, stride_l, stride_v)) return e;
+    NEXTOU_REQUIRE(scale_dev != nullptr, "ce_mean_bwd: null scale");
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)B * V;
+    const bool rows = stride_l == 1 && L % 2 == 0 && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(grad_logits)) & 15u) == 0;
+    ProfScope prof(s, kBoundHbm, (8.0 * L + 8.0) * (double)total, "ce_mean_bwd_kernel[B%d L%d V%lld %s]", B, L, (long long)V,
+                   stride_l == 1 ? "rows" : "planes");
+    long long blocks = cdiv64(total, 256);
+    if (blocks > 8192) blocks = 8192;
+    const dim3 grid((unsigned)blocks), block(256);
+#define NEXTOU_CE_BWD(LM, R)                                                                                                     \
+    hipLaunchKernelGGL((ce_mean_bwd_kernel<LM, R>), grid, block, 0, s, logits, (const long long*)target, scale_dev, grad_logits, L, \
+                       total, (long long)V, (long long)stride_l, (long long)stride_v, (long long)ignore_index)
+    if (L <= 16) { if (rows) NEXTOU_CE_BWD(16, true); else NEXTOU_CE_BWD(16, false); }
+    else { if (rows) NEXTOU_CE_BWD(32, true); else NEXTOU_CE_BWD(32, false); }
+#undef NEXTOU_CE_BWD
+    return check_launch("ce_mean_bwd_kernel");
 }

@@ -261,6 +261,35 @@ class _HipBackend:
         return grad
 
     @staticmethod
+    def ce_mean_fwd(logits, target, ignore_index):
+        """logits (B, L, *sp) fp32, dense NCDHW or dense channels-last; target int64 (B, *sp) -> (loss sum, counted voxels) float64 scalars."""
+        L_ = _lib.lib()
+        B, nl = logits.shape[:2]
+        V = logits.numel() // (B * nl)
+        sl, sv = (1, nl) if _dense_channels_last(logits) is not None else (V, 1)
+        partial = torch.empty((L_.nextou_ce_mean_partials(), 2), dtype=torch.float64, device=logits.device)
+        with torch.cuda.device(logits.device):
+            rc = L_.nextou_ce_mean_fwd(logits.data_ptr(), target.data_ptr(), partial.data_ptr(), B, nl, V, sl, sv, int(ignore_index),
+                                       _stream_ptr(logits.device))
+        _lib.check(rc, "ce_mean_fwd")
+        tot = partial.sum(0)
+        return tot[0], tot[1]
+
+    @staticmethod
+    def ce_mean_bwd(logits, target, scale, ignore_index):
+        """scale: 0-dim fp32 device tensor (upstream gradient / count) -> gradient in the layout of ``logits``."""
+        L_ = _lib.lib()
+        B, nl = logits.shape[:2]
+        V = logits.numel() // (B * nl)
+        sl, sv = (1, nl) if _dense_channels_last(logits) is not None else (V, 1)
+        grad = torch.empty_like(logits)             # preserves the (dense) layout
+        with torch.cuda.device(logits.device):
+            rc = L_.nextou_ce_mean_bwd(logits.data_ptr(), target.data_ptr(), scale.data_ptr(), grad.data_ptr(), B, nl, V, sl, sv,
+                                       int(ignore_index), _stream_ptr(logits.device))
+        _lib.check(rc, "ce_mean_bwd")
+        return grad
+
+    @staticmethod
     def norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period,
                      pre_bias=None, channels_last=False):
         """x (B,C,S) f32/bf16 — or, with ``channels_last``, a dense channels_last(_3d) tensor (B,C,*sp) —
@@ -745,6 +774,41 @@ def critical_cross_entropy(logits: torch.Tensor, target: torch.Tensor, critical:
     ``CrossEntropyLoss(reduction='none')(x.double(), y) * critical`` + sum (reference bti_loss.py:141-143).
     """
     return _CriticalCE.apply(_f32c(logits), target.contiguous(), critical.contiguous())
+
+
+class _MeanCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        total, count = _HIP.ce_mean_fwd(logits, target, ignore_index)
+        ctx.save_for_backward(logits, target, count)
+        ctx.ignore_index = ignore_index
+        return (total / count).to(torch.float32)          # (0 / 0 = NaN when nothing counts, as torch.nn.CrossEntropyLoss)
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, count = ctx.saved_tensors
+        scale = (g.to(torch.float64) / count).to(torch.float32).reshape(1)
+        return _HIP.ce_mean_bwd(logits, target, scale, ctx.ignore_index), None, None
+
+
+def cross_entropy_mean_eligible(logits: torch.Tensor, target: torch.Tensor) -> bool:
+    """fp32 device logits (B, L <= 32, *spatial), dense in NCDHW or channels-last memory, int64 class-index target (B, *spatial)."""
+    import os
+    if os.environ.get("NEXTOU_FUSED_CE", "1") == "0":
+        return False
+    if not logits.is_cuda or logits.dtype != torch.float32 or logits.dim() < 3 or logits.shape[1] > 32 or logits.shape[1] < 2:
+        return False
+    if target.dtype != torch.int64 or target.device != logits.device or tuple(target.shape) != (logits.shape[0],) + tuple(logits.shape[2:]):
+        return False
+    return logits.is_contiguous() or _dense_channels_last(logits) is not None
+
+
+def cross_entropy_mean(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """``torch.nn.functional.cross_entropy(logits, target, reduction='mean', ignore_index=...)`` as one kernel each way over the logits
+    where they lie (K5c, csrc/bti_critical.hip): the deep-supervision CE of the NexToU trainers' losses (reference
+    nnUNetTrainer_NexToU*.py via nnU-Net's RobustCrossEntropyLoss).  fp32 arithmetic as ATen's; float64 partial sums in a fixed order;
+    the gradient comes back in the logits' own memory layout (channels-last stays channels-last)."""
+    return _MeanCE.apply(logits, target.contiguous(), int(ignore_index))
 
 
 class _NormAct(torch.autograd.Function):

@@ -87,7 +87,12 @@ except ImportError:
             if target.ndim == input.ndim:
                 assert target.shape[1] == 1
                 target = target[:, 0]
-            return super().forward(input, target.long())
+            target = target.long()
+            if self.weight is None and self.reduction == "mean" and self.label_smoothing == 0.0:
+                from .. import graph_ops
+                if graph_ops.cross_entropy_mean_eligible(input, target):        # one kernel each way, in the logits' own layout (K5c)
+                    return graph_ops.cross_entropy_mean(input, target, self.ignore_index)
+            return super().forward(input, target)
 
     class DeepSupervisionWrapper(nn.Module):
         """sum_i w_i * loss(output_i, target_i); zero weights are skipped."""

@@ -427,3 +427,36 @@ def test_small_volume_pointwise_conv_as_rows_gemm(ops, monkeypatch, shape, cin, 
     big = torch.randn((2, cin, 32, 32, 32) if len(shape) == 3 else (2, cin, 128, 128), device=DEV).contiguous(memory_format=mf)
     monkeypatch.delenv("NEXTOU_PW_MM_MAX_POINTS")
     assert not ops.rows_gemm_eligible(conv, big, conv.weight)      # 65 536 / 32 768 points: MIOpen's kernels
+
+
+@pytest.mark.parametrize("shape,classes,layout", [((2, 14, 9, 21, 17), 14, "cl"), ((2, 14, 9, 21, 17), 14, "nc"), ((3, 5, 33, 20), 5, "cl"),
+                                                   ((1, 20, 6, 10, 11), 20, "cl"), ((2, 3, 4000), 3, "nc")])
+def test_fused_mean_cross_entropy(ops, monkeypatch, shape, classes, layout):
+    """K5c (nextou_ce_mean_fwd / _bwd through graph_ops.cross_entropy_mean and the trainers' RobustCrossEntropyLoss) against
+    torch.nn.functional.cross_entropy in float64: loss and logit gradient, channels-last and NCDHW logits, ignored voxels, an odd class
+    count, more than 16 classes; the gradient keeps the logits' memory layout."""
+    import torch.nn.functional as F
+    from nextou_amd.loss.nnunet_losses import HAVE_NNUNET, RobustCrossEntropyLoss
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=gen) * 3).to(DEV)
+    mf = {4: torch.channels_last, 5: torch.channels_last_3d}.get(len(shape))
+    if layout == "cl" and mf is not None:
+        x = x.contiguous(memory_format=mf)
+    x.requires_grad_(True)
+    t = torch.randint(0, classes, (shape[0],) + shape[2:], generator=gen).to(DEV)
+    t[0].view(-1)[::7] = -100                                     # ignored voxels
+    assert ops.cross_entropy_mean_eligible(x, t)
+    loss = ops.cross_entropy_mean(x, t)
+    gx, = torch.autograd.grad(loss * 1.7, x)
+    x64 = x.detach().double().requires_grad_(True)
+    want = F.cross_entropy(x64, t)
+    gw, = torch.autograd.grad(want * 1.7, x64)
+    assert abs(float(loss) - float(want)) <= 2e-6 * abs(float(want))
+    assert float((gx.double() - gw).abs().max()) <= 2e-6 * float(gw.abs().max())
+    assert gx.stride() == x.stride()
+    if not HAVE_NNUNET:
+        ce = RobustCrossEntropyLoss()
+        got = ce(x, t.unsqueeze(1).float())                       # nnU-Net hands the target as (B, 1, ...) float
+        assert float(got) == float(loss)
+        monkeypatch.setenv("NEXTOU_FUSED_CE", "0")
+        assert abs(float(ce(x, t.unsqueeze(1).float())) - float(want)) <= 1e-5 * abs(float(want))
