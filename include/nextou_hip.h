@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NEXTOU_ABI_VERSION 7
+#define NEXTOU_ABI_VERSION 8
 
 #define NEXTOU_EINVAL   (-1)  /* bad argument (null pointer, non-positive size, k > M ...) */
 #define NEXTOU_ENOSPACE (-2)  /* workspace too small */
@@ -295,6 +295,12 @@ int nextou_cell_scatter(const float* src_cm, const uint8_t* cell, float* out_cl,
  *     NexToU_Encoder_Decoder.py:125-136, :281-298) as input channels: its weight gradient becomes the 2-D problem
  *     (B*D, 3C, H, W) x (B*D, Cout, H, W) that MIOpen's 2-D kernels run 15-20 % faster than the 3-D one.  C % 4 == 0. */
 int nextou_depth_unroll(const float* x_cl, float* out_cl, int B, int C, int D, int H, int W, nextou_stream_t stream);
+
+/* nextou_cat_bias_rows (ABI v8)  out[p, :] = [a[p, :] + bias, b[p, :]] over channels-last rows (P, C1) and (P, C2), float32, C1 and C2 multiples
+ *     of 4, C1 + C2 <= 1024, bias (C1 floats) may be NULL: the decoder's torch.cat((up-convolution output, skip), 1) (reference
+ *     NexToU_Encoder_Decoder.py:311-337) with the up-convolution's bias folded in — the convolution runs bias-free and ATen's separate bias-add pass
+ *     over its output never runs.  One read of a and b, one write. */
+int nextou_cat_bias_rows(const float* a, const float* bias, const float* b, float* out, int64_t P, int C1, int C2, nextou_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K7  point-wise (kernel 1, stride 1) convolutions on channels-last rows — the 1x1 convolutions of the Grapher / FFN

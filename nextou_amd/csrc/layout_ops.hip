@@ -401,6 +401,50 @@ extern "C" int nextou_cell_scatter(const float* src_cm, const uint8_t* cell, flo
     return check_launch("cell_scatter_kernel");
 }
 
+// out[p, :] = [a[p, :] + bias, b[p, :]] over channels-last rows: the decoder's torch.cat((up-convolution output, skip), 1)
+// (reference NexToU_Encoder_Decoder.py:311-337) with the up-convolution's bias folded in, so that the convolution runs bias-free
+// and ATen's separate bias-add pass over its output (288 us at stage 0) never runs.  One read of a and b, one write.
+namespace nextou {
+__global__ __launch_bounds__(256) void cat_bias_rows_kernel(const float4* __restrict__ a, const float4* __restrict__ bias,
+                                                            const float4* __restrict__ b, float4* __restrict__ out, long long P,
+                                                            int c1q, int c2q, int rows_per_pass) {
+    const int cq = c1q + c2q;
+    const int r_local = threadIdx.x / cq, q = threadIdx.x - r_local * cq;
+    if (r_local >= rows_per_pass) return;
+    const bool first = q < c1q;
+    const float4 bv = (first && bias) ? bias[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long step = (long long)gridDim.x * rows_per_pass;
+    for (long long row = (long long)blockIdx.x * rows_per_pass + r_local; row < P; row += step) {
+        float4 v;
+        if (first) {
+            v = a[row * c1q + q];
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        } else {
+            v = b[row * c2q + (q - c1q)];
+        }
+        out[row * cq + q] = v;
+    }
+}
+}  // namespace nextou
+
+extern "C" int nextou_cat_bias_rows(const float* a, const float* bias, const float* b, float* out, int64_t P, int C1, int C2,
+                                    nextou_stream_t stream) {
+    NEXTOU_REQUIRE(a && b && out, "cat_bias_rows: null pointer");
+    NEXTOU_REQUIRE(P > 0 && C1 > 0 && C2 > 0 && C1 % 4 == 0 && C2 % 4 == 0 && (C1 + C2) / 4 <= 256,
+                   "cat_bias_rows: bad size P=%lld C1=%d C2=%d (multiples of 4, C1 + C2 <= 1024)", (long long)P, C1, C2);
+    NEXTOU_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out) |
+                     reinterpret_cast<uintptr_t>(bias)) & 15u) == 0, "cat_bias_rows: tensors must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int cq = (C1 + C2) / 4, rpp = 256 / cq;
+    long long blocks = (P + rpp - 1) / rpp;
+    if (blocks > 16384) blocks = 16384;
+    ProfScope prof(s, kBoundHbm, 8.0 * (double)P * (C1 + C2), "cat_bias_rows_kernel[P%lld C%d+%d]", (long long)P, C1, C2);
+    hipLaunchKernelGGL(nextou::cat_bias_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(a),
+                       reinterpret_cast<const float4*>(bias), reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out),
+                       (long long)P, C1 / 4, C2 / 4, rpp);
+    return check_launch("cat_bias_rows_kernel");
+}
+
 extern "C" int nextou_depth_unroll(const float* x_cl, float* out_cl, int B, int C, int D, int H, int W, nextou_stream_t stream) {
     NEXTOU_REQUIRE(x_cl && out_cl, "depth_unroll: null pointer");
     if (int e = check_vol("depth_unroll", B, C, D, H, W)) return e;

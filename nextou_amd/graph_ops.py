@@ -1426,6 +1426,48 @@ def conv_dgrad_as_forward(x, weight, padding):
     return _ConvDgradAsForward.apply(x, weight, padding)
 
 
+class _CatBias(torch.autograd.Function):
+    """``torch.cat((y + bias, skip), 1)`` of two dense channels-last fp32 volumes as one pass (nextou_cat_bias_rows)."""
+
+    @staticmethod
+    def forward(ctx, y, bias, skip):
+        L_ = _lib.lib()
+        c1, c2 = y.shape[1], skip.shape[1]
+        P = y.numel() // c1
+        out = _empty_channels_last((y.shape[0], c1 + c2) + tuple(y.shape[2:]), y.device)
+        b = None if bias is None else bias.contiguous()
+        with torch.cuda.device(y.device):
+            rc = L_.nextou_cat_bias_rows(y.data_ptr(), _ptr(b), skip.data_ptr(), out.data_ptr(), P, c1, c2, _stream_ptr(y.device))
+        _lib.check(rc, "cat_bias_rows")
+        ctx.c1, ctx.has_bias = c1, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        c1 = ctx.c1
+        mf = {4: torch.channels_last, 5: torch.channels_last_3d}[g.dim()]
+        gy = g.narrow(1, 0, c1).contiguous(memory_format=mf)         # the copy the convolution's backward would make anyway
+        gb = _HIP.channel_sum(gy, channels_last=True) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        return gy, gb, g.narrow(1, c1, g.shape[1] - c1)
+
+
+def cat_bias_eligible(y: torch.Tensor, bias, skip: torch.Tensor) -> bool:
+    import os
+    if os.environ.get("NEXTOU_CAT_BIAS", "1") == "0":
+        return False
+    if not (y.is_cuda and skip.is_cuda) or y.dtype != torch.float32 or skip.dtype != torch.float32 or torch.is_autocast_enabled("cuda"):
+        return False
+    if y.shape[0] != skip.shape[0] or y.shape[2:] != skip.shape[2:] or y.shape[1] % 4 or skip.shape[1] % 4 or y.shape[1] + skip.shape[1] > 1024:
+        return False
+    if _dense_channels_last(y) is None or _dense_channels_last(skip) is None:
+        return False
+    return bias is None or (bias.dtype == torch.float32 and bias.shape[0] == y.shape[1])
+
+
+def cat_bias(y: torch.Tensor, bias, skip: torch.Tensor) -> torch.Tensor:
+    return _CatBias.apply(y, bias, skip)
+
+
 def conv_own_bias_grad(x, weight, bias, stride, padding, dilation, transposed, output_padding, groups):
     """N-d (transposed) convolution with bias on the GPU; see :class:`_ConvOwnBiasGrad`."""
     if flat_depth_eligible(x, weight, stride, padding, dilation, output_padding):

@@ -34,6 +34,7 @@ from torch.nn.modules.dropout import _DropoutNd
 from .. import graph_ops
 from .conv_blocks import StackedConvBlocks, get_matching_convtransp, maybe_convert_scalar_to_list
 from .layout import is_channels_last_volume, set_stage_layout
+from .norm_act import up_conv_cat
 from .pos_embed import get_2d_relative_pos_embed, get_3d_relative_pos_embed  # noqa: F401 (re-export)
 from .pos_embed import get_nd_relative_pos_embed
 from .torch_edge import DenseDilatedKnnGraph
@@ -741,8 +742,7 @@ class NexToU_Decoder(nn.Module):
         for s, stage in enumerate(self.stages):
             # decoder stage s works at the resolution (and in the memory layout) of encoder stage last - s
             x = set_stage_layout(x, (last - s) in self.encoder.channels_last_stages, self.encoder.reduced_precision_layout_ok)
-            x = self.transpconvs[s](x)
-            x = stage(torch.cat((x, skips[-(s + 2)]), 1))
+            x = stage(up_conv_cat(self.transpconvs[s], x, skips[-(s + 2)]))     # torch.cat((up-convolution(x), skip), 1)
             if self.deep_supervision:
                 outputs.append(self.seg_layers[s](x))
             elif s == last:

@@ -27,7 +27,7 @@ from .channel_pad import norm_input_is_padded, pad_image_channels, padded_conv_p
 
 __all__ = ["BatchNormAct1d", "BatchNormAct2d", "BatchNormAct3d", "InstanceNormAct1d", "InstanceNormAct2d",
            "InstanceNormAct3d", "ConvBiasFolded1d", "ConvBiasFolded2d", "ConvBiasFolded3d", "ConvOwnBias2d",
-           "ConvOwnBias3d", "ConvTransposeOwnBias2d", "ConvTransposeOwnBias3d", "fuse_norm_act", "fusion_enabled"]
+           "ConvOwnBias3d", "ConvTransposeOwnBias2d", "ConvTransposeOwnBias3d", "fuse_norm_act", "fusion_enabled", "up_conv_cat"]
 
 
 def _pre_bias(norm: nn.Module):
@@ -105,6 +105,23 @@ class _ConvOwnBias:
         # CPU checker path of a padded module: the same convolution through ATen's autograd
         return torch.convolution(x, weight, bias, self.stride, self.padding, self.dilation, self.transposed, out_pad,
                                  self.groups)
+
+
+def up_conv_cat(up: nn.Module, x: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:
+    """The decoder's ``torch.cat((up(x), skip), 1)``.  For an own-bias (transposed) convolution on dense channels-last fp32 tensors the
+    convolution runs WITHOUT its bias and one pass writes ``[conv(x) + bias, skip]`` (graph_ops.cat_bias): ATen's separate bias-add pass
+    over the up-sampled tensor disappears.  Anything else: the plain concatenation."""
+    if isinstance(up, _ConvOwnBias) and up._own(x) and not torch.is_autocast_enabled("cuda") and x.dtype == torch.float32:
+        n = len(up.stride)
+        out_pad = up._output_padding(x, None, up.stride, up.padding, up.kernel_size, n, up.dilation) if up.transposed else (0,) * n
+        weight, bias = padded_conv_params(up, x, with_bias=True)
+        y = graph_ops.conv_own_bias_grad(x, weight, None, up.stride, up.padding, up.dilation, up.transposed, out_pad, up.groups)
+        if graph_ops.cat_bias_eligible(y, bias, skip):
+            return graph_ops.cat_bias(y, bias, skip)
+        if bias is not None:
+            y = y + bias.view(1, -1, *([1] * n))
+        return torch.cat((y, skip), 1)
+    return torch.cat((up(x), skip), 1)
 
 
 class ConvOwnBias2d(_ConvOwnBias, nn.Conv2d):

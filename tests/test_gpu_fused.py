@@ -460,3 +460,30 @@ def test_fused_mean_cross_entropy(ops, monkeypatch, shape, classes, layout):
         assert float(got) == float(loss)
         monkeypatch.setenv("NEXTOU_FUSED_CE", "0")
         assert abs(float(ce(x, t.unsqueeze(1).float())) - float(want)) <= 1e-5 * abs(float(want))
+
+
+@pytest.mark.parametrize("dims,cin,cout,cskip", [(3, 72, 40, 40), (3, 324, 324, 324), (2, 24, 16, 16)])
+def test_up_convolution_bias_folded_into_the_concatenation(ops, monkeypatch, dims, cin, cout, cskip):
+    """norm_act.up_conv_cat (the decoder's cat((up-convolution(x), skip), 1) with the convolution run bias-free and its bias added by the
+    one-pass concatenation kernel) against the plain path (NEXTOU_CAT_BIAS=0): same values, same gradients for x, weight, bias, skip."""
+    from nextou_amd.network_architecture.norm_act import ConvTransposeOwnBias2d, ConvTransposeOwnBias3d, up_conv_cat
+    gen = torch.Generator().manual_seed(cin + cout)
+    mf = torch.channels_last_3d if dims == 3 else torch.channels_last
+    sp = (4, 6, 5) if dims == 3 else (9, 7)
+    k = (1, 2, 2) if dims == 3 else (2, 2)
+    up = (ConvTransposeOwnBias3d if dims == 3 else ConvTransposeOwnBias2d)(cin, cout, k, k, bias=True).to(DEV)
+    x = torch.randn((2, cin) + sp, generator=gen).to(DEV).contiguous(memory_format=mf).requires_grad_(True)
+    out_sp = tuple(s * f for s, f in zip(sp, k))
+    skip = torch.randn((2, cskip) + out_sp, generator=gen).to(DEV).contiguous(memory_format=mf).requires_grad_(True)
+    g = torch.randn((2, cout + cskip) + out_sp, generator=gen).to(DEV).contiguous(memory_format=mf)
+
+    def run():
+        y = up_conv_cat(up, x, skip)
+        return y, torch.autograd.grad(y, [x, up.weight, up.bias, skip], g)
+    y1, g1 = run()
+    monkeypatch.setenv("NEXTOU_CAT_BIAS", "0")
+    y0, g0 = run()
+    assert ops._dense_channels_last(y1) is mf and y1.shape == y0.shape
+    assert torch.equal(y1, y0) or float((y1 - y0).abs().max()) <= 1e-6 * float(y0.abs().max())
+    for a, b in zip(g1, g0):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
