@@ -291,3 +291,28 @@ def test_depth_unroll_formulation_of_the_3d_gradients():
         y3 = F.conv2d(x2, w3, None, stride=stride[1:], padding=1)
         gx2, = torch.autograd.grad(y3, x2, depth_unroll_ref(gy))
         assert torch.allclose(gx2.reshape(b, d, ci, h, w).permute(0, 2, 1, 3, 4), gx, atol=1e-10)
+
+
+def test_rows_gemm_view_algebra_and_cpu_fallbacks():
+    """Round-3 routing helpers on the host: graph_ops.rows_gemm is the 1x1 convolution of a channels-last volume (views only, channels-last
+    result); on CPU tensors nothing is re-routed — rows_gemm_eligible / cross_entropy_mean_eligible say no and norm_act.up_conv_cat is the
+    plain torch.cat((up(x), skip), 1)."""
+    import torch.nn.functional as F
+    from nextou_amd import graph_ops
+    from nextou_amd.network_architecture.norm_act import ConvBiasFolded3d, ConvTransposeOwnBias3d, up_conv_cat
+    torch.manual_seed(3)
+    x = torch.randn(2, 12, 3, 4, 5).contiguous(memory_format=torch.channels_last_3d)
+    w = torch.randn(7, 12, 1, 1, 1)
+    y = graph_ops.rows_gemm(x, w)
+    assert y.shape == (2, 7, 3, 4, 5) and y.is_contiguous(memory_format=torch.channels_last_3d)
+    assert torch.allclose(y, F.conv3d(x, w), atol=1e-5)
+    conv = ConvBiasFolded3d(12, 7, 1, bias=True)
+    assert not graph_ops.rows_gemm_eligible(conv, x, conv.weight)                    # CPU tensor
+    up = ConvTransposeOwnBias3d(12, 8, (1, 2, 2), (1, 2, 2), bias=True)
+    skip = torch.randn(2, 8, 3, 8, 10)
+    assert torch.equal(up_conv_cat(up, x, skip), torch.cat((up(x), skip), 1))
+    logits, target = torch.randn(2, 5, 3, 4, 5), torch.randint(0, 5, (2, 3, 4, 5))
+    assert not graph_ops.cross_entropy_mean_eligible(logits, target)
+    from nextou_amd.loss.nnunet_losses import HAVE_NNUNET, RobustCrossEntropyLoss
+    if not HAVE_NNUNET:
+        assert torch.allclose(RobustCrossEntropyLoss()(logits, target.unsqueeze(1).float()), F.cross_entropy(logits, target))
