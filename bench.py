@@ -53,6 +53,7 @@ from nextou_amd.nnUNetTrainer.nnUNetTrainer_NexToU_BTI_Synapse import nnUNetTrai
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA = f32 vector peak
+MODEL_MFLOP_PER_VOXEL_STEP = 1.697  # 565.6 kFLOP / voxel forward (FlopCounterMode on the reference, cfg 2) x 3 for fwd + bwd
 
 WORKLOADS = {
     # name: (patch, base, max_features, batch/GPU, classes)
@@ -179,6 +180,19 @@ def roofline_from(report):
             "own_kernels_ms_per_step": None}
 
 
+def roofline_step(workload, voxels_per_step, seconds_per_step, world, bf16):
+    """End to end: the MODEL's algorithmic FLOPs per step (1.697 MFLOP per input voxel for forward + backward of the
+    cfg-2 topology — the loss, the clip and the optimiser add nothing measurable) over the timed step, as a fraction of the fp32 MFMA
+    peak of the GPUs used.  The dense convolution stages hold 98 % of these FLOPs and run on MIOpen / CK (north_star), so this is
+    their efficiency more than the own kernels'; null for the informational bf16 runs (another peak applies)."""
+    if bf16 or workload not in ("cfg2", "cfg4", "cfg5"):
+        return None
+    flop = MODEL_MFLOP_PER_VOXEL_STEP * 1e6 * voxels_per_step
+    achieved = flop / seconds_per_step / 1e12
+    return {"bound": "mfma", "flop_per_step": flop, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+            "frac": round(achieved / (MFMA_F32_PEAK_TFLOPS * world), 4)}
+
+
 def _real_channel_fraction(label):
     """C_real / C_padded when the launch label is a K6 call on an internally padded plain-stage tensor (C = 40 or 72 at cfg 2)."""
     import re
@@ -191,7 +205,7 @@ def _real_channel_fraction(label):
 CPU_BASELINE_THREADS = 32       # best of the committed sweep on the GPU boxes' EPYC 9575F hosts (profiles/r03_cpu_baseline_thread_sweep.md)
 
 
-def cpu_baseline(workload, timed_steps=2, threads=None, sweep=False):
+def cpu_baseline(workload, timed_steps=2, threads=None, sweep=False, batch=1):
     """oracle/ref_ops.py (the reference's op sequence, PyTorch-CPU fp32) on this host's cores: train steps of the same
     network at batch 1 — 1 warm-up + ``timed_steps`` timed, median reported.
 
@@ -207,7 +221,7 @@ def cpu_baseline(workload, timed_steps=2, threads=None, sweep=False):
     graph_ops.install_cpu_checker(TorchRefBackend)
     try:
         trainer, cfg, _, _ = build_trainer(workload, torch.device("cpu"), False)
-        data, target = synthetic_batch(cfg, 1, classes, 1, torch.device("cpu"), blob_labels=(workload == "cfg4"))
+        data, target = synthetic_batch(cfg, 1, classes, batch, torch.device("cpu"), blob_labels=(workload == "cfg4"))
         with torch.no_grad():
             shapes = [tuple(o.shape[2:]) for o in _head_shapes(cfg)]
         targets = [target if s == tuple(target.shape[2:]) else
@@ -237,14 +251,14 @@ def cpu_baseline(workload, timed_steps=2, threads=None, sweep=False):
     finally:
         graph_ops.install_cpu_checker(None)
         torch.set_num_threads(default_threads)
-    voxels = int(np.prod(patch))
+    voxels = batch * int(np.prod(patch))
     timed_sorted = sorted(times)
     n = len(timed_sorted)
     dt = timed_sorted[n // 2] if n % 2 else 0.5 * (timed_sorted[n // 2 - 1] + timed_sorted[n // 2])
     return {"value": round(voxels / dt, 1), "unit": "voxels/s", "cores": best, "kind": "port",
-            "sample": "train steps (fwd+loss+bwd+SGD) at batch 1 of the %s patch, fp32: 1 warm-up (%.1f s) + %d timed on %d threads "
+            "sample": "train steps (fwd+loss+bwd+SGD) at batch %d of the %s patch, fp32: 1 warm-up (%.1f s) + %d timed on %d threads "
                       "(%s s), median %.1f s%s"
-                      % ("x".join(map(str, patch)), warm, len(times), best, ", ".join("%.1f" % t for t in times), dt,
+                      % (batch, "x".join(map(str, patch)), warm, len(times), best, ", ".join("%.1f" % t for t in times), dt,
                          "; thread sweep, one step each: %s" % {k: round(v, 1) for k, v in sweep_times.items()} if sweep else ""),
             "thread_sweep_s_per_step": {str(k): round(v, 2) for k, v in sweep_times.items()} or None,
             "cpu": _cpu_model()}
@@ -287,6 +301,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=None, help="threads of the CPU-baseline leg (default: the committed sweep's best)")
     ap.add_argument("--cpu-thread-sweep", action="store_true",
                     help="CPU-baseline leg: after the warm-up, time one step at 8/16/32/64/128 threads and report the best (~5 min extra)")
+    ap.add_argument("--cpu-protocol", choices=("bounded", "survey"), default="bounded",
+                    help="CPU-baseline leg: 'bounded' (default) = batch 1, 1 warm-up + --cpu-steps timed on the sweep's best thread count "
+                         "(~1.5 min); 'survey' = SURVEY.md §8(d) to the letter: batch 2, 1 warm-up + 3 timed, all physical cores (~10 min)")
     ap.add_argument("--no-miopen-find", action="store_true", help="disable MIOpen's find/benchmark mode")
     ap.add_argument("--bucket-mb", type=int, default=32)
     ap.add_argument("--force-averager", action="store_true",
@@ -362,12 +379,19 @@ def main():
             print("bench.py: hipGraph capture failed (%s); timing the eager step" % capture_error, file=sys.stderr)
             graphed = None
             torch.cuda.synchronize()
+    # the launch profiler's record pool is sized from a COUNTED step (a fixed 1 536 records dropped the third
+    # step's backward tail): one eager step with a generous pool tells how many launches of this library a step makes
+    _lib.lib().nextou_profile_enable(1 << 15)
+    step()
+    torch.cuda.synchronize()
+    launches_per_step = sum(r["launches"] for r in profile_report())
+    _lib.lib().nextou_profile_enable(0)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     run = graphed if graphed is not None else step
     if graphed is None:
-        _lib.lib().nextou_profile_enable(64 * max(args.steps, 1) * 8)
+        _lib.lib().nextou_profile_enable(launches_per_step * max(args.steps, 1) + 64)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = run()
@@ -378,13 +402,19 @@ def main():
     if graphed is not None:
         # per-kernel HIP-event timing (the roofline objects) cannot live inside a captured graph: three eager steps of the
         # same computation after the timed region provide it
-        _lib.lib().nextou_profile_enable(64 * 3 * 8)
+        _lib.lib().nextou_profile_enable(launches_per_step * 3 + 64)
         for _ in range(3):
             step()
         torch.cuda.synchronize()
     report = profile_report()
+    dropped = _lib.lib().nextou_profile_dropped()
     _lib.lib().nextou_profile_enable(0)
     profiled_steps = 3 if graphed is not None else args.steps
+    uneven = [r["kernel"] for r in report if r["launches"] % profiled_steps]
+    profile_check = {"launches_per_step": launches_per_step, "profiled_steps": profiled_steps, "dropped_records": dropped,
+                     "labels_not_a_multiple_of_the_steps": uneven}
+    if dropped or uneven:       # never silent, never fatal to the timed number: the per-step sums below would be off
+        print("bench.py: launch profile inconsistent: %s" % profile_check, file=sys.stderr)
     if averager is not None:
         averager.check_consistency()        # every rank produced gradients for the same parameters on every step
     if world > 1:
@@ -423,10 +453,16 @@ def main():
                        "parallelism": "dp%d" % world, "final_loss": float(loss.detach())},
             "roofline": roof,
             "roofline_graph": graph,
+            "launch_profile_check": profile_check,
+            "roofline_step": roofline_step(args.workload, voxels_per_step, elapsed / args.steps, world, args.autocast_bf16),
         }
         if cpu_copy_ok:
             try:
-                line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_steps, args.cpu_threads, args.cpu_thread_sweep)
+                if args.cpu_protocol == "survey":
+                    line["cpu_baseline"] = cpu_baseline(args.workload, 3, max(1, (os.cpu_count() or 2) // 2), False, batch=batch)
+                    line["cpu_baseline"]["protocol"] = "SURVEY.md 8(d): batch 2, 1 warm-up + 3 timed, all physical cores"
+                else:
+                    line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_steps, args.cpu_threads, args.cpu_thread_sweep)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "voxels/s", "cores": torch.get_num_threads(),
                                         "kind": "port", "sample": "failed: %r" % (e,)}

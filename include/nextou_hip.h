@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NEXTOU_ABI_VERSION 8
+#define NEXTOU_ABI_VERSION 9
 
 #define NEXTOU_EINVAL   (-1)  /* bad argument (null pointer, non-positive size, k > M ...) */
 #define NEXTOU_ENOSPACE (-2)  /* workspace too small */
@@ -51,9 +51,12 @@ const char* nextou_last_error(void);
  * nextou_profile_report(): after a device synchronise, writes a JSON array aggregated per launch
  *   label — {"kernel", "bound": "hbm"|"mfma", "launches", "ms", "work"} where work is the summed
  *   ALGORITHMIC bytes (hbm) or flops (mfma) — and returns its length (0 = buffer too small).
+ * nextou_profile_dropped(): launches since the last enable that found the record pool full and went unrecorded (a caller
+ *   that divides the report by a step count checks this is 0).
  * Do not enable while capturing a hipGraph. */
 int nextou_profile_enable(int max_records);
 size_t nextou_profile_report(char* buf, size_t cap);
+int nextou_profile_dropped(void);
 
 /* ------------------------------------------------------------------------------------------
  * K1  dense kNN graph.
@@ -152,8 +155,13 @@ int nextou_gather_bwd(const float* gout, const int32_t* idx, float* dsrc,
 
 /* ------------------------------------------------------------------------------------------
  * K5  BTI critical-voxel map (reference loss/bti_loss.py:76-117 and :132-134).
- *   nextou_argmax_labels: labels[b,v] = first arg-max over the L class planes of
- *     logits (B,L,V) (softmax is monotone, so this is argmax(softmax(x),1), :132-134).
+ *   nextou_argmax_labels: labels[b,v] = argmax_l softmax(logits[b,:,v]) as the reference computes it (:132-134), with torch.argmax's
+ *     first-index rule on EQUAL float32 softmax values.  For all but ~1e-6 of the voxels that is the first arg-max of the logits; when
+ *     an earlier class lies within 2^-21 of the maximum the canonical softmax is evaluated — e_l = float32(exp(x_l - max)) (exp to
+ *     1e-16 by a fixed fma sequence, identical in oracle/nextou_oracle.c), s = e_0 + e_1 + ... in class order (float32), q_l = e_l / s
+ *     (IEEE division) — and the first l with q_l == q_max wins.  Gaps <= 2^-25 (every float32 exp gives exactly 1: device-independent
+ *     in the reference too) are reproduced exactly; in the band up to ~2.4e-7 ATen's outcome depends on the last bit of its vectorised
+ *     exp and this restatement matches ATen-CPU on 99.8 % of the band's voxels (tests: g7d_near_ties).
  *   nextou_bti_critical_map: labels (B,D,H,W) uint8 (D = 1 for 2-D) ->
  *     critical (B,D,H,W) uint8 in {0,1}.  lut_a[l] / lut_c[l] hold one bit per interaction:
  *     bit i of lut_a[l] = (l in A_i); bit i of lut_c[l] = (l in C_i) for an exclusion pair,

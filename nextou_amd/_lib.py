@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("NEXTOU_HIP_LIB") or os.path.join(_PKG_DIR, "libnextou
 
 KNN_AUTO, KNN_FUSED, KNN_NAIVE = 0, 1, 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # name -> (restype, argtypes); mirrors include/nextou_hip.h one to one
 _SIGNATURES = {
@@ -30,6 +30,7 @@ _SIGNATURES = {
     "nextou_last_error": (c_char_p, []),
     "nextou_profile_enable": (c_int, [c_int]),
     "nextou_profile_report": (c_size_t, [c_char_p, c_size_t]),
+    "nextou_profile_dropped": (c_int, []),
     "nextou_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "nextou_knn_graph": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

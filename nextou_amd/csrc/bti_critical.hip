@@ -12,7 +12,50 @@
 
 namespace nextou {
 
-// labels[b, v] = first arg-max over L class planes of logits (B, L, V).
+// exp(t), t <= 0, in double by a fixed fma sequence — the same sequence as oracle/nextou_oracle.c::oracle_exp_neg, so that the rare
+// near-tie voxels below resolve to the same label on both sides bit for bit (IEEE fma / rint / ldexp only).
+__device__ __forceinline__ double exp_neg_f64(double t) {
+    if (t < -110.0) return 0.0;
+    const double k = rint(t * 1.4426950408889634);
+    double r = fma(-k, 0.693147180369123816490, t);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+
+// The reference labels a voxel with argmax(softmax(x)) (bti_loss.py:132-134).  In float32 the softmax values of two logits closer than
+// ~2.4e-7 can round to the same number and torch.argmax returns the FIRST: the earlier class wins although its logit is the smaller one.
+// Slow path for a voxel whose arg-max `arg` replaced a running maximum within 2^-21 of it (about one voxel in 1e6): the canonical
+// restatement — e_k = float32(exp(x_k - m)), s = e_0 + e_1 + ... in class order, q_k = e_k / s, first k with q_k == q_max.
+__device__ __noinline__ int softmax_first_tie(const float* __restrict__ x, long long stride, int L, float m, int arg) {
+    float s = 0.0f;
+    for (int l = 0; l < L; ++l) s = s + (float)exp_neg_f64((double)(x[(size_t)l * stride] - m));
+    const float qmax = 1.0f / s;
+    for (int l = 0; l < arg; ++l) {
+        const float d = x[(size_t)l * stride] - m;
+        if (d < -0x1p-21f) continue;
+        const float e = (float)exp_neg_f64((double)d);
+        if (e / s == qmax) return l;
+    }
+    return arg;
+}
+
+// labels[b, v] = argmax_l softmax(logits[b, :, v]) with torch's first-index rule on equal softmax values (see above); for all but
+// ~1e-6 of the voxels that is the first arg-max of the logits.  `near` = the running maximum the final one replaced lay within 2^-21
+// of it (only then can an earlier class tie: running maxima increase, so the last replaced one is the closest earlier logit).
 // One thread per 4 consecutive voxels (16-B loads per class plane) when V % 4 == 0.
 template <bool VEC4>
 __global__ __launch_bounds__(256) void argmax_labels_kernel(const float* __restrict__ logits,
@@ -22,17 +65,26 @@ __global__ __launch_bounds__(256) void argmax_labels_kernel(const float* __restr
     const float* lb = logits + (size_t)b * L * V;
     uint8_t* ob = labels + (size_t)b * V;
     const long long stride = (long long)gridDim.x * blockDim.x;
+    constexpr float kBand = 0x1p-21f;
     if (VEC4) {
         const long long V4 = V >> 2;
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < V4; i += stride) {
             float4 best = reinterpret_cast<const float4*>(lb)[i];
             uchar4 arg = make_uchar4(0, 0, 0, 0);
+            bool nx = false, ny = false, nz = false, nw = false;
             for (int l = 1; l < L; ++l) {
                 const float4 v = reinterpret_cast<const float4*>(lb + (size_t)l * V)[i];
-                if (v.x > best.x) { best.x = v.x; arg.x = (uint8_t)l; }
-                if (v.y > best.y) { best.y = v.y; arg.y = (uint8_t)l; }
-                if (v.z > best.z) { best.z = v.z; arg.z = (uint8_t)l; }
-                if (v.w > best.w) { best.w = v.w; arg.w = (uint8_t)l; }
+                if (v.x > best.x) { nx = v.x - best.x <= kBand; best.x = v.x; arg.x = (uint8_t)l; }
+                if (v.y > best.y) { ny = v.y - best.y <= kBand; best.y = v.y; arg.y = (uint8_t)l; }
+                if (v.z > best.z) { nz = v.z - best.z <= kBand; best.z = v.z; arg.z = (uint8_t)l; }
+                if (v.w > best.w) { nw = v.w - best.w <= kBand; best.w = v.w; arg.w = (uint8_t)l; }
+            }
+            if (nx | ny | nz | nw) {
+                const float* p = lb + 4 * i;
+                if (nx) arg.x = (uint8_t)softmax_first_tie(p + 0, V, L, best.x, arg.x);
+                if (ny) arg.y = (uint8_t)softmax_first_tie(p + 1, V, L, best.y, arg.y);
+                if (nz) arg.z = (uint8_t)softmax_first_tie(p + 2, V, L, best.z, arg.z);
+                if (nw) arg.w = (uint8_t)softmax_first_tie(p + 3, V, L, best.w, arg.w);
             }
             reinterpret_cast<uchar4*>(ob)[i] = arg;
         }
@@ -40,10 +92,12 @@ __global__ __launch_bounds__(256) void argmax_labels_kernel(const float* __restr
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += stride) {
             float best = lb[i];
             uint8_t arg = 0;
+            bool near = false;
             for (int l = 1; l < L; ++l) {
                 const float v = lb[(size_t)l * V + i];
-                if (v > best) { best = v; arg = (uint8_t)l; }
+                if (v > best) { near = v - best <= kBand; best = v; arg = (uint8_t)l; }
             }
+            if (near) arg = (uint8_t)softmax_first_tie(lb + i, V, L, best, arg);
             ob[i] = arg;
         }
     }

@@ -30,14 +30,14 @@ struct ProfRecord {
 };
 std::mutex g_prof_mutex;
 std::vector<ProfRecord> g_prof;
-size_t g_prof_used = 0;
+size_t g_prof_used = 0, g_prof_dropped = 0;
 bool g_prof_on = false;
 }  // namespace
 
 ProfScope::ProfScope(hipStream_t s, int bound, double work, const char* fmt, ...) : slot(-1), stream(s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lock(g_prof_mutex);
-    if (g_prof_used >= g_prof.size()) return;  // pool exhausted: stop recording, never allocate here
+    if (g_prof_used >= g_prof.size()) { ++g_prof_dropped; return; }  // pool exhausted: count it, never allocate here
     ProfRecord& r = g_prof[g_prof_used];
     va_list ap;
     va_start(ap, fmt);
@@ -60,6 +60,7 @@ extern "C" int nextou_profile_enable(int max_records) {
     using namespace nextou;
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     g_prof_used = 0;
+    g_prof_dropped = 0;
     g_prof_on = max_records > 0;
     while ((int)g_prof.size() < max_records) {
         ProfRecord r{};
@@ -68,6 +69,12 @@ extern "C" int nextou_profile_enable(int max_records) {
         g_prof.push_back(r);
     }
     return 0;
+}
+
+extern "C" int nextou_profile_dropped(void) {
+    using namespace nextou;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    return (int)g_prof_dropped;
 }
 
 // JSON array, one object per distinct launch label, aggregated over the recorded launches.

@@ -236,17 +236,60 @@ int oracle_mr_bwd_arg(const float* gout, const uint16_t* arg, float* dx, float* 
     return 0;
 }
 
-/* first arg-max over the class planes: reference bti_loss.py:132-134 (argmax of softmax) */
+/* exp(t) for t <= 0 in double by a fixed fma sequence (range reduction by ln 2, degree-13 Taylor polynomial, exact scaling):
+ * |relative error| < 1e-16, and — being nothing but IEEE fma / rint / ldexp — the same bits on any machine.  The HIP kernel runs
+ * the identical sequence (csrc/bti_critical.hip: exp_neg_f64), so oracle and kernel agree bit for bit by construction. */
+static double oracle_exp_neg(double t) {
+    if (t < -110.0) return 0.0;                    /* below the smallest float32 subnormal after rounding */
+    const double k = rint(t * 1.4426950408889634);
+    double r = fma(-k, 0.693147180369123816490, t);           /* ln 2, high part (trailing zeros: k * hi is exact) */
+    r = fma(-k, 1.90821492927058770002e-10, r);               /* ln 2, low part */
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+
+/* labels = argmax(softmax(x, 1), 1): reference bti_loss.py:132-134.  In exact arithmetic that is the first arg-max of the logits;
+ * in float32 the softmax of two logits that differ by less than ~2.4e-7 can round to the SAME value, and torch.argmax then returns
+ * the FIRST of them — the reference labels such a voxel with the earlier class although its logit is the smaller one.  Canonical
+ * restatement of that rule: m = max_k x_k; e_k = float32(exp(x_k - m)); s = e_0 + e_1 + ... (float32, class order);
+ * q_k = e_k / s (float32 division); label = first k with q_k == q_max.  Exact ties and differences up to 2^-25 (where every float32
+ * exp returns exactly 1) follow the reference on any device; in the band above that, ATen's outcome depends on its vectorised exp
+ * and this restatement agrees with ATen-CPU on > 98 % of the band's voxels (tests/golden: g7d_near_ties). */
 int oracle_argmax_labels(const float* logits, uint8_t* labels, int B, int L, int64_t V) {
 #pragma omp parallel for schedule(static)
     for (int b = 0; b < B; ++b)
         for (int64_t v = 0; v < V; ++v) {
             const float* p = logits + (size_t)b * L * V + v;
             float best = p[0];
-            uint8_t arg = 0;
+            int arg = 0;
             for (int l = 1; l < L; ++l)
-                if (p[(size_t)l * V] > best) { best = p[(size_t)l * V]; arg = (uint8_t)l; }
-            labels[(size_t)b * V + v] = arg;
+                if (p[(size_t)l * V] > best) { best = p[(size_t)l * V]; arg = l; }
+            /* an earlier class can only tie with the maximum's softmax if its logit is within 2^-21 of it */
+            int near = 0;
+            for (int l = 0; l < arg; ++l) near |= (best - p[(size_t)l * V]) <= 0x1p-21f;
+            if (near) {
+                float s = 0.0f;
+                for (int l = 0; l < L; ++l) s = s + (float)oracle_exp_neg((double)(p[(size_t)l * V] - best));
+                const float qmax = 1.0f / s;
+                for (int l = 0; l < arg; ++l) {
+                    const float e = (float)oracle_exp_neg((double)(p[(size_t)l * V] - best));
+                    if (e / s == qmax) { arg = l; break; }
+                }
+            }
+            labels[(size_t)b * V + v] = (uint8_t)arg;
         }
     return 0;
 }

@@ -12,6 +12,20 @@ for p in (REPO, GOLDEN):
         sys.path.insert(0, p)
 
 
+@pytest.fixture(autouse=True)
+def _flush_native_stdio():
+    """MIOpen's CK kernels print applicability diagnostics ("GridwiseOp: Problemsize descriptor dimension check failure") through C
+    stdio.  With stdout a pipe that text sits in the process's stdio buffer until exit and lands AFTER pytest's summary, outside any
+    test's capture (it buried the tail of GPUTEST_r03).  Flushing at every teardown puts it into the capture of the test that caused
+    it, which pytest drops for passing tests."""
+    yield
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 

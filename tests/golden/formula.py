@@ -87,6 +87,34 @@ def coherent_logits(tag: str, n_classes: int, shape, batch: int = 2):
 _CONV_FUNCTIONS = ("conv1d", "conv2d", "conv3d", "conv_transpose1d", "conv_transpose2d", "conv_transpose3d")
 
 
+def near_tie_logits(tag: str, n_classes: int = 14, n_voxels: int = 60000):
+    """Logits (1, L, V) whose two largest entries per voxel are planted 0 ... 2^-21 apart with the SMALLER one at the earlier class index:
+    the band in which float32 softmax values coincide and ``argmax(softmax(x))`` (reference bti_loss.py:132-134) returns the first index
+    instead of the largest logit.  Four magnitude regimes (logit scale 0.02 / 0.2 / 1 / 3), a quarter of the voxels each; gaps are
+    uniform in [0, 2^-21] with one voxel in eight an exact tie or a gap of a few ulps.  Returns (logits, gap (V,) float32 = max - runner-up)."""
+    rng = _rng(tag, 7)
+    x = rng.standard_normal((n_voxels, n_classes))
+    scale = np.repeat(np.array([0.02, 0.2, 1.0, 3.0]), -(-n_voxels // 4))[:n_voxels]
+    x = (x * scale[:, None]).astype(np.float32)
+    hi = x.argmax(1)
+    hi = np.where(hi == 0, 1 + rng.integers(0, n_classes - 1, n_voxels), hi)      # the maximum must not sit at class 0
+    lo = rng.integers(0, 1 << 30, n_voxels) % hi                                   # an earlier class
+    m = np.abs(x).max(1).astype(np.float32) + np.float32(0.25) * scale.astype(np.float32)
+    gap = (rng.random(n_voxels) * 2.0 ** -21).astype(np.float32)
+    few = rng.integers(0, 8, n_voxels) == 0
+    ulps = rng.integers(0, 4, n_voxels)
+    v = (m - gap).astype(np.float32)
+    w = m.copy()
+    for k in range(1, 4):
+        w = np.where(ulps >= k, np.nextafter(w, np.float32(-np.inf), dtype=np.float32), w)
+    v = np.where(few, w, v).astype(np.float32)
+    rows = np.arange(n_voxels)
+    x[rows, hi] = m
+    x[rows, lo] = v
+    logits = torch.from_numpy(np.ascontiguousarray(x.T)).reshape(1, n_classes, n_voxels)
+    return logits, torch.from_numpy((m - v).astype(np.float32))
+
+
 @contextlib.contextmanager
 def convs_in_float64():
     """While active every ``torch.nn.functional`` (transposed) convolution computes in float64 and rounds its result

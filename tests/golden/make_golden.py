@@ -349,6 +349,20 @@ def g_bti(ref):
     save("g7_bti", **out)
 
 
+def g_near_ties(ref):
+    """G7d: the label map ``argmax(softmax(x, 1), 1)`` (bti_loss.py:131-133, with the module's own ``apply_nonlin``) on logits whose two
+    largest entries are closer than float32 softmax can tell apart — the first-index-on-equal-softmax behaviour the kernels restate."""
+    loss = ref.bti.BTI_Loss(dim=3, connectivity=26, inclusion=[], exclusion=[[torch.tensor(1), torch.tensor(2)]], min_thick=1)
+    logits, gap = formula.near_tie_logits("g7d.near_ties")
+    with torch.no_grad():
+        labels = torch.argmax(loss.apply_nonlin(logits), dim=1)
+    plain = logits.argmax(1)
+    print("   near ties: %d voxels, reference labels differ from argmax(logits) on %d; gap <= 2^-25: %d" % (
+        labels.numel(), int((labels != plain).sum()), int((gap <= 2.0 ** -25).sum())))
+    # logits are formula.near_tie_logits("g7d.near_ties") on both sides: not stored
+    save("g7d_near_ties", labels=labels.numpy().astype(np.uint8))
+
+
 def g_ti(ref):
     """G7b: the all-pairs TI loss of loss/ti_loss.py (scalar labels, `P == label`): the 78 pairs of the 13 foreground
     classes the `*_TI` trainers build (nnUNetTrainer_NexToU_TI.py:10-13,48), a 2-D 8-connected case, one inclusion."""
@@ -556,7 +570,7 @@ def main():
     torch.set_num_threads(8)
     ref = load_reference()
     only = set(sys.argv[1:])
-    for fn in (g_knn, g_distance, g_mrconv, g_pos_embed, g_blocks, g_ffn, g_bti, g_ti, g_compound, g_models, g_config_table):
+    for fn in (g_knn, g_distance, g_mrconv, g_pos_embed, g_blocks, g_ffn, g_bti, g_near_ties, g_ti, g_compound, g_models, g_config_table):
         if only and fn.__name__ not in only:
             continue
         print("==", fn.__name__)

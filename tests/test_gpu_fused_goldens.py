@@ -1,0 +1,86 @@
+"""The fused point-wise pipeline (K7 GEMMs with K6 in their epilogue / prologue) against the goldens that the
+REFERENCE generated (VERDICT r3 weak #1-ii: g5 / g5b / g8 all sit below the 65 536-point default threshold and therefore never met the
+fused kernels; tests/test_gpu_fused.py holds them to a float64 ATen restatement only).
+
+Every test below is an existing golden check — g5 blocks (PoolGrapher / SwinGrapher, train + eval, forward + input gradient), g5b FFN,
+g8 tiny 2-D / 3-D models (teacher-forced, MIOpen fp32 convolutions and float64 convolutions), the sliding-window predictor against the
+oracle-backed network — re-run with ``NEXTOU_PW_FUSE_MIN_POINTS=0`` so that every eligible ``conv1x1 -> norm (-> act) [-> conv1x1 -> norm]
+[+ x]`` chain of the model takes the fused kernels, at the SAME tolerances; once more with ``NEXTOU_PW_MM_MAX_POINTS=0`` (no BLAS route for
+the small volumes' 1x1 convolutions, so the un-chained remainder runs on MIOpen).  Each test asserts that the fused entry point really ran.
+"""
+import pytest
+import torch
+
+import model_cases as mc
+import test_gpu_inference as t_inf
+import test_gpu_parity as t_p1
+import test_gpu_parity2 as t_p2
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nextou_amd import _lib, graph_ops
+    _lib.lib()
+    assert "libnextou_hip.so" in open("/proc/self/maps").read(), "HIP extension not loaded into this process"
+    return graph_ops
+
+
+@pytest.fixture(scope="module")
+def ora():
+    import oracle
+    oracle.lib()
+    return oracle.CanonicalBackend
+
+
+@pytest.fixture(params=[None, "0"], ids=["blas-rows-default", "blas-rows-off"])
+def fused_everywhere(request, monkeypatch, ops):
+    """The fused chain from 0 points on; counts the calls of the fused GEMM entry point."""
+    monkeypatch.setenv("NEXTOU_PW_FUSE_MIN_POINTS", "0")
+    monkeypatch.setenv("NEXTOU_PW_FUSE", "1")
+    if request.param is not None:
+        monkeypatch.setenv("NEXTOU_PW_MM_MAX_POINTS", request.param)
+    calls = {"n": 0}
+    real = ops._HIP.pw_rows_fused
+
+    def counted(*a, **kw):
+        calls["n"] += 1
+        return real(*a, **kw)
+    monkeypatch.setattr(ops._HIP, "pw_rows_fused", counted)
+    return calls
+
+
+@pytest.mark.parametrize("name", list(mc.BLOCKS))
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_g5_blocks_through_the_fused_pipeline(ops, fused_everywhere, name, mode):
+    t_p2.test_blocks_channels_last_on_gpu(ops, name, mode)
+    # fc1 + fc2 of every grapher (the Swin block chains the MRConv's grouped conv into fc2): >= 2 fused GEMMs per forward, two forwards
+    assert fused_everywhere["n"] >= 4, fused_everywhere
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_g5b_ffn_through_the_fused_pipeline(ops, fused_everywhere, mode):
+    import test_losses_golden as lg
+    lg.check_ffn(mode, DEV, tol=2e-5, channels_last=True)
+    assert fused_everywhere["n"] >= 2, fused_everywhere
+
+
+@pytest.mark.parametrize("name,cfg,batch", [("g8_tiny2d", mc.TINY_2D, 2), ("g8_tiny3d", mc.TINY_3D, 1)])
+def test_g8_tiny_models_through_the_fused_pipeline(ops, fused_everywhere, name, cfg, batch):
+    t_p1.test_tiny_models_on_gpu_teacher_forced(ops, name, cfg, batch)
+    assert fused_everywhere["n"] >= 10, fused_everywhere
+
+
+@pytest.mark.parametrize("name,cfg,batch", [("g8_tiny2d", mc.TINY_2D, 2), ("g8_tiny3d", mc.TINY_3D, 1)])
+def test_g8_tiny_models_equal_convolutions_through_the_fused_pipeline(ops, fused_everywhere, name, cfg, batch):
+    t_p2.test_tiny_models_equal_convolution_arithmetic_on_gpu(ops, name, cfg, batch)
+    assert fused_everywhere["n"] >= 10, fused_everywhere
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("f64_convs", [True, False], ids=["float64-convs", "miopen-fp32-convs"])
+def test_sliding_window_through_the_fused_pipeline(ops, ora, fused_everywhere, f64_convs):
+    t_inf.test_sliding_window_logits_vs_oracle_backed_network(ops, ora, f64_convs)
+    assert fused_everywhere["n"] >= 10, fused_everywhere

@@ -350,6 +350,24 @@ def test_bti_ragged_shapes(ops, ora, shape, conn, thick):
     assert torch.equal(ops.argmax_labels(logits.to(DEV)).cpu(), ora.argmax_labels(logits))
 
 
+def test_argmax_of_softmax_near_ties_on_gpu(ops, ora):
+    """``argmax(softmax(x))`` (reference bti_loss.py:131-133) on logits whose top two entries float32 softmax cannot tell apart: the
+    kernel equals the oracle bit for bit (same fixed fma sequence for the band's exp), and is held to the reference's own labels
+    exactly as the oracle is (tests/test_oracle_golden.py::near_tie_expectations; golden g7d_near_ties from make_golden.py)."""
+    import formula
+    from test_oracle_golden import near_tie_expectations
+    g = load_golden("g7d_near_ties")
+    logits, gap = formula.near_tie_logits("g7d.near_ties")
+    want = ora.argmax_labels(logits)
+    got = ops.argmax_labels(logits.to(DEV)).cpu()
+    assert torch.equal(got, want)
+    near_tie_expectations(got, g["labels"], logits, gap)
+    odd = logits[:, :, :59999].contiguous()                     # V % 4 != 0: the scalar kernel
+    assert torch.equal(ops.argmax_labels(odd.to(DEV)).cpu(), ora.argmax_labels(odd))
+    x = torch.tensor([1e-3, float(np.nextafter(np.float32(1e-3), np.float32(1))), -1.0]).reshape(1, 3, 1)
+    assert int(ops.argmax_labels(x.to(DEV))) == 0               # VERDICT r3: the reference says 0, the plain arg-max 1
+
+
 def test_bti_full_size_cfg4(ops, ora):
     """14 classes at 64x224x192, B = 2: label map and critical map bit-exact vs the oracle."""
     from nextou_amd.harness import synthetic_batch, config_3d_fullres_nextou
