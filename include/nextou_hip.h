@@ -199,7 +199,8 @@ int nextou_bti_ce_bwd(const float* logits, const uint8_t* target, const uint8_t*
  * (nnUNetTrainer_NexToU.py / *_BTI_*.py -> nnU-Net's RobustCrossEntropyLoss = torch.nn.CrossEntropyLoss(reduction='mean')), which ATen runs as
  * log_softmax -> nll_loss over NCDHW tensors (with channels-last logits: a layout copy in, two passes each way, a copy of the gradient back).
  *   logits: element (b, l, v) at b * L * V + l * stride_l + v * stride_v; (stride_l, stride_v) = (1, L) — channels-last rows, what the network
- *           emits — or (V, 1) — NCDHW planes.  L <= 32.  target: int64 (B * V); voxels whose target is ignore_index or outside [0, L) do not count.
+ *           emits — or (V, 1) — NCDHW planes.  L <= 32.  target: int64 (B * V); voxels whose target is ignore_index do not count; a target outside [0, L) that is
+ *           not ignore_index makes the loss NaN (torch raises a device assert there; no gradient flows to that voxel).
  *   fwd: partial[2 i + {0, 1}], i < nextou_ce_mean_partials(): (sum of -log softmax(x)[target], number of counted voxels) of block i as doubles;
  *        the caller adds them (fixed order) and divides.
  *   bwd: grad_logits (same layout as logits) = scale * (softmax(x) - onehot(target)) for counted voxels, 0 for the others; scale_dev: ONE device

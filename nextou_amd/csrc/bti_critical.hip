@@ -457,7 +457,11 @@ __global__ __launch_bounds__(256) void ce_mean_fwd_kernel(const float* __restric
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
         const long long y = target[p];
-        if (y == ignore_index || y < 0 || y >= L) continue;
+        if (y == ignore_index) continue;
+        if (y < 0 || y >= L) {         // a label outside [0, L) that is not the ignore index: torch.nn.CrossEntropyLoss raises a device
+            acc += (double)NAN;        // assert; here the LOSS turns NaN (loud, capturable, no host sync) instead of the voxel silently
+            continue;                  // dropping out of the mean
+        }
         float x[LMAX];
         if constexpr (ROWS) {
             const float* base = logits + (size_t)p * L;

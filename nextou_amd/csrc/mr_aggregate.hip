@@ -458,6 +458,164 @@ __global__ __launch_bounds__(256) void mr_bwd_arg_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward from the saved arg-max ids with FIXED-POINT accumulators (round 4; the default).
+//
+// mr_bwd_arg_kernel above is bound by its LDS float atomics: ds_add_f32 retires one wave-instruction per ~195 CU cycles on gfx950
+// WHATEVER the addresses (conflict-free included), ds_add_u64 one per 12-18 cycles with random addresses and 56 with runs of equal
+// ones (tools/micro/lds_atomic_bench.hip, profiles/r04_lds_atomics.md) — an 11-16x gap.  So the scattered term is accumulated as
+// 64-bit integers: every g_mr of the workgroup's tile becomes q = round(g * 2^(S + 127 - e_max)) with e_max the biased exponent of
+// the tile's largest |g| (one extra sweep over g_mr: L2-hot in the second) and S = 47 (less for rows longer than 32 768 points), so
+// |q| < 2^(S + 1) and a row's sum stays below 2^63; the sums are exact integers, hence independent of the order the atomics retire in:
+//   * gradients are BIT-REPRODUCIBLE run to run (VERDICT r3 weak #1-iii: the float scatter was not);
+//   * each addend is rounded to 2^-S of the tile's maximum (2^-47: values down to 2^-23 of the maximum keep their whole mantissa),
+//     the sum itself is exact, and the result is rounded to float32 once — tighter than any fp32 summation order, the oracle's included.
+// A non-finite gradient anywhere in the tile (inf / NaN from an overflowing fp16 loss scale) poisons the tile's outputs with NaN so
+// that torch.amp.GradScaler still sees it.  Same grid, LDS bytes and data movement as the float kernel (8 bytes per accumulator).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long fix_from_float(float g, int e_max, int S) {
+    const unsigned u = __float_as_uint(g);
+    const int ex = (int)((u >> 23) & 0xffu);
+    const unsigned man = (u & 0x7fffffu) | (ex ? 0x800000u : 0u);
+    const int sh = (ex ? ex : 1) - e_max + (S - 23);                 // <= S - 23 because ex <= e_max
+    unsigned long long q;
+    if (sh >= 0) {
+        q = (unsigned long long)man << sh;
+    } else {
+        const int r = -sh;
+        q = r > 25 ? 0ull : (((unsigned long long)man + (1ull << (r - 1))) >> r);      // round half away from zero
+    }
+    return (u >> 31) ? -(long long)q : (long long)q;
+}
+
+__device__ __forceinline__ float fix_to_float(long long acc, int e_max, int S) {
+    return (float)ldexp((double)acc, e_max - S - 127);
+}
+
+template <bool SELF, bool VEC4>
+__global__ __launch_bounds__(256) void mr_bwd_fix_kernel(const float* __restrict__ gout, const uint16_t* __restrict__ arg,
+                                                         float* __restrict__ dx, float* __restrict__ dy, int C, int N, int M,
+                                                         int chunk, unsigned magic, int S) {
+    constexpr int W = VEC4 ? 4 : 1;
+    constexpr int U = VEC4 ? 2 : 4;
+    extern __shared__ __attribute__((aligned(16))) long long facc[];
+    __shared__ unsigned wave_max[4];
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * chunk;
+    const int nc = (C - c0 < chunk) ? (C - c0) : chunk;
+    for (int e = threadIdx.x; e < nc * M; e += blockDim.x) facc[e] = 0ll;
+    const unsigned row_items = (unsigned)N / W;
+    const unsigned total = (unsigned)nc * row_items;
+    const float* gbase = gout + ((size_t)b * 2 * C + 2 * c0) * N;
+    const uint16_t* abase = arg + ((size_t)b * C + c0) * N;
+    float* dxbase = dx + ((size_t)b * C + c0) * N;
+    // sweep 0: the tile's largest |g_mr| (as float bits: monotone for non-negative values, inf / NaN sort on top)
+    unsigned mx = 0u;
+    for (unsigned it = threadIdx.x; it < total; it += blockDim.x) {
+        const unsigned c = (row_items == 1) ? it : __umulhi(it, magic);
+        const unsigned n = (it - c * row_items) * W;
+        const float* g = gbase + (size_t)2 * c * N + N + n;
+        if (VEC4) {
+            const float4 v = *reinterpret_cast<const float4*>(g);
+            mx = max(max(mx, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+            mx = max(max(mx, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+        } else {
+            mx = max(mx, __float_as_uint(g[0]) & 0x7fffffffu);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    const int e_raw = (int)(mx >> 23);
+    const bool bad = e_raw == 255;                       // inf / NaN somewhere in the tile
+    const int e_max = e_raw ? e_raw : 1;
+    // sweep 1: scatter (and, for the pooled graph, dx = g_x - g_mr on the way)
+    for (unsigned base = 0; base < total; base += blockDim.x * U) {
+        float g0[U][W], g1[U][W];
+        unsigned short a[U][W];
+        unsigned cc[U], nn[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned it = base + u * blockDim.x + threadIdx.x;
+            ok[u] = it < total;
+            const unsigned c = (row_items == 1) ? it : __umulhi(it, magic);
+            const unsigned n = (it - c * row_items) * W;
+            cc[u] = c;
+            nn[u] = n;
+            const float* g = gbase + (size_t)2 * c * N + n;
+            const uint16_t* ap = abase + (size_t)c * N + n;
+            if (VEC4) {
+                float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                uint2 av = make_uint2(0u, 0u);
+                if (ok[u]) {
+                    if (!SELF) v0 = *reinterpret_cast<const float4*>(g);
+                    v1 = *reinterpret_cast<const float4*>(g + N);
+                    av = *reinterpret_cast<const uint2*>(ap);
+                }
+                g0[u][0] = v0.x; g0[u][1 % W] = v0.y; g0[u][2 % W] = v0.z; g0[u][3 % W] = v0.w;
+                g1[u][0] = v1.x; g1[u][1 % W] = v1.y; g1[u][2 % W] = v1.z; g1[u][3 % W] = v1.w;
+                a[u][0] = (unsigned short)(av.x & 0xffffu); a[u][1 % W] = (unsigned short)(av.x >> 16);
+                a[u][2 % W] = (unsigned short)(av.y & 0xffffu); a[u][3 % W] = (unsigned short)(av.y >> 16);
+            } else {
+                g0[u][0] = (ok[u] && !SELF) ? g[0] : 0.f;
+                g1[u][0] = ok[u] ? g[N] : 0.f;
+                a[u][0] = ok[u] ? ap[0] : (unsigned short)0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            unsigned long long* acc = reinterpret_cast<unsigned long long*>(facc) + cc[u] * M;
+            if (!bad) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) atomicAdd(&acc[a[u][w]], (unsigned long long)fix_from_float(g1[u][w], e_max, S));
+            }
+            if (!SELF) {
+                float* o = dxbase + (size_t)cc[u] * N + nn[u];
+                if (VEC4)
+                    *reinterpret_cast<float4*>(o) = make_float4(g0[u][0] - g1[u][0], g0[u][1 % W] - g1[u][1 % W],
+                                                                g0[u][2 % W] - g1[u][2 % W], g0[u][3 % W] - g1[u][3 % W]);
+                else
+                    o[0] = g0[u][0] - g1[u][0];
+            }
+        }
+    }
+    __syncthreads();
+    const float poison = __uint_as_float(0x7fc00000u);
+    if (!SELF) {
+        float* o = dy + ((size_t)b * C + c0) * M;
+        for (int e = threadIdx.x; e < nc * M; e += blockDim.x) o[e] = bad ? poison : fix_to_float(facc[e], e_max, S);
+        return;
+    }
+    // sweep 2 (self graph): dx = scattered + (g_x - g_mr); g is re-read (L2-hot)
+    for (unsigned base = 0; base < total; base += blockDim.x * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned it = base + u * blockDim.x + threadIdx.x;
+            if (it >= total) continue;
+            const unsigned c = (row_items == 1) ? it : __umulhi(it, magic);
+            const unsigned n = (it - c * row_items) * W;
+            const float* g = gbase + (size_t)2 * c * N + n;
+            const long long* acc = facc + c * M + n;
+            float* o = dxbase + (size_t)c * N + n;
+            if (VEC4) {
+                const float4 v0 = *reinterpret_cast<const float4*>(g);
+                const float4 v1 = *reinterpret_cast<const float4*>(g + N);
+                float s4[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) s4[w] = bad ? poison : fix_to_float(acc[w], e_max, S);
+                *reinterpret_cast<float4*>(o) = make_float4(s4[0] + (v0.x - v1.x), s4[1] + (v0.y - v1.y),
+                                                            s4[2] + (v0.z - v1.z), s4[3] + (v0.w - v1.w));
+            } else {
+                o[0] = (bad ? poison : fix_to_float(acc[0], e_max, S)) + (g[0] - g[N]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward of a SELF window graph (N = M <= 512) as a GATHER over reverse neighbour lists — no float atomics.
 //   dx[c, m] = (g_x - g_mr)[c, m] + sum over the queries n that list m among their neighbours of [arg[c, n] == m] * g_mr[c, n]
 // The scatter version above spends 81 % of its wave cycles waiting on ds_add_f32 (rocprofv3 SQ_WAIT_INST_LDS 4.9e8 of 6.05e8,
@@ -868,7 +1026,10 @@ extern "C" int nextou_mr_aggregate_bwd_arg(const float* gout, const uint16_t* ar
     NEXTOU_REQUIRE(dy != nullptr || M == N, "mr_aggregate_bwd_arg: dy == NULL (self graph) needs M == N");
     hipStream_t s = (hipStream_t)stream;
     const bool self = (dy == nullptr);
-    const int budget = 32 * 1024 / (int)sizeof(float);  // <= 32 KB of accumulators per workgroup
+    // NEXTOU_MR_BWD=float keeps the round-1 LDS float-atomic scatter for A/B runs; the default accumulates in 64-bit fixed point
+    static const bool float_atomics = [] { const char* e = getenv("NEXTOU_MR_BWD"); return e != nullptr && e[0] == 'f'; }();
+    const int acc_bytes = float_atomics ? 4 : 8;
+    const int budget = 32 * 1024 / acc_bytes;  // <= 32 KB of accumulators per workgroup
     int chunk = budget / M;
     if (chunk < 1) return fail(NEXTOU_ENOTSUP, "mr_aggregate_bwd_arg: M=%d rows do not fit the LDS accumulators", M);
     if (chunk > C) chunk = C;
@@ -881,9 +1042,25 @@ extern "C" int nextou_mr_aggregate_bwd_arg(const float* gout, const uint16_t* ar
     const unsigned row_items = (unsigned)(vec4 ? N / 4 : N);
     const unsigned magic = (unsigned)((0x100000000ull + row_items - 1) / row_items);  // it / row_items by umulhi
     const double bytes = 8.0 * B * C * (double)N + 2.0 * B * C * (double)N + 4.0 * B * C * ((double)N + (self ? 0 : M));
-    ProfScope prof(s, kBoundHbm, bytes, "mr_bwd_arg_kernel<%s>[B%d C%d N%d M%d]", self ? "self" : "xy", B, C, N, M);
+    ProfScope prof(s, kBoundHbm, bytes, "%s<%s>[B%d C%d N%d M%d]", float_atomics ? "mr_bwd_arg_kernel" : "mr_bwd_fix_kernel", self ? "self" : "xy",
+                   B, C, N, M);
     dim3 grid(cdiv(C, chunk), B);
-    const size_t lds = (size_t)chunk * M * sizeof(float);
+    const size_t lds = (size_t)chunk * M * acc_bytes;
+    if (!float_atomics) {
+        // |q| < 2^(S + 1) per addend, at most N addends per accumulator: S + 1 + ceil(log2 N) <= 62
+        int lg = 0;
+        while ((1ll << lg) < N) ++lg;
+        const int S = lg <= 14 ? 47 : 61 - lg;
+#define NEXTOU_MR_BWD_FIX(SELF, VEC)                                                                            \
+    hipLaunchKernelGGL((mr_bwd_fix_kernel<SELF, VEC>), grid, dim3(threads), lds, s, gout, arg, dx, dy, C, N, M, chunk, \
+                       magic, S)
+        if (self && vec4) NEXTOU_MR_BWD_FIX(true, true);
+        else if (self) NEXTOU_MR_BWD_FIX(true, false);
+        else if (vec4) NEXTOU_MR_BWD_FIX(false, true);
+        else NEXTOU_MR_BWD_FIX(false, false);
+#undef NEXTOU_MR_BWD_FIX
+        return check_launch("mr_bwd_fix_kernel");
+    }
 #define NEXTOU_MR_BWD_ARG(SELF, VEC)                                                                            \
     hipLaunchKernelGGL((mr_bwd_arg_kernel<SELF, VEC>), grid, dim3(threads), lds, s, gout, arg, dx, dy, C, N, M, chunk, \
                        magic)

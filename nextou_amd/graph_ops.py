@@ -1261,8 +1261,8 @@ def pointwise_chain_eligible(x, residual, conv1, norm1, conv2=None, norm2=None) 
             return False
         if conv.bias is not None and getattr(norm, "_pre_bias_src", (None,))[0] is not conv:
             return False            # a bias that is really added to the conv output: not this pipeline
-        if norm.num_features != conv.weight.shape[0] or (norm.weight is None) != (norm.bias is None):
-            return False
+        if norm.num_features != conv.weight.shape[0] or norm.weight is None or norm.bias is None:
+            return False            # affine norms only: the fused backward's gradient-statistics epilogue reads weight and bias
         batch_stats = norm.training or (norm.running_mean is None and norm.running_var is None)
         if not batch_stats and norm.running_mean is None:
             return False

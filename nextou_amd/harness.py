@@ -199,7 +199,7 @@ def assert_capturable(network: torch.nn.Module) -> None:
     the result and is never made; set ``epsilon = 0`` / ``stochastic = False`` on the blocks to capture anything else."""
     from .network_architecture.torch_edge import DenseDilatedKnnGraph, reference_rng_stream
     for name, m in network.named_modules():
-        if isinstance(m, DenseDilatedKnnGraph) and m.stochastic and m.epsilon > 0 and network.training and \
+        if isinstance(m, DenseDilatedKnnGraph) and m.stochastic and m.epsilon > 0 and m.training and \
                 (m.dilation > 1 or reference_rng_stream()):
             raise RuntimeError("GraphedTrainStep: %s draws its stochastic dilation on the host every call (dilation %d, epsilon %g); "
                                "a captured step would freeze the draw" % (name, m.dilation, m.epsilon))

@@ -13,7 +13,7 @@ from torch import nn
 
 try:
     from nnunetv2.training.loss.dice import MemoryEfficientSoftDiceLoss, SoftDiceLoss  # type: ignore
-    from nnunetv2.training.loss.robust_ce_loss import RobustCrossEntropyLoss  # type: ignore
+    from nnunetv2.training.loss.robust_ce_loss import RobustCrossEntropyLoss as _BaseRobustCE  # type: ignore
     from nnunetv2.training.loss.deep_supervision import DeepSupervisionWrapper  # type: ignore
     from nnunetv2.utilities.helpers import softmax_helper_dim1  # type: ignore
     HAVE_NNUNET = True
@@ -80,19 +80,14 @@ except ImportError:
 
     SoftDiceLoss = MemoryEfficientSoftDiceLoss  # same value; the memory-hungry variant is not needed
 
-    class RobustCrossEntropyLoss(nn.CrossEntropyLoss):
-        """CrossEntropyLoss that accepts a (B,1,...) float target."""
+    class _BaseRobustCE(nn.CrossEntropyLoss):
+        """CrossEntropyLoss that accepts a (B,1,...) float target (restatement of nnU-Net's class)."""
 
         def forward(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
             if target.ndim == input.ndim:
                 assert target.shape[1] == 1
                 target = target[:, 0]
-            target = target.long()
-            if self.weight is None and self.reduction == "mean" and self.label_smoothing == 0.0:
-                from .. import graph_ops
-                if graph_ops.cross_entropy_mean_eligible(input, target):        # one kernel each way, in the logits' own layout (K5c)
-                    return graph_ops.cross_entropy_mean(input, target, self.ignore_index)
-            return super().forward(input, target)
+            return super().forward(input, target.long())
 
     class DeepSupervisionWrapper(nn.Module):
         """sum_i w_i * loss(output_i, target_i); zero weights are skipped."""
@@ -108,3 +103,23 @@ except ImportError:
                 f"all args must be either tuple or list, got {[type(i) for i in args]}"
             weights = self.weight_factors if self.weight_factors is not None else (1,) * len(args[0])
             return sum(weights[i] * self.loss(*inputs) for i, inputs in enumerate(zip(*args)) if weights[i] != 0.0)
+
+
+class RobustCrossEntropyLoss(_BaseRobustCE):
+    """nnU-Net's ``RobustCrossEntropyLoss`` (the real class inside an nnU-Net installation, its restatement otherwise) whose plain
+    mean-reduced case runs as ONE kernel each way over the logits where they lie (K5c, ``graph_ops.cross_entropy_mean``: channels-last
+    logits stay channels-last, no log_softmax / nll_loss passes, no layout copies).  Defined for both import outcomes (wired
+    into the fallback class only, the trainers' deep-supervision CE never took the kernel inside nnU-Net).  Class weights, label
+    smoothing, other reductions and ineligible tensors (CPU, reduced precision, > 32 classes) take the base class unchanged."""
+
+    def forward(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        if self.weight is None and self.reduction == "mean" and self.label_smoothing == 0.0:
+            t = target
+            if t.ndim == input.ndim:
+                assert t.shape[1] == 1
+                t = t[:, 0]
+            t = t.long()
+            from .. import graph_ops
+            if graph_ops.cross_entropy_mean_eligible(input, t):
+                return graph_ops.cross_entropy_mean(input, t, self.ignore_index)
+        return super().forward(input, target)

@@ -67,7 +67,7 @@ class NexToU(nn.Module):
             self.padded_modules = pad_plain_stage_channels(self, pad_multiple())
             # reduced-precision autocast keeps NDHWC only when the plain stages really run multiple-of-8 channel counts
             plain = list(self.encoder.output_channels)[:self.encoder.n_conv_stages]
-            self.encoder.reduced_precision_layout_ok = bool(self.padded_modules) or all(f % 8 == 0 for f in plain)
+            self.encoder.reduced_precision_layout_ok = bool(self.padded_modules) or all(f % max(pad_multiple(), 1) == 0 for f in plain)
 
     def forward(self, x):
         return self.decoder(self.encoder(x))

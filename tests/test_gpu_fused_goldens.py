@@ -67,14 +67,23 @@ def test_g5b_ffn_through_the_fused_pipeline(ops, fused_everywhere, mode):
     assert fused_everywhere["n"] >= 2, fused_everywhere
 
 
+def _channels_last_for_2d(monkeypatch, cfg):
+    """The layout policy keeps 2-D models NCHW (layout.channels_last_stages: MIOpen's 2-D kernels have no transposes to save), and the
+    fused chain takes channels-last volumes only: for the 2-D golden every stage is switched to NHWC so that its blocks are eligible."""
+    if len(cfg["patch"]) == 2:
+        monkeypatch.setenv("NEXTOU_CHANNELS_LAST_STAGES", ",".join(str(i) for i in range(len(cfg["strides"]))))
+
+
 @pytest.mark.parametrize("name,cfg,batch", [("g8_tiny2d", mc.TINY_2D, 2), ("g8_tiny3d", mc.TINY_3D, 1)])
-def test_g8_tiny_models_through_the_fused_pipeline(ops, fused_everywhere, name, cfg, batch):
+def test_g8_tiny_models_through_the_fused_pipeline(ops, fused_everywhere, monkeypatch, name, cfg, batch):
+    _channels_last_for_2d(monkeypatch, cfg)
     t_p1.test_tiny_models_on_gpu_teacher_forced(ops, name, cfg, batch)
     assert fused_everywhere["n"] >= 10, fused_everywhere
 
 
 @pytest.mark.parametrize("name,cfg,batch", [("g8_tiny2d", mc.TINY_2D, 2), ("g8_tiny3d", mc.TINY_3D, 1)])
-def test_g8_tiny_models_equal_convolutions_through_the_fused_pipeline(ops, fused_everywhere, name, cfg, batch):
+def test_g8_tiny_models_equal_convolutions_through_the_fused_pipeline(ops, fused_everywhere, monkeypatch, name, cfg, batch):
+    _channels_last_for_2d(monkeypatch, cfg)
     t_p2.test_tiny_models_equal_convolution_arithmetic_on_gpu(ops, name, cfg, batch)
     assert fused_everywhere["n"] >= 10, fused_everywhere
 
