@@ -314,8 +314,8 @@ def main():
                          "never the headline number")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
                     help="replay the training step as one captured hipGraph (harness.GraphedTrainStep).  auto = on for every N "
-                         "(the averaged step captures its RCCL collectives) except cfg 4 (host-side target validation); auto "
-                         "falls back to the eager step if the capture fails and reports the error in the JSON line, on raises")
+                         "(the averaged step captures its RCCL collectives) and every workload (cfg 4: the BTI target validation runs "
+                         "on the device, checked after timing); auto falls back to the eager step if the capture fails and reports the error in the JSON line, on raises")
     ap.add_argument("--channels-last", action="store_true",
                     help="experiment: run the dense stages in channels_last_3d (NDHWC) memory format")
     args = ap.parse_args()
@@ -363,11 +363,11 @@ def main():
     # auto: the whole step as one hipGraph, N = 1 and N > 1 alike (the averaged step is capturable: RCCL collectives on their
     # own stream, no host synchronisation in the hooks or in finalize() once the warm-up steps have seen the gradient pattern)
     # (gloo — the two-ranks-on-one-GPU test backend — synchronises with the host inside its collectives and cannot be captured)
-    want_graph = args.graph == "on" or (args.graph == "auto" and args.workload != "cfg4" and (averager is None or backend == "nccl"))
+    want_graph = args.graph == "on" or (args.graph == "auto" and (averager is None or backend == "nccl"))
     graphed, capture_error = None, None
     if want_graph:
         try:
-            graphed = GraphedTrainStep(step, warmup=1, network=trainer.network)
+            graphed = GraphedTrainStep(step, warmup=1, network=trainer.network, loss=trainer.loss)
             for _ in range(2):
                 graphed()
         except Exception as exc:
@@ -415,6 +415,8 @@ def main():
                      "labels_not_a_multiple_of_the_steps": uneven}
     if dropped or uneven:       # never silent, never fatal to the timed number: the per-step sums below would be off
         print("bench.py: launch profile inconsistent: %s" % profile_check, file=sys.stderr)
+    if graphed is not None:
+        graphed.check()                     # deferred (B)TI target validation of the captured step
     if averager is not None:
         averager.check_consistency()        # every rank produced gradients for the same parameters on every step
     if world > 1:

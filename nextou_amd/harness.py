@@ -165,15 +165,22 @@ class GraphedTrainStep:
     graph blocks are a few microseconds of arithmetic behind ~100 launches each) and closes the idle gaps between kernels.
 
     ``step_fn`` must read its batch from tensors that live across replays (copy each new batch into them with ``copy_``) and
-    must not synchronise with the host: no ``.item()``, no stochastic dilation (``torch.rand`` on the CPU), no BTI target
-    validation.  ``warmup`` eager steps run first on a side stream (MIOpen's find, lazy momentum buffers, the library's
+    must not synchronise with the host: no ``.item()``, no stochastic dilation (``torch.rand`` on the CPU); the (B)TI losses'
+    target validation is switched to its deferred, device-side form when ``loss`` is given (see :meth:`check`).  ``warmup`` eager steps run first on a side stream (MIOpen's find, lazy momentum buffers, the library's
     one-time attribute calls); then one step is captured.  ``__call__`` replays it and returns the captured loss tensor.
     Same numbers as the eager step (same kernels, same order)."""
 
-    def __init__(self, step_fn, warmup: int = 3, network: Optional[torch.nn.Module] = None):
+    def __init__(self, step_fn, warmup: int = 3, network: Optional[torch.nn.Module] = None, loss: Optional[torch.nn.Module] = None):
         from . import _lib
+        from .loss.bti_loss import BTI_Loss
         if network is not None:
             assert_capturable(network)
+        # (B)TI losses validate their targets with a host read per call (the reference's CrossEntropyLoss raises there,
+        # bti_loss.py:141): inside a captured step the check runs on the device instead — a bad target turns the loss NaN and is
+        # counted; check() raises the IndexError afterwards
+        self._deferred = [m for m in (loss.modules() if loss is not None else ()) if isinstance(m, BTI_Loss) and m.validate_targets is True]
+        for m in self._deferred:
+            m.validate_targets = "deferred"
         _lib.lib().nextou_profile_enable(0)        # event records do not belong inside a captured graph
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -189,6 +196,11 @@ class GraphedTrainStep:
     def __call__(self):
         self.graph.replay()
         return self.loss
+
+    def check(self) -> None:
+        """Raise what the eager step would have raised on the way (one host synchronisation): out-of-range (B)TI targets."""
+        for m in self._deferred:
+            m.check_targets()
 
 
 def assert_capturable(network: torch.nn.Module) -> None:

@@ -61,9 +61,12 @@ class BTI_Loss(torch.nn.Module):
                                      "uint8 label map of the HIP critical-voxel kernel" % label)
         self._luts = self._build_luts(self.interaction_list)
         self._device_luts = {}
-        # one host sync per call; the reference raises IndexError from its CrossEntropyLoss for such targets
-        # (bti_loss.py:141) — switch off only when the targets are known to be clean
+        # True: one host sync per call, raises IndexError as the reference's CrossEntropyLoss does for such targets
+        # (bti_loss.py:141).  "deferred": no host sync — the check runs on the device, a bad target turns the loss NaN and is
+        # counted in a device counter that :meth:`check_targets` reads (and raises from) later; what a captured hipGraph step
+        # uses (harness.GraphedTrainStep).  False: no check (targets known to be clean).
         self.validate_targets = True
+        self._bad_targets = None
 
     @staticmethod
     def _build_luts(interactions: Sequence) -> List[np.ndarray]:
@@ -115,7 +118,14 @@ class BTI_Loss(torch.nn.Module):
         n_classes = x.shape[1]
         if n_classes > 256:
             raise ValueError("BTI_Loss: %d classes do not fit the uint8 label map (at most 256)" % n_classes)
-        if self.validate_targets:
+        bad = None
+        if self.validate_targets == "deferred":
+            lo, hi = torch.aminmax(y.detach())
+            bad = (lo < 0) | (hi >= n_classes)
+            if self._bad_targets is None or self._bad_targets.device != y.device:
+                self._bad_targets = torch.zeros((), dtype=torch.int64, device=y.device)
+            self._bad_targets += bad
+        elif self.validate_targets:
             lo, hi = (float(v) for v in torch.stack(torch.aminmax(y.detach())).tolist())
             if lo < 0 or hi >= n_classes:
                 raise IndexError("Target %d is out of bounds." % int(hi if hi >= n_classes else lo))
@@ -124,7 +134,18 @@ class BTI_Loss(torch.nn.Module):
         # :141-143  CE(x.double(), y, 'none') * critical, summed over voxels, mean over the batch —
         # one fused float64 kernel that only touches critical voxels
         per_sample = graph_ops.critical_cross_entropy(x, y[:, 0].to(torch.uint8), critical)
-        return per_sample.mean()
+        loss = per_sample.mean()
+        if bad is not None:
+            loss = torch.where(bad, torch.full_like(loss, float("nan")), loss)
+        return loss
+
+    def check_targets(self) -> None:
+        """With ``validate_targets = "deferred"``: raise (one host sync) if any call since the last check saw a target outside
+        [0, n_classes) — the IndexError the eager path raises at once."""
+        if self._bad_targets is not None and int(self._bad_targets) > 0:
+            n = int(self._bad_targets)
+            self._bad_targets.zero_()
+            raise IndexError("Target out of bounds in %d BTI_Loss call(s) (deferred validation)." % n)
 
 
 class TI_Loss(BTI_Loss):

@@ -92,4 +92,5 @@ def test_g8_tiny_models_equal_convolutions_through_the_fused_pipeline(ops, fused
 @pytest.mark.parametrize("f64_convs", [True, False], ids=["float64-convs", "miopen-fp32-convs"])
 def test_sliding_window_through_the_fused_pipeline(ops, ora, fused_everywhere, f64_convs):
     t_inf.test_sliding_window_logits_vs_oracle_backed_network(ops, ora, f64_convs)
-    assert fused_everywhere["n"] >= 10, fused_everywhere
+    # (float64 convolutions replace every convolution call, the 1x1 ones of the chains included: only the fp32 variant can take the kernels)
+    assert f64_convs or fused_everywhere["n"] >= 10, fused_everywhere
