@@ -171,7 +171,7 @@ int nextou_gather_bwd(const float* gout, const int32_t* idx, float* dsrc,
  *     cross otherwise (:52-73).  Up to 32 interactions per call.
  * ---------------------------------------------------------------------------------------- */
 int nextou_argmax_labels(const float* logits, uint8_t* labels,
-                         int B, int L, int64_t V, nextou_stream_t stream);
+                         int B, int L, int64_t V, int64_t stride_l, int64_t stride_v, nextou_stream_t stream);
 
 int nextou_bti_critical_map(const uint8_t* labels,
                             const uint32_t* lut_a, const uint32_t* lut_c, int n_labels,
@@ -187,13 +187,32 @@ int nextou_bti_critical_map(const uint8_t* labels,
  *   bwd: grad_logits[b,l,v] = scale_dev[b] * critical[b,v] * (softmax_l(x[b,:,v]) - [l == target[b,v]]),
  *        fp32, every voxel written; scale_dev (B) are DEVICE doubles (the upstream gradient of every
  *        sample's sum) so that no host synchronisation is needed.  target / critical: uint8 (B,V); targets >= L
- *        contribute nothing. */
+ *        contribute nothing.
+ *   Layout (ABI v9, also nextou_argmax_labels): logits element (b, l, v) at b * L * V + l * stride_l + v * stride_v with
+ *        (stride_l, stride_v) = (V, 1) — NCDHW planes — or (1, L) — channels-last rows, what the network's heads emit: no (B, L, V)
+ *        copy of the logits is made on the way in, and grad_logits comes back in the same layout. */
 int nextou_bti_ce_partials(void);
 int nextou_bti_ce_fwd(const float* logits, const uint8_t* target, const uint8_t* critical,
-                      double* partial, int B, int L, int64_t V, nextou_stream_t stream);
+                      double* partial, int B, int L, int64_t V, int64_t stride_l, int64_t stride_v, nextou_stream_t stream);
 int nextou_bti_ce_bwd(const float* logits, const uint8_t* target, const uint8_t* critical,
                       const double* scale_dev, float* grad_logits, int B, int L, int64_t V,
-                      nextou_stream_t stream);
+                      int64_t stride_l, int64_t stride_v, nextou_stream_t stream);
+
+/* K5d  soft-Dice statistics of the segmentation logits (ABI v9) — the three volume reductions nnU-Net's (MemoryEfficient)SoftDiceLoss needs
+ * (reference loss/compound_bti_loss.py:29-30, :53-55 -> nnunetv2/training/loss/dice.py, softmax_helper_dim1 as apply_nonlin), which ATen runs as
+ * softmax, a one-hot scatter, three products and three reductions over every logit.  p = softmax over the L classes (fp32), w = mask or 1:
+ *   fwd: partial[((b * T + t) * L + l) * 3 + {0, 1, 2}], T = nextou_dice_stats_partials(): block-wise doubles of
+ *        (sum_v w p[l] [target == l], sum_v w p[l], sum_v w [target == l]); the caller adds the T blocks (fixed order);
+ *   bwd: g_intersect / g_sum_pred: DEVICE doubles (B, L) = d loss / d intersect, d loss / d sum_pred;
+ *        grad_logits[k] = p_k (G_k - sum_l G_l p_l), G_l = w (g_sum_pred[b, l] + g_intersect[b, l] [target == l]), in the logits' layout.
+ *   logits layout as nextou_ce_mean_*: (stride_l, stride_v) = (1, L) channels-last rows (L even) or (V, 1) planes; 2 <= L <= 32.
+ *   target: uint8 (B, V) class indices (>= L: counted nowhere); mask: uint8 (B, V) or NULL. */
+int nextou_dice_stats_partials(void);
+int nextou_dice_stats_fwd(const float* logits, const uint8_t* target, const uint8_t* mask, double* partial, int B, int L, int64_t V,
+                          int64_t stride_l, int64_t stride_v, nextou_stream_t stream);
+int nextou_dice_stats_bwd(const float* logits, const uint8_t* target, const uint8_t* mask, const double* g_intersect,
+                          const double* g_sum_pred, float* grad_logits, int B, int L, int64_t V, int64_t stride_l, int64_t stride_v,
+                          nextou_stream_t stream);
 
 /* K5c  mean cross-entropy of the segmentation logits, fp32 (ABI v7) — the deep-supervision CE inside every NexToU trainer's loss
  * (nnUNetTrainer_NexToU.py / *_BTI_*.py -> nnU-Net's RobustCrossEntropyLoss = torch.nn.CrossEntropyLoss(reduction='mean')), which ATen runs as
@@ -344,7 +363,8 @@ int nextou_pw_wgrad(const float* gy, const float* x, float* dw, float* workspace
  *     A = x, or — operand prologue, pro_scale != NULL — A[p, c] = leaky_relu(fmaf(x[p, c], pro_scale[c], pro_shift[c]), pro_slope)
  *         (c = g*K + k over all groups*K input channels; exactly K6's apply arithmetic);
  *     stats_partial != NULL, bwd_h == NULL: statistics epilogue — stats_partial[(c * T + t) * 2 + {0, 1}] = (sum, sum of squares)
- *         of y[:, c] over point tile t, T = nextou_pw_rows_tiles(P, N, K, groups), c over groups*N output channels: the `partial`
+ *         of y[:, c] over point tile t, T = nextou_pw_rows_tiles(P, N, K, groups, ldx, ldy, prologue, grad_stats) of the SAME launch
+ *         arguments (stats_tiles hands it back: a mismatch is NEXTOU_EINVAL, never an overrun), c over groups*N output channels: the `partial`
  *         input of nextou_norm_finalize;
  *     bwd_h != NULL: gradient-statistics epilogue of a data-gradient GEMM (y = d loss / d activated): with h = bwd_h[p, c]
  *         (row stride ldh), z = fmaf(h, scale, shift), dz = y * (z > 0 ? 1 : bwd_slope), xhat = (h - bwd_mean[c]) * bwd_invstd[c]
@@ -360,9 +380,9 @@ int nextou_pw_wgrad(const float* gy, const float* x, float* dw, float* workspace
  * nextou_norm_bwd_finalize / nextou_norm_bwd_apply_rows   the two halves of K6's backward after the reduce: coeff (2C floats) +
  *     parameter gradients from (sum dz, sum dz*xhat) partials; gx = scale * ((dz - coeff[2c]) - xhat * coeff[2c+1]).
  * ---------------------------------------------------------------------------------------- */
-int nextou_pw_rows_tiles(int64_t P, int N, int K, int groups);
+int nextou_pw_rows_tiles(int64_t P, int N, int K, int groups, int64_t ldx, int64_t ldy, int prologue, int grad_stats);
 int nextou_pw_rows_fused(const float* x, const float* w, float* y, int64_t P, int N, int K, int groups, int64_t ldx, int64_t ldy,
-                         const float* pro_scale, const float* pro_shift, float pro_slope, double* stats_partial,
+                         const float* pro_scale, const float* pro_shift, float pro_slope, double* stats_partial, int stats_tiles,
                          const float* bwd_h, int64_t ldh, const float* bwd_weight, const float* bwd_bias, const float* bwd_mean,
                          const float* bwd_invstd, float bwd_slope, nextou_stream_t stream);
 int nextou_pw_wgrad_fused(const float* gy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int64_t P, int N,

@@ -53,11 +53,15 @@ _SIGNATURES = {
                                   c_void_p]),
     "nextou_gather_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                   c_void_p]),
-    "nextou_argmax_labels": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "nextou_argmax_labels": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_void_p]),
     "nextou_bti_ce_partials": (c_int, []),
-    "nextou_bti_ce_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
-    "nextou_bti_ce_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
+    "nextou_bti_ce_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_void_p]),
+    "nextou_bti_ce_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64,
                                   c_void_p]),
+    "nextou_dice_stats_partials": (c_int, []),
+    "nextou_dice_stats_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_void_p]),
+    "nextou_dice_stats_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64,
+                                      c_void_p]),
     "nextou_ce_mean_partials": (c_int, []),
     "nextou_ce_mean_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "nextou_ce_mean_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
@@ -83,9 +87,9 @@ _SIGNATURES = {
     "nextou_pw_wgrad_workspace": (c_int, [c_int64, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "nextou_pw_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int64, c_int64,
                                 c_int, c_void_p]),
-    "nextou_pw_rows_tiles": (c_int, [c_int64, c_int, c_int, c_int]),
+    "nextou_pw_rows_tiles": (c_int, [c_int64, c_int, c_int, c_int, c_int64, c_int64, c_int, c_int]),
     "nextou_pw_rows_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64,
-                                     c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_float, c_void_p]),
     "nextou_pw_wgrad_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int64, c_int64,
                                       c_int, c_void_p, c_void_p, c_float, c_void_p]),

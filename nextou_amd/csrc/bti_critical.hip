@@ -103,6 +103,36 @@ __global__ __launch_bounds__(256) void argmax_labels_kernel(const float* __restr
     }
 }
 
+// The same labels from channels-last logits: element (row, l) at row * L + l — what the network's heads emit (the planes kernel above
+// needed a (B, L, V) copy of them: 308 MB each way at cfg 4's full resolution).  A lane owns one voxel and reads its row as 8-byte pairs
+// (rows of a wave are one contiguous 64 * L * 4-byte run, served out of L1 between the L / 2 loads — ce_mean_fwd_kernel's pattern).
+template <int LMAX>
+__global__ __launch_bounds__(256) void argmax_labels_rows_kernel(const float* __restrict__ logits, uint8_t* __restrict__ labels, int L,
+                                                                 long long rows) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    constexpr float kBand = 0x1p-21f;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < rows; p += stride) {
+        const float* base = logits + (size_t)p * L;
+        float x[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; l += 2) {
+            float2 t = make_float2(-INFINITY, -INFINITY);
+            if (l + 1 < L) t = *reinterpret_cast<const float2*>(base + l);
+            else if (l < L) t.x = base[l];
+            x[l] = t.x;
+            if (l + 1 < LMAX) x[l + 1] = t.y;
+        }
+        float best = x[0];
+        int arg = 0;
+        bool near = false;
+#pragma unroll
+        for (int l = 1; l < LMAX; ++l)
+            if (l < L && x[l] > best) { near = x[l] - best <= kBand; best = x[l]; arg = l; }
+        if (near) arg = softmax_first_tie(base, 1, L, best, arg);
+        labels[p] = (uint8_t)arg;
+    }
+}
+
 // Round-1 kernel, kept as the fallback for min_thick > 3: one thread per voxel; the two LUTs live in LDS; neighbour labels come
 // through L1/L2 (each label byte is touched by at most 27 threads of neighbouring rows).  81 memory instructions per voxel at
 // connectivity 26: 96 us for the 2 x 64 x 224 x 192 volume of cfg 4 = 1.4 % of the HBM roofline (profiles/r03_kernel_bench_k5_start.md).
@@ -324,7 +354,9 @@ template <int LMAX>
 __global__ __launch_bounds__(256) void bti_ce_fwd_kernel(const float* __restrict__ logits,
                                                          const uint8_t* __restrict__ target,
                                                          const uint8_t* __restrict__ critical,
-                                                         double* __restrict__ partial, int L, long long V) {
+                                                         double* __restrict__ partial, int L, long long V, long long sl,
+                                                         long long sv) {
+    // element (b, l, v) at b * L * V + l * sl + v * sv: (sl, sv) = (V, 1) planes, (1, L) channels-last rows
     __shared__ double wsum[4];
     const int b = blockIdx.y;
     const float* lb = logits + (size_t)b * L * V;
@@ -341,7 +373,7 @@ __global__ __launch_bounds__(256) void bti_ce_fwd_kernel(const float* __restrict
             if constexpr (LMAX > 0) {
                 float x[LMAX];
 #pragma unroll
-                for (int l = 0; l < LMAX; ++l) x[l] = l < L ? lb[(size_t)l * V + v] : -INFINITY;
+                for (int l = 0; l < LMAX; ++l) x[l] = l < L ? lb[(size_t)l * sl + (size_t)v * sv] : -INFINITY;
                 float mf = x[0];
 #pragma unroll
                 for (int l = 1; l < LMAX; ++l) mf = fmaxf(mf, x[l]);          // max of floats == max of their doubles
@@ -354,14 +386,14 @@ __global__ __launch_bounds__(256) void bti_ce_fwd_kernel(const float* __restrict
                 }
                 if (y < L) acc += (m + log(s)) - xy;
             } else {
-                double m = (double)lb[v], xy = (y == 0) ? m : 0.0;
+                double m = (double)lb[(size_t)v * sv], xy = (y == 0) ? m : 0.0;
                 for (int l = 1; l < L; ++l) {
-                    const double x = (double)lb[(size_t)l * V + v];
+                    const double x = (double)lb[(size_t)l * sl + (size_t)v * sv];
                     if (l == y) xy = x;
                     m = fmax(m, x);
                 }
                 double s = 0.0;
-                for (int l = 0; l < L; ++l) s += exp((double)lb[(size_t)l * V + v] - m);
+                for (int l = 0; l < L; ++l) s += exp((double)lb[(size_t)l * sl + (size_t)v * sv] - m);
                 if (y < L) acc += (m + log(s)) - xy;
             }
         }
@@ -378,7 +410,7 @@ __global__ __launch_bounds__(256) void bti_ce_bwd_kernel(const float* __restrict
                                                          const uint8_t* __restrict__ target,
                                                          const uint8_t* __restrict__ critical,
                                                          const double* __restrict__ scale_dev,
-                                                         float* __restrict__ grad, int L, long long V) {
+                                                         float* __restrict__ grad, int L, long long V, long long sl, long long sv) {
     const int b = blockIdx.y;
     const float* lb = logits + (size_t)b * L * V;
     float* gb = grad + (size_t)b * L * V;
@@ -388,14 +420,14 @@ __global__ __launch_bounds__(256) void bti_ce_bwd_kernel(const float* __restrict
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
         if (cb[v] == 0) {
-            for (int l = 0; l < L; ++l) gb[(size_t)l * V + v] = 0.f;
+            for (int l = 0; l < L; ++l) gb[(size_t)l * sl + (size_t)v * sv] = 0.f;
             continue;
         }
         const int y = tb[v];
         if constexpr (LMAX > 0) {
             float x[LMAX];
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) x[l] = l < L ? lb[(size_t)l * V + v] : -INFINITY;
+            for (int l = 0; l < LMAX; ++l) x[l] = l < L ? lb[(size_t)l * sl + (size_t)v * sv] : -INFINITY;
             float mf = x[0];
 #pragma unroll
             for (int l = 1; l < LMAX; ++l) mf = fmaxf(mf, x[l]);
@@ -411,17 +443,17 @@ __global__ __launch_bounds__(256) void bti_ce_bwd_kernel(const float* __restrict
             for (int l = 0; l < LMAX; ++l) {
                 if (l >= L) break;
                 const double p = e[l] * inv;
-                gb[(size_t)l * V + v] = (float)(l == y ? p - ((y < L) ? scale : 0.0) : p);
+                gb[(size_t)l * sl + (size_t)v * sv] = (float)(l == y ? p - ((y < L) ? scale : 0.0) : p);
             }
         } else {
-            double m = (double)lb[v];
-            for (int l = 1; l < L; ++l) m = fmax(m, (double)lb[(size_t)l * V + v]);
+            double m = (double)lb[(size_t)v * sv];
+            for (int l = 1; l < L; ++l) m = fmax(m, (double)lb[(size_t)l * sl + (size_t)v * sv]);
             double s = 0.0;
-            for (int l = 0; l < L; ++l) s += exp((double)lb[(size_t)l * V + v] - m);
+            for (int l = 0; l < L; ++l) s += exp((double)lb[(size_t)l * sl + (size_t)v * sv] - m);
             const double inv = (y < L) ? scale / s : 0.0;
             for (int l = 0; l < L; ++l) {
-                const double p = exp((double)lb[(size_t)l * V + v] - m) * inv;
-                gb[(size_t)l * V + v] = (float)(l == y ? p - ((y < L) ? scale : 0.0) : p);
+                const double p = exp((double)lb[(size_t)l * sl + (size_t)v * sv] - m) * inv;
+                gb[(size_t)l * sl + (size_t)v * sv] = (float)(l == y ? p - ((y < L) ? scale : 0.0) : p);
             }
         }
     }
@@ -568,50 +600,215 @@ __global__ __launch_bounds__(256) void ce_mean_bwd_kernel(const float* __restric
     }
 }
 
+
+// --------------------------------------------------------------------------------------------
+// K5d — soft-Dice statistics of the segmentation logits (round 4).  Every NexToU trainer's loss holds nnU-Net's (Memory-
+// Efficient)SoftDiceLoss next to the cross-entropy (reference loss/compound_bti_loss.py:29-30, :53-55 -> nnunetv2 dice.py): softmax over
+// the classes, a one-hot scatter of the target, three products and three reductions over the volume — ~8 ms of the cfg-4 step as
+// generic ATen passes over the 99 M logits of the four weighted heads (profiles/r03_cfg4_step_kernel_trace_start.md).  What the loss
+// needs from the volume are three sums per (sample, class):
+//   intersect[b,l] = sum_v w p[b,l,v] [y = l],   sum_pred[b,l] = sum_v w p[b,l,v],   sum_gt[b,l] = sum_v w [y = l]
+// (p = softmax over l in fp32 as ATen computes it, w = loss mask or 1), after which Dice is arithmetic on (B, L) numbers that stays
+// in PyTorch (do_bg, batch_dice, smooth, the DDP all-gather: nnU-Net's own formula on the sums).
+//   fwd: one pass over the logits where they lie -> partial[b][block][l][3] doubles (fixed order; the caller adds the blocks);
+//   bwd: with gi = dLoss/d intersect, gp = dLoss/d sum_pred (device (B, L) doubles): G_l = w (gp[l] + gi[l][y = l]),
+//        grad[k] = p_k (G_k - sum_l G_l p_l) — softmax's Jacobian applied once, written in the logits' layout.
+// Logits element (b, l, v) at b L V + l sl + v sv: (V, 1) planes or (1, L) channels-last rows.  target: uint8 labels; mask: uint8 or NULL.
+// --------------------------------------------------------------------------------------------
+constexpr int kDiceBlocks = 512;
+
+template <int LMAX>
+__global__ __launch_bounds__(256) void dice_stats_fwd_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ target,
+                                                             const uint8_t* __restrict__ mask, double* __restrict__ partial, int L,
+                                                             long long V, long long sl, long long sv) {
+    __shared__ float red[4][3 * LMAX];
+    const int b = blockIdx.y;
+    const float* lb = logits + (size_t)b * L * V;
+    const uint8_t* tb = target + (size_t)b * V;
+    const uint8_t* mb = mask ? mask + (size_t)b * V : nullptr;
+    float si[LMAX], sp[LMAX], sg[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) si[l] = sp[l] = sg[l] = 0.f;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
+        float x[LMAX];
+        if (sl == 1) {
+            const float* base = lb + (size_t)v * sv;
+#pragma unroll
+            for (int l = 0; l < LMAX; l += 2) {
+                float2 t = make_float2(-INFINITY, -INFINITY);
+                if (l + 1 < L) t = *reinterpret_cast<const float2*>(base + l);
+                x[l] = t.x;
+                if (l + 1 < LMAX) x[l + 1] = t.y;
+            }
+        } else {
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) x[l] = l < L ? lb[(size_t)l * sl + v] : -INFINITY;
+        }
+        const int y = tb[v];
+        const float w = mb ? (mb[v] ? 1.f : 0.f) : 1.f;
+        float m = x[0];
+#pragma unroll
+        for (int l = 1; l < LMAX; ++l) m = fmaxf(m, x[l]);
+        float e[LMAX], ssum = 0.f;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) { e[l] = l < L ? expf(x[l] - m) : 0.f; ssum += e[l]; }
+        const float inv = w / ssum;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            const float p = e[l] * inv;            // w * softmax
+            sp[l] += p;
+            if (l == y) { si[l] += p; sg[l] += w; }
+        }
+    }
+    // lanes -> wave (fp32 tree over <= a few dozen addends each), waves -> block in double, fixed order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+        float a = si[l], c = sp[l], d = sg[l];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); c += __shfl_xor(c, off); d += __shfl_xor(d, off); }
+        if (lane == 0) { red[wave][3 * l] = a; red[wave][3 * l + 1] = c; red[wave][3 * l + 2] = d; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * L; i += blockDim.x)
+        partial[((size_t)b * gridDim.x + blockIdx.x) * 3 * L + i] =
+            (((double)red[0][i] + (double)red[1][i]) + (double)red[2][i]) + (double)red[3][i];
+}
+
+template <int LMAX>
+__global__ __launch_bounds__(256) void dice_stats_bwd_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ target,
+                                                             const uint8_t* __restrict__ mask, const double* __restrict__ g_inter,
+                                                             const double* __restrict__ g_pred, float* __restrict__ grad, int L,
+                                                             long long V, long long sl, long long sv) {
+    __shared__ float gi_s[LMAX], gp_s[LMAX];
+    const int b = blockIdx.y;
+    if (threadIdx.x < LMAX) {
+        gi_s[threadIdx.x] = threadIdx.x < L ? (float)g_inter[(size_t)b * L + threadIdx.x] : 0.f;
+        gp_s[threadIdx.x] = threadIdx.x < L ? (float)g_pred[(size_t)b * L + threadIdx.x] : 0.f;
+    }
+    __syncthreads();
+    float gi[LMAX], gp[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) { gi[l] = gi_s[l]; gp[l] = gp_s[l]; }
+    const float* lb = logits + (size_t)b * L * V;
+    float* gb = grad + (size_t)b * L * V;
+    const uint8_t* tb = target + (size_t)b * V;
+    const uint8_t* mb = mask ? mask + (size_t)b * V : nullptr;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
+        float x[LMAX];
+        if (sl == 1) {
+            const float* base = lb + (size_t)v * sv;
+#pragma unroll
+            for (int l = 0; l < LMAX; l += 2) {
+                float2 t = make_float2(-INFINITY, -INFINITY);
+                if (l + 1 < L) t = *reinterpret_cast<const float2*>(base + l);
+                x[l] = t.x;
+                if (l + 1 < LMAX) x[l + 1] = t.y;
+            }
+        } else {
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) x[l] = l < L ? lb[(size_t)l * sl + v] : -INFINITY;
+        }
+        const int y = tb[v];
+        const float w = mb ? (mb[v] ? 1.f : 0.f) : 1.f;
+        float m = x[0];
+#pragma unroll
+        for (int l = 1; l < LMAX; ++l) m = fmaxf(m, x[l]);
+        float e[LMAX], ssum = 0.f;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) { e[l] = l < L ? expf(x[l] - m) : 0.f; ssum += e[l]; }
+        const float inv = 1.f / ssum;
+        float dot = 0.f;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            e[l] *= inv;                                            // p_l
+            const float G = w * (gp[l] + (l == y ? gi[l] : 0.f));
+            x[l] = G;
+            dot = fmaf(G, e[l], dot);
+        }
+        if (sl == 1) {
+            float* base = gb + (size_t)v * sv;
+#pragma unroll
+            for (int l = 0; l < LMAX; l += 2)
+                if (l + 1 < L) *reinterpret_cast<float2*>(base + l) = make_float2(e[l] * (x[l] - dot), e[l + 1 < LMAX ? l + 1 : l] * (x[l + 1 < LMAX ? l + 1 : l] - dot));
+        } else {
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l)
+                if (l < L) gb[(size_t)l * sl + v] = e[l] * (x[l] - dot);
+        }
+    }
+}
+
 }  // namespace nextou
 
 extern "C" int nextou_bti_ce_partials(void) { return kCeBlocks; }
 
+static int check_strides(const char* who, int L, long long V, long long sl, long long sv) {
+    NEXTOU_REQUIRE((sl == 1 && sv == L) || (sl == V && sv == 1), "%s: strides (%lld, %lld) are neither channels-last rows (1, L) nor planes (V, 1)",
+                   who, sl, sv);
+    return 0;
+}
+
 extern "C" int nextou_bti_ce_fwd(const float* logits, const uint8_t* target, const uint8_t* critical,
-                                 double* partial, int B, int L, int64_t V, nextou_stream_t stream) {
+                                 double* partial, int B, int L, int64_t V, int64_t stride_l, int64_t stride_v, nextou_stream_t stream) {
     NEXTOU_REQUIRE(logits && target && critical && partial, "bti_ce_fwd: null pointer");
     NEXTOU_REQUIRE(B > 0 && L > 0 && L <= 256 && V > 0 && B <= 65535, "bti_ce_fwd: bad size B=%d L=%d V=%lld", B, L, (long long)V);
+    if (int e = check_strides("bti_ce_fwd", L, V, stride_l, stride_v)) return e;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(s, kBoundHbm, (4.0 * L + 2.0) * B * (double)V, "bti_ce_fwd_kernel[B%d L%d V%lld]", B, L, (long long)V);
+    ProfScope prof(s, kBoundHbm, (4.0 * L + 2.0) * B * (double)V, "bti_ce_fwd_kernel[B%d L%d V%lld %s]", B, L, (long long)V,
+                   stride_l == 1 ? "rows" : "planes");
     if (L <= 16)
-        hipLaunchKernelGGL(bti_ce_fwd_kernel<16>, dim3(kCeBlocks, B), dim3(256), 0, s, logits, target, critical, partial, L, (long long)V);
+        hipLaunchKernelGGL(bti_ce_fwd_kernel<16>, dim3(kCeBlocks, B), dim3(256), 0, s, logits, target, critical, partial, L, (long long)V,
+                           (long long)stride_l, (long long)stride_v);
     else
-        hipLaunchKernelGGL(bti_ce_fwd_kernel<0>, dim3(kCeBlocks, B), dim3(256), 0, s, logits, target, critical, partial, L, (long long)V);
+        hipLaunchKernelGGL(bti_ce_fwd_kernel<0>, dim3(kCeBlocks, B), dim3(256), 0, s, logits, target, critical, partial, L, (long long)V,
+                           (long long)stride_l, (long long)stride_v);
     return check_launch("bti_ce_fwd_kernel");
 }
 
 extern "C" int nextou_bti_ce_bwd(const float* logits, const uint8_t* target, const uint8_t* critical,
-                                 const double* scale_dev, float* grad_logits, int B, int L, int64_t V,
+                                 const double* scale_dev, float* grad_logits, int B, int L, int64_t V, int64_t stride_l, int64_t stride_v,
                                  nextou_stream_t stream) {
     NEXTOU_REQUIRE(logits && target && critical && scale_dev && grad_logits, "bti_ce_bwd: null pointer");
     NEXTOU_REQUIRE(B > 0 && L > 0 && L <= 256 && V > 0 && B <= 65535, "bti_ce_bwd: bad size B=%d L=%d V=%lld", B, L, (long long)V);
+    if (int e = check_strides("bti_ce_bwd", L, V, stride_l, stride_v)) return e;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(s, kBoundHbm, (8.0 * L + 2.0) * B * (double)V, "bti_ce_bwd_kernel[B%d L%d V%lld]", B, L, (long long)V);
+    ProfScope prof(s, kBoundHbm, (8.0 * L + 2.0) * B * (double)V, "bti_ce_bwd_kernel[B%d L%d V%lld %s]", B, L, (long long)V,
+                   stride_l == 1 ? "rows" : "planes");
     long long blocks = cdiv64(V, 256);
     if (blocks > 8192) blocks = 8192;
     if (L <= 16)
         hipLaunchKernelGGL(bti_ce_bwd_kernel<16>, dim3((unsigned)blocks, B), dim3(256), 0, s, logits, target, critical, scale_dev, grad_logits, L,
-                           (long long)V);
+                           (long long)V, (long long)stride_l, (long long)stride_v);
     else
         hipLaunchKernelGGL(bti_ce_bwd_kernel<0>, dim3((unsigned)blocks, B), dim3(256), 0, s, logits, target, critical, scale_dev, grad_logits, L,
-                           (long long)V);
+                           (long long)V, (long long)stride_l, (long long)stride_v);
     return check_launch("bti_ce_bwd_kernel");
 }
 
-extern "C" int nextou_argmax_labels(const float* logits, uint8_t* labels, int B, int L, int64_t V,
+extern "C" int nextou_argmax_labels(const float* logits, uint8_t* labels, int B, int L, int64_t V, int64_t stride_l, int64_t stride_v,
                                     nextou_stream_t stream) {
     NEXTOU_REQUIRE(logits && labels, "argmax_labels: null pointer");
     NEXTOU_REQUIRE(B > 0 && L > 0 && L <= 256 && V > 0 && B <= 65535,
                    "argmax_labels: bad size B=%d L=%d V=%lld (L <= 256)", B, L, (long long)V);
+    if (int e = check_strides("argmax_labels", L, V, stride_l, stride_v)) return e;
     hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(s, kBoundHbm, (4.0 * L + 1.0) * B * (double)V, "argmax_labels_kernel[B%d L%d V%lld %s]", B, L, (long long)V,
+                   stride_l == 1 && L > 1 ? "rows" : "planes");
+    if (stride_l == 1 && L > 1) {                       // channels-last rows (L = 1: both layouts are the same bytes)
+        NEXTOU_REQUIRE(L <= 32 && L % 2 == 0 && (reinterpret_cast<uintptr_t>(logits) & 7u) == 0,
+                       "argmax_labels: channels-last rows need an even class count <= 32 and 8-byte aligned logits (L=%d)", L);
+        const long long rows = (long long)B * V;
+        long long blocks = cdiv64(rows, 256);
+        if (blocks > 16384) blocks = 16384;
+        if (L <= 16) hipLaunchKernelGGL(argmax_labels_rows_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, logits, labels, L, rows);
+        else hipLaunchKernelGGL(argmax_labels_rows_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, s, logits, labels, L, rows);
+        return check_launch("argmax_labels_rows_kernel");
+    }
     const bool vec = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15u) == 0) &&
                      ((reinterpret_cast<uintptr_t>(labels) & 3u) == 0);
-    ProfScope prof(s, kBoundHbm, (4.0 * L + 1.0) * B * (double)V, "argmax_labels_kernel[B%d L%d V%lld]", B, L, (long long)V);
     const long long items = vec ? V / 4 : V;
     long long blocks = cdiv64(items, 256);
     if (blocks > 8192) blocks = 8192;  // grid-stride the rest
@@ -658,6 +855,53 @@ extern "C" int nextou_bti_critical_map(const uint8_t* labels, const uint32_t* lu
     else NEXTOU_CRIT(3, true);
 #undef NEXTOU_CRIT
     return check_launch("bti_critical_kernel");
+}
+
+extern "C" int nextou_dice_stats_partials(void) { return kDiceBlocks; }
+
+static int check_dice(const char* who, const void* a, const void* b, const void* c, int B, int L, long long V, long long sl, long long sv) {
+    NEXTOU_REQUIRE(a && b && c, "%s: null pointer", who);
+    NEXTOU_REQUIRE(B > 0 && B <= 65535 && L > 1 && L <= 32 && V > 0, "%s: bad size B=%d L=%d V=%lld (2 <= L <= 32)", who, B, L, V);
+    NEXTOU_REQUIRE((sl == 1 && sv == L && L % 2 == 0 && (reinterpret_cast<uintptr_t>(a) & 7u) == 0) || (sl == V && sv == 1),
+                   "%s: strides (%lld, %lld) are neither channels-last rows (1, L; L even, 8-byte aligned) nor planes (V, 1)", who, sl, sv);
+    return 0;
+}
+
+extern "C" int nextou_dice_stats_fwd(const float* logits, const uint8_t* target, const uint8_t* mask, double* partial, int B, int L,
+                                     int64_t V, int64_t stride_l, int64_t stride_v, nextou_stream_t stream) {
+    if (int e = check_dice("dice_stats_fwd", logits, target, partial, B, L, V, stride_l, stride_v)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(s, kBoundHbm, (4.0 * L + (mask ? 2.0 : 1.0)) * B * (double)V, "dice_stats_fwd_kernel[B%d L%d V%lld %s]", B, L, (long long)V,
+                   stride_l == 1 ? "rows" : "planes");
+    const dim3 grid(kDiceBlocks, B), block(256);
+    if (L <= 16)
+        hipLaunchKernelGGL(dice_stats_fwd_kernel<16>, grid, block, 0, s, logits, target, mask, partial, L, (long long)V, (long long)stride_l,
+                           (long long)stride_v);
+    else
+        hipLaunchKernelGGL(dice_stats_fwd_kernel<32>, grid, block, 0, s, logits, target, mask, partial, L, (long long)V, (long long)stride_l,
+                           (long long)stride_v);
+    return check_launch("dice_stats_fwd_kernel");
+}
+
+extern "C" int nextou_dice_stats_bwd(const float* logits, const uint8_t* target, const uint8_t* mask, const double* g_intersect,
+                                     const double* g_sum_pred, float* grad_logits, int B, int L, int64_t V, int64_t stride_l,
+                                     int64_t stride_v, nextou_stream_t stream) {
+    if (int e = check_dice("dice_stats_bwd", logits, target, grad_logits, B, L, V, stride_l, stride_v)) return e;
+    NEXTOU_REQUIRE(g_intersect && g_sum_pred, "dice_stats_bwd: null gradient");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(s, kBoundHbm, (8.0 * L + (mask ? 2.0 : 1.0)) * B * (double)V, "dice_stats_bwd_kernel[B%d L%d V%lld %s]", B, L, (long long)V,
+                   stride_l == 1 ? "rows" : "planes");
+    long long blocks = cdiv64(V, 256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    const dim3 grid((unsigned)blocks, B), block(256);
+    if (L <= 16)
+        hipLaunchKernelGGL(dice_stats_bwd_kernel<16>, grid, block, 0, s, logits, target, mask, g_intersect, g_sum_pred, grad_logits, L,
+                           (long long)V, (long long)stride_l, (long long)stride_v);
+    else
+        hipLaunchKernelGGL(dice_stats_bwd_kernel<32>, grid, block, 0, s, logits, target, mask, g_intersect, g_sum_pred, grad_logits, L,
+                           (long long)V, (long long)stride_l, (long long)stride_v);
+    return check_launch("dice_stats_bwd_kernel");
 }
 
 extern "C" int nextou_ce_mean_partials(void) { return kCeMeanBlocks; }

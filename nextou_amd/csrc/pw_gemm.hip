@@ -1395,17 +1395,32 @@ extern "C" int nextou_pw_rows(const float* x, const float* w, const float* bias,
     return dispatch_rows<0, 0>(q, x, w, bias, y, (int)P, N, K, groups, (long)ldx, (long)ldy, vec_store, PwFuse{}, s);
 }
 
-extern "C" int nextou_pw_rows_tiles(int64_t P, int N, int K, int groups) {
+// Which kernel a fused launch takes and how many statistics partials per channel it writes — ONE function for the launch and for the
+// size query (the query assumed dense rows and no prologue while the launch re-planned with the caller's strides, so a strided
+// caller of the C-ABI was told the stationary kernel's count and got pw_rows_kernel's many more partials written past its buffer).
+struct FusedChoice { int kind, tiles; GrpPlan gp; SwPlan sw; RowsPlan q; };     // kind: 0 grouped rows, 1 stationary weights, 2 LDS-tiled
+static FusedChoice choose_rows_fused(int64_t P, int N, int K, int groups, int64_t ldx, int64_t ldy, bool pro, int epi) {
+    FusedChoice c{};
+    c.q = plan_rows((int)P, N, groups);
+    if (!pro && epi != 2 && groups > 1) {
+        c.gp = plan_rows_grp(P, N, K, groups, ldx, ldy);
+        if (c.gp.ok) { c.kind = 0; c.tiles = c.gp.grid; return c; }
+    }
+    c.sw = ldx == (int64_t)groups * K ? plan_rows_sw(P, N, K, groups, pro) : SwPlan{-1, 0, 0, 0, 0, 0, 0};
+    if (c.sw.cfg >= 0) { c.kind = 1; c.tiles = c.sw.grid; return c; }
+    c.kind = 2;
+    c.tiles = c.q.nb_p;
+    return c;
+}
+
+extern "C" int nextou_pw_rows_tiles(int64_t P, int N, int K, int groups, int64_t ldx, int64_t ldy, int prologue, int grad_stats) {
     if (P <= 0 || N <= 0 || K <= 0 || groups <= 0) return 0;
-    const GrpPlan gp = plan_rows_grp(P, N, K, groups, (int64_t)groups * K, (int64_t)groups * N);
-    if (gp.ok) return gp.grid;
-    const SwPlan sw = plan_rows_sw(P, N, K, groups, false);
-    if (sw.cfg >= 0) return sw.grid;
-    return plan_rows((int)P, N, groups).nb_p;
+    return choose_rows_fused(P, N, K, groups, ldx, ldy, prologue != 0, grad_stats ? 2 : 1).tiles;
 }
 
 extern "C" int nextou_pw_rows_fused(const float* x, const float* w, float* y, int64_t P, int N, int K, int groups, int64_t ldx, int64_t ldy,
-                                    const float* pro_scale, const float* pro_shift, float pro_slope, double* stats_partial, const float* bwd_h, int64_t ldh, const float* bwd_weight,
+                                    const float* pro_scale, const float* pro_shift, float pro_slope, double* stats_partial, int stats_tiles,
+                                    const float* bwd_h, int64_t ldh, const float* bwd_weight,
                                     const float* bwd_bias, const float* bwd_mean, const float* bwd_invstd, float bwd_slope,
                                     nextou_stream_t stream) {
     NEXTOU_REQUIRE(x && w && y, "pw_rows_fused: null pointer");
@@ -1421,7 +1436,11 @@ extern "C" int nextou_pw_rows_fused(const float* x, const float* w, float* y, in
                                 aligned16(bwd_invstd)),
                    "pw_rows_fused: the gradient-statistics epilogue needs partials, h (row stride %lld) and the norm's four vectors", (long long)ldh);
     NEXTOU_REQUIRE(!(pro && epi == 2), "pw_rows_fused: prologue + gradient-statistics epilogue is not an instantiated combination");
-    const RowsPlan q = plan_rows((int)P, N, groups);
+    const FusedChoice ch = choose_rows_fused(P, N, K, groups, ldx, ldy, pro, epi);
+    NEXTOU_REQUIRE(epi == 0 || stats_tiles == ch.tiles,
+                   "pw_rows_fused: stats_partial was sized for %d partials per channel, this launch writes %d — size it with "
+                   "nextou_pw_rows_tiles(P, N, K, groups, ldx, ldy, prologue, grad_stats) of the SAME arguments", stats_tiles, ch.tiles);
+    const RowsPlan& q = ch.q;
     PwFuse fz{};
     fz.pro_scale = pro_scale; fz.pro_shift = pro_shift; fz.pro_slope = pro_slope;
     fz.partial = reinterpret_cast<double2*>(stats_partial);
@@ -1429,18 +1448,15 @@ extern "C" int nextou_pw_rows_fused(const float* x, const float* w, float* y, in
     fz.epi_slope = bwd_slope;
     hipStream_t s = (hipStream_t)stream;
     const int Pi = (int)P;
-    if (!pro && epi != 2 && groups > 1) {
-        // (nextou_pw_rows_tiles assumes dense rows; a strided caller gets the same plan as long as the strides cover the row)
-        const GrpPlan gp = plan_rows_grp(P, N, K, groups, ldx, ldy);
-        if (gp.ok) {
-            ProfScope prof(s, kBoundHbm, 8.0 * (double)P * groups * K, "pw_rows_grp_kernel<%d,%d|%s>[P%lld N%d K%d g%d]", gp.nt, gp.ksteps,
-                           epi == 1 ? "stats" : "plain", (long long)P, N, K, groups);
-            if (epi == 1) return dispatch_rows_grp<1>(gp, x, w, y, Pi, N, K, groups, (long)ldx, (long)ldy, fz.partial, s);
-            return dispatch_rows_grp<0>(gp, x, w, y, Pi, N, K, groups, (long)ldx, (long)ldy, nullptr, s);
-        }
+    if (ch.kind == 0) {
+        const GrpPlan& gp = ch.gp;
+        ProfScope prof(s, kBoundHbm, 8.0 * (double)P * groups * K, "pw_rows_grp_kernel<%d,%d|%s>[P%lld N%d K%d g%d]", gp.nt, gp.ksteps,
+                       epi == 1 ? "stats" : "plain", (long long)P, N, K, groups);
+        if (epi == 1) return dispatch_rows_grp<1>(gp, x, w, y, Pi, N, K, groups, (long)ldx, (long)ldy, fz.partial, s);
+        return dispatch_rows_grp<0>(gp, x, w, y, Pi, N, K, groups, (long)ldx, (long)ldy, nullptr, s);
     }
-    const SwPlan sw = ldx == (int64_t)groups * K ? plan_rows_sw(P, N, K, groups, pro) : SwPlan{-1, 0, 0, 0, 0, 0, 0};
-    if (sw.cfg >= 0) {
+    if (ch.kind == 1) {
+        const SwPlan& sw = ch.sw;
         ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K, "pw_rows_sw_kernel<%d,%d|%s%s>[P%lld N%d K%d]", sw.tnw, sw.nw, pro ? "norm-act," : "",
                        epi == 2 ? "grad-stats" : (epi == 1 ? "stats" : "plain"), (long long)P, N, K);
         if (!pro && epi == 1) return dispatch_rows_sw<0, 1>(sw, x, w, y, Pi, N, K, (long)ldx, (long)ldy, fz, s);

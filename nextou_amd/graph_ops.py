@@ -209,13 +209,14 @@ class _HipBackend:
 
     @staticmethod
     def argmax_labels(logits):
+        """logits (B, L, *sp) fp32, dense NCDHW or dense channels-last (read where they lie)."""
         L = _lib.lib()
         B, nl = logits.shape[:2]
-        V = logits[0, 0].numel()
+        V = logits.numel() // (B * nl)
+        sl, sv = _logit_strides(logits, nl, V)
         out = torch.empty((B,) + tuple(logits.shape[2:]), dtype=torch.uint8, device=logits.device)
         with torch.cuda.device(logits.device):
-            rc = L.nextou_argmax_labels(logits.data_ptr(), out.data_ptr(), B, nl, V,
-                                        _stream_ptr(logits.device))
+            rc = L.nextou_argmax_labels(logits.data_ptr(), out.data_ptr(), B, nl, V, sl, sv, _stream_ptr(logits.device))
         _lib.check(rc, "argmax_labels")
         return out
 
@@ -240,11 +241,12 @@ class _HipBackend:
     def bti_ce_fwd(logits, target, critical):
         L_ = _lib.lib()
         B, nl = logits.shape[:2]
-        V = logits[0, 0].numel()
+        V = logits.numel() // (B * nl)
+        sl, sv = _logit_strides(logits, nl, V)
         partial = torch.empty((B, L_.nextou_bti_ce_partials()), dtype=torch.float64, device=logits.device)
         with torch.cuda.device(logits.device):
             rc = L_.nextou_bti_ce_fwd(logits.data_ptr(), target.data_ptr(), critical.data_ptr(), partial.data_ptr(),
-                                      B, nl, V, _stream_ptr(logits.device))
+                                      B, nl, V, sl, sv, _stream_ptr(logits.device))
         _lib.check(rc, "bti_ce_fwd")
         return partial.sum(1)
 
@@ -252,12 +254,41 @@ class _HipBackend:
     def bti_ce_bwd(logits, target, critical, scale):
         L_ = _lib.lib()
         B, nl = logits.shape[:2]
-        V = logits[0, 0].numel()
-        grad = torch.empty_like(logits)
+        V = logits.numel() // (B * nl)
+        sl, sv = _logit_strides(logits, nl, V)
+        grad = torch.empty_like(logits)             # preserves the (dense) layout
         with torch.cuda.device(logits.device):
             rc = L_.nextou_bti_ce_bwd(logits.data_ptr(), target.data_ptr(), critical.data_ptr(), scale.data_ptr(),
-                                      grad.data_ptr(), B, nl, V, _stream_ptr(logits.device))
+                                      grad.data_ptr(), B, nl, V, sl, sv, _stream_ptr(logits.device))
         _lib.check(rc, "bti_ce_bwd")
+        return grad
+
+    @staticmethod
+    def dice_stats_fwd(logits, target, mask):
+        """-> (B, L, 3) float64: (intersect, sum_pred, sum_gt) per sample and class (softmax over L inside the kernel)."""
+        L_ = _lib.lib()
+        B, nl = logits.shape[:2]
+        V = logits.numel() // (B * nl)
+        sl, sv = _logit_strides(logits, nl, V)
+        T = int(L_.nextou_dice_stats_partials())
+        partial = torch.empty((B, T, nl, 3), dtype=torch.float64, device=logits.device)
+        with torch.cuda.device(logits.device):
+            rc = L_.nextou_dice_stats_fwd(logits.data_ptr(), target.data_ptr(), _ptr(mask), partial.data_ptr(), B, nl, V, sl, sv,
+                                          _stream_ptr(logits.device))
+        _lib.check(rc, "dice_stats_fwd")
+        return partial.sum(1)
+
+    @staticmethod
+    def dice_stats_bwd(logits, target, mask, g_inter, g_pred):
+        L_ = _lib.lib()
+        B, nl = logits.shape[:2]
+        V = logits.numel() // (B * nl)
+        sl, sv = _logit_strides(logits, nl, V)
+        grad = torch.empty_like(logits)             # preserves the (dense) layout
+        with torch.cuda.device(logits.device):
+            rc = L_.nextou_dice_stats_bwd(logits.data_ptr(), target.data_ptr(), _ptr(mask), g_inter.data_ptr(), g_pred.data_ptr(),
+                                          grad.data_ptr(), B, nl, V, sl, sv, _stream_ptr(logits.device))
+        _lib.check(rc, "dice_stats_bwd")
         return grad
 
     @staticmethod
@@ -482,15 +513,15 @@ class _HipBackend:
         P = x_cl.numel() // cin
         N, K = w2.shape[0] // groups, w2.shape[1]
         y = _empty_channels_last((x_cl.shape[0], w2.shape[0]) + tuple(x_cl.shape[2:]), x_cl.device)
-        partial = None
+        partial, tiles = None, 0
         if want_stats or bwd is not None:
-            tiles = int(L_.nextou_pw_rows_tiles(P, N, K, groups))
+            tiles = int(L_.nextou_pw_rows_tiles(P, N, K, groups, cin, w2.shape[0], int(pro is not None), int(bwd is not None)))
             partial = torch.empty((w2.shape[0], tiles, 2), dtype=torch.float64, device=x_cl.device)
         ps, psh, pslope = (pro[0], pro[1], float(pro[2])) if pro is not None else (None, None, 1.0)
         bh, bw, bb, bm, bi, bslope = bwd if bwd is not None else (None, None, None, None, None, 1.0)
         with torch.cuda.device(x_cl.device):
             rc = L_.nextou_pw_rows_fused(x_cl.data_ptr(), w2.data_ptr(), y.data_ptr(), P, N, K, groups, cin, w2.shape[0],
-                                         _ptr(ps), _ptr(psh), pslope, _ptr(partial), _ptr(bh), 0 if bh is None else bh.shape[1],
+                                         _ptr(ps), _ptr(psh), pslope, _ptr(partial), tiles, _ptr(bh), 0 if bh is None else bh.shape[1],
                                          _ptr(bw), _ptr(bb), _ptr(bm), _ptr(bi), float(bslope), _stream_ptr(x_cl.device))
         _lib.check(rc, "pw_rows_fused")
         return y, partial
@@ -559,6 +590,22 @@ class _HipBackend:
                                                _stream_ptr(x_cl.device))
         _lib.check(rc, "norm_bwd_apply_rows")
         return gx
+
+
+def _logit_strides(logits, nl, V):
+    """(stride_l, stride_v) of dense logits (B, L, *sp): (1, L) when stored channels-last (even class count: the rows kernels read
+    8-byte pairs), else (V, 1) — the caller made NCDHW-dense tensors of everything else (:func:`_logits_in_place`)."""
+    return (1, nl) if (_dense_channels_last(logits) is not None and nl % 2 == 0 and nl <= 32) else (V, 1)
+
+
+def _logits_in_place(t: torch.Tensor) -> torch.Tensor:
+    """fp32 logits the K5 kernels can read where they lie: dense channels-last with an even class count <= 32 stays as it is,
+    anything else becomes an NCDHW-contiguous fp32 tensor."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.is_cuda and _dense_channels_last(t) is not None and t.shape[1] % 2 == 0 and t.shape[1] <= 32:
+        return t
+    return t.contiguous()
 
 
 def _dhw(sizes, fill=1):
@@ -773,7 +820,7 @@ def critical_cross_entropy(logits: torch.Tensor, target: torch.Tensor, critical:
     logits (B,L,*sp) float32, target / critical (B,*sp) uint8.  The fused replacement of
     ``CrossEntropyLoss(reduction='none')(x.double(), y) * critical`` + sum (reference bti_loss.py:141-143).
     """
-    return _CriticalCE.apply(_f32c(logits), target.contiguous(), critical.contiguous())
+    return _CriticalCE.apply(_logits_in_place(logits), target.contiguous(), critical.contiguous())
 
 
 class _MeanCE(torch.autograd.Function):
@@ -809,6 +856,51 @@ def cross_entropy_mean(logits: torch.Tensor, target: torch.Tensor, ignore_index:
     nnUNetTrainer_NexToU*.py via nnU-Net's RobustCrossEntropyLoss).  fp32 arithmetic as ATen's; float64 partial sums in a fixed order;
     the gradient comes back in the logits' own memory layout (channels-last stays channels-last)."""
     return _MeanCE.apply(logits, target.contiguous(), int(ignore_index))
+
+
+class _DiceStats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, mask):
+        stats = _HIP.dice_stats_fwd(logits, target, mask)                  # (B, L, 3) float64
+        ctx.save_for_backward(logits, target, mask if mask is not None else target.new_empty(0))
+        ctx.has_mask = mask is not None
+        out = stats.to(torch.float32)
+        return out[..., 0].contiguous(), out[..., 1].contiguous(), out[..., 2].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_inter, g_pred, g_gt):
+        logits, target, mask = ctx.saved_tensors
+        gi = torch.zeros(logits.shape[:2], dtype=torch.float64, device=logits.device) if g_inter is None else g_inter.to(torch.float64).contiguous()
+        gp = torch.zeros(logits.shape[:2], dtype=torch.float64, device=logits.device) if g_pred is None else g_pred.to(torch.float64).contiguous()
+        return _HIP.dice_stats_bwd(logits, target, mask if ctx.has_mask else None, gi, gp), None, None
+
+
+def dice_stats_eligible(logits: torch.Tensor, target: torch.Tensor) -> bool:
+    """fp32 device logits (B, 2 <= L <= 32, *spatial), dense in NCDHW or channels-last memory, outside autocast; a label-map target
+    (B, 1, *spatial) or (B, *spatial) of any real dtype (not one-hot).  ``NEXTOU_FUSED_DICE=0`` keeps nnU-Net's op sequence (A/B)."""
+    import os
+    if os.environ.get("NEXTOU_FUSED_DICE", "1") == "0":
+        return False
+    if not logits.is_cuda or logits.dtype != torch.float32 or logits.dim() < 3 or not 2 <= logits.shape[1] <= 32:
+        return False
+    if torch.is_autocast_enabled("cuda") or target.device != logits.device or target.is_complex():
+        return False
+    if tuple(target.shape) not in ((logits.shape[0], 1) + tuple(logits.shape[2:]), (logits.shape[0],) + tuple(logits.shape[2:])):
+        return False
+    return logits.is_contiguous() or _dense_channels_last(logits) is not None
+
+
+def dice_stats(logits: torch.Tensor, target: torch.Tensor, loss_mask: Optional[torch.Tensor] = None):
+    """``(intersect, sum_pred, sum_gt)``, each (B, L) float32: the volume sums of nnU-Net's soft Dice with ``softmax(x, 1)`` as its
+    non-linearity — ``sum_v w p [y = l]``, ``sum_v w p``, ``sum_v w [y = l]`` (w = ``loss_mask`` or 1) — from ONE pass over the logits
+    where they lie (K5d, csrc/bti_critical.hip); the gradient w.r.t. the logits is one more pass.  Reference call sites:
+    loss/compound_bti_loss.py:29-30, :53-55 (nnunetv2 SoftDiceLoss / MemoryEfficientSoftDiceLoss with softmax_helper_dim1)."""
+    y = target[:, 0] if target.dim() == logits.dim() else target
+    y = y.to(torch.uint8).contiguous()
+    m = None
+    if loss_mask is not None:
+        m = (loss_mask[:, 0] if loss_mask.dim() == logits.dim() else loss_mask).to(torch.uint8).contiguous()
+    return _DiceStats.apply(_logits_in_place(logits), y, m)
 
 
 class _NormAct(torch.autograd.Function):
@@ -1481,7 +1573,7 @@ def conv_own_bias_grad(x, weight, bias, stride, padding, dilation, transposed, o
 @torch.no_grad()
 def argmax_labels(logits: torch.Tensor) -> torch.Tensor:
     """uint8 arg-max over dim 1 (first index on ties) of (B,L,*spatial) float32 logits."""
-    logits = _f32c(logits.detach())
+    logits = _logits_in_place(logits.detach())
     return _backend_for(logits).argmax_labels(logits)
 
 

@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 try:
-    from nnunetv2.training.loss.dice import MemoryEfficientSoftDiceLoss, SoftDiceLoss  # type: ignore
+    from nnunetv2.training.loss.dice import MemoryEfficientSoftDiceLoss as _BaseMEDice, SoftDiceLoss as _BaseSoftDice  # type: ignore
     from nnunetv2.training.loss.robust_ce_loss import RobustCrossEntropyLoss as _BaseRobustCE  # type: ignore
     from nnunetv2.training.loss.deep_supervision import DeepSupervisionWrapper  # type: ignore
     from nnunetv2.utilities.helpers import softmax_helper_dim1  # type: ignore
@@ -41,7 +41,7 @@ except ImportError:
             dist.all_reduce(grad, op=dist.ReduceOp.SUM)
             return grad[dist.get_rank()]
 
-    class MemoryEfficientSoftDiceLoss(nn.Module):
+    class _BaseMEDice(nn.Module):
         def __init__(self, apply_nonlin=None, batch_dice: bool = False, do_bg: bool = True, smooth: float = 1.,
                      ddp: bool = True):
             super().__init__()
@@ -78,7 +78,7 @@ except ImportError:
             dc = (2 * intersect + self.smooth) / (torch.clip(sum_gt + sum_pred + self.smooth, 1e-8))
             return -dc.mean()
 
-    SoftDiceLoss = MemoryEfficientSoftDiceLoss  # same value; the memory-hungry variant is not needed
+    _BaseSoftDice = _BaseMEDice  # same value; the memory-hungry variant is not needed
 
     class _BaseRobustCE(nn.CrossEntropyLoss):
         """CrossEntropyLoss that accepts a (B,1,...) float target (restatement of nnU-Net's class)."""
@@ -123,3 +123,41 @@ class RobustCrossEntropyLoss(_BaseRobustCE):
             if graph_ops.cross_entropy_mean_eligible(input, t):
                 return graph_ops.cross_entropy_mean(input, t, self.ignore_index)
         return super().forward(input, target)
+
+
+def _gathered_sum(t: torch.Tensor) -> torch.Tensor:
+    """batch-dice under DDP: all-gather with gradient, summed over the ranks (nnU-Net's AllGatherGrad / the restatement above)."""
+    if HAVE_NNUNET:
+        from nnunetv2.utilities.ddp_allgather import AllGatherGrad  # type: ignore
+        return AllGatherGrad.apply(t).sum(0)
+    return _AllGatherGrad.apply(t).sum(0)
+
+
+class _FusedDiceMixin:
+    """nnU-Net's soft Dice with the three volume reductions as ONE kernel each way (K5d, ``graph_ops.dice_stats``): with
+    ``softmax_helper_dim1`` as the non-linearity and a label-map target, ``intersect``, ``sum_pred`` and ``sum_gt`` come from a single
+    pass over the logits in their own layout, and the rest — ``do_bg``, ``batch_dice`` (+ DDP all-gather), ``smooth``, the clip, the mean
+    — is the base class's formula on (B, L) numbers.  Anything else (one-hot targets, another non-linearity, CPU, reduced precision)
+    takes the base class unchanged.  2 tp + fp + fn = sum_pred + sum_gt, so the same sums serve SoftDiceLoss."""
+
+    def forward(self, x, y, loss_mask=None):
+        from .. import graph_ops
+        if self.apply_nonlin is softmax_helper_dim1 and graph_ops.dice_stats_eligible(x, y):
+            intersect, sum_pred, sum_gt = graph_ops.dice_stats(x, y, loss_mask)
+            if not self.do_bg:
+                intersect, sum_pred, sum_gt = intersect[:, 1:], sum_pred[:, 1:], sum_gt[:, 1:]
+            if self.batch_dice:
+                if getattr(self, "ddp", False):
+                    intersect, sum_pred, sum_gt = _gathered_sum(intersect), _gathered_sum(sum_pred), _gathered_sum(sum_gt)
+                intersect, sum_pred, sum_gt = intersect.sum(0), sum_pred.sum(0), sum_gt.sum(0)
+            dc = (2 * intersect + self.smooth) / (torch.clip(sum_gt + sum_pred + self.smooth, 1e-8))
+            return -dc.mean()
+        return super().forward(x, y, loss_mask)
+
+
+class MemoryEfficientSoftDiceLoss(_FusedDiceMixin, _BaseMEDice):
+    pass
+
+
+class SoftDiceLoss(_FusedDiceMixin, _BaseSoftDice):
+    pass

@@ -462,6 +462,81 @@ def test_fused_mean_cross_entropy(ops, monkeypatch, shape, classes, layout):
         assert abs(float(ce(x, t.unsqueeze(1).float())) - float(want)) <= 1e-5 * abs(float(want))
 
 
+def test_fused_rows_partial_count_follows_the_launch(ops):
+    """nextou_pw_rows_tiles sized the statistics buffer from the dense plan while a strided launch fell back to the
+    LDS-tiled kernel and wrote its (many more) partials past the caller's buffer.  Now the size query takes the launch's strides and
+    flags, the launch re-checks the count it is handed, and strided rows give the numbers of their dense copy."""
+    from nextou_amd import _lib
+    L = _lib.lib()
+    P, K, N = 70000, 132, 264
+    x_wide = torch.randn(P, K + 12, device=DEV)                   # rows with a 12-float tail: ldx = 144 > K
+    x = x_wide[:, :K]
+    w = (torch.randn(N, K, device=DEV) * 0.1).contiguous()
+    dense_tiles = int(L.nextou_pw_rows_tiles(P, N, K, 1, K, N, 0, 0))
+    strided_tiles = int(L.nextou_pw_rows_tiles(P, N, K, 1, K + 12, N, 0, 0))
+    assert strided_tiles != dense_tiles                            # stationary-weights kernel (<= CU count) vs 128-point tiles
+
+    def launch(xp, ldx, tiles):
+        y = torch.empty(P, N, device=DEV)
+        part = torch.full((N, tiles, 2), float("nan"), dtype=torch.float64, device=DEV)
+        guard = torch.zeros(1 << 20, dtype=torch.float64, device=DEV)     # allocated right behind: an overrun would land here
+        rc = L.nextou_pw_rows_fused(xp.data_ptr(), w.data_ptr(), y.data_ptr(), P, N, K, 1, ldx, N, None, None, 1.0, part.data_ptr(), tiles,
+                                    None, 0, None, None, None, None, 1.0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return rc, y, part, guard
+    rc, _, _, _ = launch(x_wide, K + 12, dense_tiles)              # the count of ANOTHER plan: refused, nothing written
+    assert rc != 0 and b"partials per channel" in L.nextou_last_error()
+    rc, y_s, part_s, guard = launch(x_wide, K + 12, strided_tiles)
+    assert rc == 0 and float(guard.abs().sum()) == 0.0 and not bool(torch.isnan(part_s).any())
+    rc, y_d, part_d, _ = launch(x.contiguous(), K, dense_tiles)
+    assert rc == 0
+    ref = x.double() @ w.double().t()
+    for y in (y_s, y_d):
+        assert float((y.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    for part in (part_s, part_d):
+        tot = part.sum(1)
+        assert float((tot[:, 0] - ref.sum(0)).abs().max()) <= 1e-6 * float(ref.abs().sum(0).max())
+        assert float((tot[:, 1] - (ref * ref).sum(0)).abs().max()) <= 1e-6 * float((ref * ref).sum(0).max())
+
+
+@pytest.mark.parametrize("shape,layout,batch_dice,do_bg,masked", [
+    ((2, 14, 9, 21, 17), "cl", False, False, False), ((2, 14, 9, 21, 17), "nc", True, False, True), ((3, 5, 33, 20), "cl", False, True, False),
+    ((1, 20, 6, 10, 11), "cl", True, True, True), ((2, 3, 4000), "nc", False, False, False)])
+def test_fused_soft_dice(ops, monkeypatch, shape, layout, batch_dice, do_bg, masked):
+    """K5d (nextou_dice_stats_fwd / _bwd through graph_ops.dice_stats and the Dice classes of the trainers' losses) against the same
+    Dice module running nnU-Net's op sequence (softmax -> one-hot scatter -> products -> sums) in float64: loss and logit gradient,
+    channels-last and NCDHW logits, odd and > 16 class counts, loss mask, batch dice, background on / off; the three sums themselves
+    against their definition; the gradient keeps the logits' memory layout."""
+    from nextou_amd.loss.nnunet_losses import MemoryEfficientSoftDiceLoss, softmax_helper_dim1
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=gen) * 3).to(DEV)
+    mf = {4: torch.channels_last, 5: torch.channels_last_3d}.get(len(shape))
+    if layout == "cl" and mf is not None:
+        x = x.contiguous(memory_format=mf)
+    x.requires_grad_(True)
+    L = shape[1]
+    y = torch.randint(0, L, (shape[0], 1) + shape[2:], generator=gen).float().to(DEV)       # nnU-Net: (B, 1, ...) float label map
+    mask = (torch.rand((shape[0], 1) + shape[2:], generator=gen) > 0.3).to(DEV) if masked else None
+    assert ops.dice_stats_eligible(x, y)
+    inter, pred, gt = ops.dice_stats(x, y, mask)
+    p = torch.softmax(x.detach().double(), 1)
+    oh = torch.zeros_like(p).scatter_(1, y.long(), 1.0)
+    w = mask.double() if masked else torch.ones_like(y, dtype=torch.float64)
+    axes = tuple(range(2, x.dim()))
+    for got, want in ((inter, (p * oh * w).sum(axes)), (pred, (p * w).sum(axes)), (gt, (oh * w).sum(axes))):
+        assert float((got.double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+    dice = MemoryEfficientSoftDiceLoss(apply_nonlin=softmax_helper_dim1, batch_dice=batch_dice, do_bg=do_bg, smooth=1e-5, ddp=False)
+    loss = dice(x, y, loss_mask=mask)
+    gx, = torch.autograd.grad(loss * 1.3, x)
+    assert L % 2 or gx.stride() == x.stride()                    # (odd class counts go through an NCDHW copy: the rows kernels read pairs)
+    monkeypatch.setenv("NEXTOU_FUSED_DICE", "0")                 # the base class's op sequence, in float64
+    x64 = x.detach().double().contiguous().requires_grad_(True)
+    want = dice(x64, y, loss_mask=mask)
+    gw, = torch.autograd.grad(want * 1.3, x64)
+    assert abs(float(loss) - float(want)) <= 2e-6 * abs(float(want))
+    assert float((gx.double() - gw).abs().max()) <= 5e-6 * float(gw.abs().max())
+
+
 @pytest.mark.parametrize("dims,cin,cout,cskip", [(3, 72, 40, 40), (3, 324, 324, 324), (2, 24, 16, 16)])
 def test_up_convolution_bias_folded_into_the_concatenation(ops, monkeypatch, dims, cin, cout, cskip):
     """norm_act.up_conv_cat (the decoder's cat((up-convolution(x), skip), 1) with the convolution run bias-free and its bias added by the

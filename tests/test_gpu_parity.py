@@ -366,6 +366,16 @@ def test_bti_kernels_vs_oracle_and_reference(ops, ora):
         np.testing.assert_allclose(value.item(), float(g[name + "_loss"]), rtol=1e-10)
         (grad,) = torch.autograd.grad(value, logits)
         np.testing.assert_allclose(grad.cpu().numpy(), g[name + "_grad"], rtol=1e-5, atol=1e-7)
+        # the same from channels-last logits — what the network's heads hand the loss: read where they lie (ABI v9: no (B, L, V) copy);
+        # labels and the critical map identical, the float64 loss to the last bits, the gradient comes back channels-last
+        if logits.shape[1] % 2 == 0:
+            mf = torch.channels_last_3d if logits.dim() == 5 else torch.channels_last
+            cl = logits.detach().contiguous(memory_format=mf).requires_grad_(True)
+            assert torch.equal(ops.argmax_labels(cl), labels)
+            v2 = loss(cl, target)
+            np.testing.assert_allclose(v2.item(), value.item(), rtol=1e-13)
+            (g2,) = torch.autograd.grad(v2, cl)
+            assert g2.is_contiguous(memory_format=mf) and torch.equal(g2.contiguous(), grad)
 
 
 @pytest.mark.parametrize("shape,conn,thick", [((2, 7, 9, 11), 26, 1), ((1, 5, 6, 7), 26, 2), ((2, 9, 10, 13), 6, 1),
@@ -397,6 +407,8 @@ def test_argmax_of_softmax_near_ties_on_gpu(ops, ora):
     near_tie_expectations(got, g["labels"], logits, gap)
     odd = logits[:, :, :59999].contiguous()                     # V % 4 != 0: the scalar kernel
     assert torch.equal(ops.argmax_labels(odd.to(DEV)).cpu(), ora.argmax_labels(odd))
+    rows = logits.reshape(1, 14, 240, 250).to(DEV).contiguous(memory_format=torch.channels_last)      # channels-last rows kernel
+    assert torch.equal(ops.argmax_labels(rows).cpu().reshape(1, -1), want)
     x = torch.tensor([1e-3, float(np.nextafter(np.float32(1e-3), np.float32(1))), -1.0]).reshape(1, 3, 1)
     assert int(ops.argmax_labels(x.to(DEV))) == 0               # the reference says 0, the plain arg-max 1
 
