@@ -173,6 +173,11 @@ int nextou_gather_bwd(const float* gout, const int32_t* idx, float* dsrc,
 int nextou_argmax_labels(const float* logits, uint8_t* labels,
                          int B, int L, int64_t V, int64_t stride_l, int64_t stride_v, nextou_stream_t stream);
 
+/* nextou_labels_u8: a target label map (n values; src_dtype 0 = float32 as nnU-Net hands it, 1 = int64, 2 = uint8) -> the uint8 volume
+ *   the K5 kernels read, truncating as Tensor.long() does; flag[0] |= 1 (device uint32, never cleared here) when a value lies outside
+ *   [0, n_classes) — the case the reference's CrossEntropyLoss raises for (bti_loss.py:141) — so the check needs no host read. */
+int nextou_labels_u8(const void* src, int src_dtype, uint8_t* out, int64_t n, int n_classes, unsigned* flag, nextou_stream_t stream);
+
 int nextou_bti_critical_map(const uint8_t* labels,
                             const uint32_t* lut_a, const uint32_t* lut_c, int n_labels,
                             uint8_t* critical,

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "nextou_gather_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                   c_void_p]),
     "nextou_argmax_labels": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_void_p]),
+    "nextou_labels_u8": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "nextou_bti_ce_partials": (c_int, []),
     "nextou_bti_ce_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_void_p]),
     "nextou_bti_ce_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64,

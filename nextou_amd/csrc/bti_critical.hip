@@ -133,6 +133,33 @@ __global__ __launch_bounds__(256) void argmax_labels_rows_kernel(const float* __
     }
 }
 
+// Target label maps as the uint8 volumes the K5 kernels read, with the range check of the reference's CrossEntropyLoss (which raises
+// for a target outside [0, L), bti_loss.py:141) done on the way: ONE pass over the target instead of ATen's aminmax + .to(uint8), and a
+// device-side flag instead of a host read, so the (B)TI losses validate their targets inside a captured hipGraph step as well.
+// SRC: 0 float32, 1 int64, 2 uint8.  flag[0] |= 1 when any value is outside [0, L) (integer atomic: deterministic).
+template <int SRC>
+__global__ __launch_bounds__(256) void labels_u8_kernel(const void* __restrict__ src, uint8_t* __restrict__ out, long long n, int L,
+                                                        unsigned* __restrict__ flag) {
+    bool bad = false;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        long long v;
+        if (SRC == 0) {
+            const float f = static_cast<const float*>(src)[i];
+            v = (long long)f;                                   // truncation, as Tensor.long() / .to(uint8) do
+            bad |= !(f > -1.0f && f < (float)L);                // NaN and everything that truncates outside [0, L)
+        } else if (SRC == 1) {
+            v = static_cast<const long long*>(src)[i];
+            bad |= v < 0 || v >= L;
+        } else {
+            v = static_cast<const uint8_t*>(src)[i];
+            bad |= v >= L;
+        }
+        out[i] = (uint8_t)v;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
 // Round-1 kernel, kept as the fallback for min_thick > 3: one thread per voxel; the two LUTs live in LDS; neighbour labels come
 // through L1/L2 (each label byte is touched by at most 27 threads of neighbouring rows).  81 memory instructions per voxel at
 // connectivity 26: 96 us for the 2 x 64 x 224 x 192 volume of cfg 4 = 1.4 % of the HBM roofline (profiles/r03_kernel_bench_k5_start.md).
@@ -621,6 +648,7 @@ template <int LMAX>
 __global__ __launch_bounds__(256) void dice_stats_fwd_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ target,
                                                              const uint8_t* __restrict__ mask, double* __restrict__ partial, int L,
                                                              long long V, long long sl, long long sv) {
+    const bool rows = sl == 1 && sv == L && V > 1;          // (V == 1: both layouts are the same bytes -> the strided form)
     __shared__ float red[4][3 * LMAX];
     const int b = blockIdx.y;
     const float* lb = logits + (size_t)b * L * V;
@@ -632,7 +660,7 @@ __global__ __launch_bounds__(256) void dice_stats_fwd_kernel(const float* __rest
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
         float x[LMAX];
-        if (sl == 1) {
+        if (rows) {
             const float* base = lb + (size_t)v * sv;
 #pragma unroll
             for (int l = 0; l < LMAX; l += 2) {
@@ -643,7 +671,7 @@ __global__ __launch_bounds__(256) void dice_stats_fwd_kernel(const float* __rest
             }
         } else {
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) x[l] = l < L ? lb[(size_t)l * sl + v] : -INFINITY;
+            for (int l = 0; l < LMAX; ++l) x[l] = l < L ? lb[(size_t)l * sl + (size_t)v * sv] : -INFINITY;
         }
         const int y = tb[v];
         const float w = mb ? (mb[v] ? 1.f : 0.f) : 1.f;
@@ -681,6 +709,7 @@ __global__ __launch_bounds__(256) void dice_stats_bwd_kernel(const float* __rest
                                                              const uint8_t* __restrict__ mask, const double* __restrict__ g_inter,
                                                              const double* __restrict__ g_pred, float* __restrict__ grad, int L,
                                                              long long V, long long sl, long long sv) {
+    const bool rows = sl == 1 && sv == L && V > 1;
     __shared__ float gi_s[LMAX], gp_s[LMAX];
     const int b = blockIdx.y;
     if (threadIdx.x < LMAX) {
@@ -698,7 +727,7 @@ __global__ __launch_bounds__(256) void dice_stats_bwd_kernel(const float* __rest
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
         float x[LMAX];
-        if (sl == 1) {
+        if (rows) {
             const float* base = lb + (size_t)v * sv;
 #pragma unroll
             for (int l = 0; l < LMAX; l += 2) {
@@ -709,7 +738,7 @@ __global__ __launch_bounds__(256) void dice_stats_bwd_kernel(const float* __rest
             }
         } else {
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) x[l] = l < L ? lb[(size_t)l * sl + v] : -INFINITY;
+            for (int l = 0; l < LMAX; ++l) x[l] = l < L ? lb[(size_t)l * sl + (size_t)v * sv] : -INFINITY;
         }
         const int y = tb[v];
         const float w = mb ? (mb[v] ? 1.f : 0.f) : 1.f;
@@ -728,7 +757,7 @@ __global__ __launch_bounds__(256) void dice_stats_bwd_kernel(const float* __rest
             x[l] = G;
             dot = fmaf(G, e[l], dot);
         }
-        if (sl == 1) {
+        if (rows) {
             float* base = gb + (size_t)v * sv;
 #pragma unroll
             for (int l = 0; l < LMAX; l += 2)
@@ -736,7 +765,7 @@ __global__ __launch_bounds__(256) void dice_stats_bwd_kernel(const float* __rest
         } else {
 #pragma unroll
             for (int l = 0; l < LMAX; ++l)
-                if (l < L) gb[(size_t)l * sl + v] = e[l] * (x[l] - dot);
+                if (l < L) gb[(size_t)l * sl + (size_t)v * sv] = e[l] * (x[l] - dot);
         }
     }
 }
@@ -796,8 +825,8 @@ extern "C" int nextou_argmax_labels(const float* logits, uint8_t* labels, int B,
     if (int e = check_strides("argmax_labels", L, V, stride_l, stride_v)) return e;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(s, kBoundHbm, (4.0 * L + 1.0) * B * (double)V, "argmax_labels_kernel[B%d L%d V%lld %s]", B, L, (long long)V,
-                   stride_l == 1 && L > 1 ? "rows" : "planes");
-    if (stride_l == 1 && L > 1) {                       // channels-last rows (L = 1: both layouts are the same bytes)
+                   stride_l == 1 && stride_v == L && L > 1 && V > 1 ? "rows" : "planes");
+    if (stride_l == 1 && stride_v == L && L > 1 && V > 1) {     // channels-last rows (L = 1 or V = 1: both layouts are the same bytes)
         NEXTOU_REQUIRE(L <= 32 && L % 2 == 0 && (reinterpret_cast<uintptr_t>(logits) & 7u) == 0,
                        "argmax_labels: channels-last rows need an even class count <= 32 and 8-byte aligned logits (L=%d)", L);
         const long long rows = (long long)B * V;
@@ -819,6 +848,24 @@ extern "C" int nextou_argmax_labels(const float* logits, uint8_t* labels, int B,
         hipLaunchKernelGGL(argmax_labels_kernel<false>, dim3((unsigned)blocks, B), dim3(256), 0, s,
                            logits, labels, L, (long long)V);
     return check_launch("argmax_labels_kernel");
+}
+
+extern "C" int nextou_labels_u8(const void* src, int src_dtype, uint8_t* out, int64_t n, int n_classes, unsigned* flag,
+                                nextou_stream_t stream) {
+    NEXTOU_REQUIRE(src && out && flag, "labels_u8: null pointer");
+    NEXTOU_REQUIRE(n > 0 && n_classes > 0 && n_classes <= 256 && src_dtype >= 0 && src_dtype <= 2,
+                   "labels_u8: bad arguments n=%lld classes=%d dtype=%d", (long long)n, n_classes, src_dtype);
+    hipStream_t s = (hipStream_t)stream;
+    const double in_bytes = src_dtype == 0 ? 4.0 : (src_dtype == 1 ? 8.0 : 1.0);
+    ProfScope prof(s, kBoundHbm, (in_bytes + 1.0) * (double)n, "labels_u8_kernel[n%lld]", (long long)n);
+    long long blocks = cdiv64(n, 256 * 8);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (src_dtype == 0) hipLaunchKernelGGL(labels_u8_kernel<0>, grid, block, 0, s, src, out, (long long)n, n_classes, flag);
+    else if (src_dtype == 1) hipLaunchKernelGGL(labels_u8_kernel<1>, grid, block, 0, s, src, out, (long long)n, n_classes, flag);
+    else hipLaunchKernelGGL(labels_u8_kernel<2>, grid, block, 0, s, src, out, (long long)n, n_classes, flag);
+    return check_launch("labels_u8_kernel");
 }
 
 extern "C" int nextou_bti_critical_map(const uint8_t* labels, const uint32_t* lut_a,

@@ -723,7 +723,7 @@ static FusedPlan plan_fused(int B, int N, int M, int K, bool self = false) {
     static const bool window_plan = [] { const char* e = getenv("NEXTOU_KNN_WINDOW"); return !(e && e[0] == '0'); }();
     const bool window = window_plan && small && waves >= 512 && N <= 192 && M <= 192;
     if (window) p.tiles = 6;
-    if (const char* e = getenv("NEXTOU_KNN_TILES")) p.tiles = atoi(e) == 2 ? 2 : (atoi(e) == 6 ? 6 : p.tiles);   // experiments
+    if (const char* e = getenv("NEXTOU_KNN_TILES")) p.tiles = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : (atoi(e) == 6 ? 6 : p.tiles));   // experiments
     const int tm = 32 * p.tiles;
     const int chunks = cdiv(M, tm);
     long long want = cdiv64(2048, waves);
@@ -882,6 +882,7 @@ static int launch_fused_tiles(const FusedArgs& a, const FusedPlan& p, hipStream_
     // 192-wide chunks keep 96 accumulator registers per lane: beside 64 + 32 key registers that spills (54 VGPRs at
     // K = 32), so the network path is taken with 64-wide chunks only
     if (p.tiles == 2) return use_networks(KB) ? launch_fused<KB, 2, true>(a, p, s) : launch_fused<KB, 2, false>(a, p, s);
+    if (p.tiles == 4) return launch_fused<KB, 4, false>(a, p, s);
     return launch_fused<KB, 6, false>(a, p, s);
 }
 

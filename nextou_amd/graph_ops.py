@@ -221,6 +221,18 @@ class _HipBackend:
         return out
 
     @staticmethod
+    def labels_u8(target, n_classes, flag):
+        """target float32 / int64 / uint8 (any shape, contiguous) -> uint8 of the same shape; flag (1,) int32 |= 1 if out of range."""
+        L = _lib.lib()
+        code = {torch.float32: 0, torch.int64: 1, torch.uint8: 2}[target.dtype]
+        out = torch.empty(target.shape, dtype=torch.uint8, device=target.device)
+        with torch.cuda.device(target.device):
+            rc = L.nextou_labels_u8(target.data_ptr(), code, out.data_ptr(), target.numel(), int(n_classes), flag.data_ptr(),
+                                    _stream_ptr(target.device))
+        _lib.check(rc, "labels_u8")
+        return out
+
+    @staticmethod
     def bti_critical(labels, lut_a, lut_c, connectivity, min_thick):
         L = _lib.lib()
         if labels.dim() == 3:
@@ -1483,6 +1495,38 @@ def rows_gemm(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     return y.view(b, *spatial, weight.shape[0]).permute(0, nd - 1, *range(1, nd - 1))
 
 
+def grouped_cm_gemm_eligible(conv: torch.nn.Module, x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """The Pool MRConv's grouped 1x1 convolution (reference torch_nn.py:66-92 inside NexToU_Encoder_Decoder.py:401-418) on the graph
+    kernels' channel-major (B, 2C, N, 1[, 1]) tensor: per sample and group ``Y = W_g X_g`` with the N points contiguous — a strided-batched
+    BLAS GEMM over the (B, groups, 2C / groups, N) view of the same memory.  MIOpen runs this NCDHW grouped convolution through NHWC
+    kernels wrapped in layout transposes; measured on MI355X as GPU kernel time, forward / forward + backward
+    (tools/pool_basicconv_probe.py, profiles/r04_pool_basicconv_probe.md): cfg-2 Pool s2 (2 x 264 x 10 752, 6 groups) 24.5 / 142.9 us
+    against 21.7 / 75.9 us for the batched GEMM, Pool s3 (528 channels) 38.8 / 251.1 against 47.3 / 138.3; level at 1 344 points
+    (53.8 vs 52.5) and behind at 168 (49.4 vs 70.8) — hence from 4 096 points per sample (``NEXTOU_GROUPED_GEMM_MIN_POINTS``, 0 = off)."""
+    import os
+    limit = int(os.environ.get("NEXTOU_GROUPED_GEMM_MIN_POINTS", "4096"))
+    if limit <= 0 or conv.groups < 2 or conv.transposed or isinstance(conv.padding, str):
+        return False
+    if not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or torch.is_autocast_enabled("cuda"):
+        return False
+    if any(k != 1 for k in weight.shape[2:]) or any(v != 1 for v in conv.stride) or any(v != 0 for v in conv.padding) or \
+            any(v != 1 for v in conv.dilation):
+        return False
+    if not x.is_contiguous() or x.shape[1] != conv.groups * weight.shape[1] or weight.shape[0] % conv.groups:
+        return False
+    return x.numel() // (x.shape[0] * x.shape[1]) >= limit
+
+
+def grouped_cm_gemm(x: torch.Tensor, weight: torch.Tensor, groups: int) -> torch.Tensor:
+    """``conv1x1(x, weight, groups)`` (no bias) of a channel-major tensor as ``W_g @ X_g`` per (sample, group); autograd's two gradient
+    GEMMs come with ``matmul`` (the weight gradient sums over the samples)."""
+    b, c = x.shape[:2]
+    spatial = tuple(x.shape[2:])
+    co, ci = weight.shape[0] // groups, weight.shape[1]
+    y = torch.matmul(weight.reshape(groups, co, ci), x.reshape(b, groups, ci, -1))
+    return y.reshape(b, groups * co, *spatial)
+
+
 def flat_depth_eligible(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, output_padding=None) -> bool:
     """A 3-D convolution whose kernel has no extent along the depth axis (NexToU's stage 0: [1,3,3]; the (1,2,2)
     up-convolution; every 1x1x1 head) on a dense channels-last volume IS a 2-D convolution of the (B*D, C, H, W) view of
@@ -1568,6 +1612,21 @@ def conv_own_bias_grad(x, weight, bias, stride, padding, dilation, transposed, o
         return unflat_depth(y, x.shape[0], x.shape[2])
     return _ConvOwnBiasGrad.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation), bool(transposed),
                                   tuple(output_padding), int(groups))
+
+
+@torch.no_grad()
+def checked_label_map(target: torch.Tensor, n_classes: int, flag: torch.Tensor) -> torch.Tensor:
+    """uint8 copy of a label map (float32 as nnU-Net hands it, int64 or uint8) in ONE pass, with the reference's range check
+    (CrossEntropyLoss raises for targets outside [0, L), bti_loss.py:141) recorded in ``flag`` ((1,) int32 on the device, OR-ed) instead
+    of a host read.  Other dtypes are converted by ATen first."""
+    t = target.detach()
+    if t.dtype not in (torch.float32, torch.int64, torch.uint8):
+        t = t.float()
+    t = t.contiguous()
+    if not t.is_cuda:                   # CPU checker path (tests): plain torch
+        flag |= int(bool(((t < 0) | (t >= n_classes)).any()))
+        return t.to(torch.uint8)
+    return _HIP.labels_u8(t, n_classes, flag)
 
 
 @torch.no_grad()

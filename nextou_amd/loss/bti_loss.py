@@ -118,13 +118,16 @@ class BTI_Loss(torch.nn.Module):
         n_classes = x.shape[1]
         if n_classes > 256:
             raise ValueError("BTI_Loss: %d classes do not fit the uint8 label map (at most 256)" % n_classes)
-        bad = None
+        bad, y8 = None, None
         if self.validate_targets == "deferred":
-            lo, hi = torch.aminmax(y.detach())
-            bad = (lo < 0) | (hi >= n_classes)
+            # no host read and no ATen reduction: the uint8 label map the CE kernel needs anyway is produced by one kernel that also
+            # ORs an out-of-range flag on the device
+            flag = torch.zeros(1, dtype=torch.int32, device=y.device)
+            y8 = graph_ops.checked_label_map(y[:, 0], n_classes, flag)
+            bad = flag[0] > 0
             if self._bad_targets is None or self._bad_targets.device != y.device:
                 self._bad_targets = torch.zeros((), dtype=torch.int64, device=y.device)
-            self._bad_targets += bad
+            self._bad_targets += flag[0]
         elif self.validate_targets:
             lo, hi = (float(v) for v in torch.stack(torch.aminmax(y.detach())).tolist())
             if lo < 0 or hi >= n_classes:
@@ -133,7 +136,7 @@ class BTI_Loss(torch.nn.Module):
         critical = self.critical_voxels_from_labels(labels)
         # :141-143  CE(x.double(), y, 'none') * critical, summed over voxels, mean over the batch —
         # one fused float64 kernel that only touches critical voxels
-        per_sample = graph_ops.critical_cross_entropy(x, y[:, 0].to(torch.uint8), critical)
+        per_sample = graph_ops.critical_cross_entropy(x, y[:, 0].to(torch.uint8) if y8 is None else y8, critical)
         loss = per_sample.mean()
         if bad is not None:
             loss = torch.where(bad, torch.full_like(loss, float("nan")), loss)

@@ -53,6 +53,8 @@ class _ConvBiasFolded:
             return graph_ops.pointwise_conv(x, weight, None, self.groups)      # K7: 1x1 convolutions as own f32-MFMA GEMMs
         if graph_ops.rows_gemm_eligible(self, x, weight):
             return graph_ops.rows_gemm(x, weight)                              # small volumes: the BLAS GEMM over the (points, channels) view
+        if graph_ops.grouped_cm_gemm_eligible(self, x, weight):
+            return graph_ops.grouped_cm_gemm(x, weight, self.groups)           # Pool MRConv's grouped 1x1 conv on channel-major rows
         if x.requires_grad and graph_ops.dgrad_as_forward_eligible(self, x):
             return graph_ops.conv_dgrad_as_forward(x, weight, self.padding)    # backward-data as a forward convolution
         if not isinstance(self.padding, str) and self.padding_mode == "zeros" and \

@@ -462,6 +462,36 @@ def test_fused_mean_cross_entropy(ops, monkeypatch, shape, classes, layout):
         assert abs(float(ce(x, t.unsqueeze(1).float())) - float(want)) <= 1e-5 * abs(float(want))
 
 
+def test_pool_mrconv_grouped_conv_as_batched_gemm(ops, monkeypatch):
+    """The Pool MRConv's grouped 1x1 convolution on the channel-major (B, 2C, N, 1, 1) tensor as the strided-batched GEMM
+    (graph_ops.grouped_cm_gemm, reference torch_nn.py:66-92): values and all gradients against the float64 convolution, routing by
+    point count, and the reference's pooled block goldens (g5) through it."""
+    import torch.nn.functional as F
+    import model_cases as mc
+    from nextou_amd.network_architecture.norm_act import ConvBiasFolded3d
+    gen = torch.Generator().manual_seed(5)
+    for B, C2, N, g in ((2, 264, 10752, 6), (1, 48, 5000, 4), (2, 24, 4096, 6)):
+        conv = ConvBiasFolded3d(C2, C2, 1, groups=g, bias=True).to(DEV)
+        x = torch.randn(B, C2, N, 1, 1, generator=gen).to(DEV).requires_grad_(True)
+        assert ops.grouped_cm_gemm_eligible(conv, x, conv.weight)
+        y = conv(x)                                              # bias folded into the norm behind it: not added here
+        gy = torch.randn(y.shape, generator=gen).to(DEV)
+        gx, gw = torch.autograd.grad(y, [x, conv.weight], gy)
+        x64, w64 = x.detach().double().requires_grad_(True), conv.weight.detach().double().requires_grad_(True)
+        y64 = F.conv3d(x64, w64, None, groups=g)
+        gx64, gw64 = torch.autograd.grad(y64, [x64, w64], gy.double())
+        for got, want in ((y, y64), (gx, gx64), (gw, gw64)):
+            assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+        small = torch.randn(B, C2, 1344, 1, 1, device=DEV)
+        assert not ops.grouped_cm_gemm_eligible(conv, small, conv.weight)          # below the measured crossover: MIOpen
+    monkeypatch.setenv("NEXTOU_GROUPED_GEMM_MIN_POINTS", "1")
+    for name in [n for n in mc.BLOCKS if "pool" in n]:
+        for cl in (False, True):
+            out, dx, g_out, g_dx, tape, entries = mc.run_block(name, "train", DEV, teacher_forced=True, channels_last=cl)
+            assert float((out - g_out).abs().max()) <= 2e-5 * max(1.0, float(g_out.abs().max()))
+            assert float((dx - g_dx).abs().max()) <= 5e-5 * max(1.0, float(g_dx.abs().max()))
+
+
 def test_fused_rows_partial_count_follows_the_launch(ops):
     """nextou_pw_rows_tiles sized the statistics buffer from the dense plan while a strided launch fell back to the
     LDS-tiled kernel and wrote its (many more) partials past the caller's buffer.  Now the size query takes the launch's strides and
