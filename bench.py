@@ -146,6 +146,7 @@ def roofline_graph_from(report):
             "K5_argmax_labels": pick(("argmax_labels_kernel",)), "K5_bti_critical": pick(("bti_critical_kernel",)),
             "K5_bti_ce_forward": pick(("bti_ce_fwd_kernel",)), "K5_bti_ce_backward": pick(("bti_ce_bwd_kernel",)),
             "K5_ce_mean_forward": pick(("ce_mean_fwd_kernel",)), "K5_ce_mean_backward": pick(("ce_mean_bwd_kernel",)),
+            "K5_dice_stats_forward": pick(("dice_stats_fwd_kernel",)), "K5_dice_stats_backward": pick(("dice_stats_bwd_kernel",)),
             "K7_pointwise_rows": pick(("pw_rows_kernel", "pw_rows_sw_kernel")),
             "K7_pointwise_wgrad": pick(("pw_wgrad_kernel", "pw_wgrad_so_kernel")),
             "K7_pointwise_rows_worst_shape": worst(("pw_rows_kernel", "pw_rows_sw_kernel")),

@@ -263,9 +263,6 @@ int nextou_ce_mean_bwd(const float* logits, const int64_t* target, const float* 
  *        entries over the batch); either may be NULL.
  *   workspace: nextou_norm_act_workspace_bytes() bytes of device scratch, contents irrelevant.
  *   Sums are float64 in a fixed order: bit-reproducible.
- *   live_channels (ABI v9): 0, or the number of REAL channels of a channels-last tensor whose channels [live_channels, C) are exact
- *        zero padding (network_architecture/channel_pad.py: 33 -> 40, 66 -> 72 inside the plain stages, weight 1 / bias 0 there): the
- *        16-byte pieces that hold only padding are not read (x, gy) — their outputs (zeros) are still written.
  * ---------------------------------------------------------------------------------------- */
 #define NEXTOU_DTYPE_F32  0
 #define NEXTOU_DTYPE_BF16 1
@@ -278,14 +275,14 @@ int nextou_norm_act_fwd(const void* x, const float* weight, const float* bias, c
                         void* y, float* save_mean, float* save_invstd,
                         void* workspace, size_t workspace_bytes,
                         int B, int C, int64_t S, int param_period, int dtype, int channels_last,
-                        int training, float momentum, float eps, float slope, int live_channels, nextou_stream_t stream);
+                        int training, float momentum, float eps, float slope, nextou_stream_t stream);
 
 int nextou_norm_act_bwd(const void* x, const void* gy, const float* weight, const float* bias,
                         const float* save_mean, const float* save_invstd,
                         void* gx, float* gweight, float* gbias,
                         void* workspace, size_t workspace_bytes,
                         int B, int C, int64_t S, int param_period, int dtype, int channels_last,
-                        int training, float slope, int live_channels, nextou_stream_t stream);
+                        int training, float slope, nextou_stream_t stream);
 
 /* Per-channel sum over batch and space: out[c] = sum_{b,s} x[b,c,s] (float64 accumulation, fixed order) — the bias
  * gradient of a convolution that is not followed by a norm (segmentation heads, transposed convolutions), which

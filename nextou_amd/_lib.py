@@ -71,10 +71,10 @@ _SIGNATURES = {
     "nextou_norm_act_workspace_bytes": (c_size_t, [c_int, c_int, c_int64, c_int]),
     "nextou_norm_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_int, c_int, c_int64, c_int, c_int, c_int, c_int,
-                                    c_float, c_float, c_float, c_int, c_void_p]),
+                                    c_float, c_float, c_float, c_void_p]),
     "nextou_norm_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_int, c_int, c_int64, c_int, c_int, c_int, c_int,
-                                    c_float, c_int, c_void_p]),
+                                    c_float, c_void_p]),
     "nextou_channel_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int64, c_int, c_int,
                                    c_void_p]),
     "nextou_window_gather": (c_int, [c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),

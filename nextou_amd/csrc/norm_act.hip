@@ -547,22 +547,6 @@ __device__ inline void cl_channels(int C, int (&ch)[VEC]) {
     for (int j = 0; j < VEC; ++j) ch[j] = (threadIdx.x * VEC + j) % C;
 }
 
-// Zero-padded rows (channel_pad.py: 33 -> 40, 66 -> 72 channels inside the plain stages; the pad lanes hold exact zeros): a thread whose
-// VEC channels all lie at or beyond `c_live` (the real channel count) does not LOAD — its inputs are zeros by construction, and what it
-// stores is what it would have computed from them — so the padded tensors cost their real bytes on the read side (round 4, VERDICT r3
-// item 7: 1 of 10 float4 per 160-byte row at C = 40, 1 of 18 at C = 72).
-template <typename T, int VEC>
-__device__ inline void load_live(Pack<T, VEC>& p, const T* ptr, bool live, bool stream) {
-    if (live) {
-        if (stream) p.load_stream(ptr); else p.load(ptr);
-    } else {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) p.v[j] = 0.f;
-    }
-}
-template <int VEC>
-__device__ inline bool cl_thread_live(int C, int c_live) { return (int)((threadIdx.x * VEC) % C) < c_live; }
-
 // LDS meeting point: thread c < C adds the q*VEC partials of channel c in index order.
 template <int VEC>
 __device__ inline void cl_block_sums(const double (&a)[VEC], const double (&b)[VEC], int C, int tact, double2* partial,
@@ -582,8 +566,7 @@ __device__ inline void cl_block_sums(const double (&a)[VEC], const double (&b)[V
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(kThreads) void bn_cl_stats_kernel(const T* __restrict__ x, double2* __restrict__ partial,
-                                                               long long total, int C, int tact, long long span, int c_live) {
-    const bool live = cl_thread_live<VEC>(C, c_live);
+                                                               long long total, int C, int tact, long long span) {
     double s[VEC], q[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) s[j] = q[j] = 0.0;
@@ -595,7 +578,7 @@ __global__ __launch_bounds__(kThreads) void bn_cl_stats_kernel(const T* __restri
         for (; e + 3 * stride < end; e += 4 * stride) {
             Pack<T, VEC> p[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) load_live(p[u], x + e + u * stride, live, true);
+            for (int u = 0; u < 4; ++u) p[u].load_stream(x + e + u * stride);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -603,7 +586,7 @@ __global__ __launch_bounds__(kThreads) void bn_cl_stats_kernel(const T* __restri
         }
         for (; e < end; e += stride) {
             Pack<T, VEC> p;
-            load_live(p, x + e, live, true);
+            p.load_stream(x + e);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { const double v = (double)p.v[j]; s[j] += v; q[j] = fma(v, v, q[j]); }
         }
@@ -657,9 +640,8 @@ __global__ __launch_bounds__(kThreads) void bn_cl_apply_kernel(const T* __restri
                                                                const float* __restrict__ save_mean,
                                                                const float* __restrict__ save_invstd, long long total, int C,
                                                                int tact, long long span, float slope,
-                                                               const T* __restrict__ residual = nullptr, int c_live = 1 << 30) {
+                                                               const T* __restrict__ residual = nullptr) {
     if ((int)threadIdx.x >= tact) return;
-    const bool live = cl_thread_live<VEC>(C, c_live);
     int ch[VEC];
     cl_channels<VEC>(C, ch);
     float scale[VEC], shift[VEC];
@@ -687,7 +669,7 @@ __global__ __launch_bounds__(kThreads) void bn_cl_apply_kernel(const T* __restri
     for (; e + 3 * stride < end; e += 4 * stride) {
         Pack<T, VEC> p[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) load_live(p[u], x + e + u * stride, live, false);
+        for (int u = 0; u < 4; ++u) p[u].load(x + e + u * stride);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -697,7 +679,7 @@ __global__ __launch_bounds__(kThreads) void bn_cl_apply_kernel(const T* __restri
     }
     for (; e < end; e += stride) {
         Pack<T, VEC> p;
-        load_live(p, x + e, live, false);
+        p.load(x + e);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) p.v[j] = leaky(fmaf(p.v[j], scale[j], shift[j]), slope);
         p.store(y + e);
@@ -710,8 +692,7 @@ __global__ __launch_bounds__(kThreads) void bn_cl_bwd_reduce_kernel(const T* __r
                                                                     const float* __restrict__ weight, const float* __restrict__ bias,
                                                                     const float* __restrict__ save_mean,
                                                                     const float* __restrict__ save_invstd, long long total,
-                                                                    int C, int tact, long long span, float slope, int c_live) {
-    const bool live = cl_thread_live<VEC>(C, c_live);
+                                                                    int C, int tact, long long span, float slope) {
     double s1[VEC], s2[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.0;
@@ -734,7 +715,7 @@ __global__ __launch_bounds__(kThreads) void bn_cl_bwd_reduce_kernel(const T* __r
         for (; e + stride < end; e += 2 * stride) {
             Pack<T, VEC> p[2], g[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { load_live(p[u], x + e + u * stride, live, true); load_live(g[u], gy + e + u * stride, live, true); }
+            for (int u = 0; u < 2; ++u) { p[u].load_stream(x + e + u * stride); g[u].load_stream(gy + e + u * stride); }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -748,8 +729,8 @@ __global__ __launch_bounds__(kThreads) void bn_cl_bwd_reduce_kernel(const T* __r
         }
         for (; e < end; e += stride) {
             Pack<T, VEC> p, g;
-            load_live(p, x + e, live, true);
-            load_live(g, gy + e, live, true);
+            p.load_stream(x + e);
+            g.load_stream(gy + e);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float z = fmaf(p.v[j], scale[j], shift[j]);
@@ -783,9 +764,8 @@ __global__ __launch_bounds__(kThreads) void bn_cl_bwd_apply_kernel(const T* __re
                                                                    const float* __restrict__ weight, const float* __restrict__ bias,
                                                                    const float* __restrict__ save_mean,
                                                                    const float* __restrict__ save_invstd, long long total,
-                                                                   int C, int tact, long long span, float slope, int c_live) {
+                                                                   int C, int tact, long long span, float slope) {
     if ((int)threadIdx.x >= tact) return;
-    const bool live = cl_thread_live<VEC>(C, c_live);
     int ch[VEC];
     cl_channels<VEC>(C, ch);
     float scale[VEC], shift[VEC], mean[VEC], invstd[VEC], k1[VEC], k2[VEC];
@@ -807,7 +787,7 @@ __global__ __launch_bounds__(kThreads) void bn_cl_bwd_apply_kernel(const T* __re
     for (; e + stride < end; e += 2 * stride) {
         Pack<T, VEC> p[2], g[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { load_live(p[u], x + e + u * stride, live, false); load_live(g[u], gy + e + u * stride, live, false); }
+        for (int u = 0; u < 2; ++u) { p[u].load(x + e + u * stride); g[u].load(gy + e + u * stride); }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -822,8 +802,8 @@ __global__ __launch_bounds__(kThreads) void bn_cl_bwd_apply_kernel(const T* __re
     }
     for (; e < end; e += stride) {
         Pack<T, VEC> p, g;
-        load_live(p, x + e, live, false);
-        load_live(g, gy + e, live, false);
+        p.load(x + e);
+        g.load(gy + e);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float z = fmaf(p.v[j], scale[j], shift[j]);
@@ -855,7 +835,6 @@ struct NormArgs {
     long long S;
     int wmod, training;
     float momentum, eps, slope;
-    int c_live;       // channels-last: channels at or beyond this index are zero padding that need not be read (0 = all channels are real)
 };
 
 template <typename T, int VEC>
@@ -934,19 +913,16 @@ void launch_cl_fwd(const NormArgs& a, const ClPlan& p, hipStream_t s, const char
     const double bytes = (double)total * sizeof(T);
     const double count = (double)a.B * (double)a.S;
     const size_t lds = (size_t)p.tact * VEC * sizeof(double2);
-    // share of a row that is read at all: the 16-byte pieces that hold at least one real channel (see load_live)
-    const double f = a.c_live > 0 ? (double)(cdiv(a.c_live, VEC) * VEC) / a.C : 1.0;
     if (a.training) {
-        ProfScope prof(s, kBoundHbm, f * bytes, "bn_cl_stats_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
+        ProfScope prof(s, kBoundHbm, bytes, "bn_cl_stats_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
         hipLaunchKernelGGL((bn_cl_stats_kernel<T, VEC>), dim3(p.blocks), dim3(kThreads), lds, s, (const T*)a.x, a.partial,
-                           total, a.C, p.tact, p.span, a.c_live > 0 ? a.c_live : (1 << 30));
+                           total, a.C, p.tact, p.span);
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(kFinThreads), 0, s, a.partial, p.blocks, count, a.pre_bias,
                        a.running_mean, a.running_var, a.save_mean, a.save_invstd, a.training, a.momentum, a.eps);
-    ProfScope prof(s, kBoundHbm, (f + 1.0) * bytes, "bn_cl_apply_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
+    ProfScope prof(s, kBoundHbm, 2.0 * bytes, "bn_cl_apply_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
     hipLaunchKernelGGL((bn_cl_apply_kernel<T, VEC>), dim3(p.blocks), dim3(kThreads), 0, s, (const T*)a.x, (T*)a.y, a.weight,
-                       a.bias, a.save_mean, a.save_invstd, total, a.C, p.tact, p.span, a.slope, (const T*)nullptr,
-                       a.c_live > 0 ? a.c_live : (1 << 30));
+                       a.bias, a.save_mean, a.save_invstd, total, a.C, p.tact, p.span, a.slope);
 }
 
 template <typename T, int VEC>
@@ -956,19 +932,17 @@ void launch_cl_bwd(const NormArgs& a, const ClPlan& p, hipStream_t s, const char
     const double count = (double)a.B * (double)a.S;
     const size_t lds = (size_t)p.tact * VEC * sizeof(double2);
     float2* coeff = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.partial) + kCoeffOffset(a.B, a.C, a.S));
-    const double f = a.c_live > 0 ? (double)(cdiv(a.c_live, VEC) * VEC) / a.C : 1.0;
     {
-        ProfScope prof(s, kBoundHbm, 2.0 * f * bytes, "bn_cl_bwd_reduce_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
+        ProfScope prof(s, kBoundHbm, 2.0 * bytes, "bn_cl_bwd_reduce_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
         hipLaunchKernelGGL((bn_cl_bwd_reduce_kernel<T, VEC>), dim3(p.blocks), dim3(kThreads), lds, s, (const T*)a.x,
                            (const T*)a.gy, a.partial, a.weight, a.bias, a.save_mean, a.save_invstd, total, a.C, p.tact,
-                           p.span, a.slope, a.c_live > 0 ? a.c_live : (1 << 30));
+                           p.span, a.slope);
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.C), dim3(kFinThreads), 0, s, a.partial, p.blocks, count, coeff, a.gweight,
                        a.gbias, a.training);
-    ProfScope prof(s, kBoundHbm, (2.0 * f + 1.0) * bytes, "bn_cl_bwd_apply_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
+    ProfScope prof(s, kBoundHbm, 3.0 * bytes, "bn_cl_bwd_apply_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
     hipLaunchKernelGGL((bn_cl_bwd_apply_kernel<T, VEC>), dim3(p.blocks), dim3(kThreads), 0, s, (const T*)a.x, (const T*)a.gy,
-                       (T*)a.gx, coeff, a.weight, a.bias, a.save_mean, a.save_invstd, total, a.C, p.tact, p.span, a.slope,
-                       a.c_live > 0 ? a.c_live : (1 << 30));
+                       (T*)a.gx, coeff, a.weight, a.bias, a.save_mean, a.save_invstd, total, a.C, p.tact, p.span, a.slope);
 }
 
 
@@ -1333,9 +1307,8 @@ extern "C" size_t nextou_norm_act_workspace_bytes(int B, int C, int64_t S, int d
 extern "C" int nextou_norm_act_fwd(const void* x, const float* weight, const float* bias, const float* pre_bias,
                                    float* running_mean, float* running_var, void* y, float* save_mean, float* save_invstd, void* ws,
                                    size_t ws_bytes, int B, int C, int64_t S, int param_period, int dtype, int channels_last,
-                                   int training, float momentum, float eps, float slope, int live_channels, nextou_stream_t stream) {
+                                   int training, float momentum, float eps, float slope, nextou_stream_t stream) {
     NEXTOU_REQUIRE(x && y, "norm_act_fwd: null pointer");
-    NEXTOU_REQUIRE(live_channels >= 0 && live_channels <= C, "norm_act_fwd: live_channels=%d outside [0, C=%d]", live_channels, C);
     if (int rc = check_common("norm_act_fwd", B, C, S, param_period, dtype, channels_last)) return rc;
     NEXTOU_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "norm_act_fwd: running_mean / running_var must come together");
     NEXTOU_REQUIRE(training || running_mean, "norm_act_fwd: inference needs the running statistics");
@@ -1344,7 +1317,6 @@ extern "C" int nextou_norm_act_fwd(const void* x, const float* weight, const flo
     a.x = x; a.y = y; a.weight = weight; a.bias = bias; a.pre_bias = pre_bias; a.running_mean = running_mean; a.running_var = running_var;
     a.save_mean = save_mean; a.save_invstd = save_invstd; a.partial = (double2*)ws; a.B = B; a.C = C; a.S = S;
     a.wmod = param_period; a.training = training; a.momentum = momentum; a.eps = eps; a.slope = slope;
-    a.c_live = live_channels;
     if (channels_last) {
         NEXTOU_REQUIRE(save_mean && save_invstd, "norm_act_fwd: the channels-last path needs save_mean / save_invstd");
         NEXTOU_REQUIRE(!training || (ws && ws_bytes >= nextou_norm_act_workspace_bytes(B, C, S, dtype)),
@@ -1370,9 +1342,8 @@ extern "C" int nextou_norm_act_fwd(const void* x, const float* weight, const flo
 extern "C" int nextou_norm_act_bwd(const void* x, const void* gy, const float* weight, const float* bias,
                                    const float* save_mean, const float* save_invstd, void* gx, float* gweight,
                                    float* gbias, void* ws, size_t ws_bytes, int B, int C, int64_t S, int param_period,
-                                   int dtype, int channels_last, int training, float slope, int live_channels, nextou_stream_t stream) {
+                                   int dtype, int channels_last, int training, float slope, nextou_stream_t stream) {
     NEXTOU_REQUIRE(x && gy && gx && save_mean && save_invstd && ws, "norm_act_bwd: null pointer");
-    NEXTOU_REQUIRE(live_channels >= 0 && live_channels <= C, "norm_act_bwd: live_channels=%d outside [0, C=%d]", live_channels, C);
     if (int rc = check_common("norm_act_bwd", B, C, S, param_period, dtype, channels_last)) return rc;
     const int esz = dtype == NEXTOU_DTYPE_F32 ? 4 : 2;
     NormArgs a{};
@@ -1380,7 +1351,6 @@ extern "C" int nextou_norm_act_bwd(const void* x, const void* gy, const float* w
     a.save_mean = const_cast<float*>(save_mean); a.save_invstd = const_cast<float*>(save_invstd);
     a.gweight = gweight; a.gbias = gbias; a.partial = (double2*)ws; a.B = B; a.C = C; a.S = S; a.wmod = param_period;
     a.training = training; a.slope = slope;
-    a.c_live = live_channels;
     if (channels_last) {
         if (ws_bytes < nextou_norm_act_workspace_bytes(B, C, S, dtype))
             return fail(NEXTOU_ENOSPACE, "norm_act_bwd: workspace %zu < %zu bytes", ws_bytes, nextou_norm_act_workspace_bytes(B, C, S, dtype));
@@ -1481,10 +1451,10 @@ extern "C" int nextou_norm_bwd_apply_rows(const float* x, const float* gy, float
     ProfScope prof(s, kBoundHbm, 3.0 * bytes, "bn_cl_bwd_apply_kernel<f32>[R%lld C%d]", (long long)rows, C);
     if (p.vec == 4)
         hipLaunchKernelGGL((bn_cl_bwd_apply_kernel<float, 4>), dim3(p.blocks), dim3(kThreads), 0, s, x, gy, gx, k, weight, bias, save_mean, save_invstd,
-                           total, C, p.tact, p.span, slope, 1 << 30);
+                           total, C, p.tact, p.span, slope);
     else
         hipLaunchKernelGGL((bn_cl_bwd_apply_kernel<float, 1>), dim3(p.blocks), dim3(kThreads), 0, s, x, gy, gx, k, weight, bias, save_mean, save_invstd,
-                           total, C, p.tact, p.span, slope, 1 << 30);
+                           total, C, p.tact, p.span, slope);
     return check_launch("bn_cl_bwd_apply_kernel");
 }
 
@@ -1518,14 +1488,14 @@ extern "C" int nextou_channel_sum(const void* x, float* out, void* ws, size_t ws
         tiles = p.blocks;
         const size_t lds = (size_t)p.tact * p.vec * sizeof(double2);
         if (esz == 4) {
-            if (p.vec == 4) hipLaunchKernelGGL((bn_cl_stats_kernel<float, 4>), dim3(p.blocks), dim3(kThreads), lds, s, (const float*)x, partial, total, C, p.tact, p.span, 1 << 30);
-            else hipLaunchKernelGGL((bn_cl_stats_kernel<float, 1>), dim3(p.blocks), dim3(kThreads), lds, s, (const float*)x, partial, total, C, p.tact, p.span, 1 << 30);
+            if (p.vec == 4) hipLaunchKernelGGL((bn_cl_stats_kernel<float, 4>), dim3(p.blocks), dim3(kThreads), lds, s, (const float*)x, partial, total, C, p.tact, p.span);
+            else hipLaunchKernelGGL((bn_cl_stats_kernel<float, 1>), dim3(p.blocks), dim3(kThreads), lds, s, (const float*)x, partial, total, C, p.tact, p.span);
         } else if (dtype == NEXTOU_DTYPE_F16) {
-            if (p.vec == 8) hipLaunchKernelGGL((bn_cl_stats_kernel<__half, 8>), dim3(p.blocks), dim3(kThreads), lds, s, (const __half*)x, partial, total, C, p.tact, p.span, 1 << 30);
-            else hipLaunchKernelGGL((bn_cl_stats_kernel<__half, 1>), dim3(p.blocks), dim3(kThreads), lds, s, (const __half*)x, partial, total, C, p.tact, p.span, 1 << 30);
+            if (p.vec == 8) hipLaunchKernelGGL((bn_cl_stats_kernel<__half, 8>), dim3(p.blocks), dim3(kThreads), lds, s, (const __half*)x, partial, total, C, p.tact, p.span);
+            else hipLaunchKernelGGL((bn_cl_stats_kernel<__half, 1>), dim3(p.blocks), dim3(kThreads), lds, s, (const __half*)x, partial, total, C, p.tact, p.span);
         } else {
-            if (p.vec == 8) hipLaunchKernelGGL((bn_cl_stats_kernel<__hip_bfloat16, 8>), dim3(p.blocks), dim3(kThreads), lds, s, (const __hip_bfloat16*)x, partial, total, C, p.tact, p.span, 1 << 30);
-            else hipLaunchKernelGGL((bn_cl_stats_kernel<__hip_bfloat16, 1>), dim3(p.blocks), dim3(kThreads), lds, s, (const __hip_bfloat16*)x, partial, total, C, p.tact, p.span, 1 << 30);
+            if (p.vec == 8) hipLaunchKernelGGL((bn_cl_stats_kernel<__hip_bfloat16, 8>), dim3(p.blocks), dim3(kThreads), lds, s, (const __hip_bfloat16*)x, partial, total, C, p.tact, p.span);
+            else hipLaunchKernelGGL((bn_cl_stats_kernel<__hip_bfloat16, 1>), dim3(p.blocks), dim3(kThreads), lds, s, (const __hip_bfloat16*)x, partial, total, C, p.tact, p.span);
         }
     } else {
         const TilePlan p = plan_tiles(B, C, S, 16 / esz, aligned16(x));

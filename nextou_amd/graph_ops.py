@@ -334,7 +334,7 @@ class _HipBackend:
 
     @staticmethod
     def norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, period,
-                     pre_bias=None, channels_last=False, live_channels=0):
+                     pre_bias=None, channels_last=False):
         """x (B,C,S) f32/bf16 — or, with ``channels_last``, a dense channels_last(_3d) tensor (B,C,*sp) —
         -> (y, save_mean, save_invstd); running statistics updated in place."""
         L_ = _lib.lib()
@@ -350,13 +350,13 @@ class _HipBackend:
                                         _ptr(running_var),
                                         y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(),
                                         ws.numel(), B, C, S, period, dt, int(channels_last), int(training),
-                                        float(momentum), float(eps), float(slope), int(live_channels), _stream_ptr(x.device))
+                                        float(momentum), float(eps), float(slope), _stream_ptr(x.device))
         _lib.check(rc, "norm_act_fwd")
         return y, save_mean, save_invstd
 
     @staticmethod
     def norm_act_bwd(x, gy, weight, bias, save_mean, save_invstd, training, slope, period, eps=0.0,
-                     channels_last=False, live_channels=0):
+                     channels_last=False):
         """(``eps`` is only read by the CPU checker.)  -> (gx, gweight (C,), gbias (C,)) — per normalised channel;
         the caller folds instance-norm rows.  ``gy`` must have the memory layout of ``x``."""
         L_ = _lib.lib()
@@ -371,7 +371,7 @@ class _HipBackend:
             rc = L_.nextou_norm_act_bwd(x.data_ptr(), gy.data_ptr(), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
                                         save_invstd.data_ptr(), gx.data_ptr(), gw.data_ptr(), gb.data_ptr(),
                                         ws.data_ptr(), ws.numel(), B, C, S, period, dt, int(channels_last),
-                                        int(training), float(slope), int(live_channels), _stream_ptr(x.device))
+                                        int(training), float(slope), _stream_ptr(x.device))
         _lib.check(rc, "norm_act_bwd")
         return gx, gw, gb
 
@@ -951,7 +951,7 @@ class _NormAct(torch.autograd.Function):
         cl = _dense_channels_last(x) if (x.is_cuda and not instance) else None
         if cl is not None:      # NDHWC / NHWC memory goes to the channels-last kernels as it is
             y, mean, invstd = be.norm_act_fwd(x, k_weight, k_bias, k_rm, k_rv, training, momentum, eps,
-                                              slope, 0, k_pre, channels_last=True, **({"live_channels": c_real} if _skip_pad(c_real, C) else {}))
+                                              slope, 0, k_pre, channels_last=True)
             x3 = x
         else:
             x3 = x.contiguous()
@@ -978,8 +978,7 @@ class _NormAct(torch.autograd.Function):
             gy = gy.to(x3.dtype)
         if cl is not None:
             gx, gw, gb = _backend_for(x3).norm_act_bwd(x3, gy.contiguous(memory_format=cl), weight, bias, mean, invstd,
-                                                       training, slope, 0, eps, channels_last=True,
-                                                       **({"live_channels": c_real} if _skip_pad(c_real, C) else {}))
+                                                       training, slope, 0, eps, channels_last=True)
         else:
             gx, gw, gb = _backend_for(x3).norm_act_bwd(x3, gy.contiguous().view(x3.shape), weight, bias, mean, invstd,
                                                        training, slope, period, eps)
@@ -997,12 +996,6 @@ class _NormAct(torch.autograd.Function):
         gw = gw[:c_real].to(weight.dtype) if weight is not None and ctx.needs_input_grad[1] else None
         gb = gb[:c_real].to(bias.dtype) if bias is not None and ctx.needs_input_grad[2] else None
         return gx, gw, gb, None, None, None, None, None, None, None, gpre, None
-
-
-def _skip_pad(c_real: int, C: int) -> bool:
-    """K6 does not read the zero-padding lanes of an internally padded tensor (``NEXTOU_K6_SKIP_PAD=0``: read everything, for A/B)."""
-    import os
-    return c_real != C and os.environ.get("NEXTOU_K6_SKIP_PAD", "1") != "0"
 
 
 def _pad_stage(holder, C: int, c_real: int, device) -> torch.Tensor:

@@ -462,31 +462,6 @@ def test_fused_mean_cross_entropy(ops, monkeypatch, shape, classes, layout):
         assert abs(float(ce(x, t.unsqueeze(1).float())) - float(want)) <= 1e-5 * abs(float(want))
 
 
-@pytest.mark.parametrize("C,c_real,sp", [(40, 33, (6, 20, 24)), (72, 66, (4, 12, 10)), (8, 6, (5, 9, 7))])
-def test_norm_act_skips_the_zero_padding_lanes(ops, C, c_real, sp):
-    """K6 on an internally padded channels-last tensor (channel_pad.py: 33 -> 40, 66 -> 72): with ``live_channels`` the 16-byte pieces that
-    hold only padding are not read — proven by poisoning them with NaN in the gradient — and every real channel's result is bit-identical
-    to the full read; the padding lanes of y and gx come out as exact zeros."""
-    hip = ops._HIP
-    gen = torch.Generator().manual_seed(C)
-    x = torch.randn((2, C) + sp, generator=gen)
-    x[:, c_real:] = 0
-    gy = torch.randn((2, C) + sp, generator=gen)
-    xd, gd = (t.to(DEV).contiguous(memory_format=torch.channels_last_3d) for t in (x, gy))
-    w = torch.ones(C, device=DEV); w[:c_real] = torch.rand(c_real, generator=gen).to(DEV) + 0.5
-    b = torch.zeros(C, device=DEV); b[:c_real] = torch.randn(c_real, generator=gen).to(DEV) * 0.1
-    y0, m0, i0 = hip.norm_act_fwd(xd, w, b, None, None, True, 0.0, 1e-5, 0.01, 0, None, channels_last=True)
-    y1, m1, i1 = hip.norm_act_fwd(xd, w, b, None, None, True, 0.0, 1e-5, 0.01, 0, None, channels_last=True, live_channels=c_real)
-    assert torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(i0, i1) and float(y1[:, c_real:].abs().max()) == 0.0
-    gx0, gw0, gb0 = hip.norm_act_bwd(xd, gd, w, b, m0, i0, True, 0.01, 0, channels_last=True)
-    first_dead = -(-c_real // 4) * 4                    # the first channel of a float4 piece that holds padding only
-    poisoned = gd.clone()
-    poisoned[:, first_dead:] = float("nan")
-    gx1, gw1, gb1 = hip.norm_act_bwd(xd, poisoned, w, b, m0, i0, True, 0.01, 0, channels_last=True, live_channels=c_real)
-    assert torch.equal(gx0[:, :c_real], gx1[:, :c_real]) and torch.equal(gw0[:c_real], gw1[:c_real]) and torch.equal(gb0[:c_real], gb1[:c_real])
-    assert not bool(torch.isnan(gx1[:, :first_dead]).any()) and float(gx1[:, first_dead:].abs().max()) == 0.0
-
-
 def test_pool_mrconv_grouped_conv_as_batched_gemm(ops, monkeypatch):
     """The Pool MRConv's grouped 1x1 convolution on the channel-major (B, 2C, N, 1, 1) tensor as the strided-batched GEMM
     (graph_ops.grouped_cm_gemm, reference torch_nn.py:66-92): values and all gradients against the float64 convolution, routing by
