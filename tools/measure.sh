@@ -1,0 +1,83 @@
+#!/bin/bash
+# One measurement driver for the GPU box (replaces the one-shot tools/r0N_*.sh scripts of rounds 2-4; those are in the git history).
+# Run from the repo root on the box:  tools/gpu_retry.sh <timeout> 'bash tools/measure.sh <task> [tag]'
+#   tests      full `pytest -m gpu` + smoke, tail of the log
+#   margins    the parity tests that print their logit margins (-s), -> <out>/parity_margins.txt
+#   bench      headline bench line (cfg 2, with cpu_baseline) + a second line without
+#   configs    cfg 4, cfg 2 bf16, cfg 5 bf16 bench lines
+#   stages     GNN blocks stand-alone: eager + hipGraph-replay columns, default and NEXTOU_PW_FUSE=0, MIN_POINTS=0
+#   kernels    tools/kernel_bench.py at the cfg-2 and cfg-5 shapes, K5 (--bti), K6 (--norm --cl)
+#   trace      rocprofv3 --kernel-trace --stats of the eager cfg-2 step -> one steady-state step as a markdown table
+#   pmc5       PMC FETCH_SIZE / WRITE_SIZE (separate passes) of the graph kernels at the cfg-5 shapes "s2 Swin" and "s3 Pool"
+#   cpusurvey  bench.py --cpu-protocol survey (batch 2, 1 + 3 steps, all physical cores; ~10 min of host time)
+#   closing    tests margins bench configs stages kernels trace pmc5 in that order
+TASK=${1:-closing}
+TAG=${2:-r04}
+R=$PWD
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+export MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD=0 MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD=0 MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW=0
+export MIOPEN_LOG_LEVEL=1
+
+field() { python -c "import json,sys;d=json.load(open('$1'));print('$(basename $1)', d['ms_per_step'], 'ms/step', round(d['value']/1e6,2), 'Mvox/s graph', d['config']['step_replayed_as_hipgraph'], d['config']['graph_capture_error'])"; }
+
+t_tests() {
+  python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt
+  python -m pytest tests -q -m gpu --durations=10 2>&1 | grep -v "MIOpen\|GridwiseOp\|amdgpu.ids" | tail -26 > $OUT/pytest_gpu_full.txt; tail -4 $OUT/pytest_gpu_full.txt
+}
+t_margins() {
+  python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity2.py tests/test_gpu_fused_goldens.py -q -s -m gpu \
+      -k "tiny_models or forward_parity or equal_conv" 2>&1 | grep -E "max \|dlogit\||teacher-forced|full-size forward|equal \(fp64\)|passed|failed" > $OUT/parity_margins.txt
+  cat $OUT/parity_margins.txt
+}
+t_bench() {
+  python bench.py > $OUT/bench_cfg2_default.json 2> $OUT/bench_cfg2_default.log; field $OUT/bench_cfg2_default.json
+  python bench.py --no-cpu-baseline > $OUT/bench_cfg2_again.json 2> $OUT/bench_cfg2_again.log; field $OUT/bench_cfg2_again.json
+}
+t_configs() {
+  python bench.py --no-cpu-baseline --steps 10 --warmup 3 --workload cfg4 > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.log; field $OUT/bench_cfg4.json
+  python bench.py --no-cpu-baseline --steps 10 --warmup 3 --autocast-bf16 > $OUT/bench_cfg2_bf16.json 2> $OUT/bench_cfg2_bf16.log; field $OUT/bench_cfg2_bf16.json
+  python bench.py --no-cpu-baseline --steps 5 --warmup 3 --workload cfg5 --autocast-bf16 > $OUT/bench_cfg5_bf16.json 2> $OUT/bench_cfg5_bf16.log; field $OUT/bench_cfg5_bf16.json
+}
+t_stages() {
+  python tools/gnn_stage_profile.py --cl --graph --iters 20 > $OUT/gnn_stage_default.txt 2>&1; grep -E "^sum|^as " $OUT/gnn_stage_default.txt
+  NEXTOU_PW_FUSE=0 python tools/gnn_stage_profile.py --cl --graph --iters 20 > $OUT/gnn_stage_unfused.txt 2>&1; grep -E "^sum|^as " $OUT/gnn_stage_unfused.txt
+  NEXTOU_PW_FUSE_MIN_POINTS=0 python tools/gnn_stage_profile.py --cl --graph --iters 20 --stages 3,4,5 > $OUT/gnn_stage_min0.txt 2>&1; grep -E "^sum|^as " $OUT/gnn_stage_min0.txt
+}
+t_kernels() {
+  python tools/kernel_bench.py --cfg 2 --iters 10 > $OUT/kernel_bench_cfg2.txt 2>&1
+  python tools/kernel_bench.py --cfg 5 --iters 5 > $OUT/kernel_bench_cfg5.txt 2>&1
+  python tools/kernel_bench.py --bti --iters 10 > $OUT/kernel_bench_k5.txt 2>&1
+  python tools/kernel_bench.py --norm --cl --iters 10 > $OUT/kernel_bench_norm_cl.txt 2>&1
+  grep -E "knn_fused|mr_" $OUT/kernel_bench_cfg2.txt | head -24
+}
+t_trace() {
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf /tmp/kt_$TAG
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -o kt -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --graph off > $OUT/kt_bench.log 2>&1
+  python $R/tools/rocprof_summary.py /tmp/kt_$TAG $OUT/cfg2_step_kernel_trace.md "cfg 2 train step, eager (rocprofv3 --kernel-trace --stats of python bench.py --steps 4 --warmup 3 --no-cpu-baseline --graph off)" --steady "knn_fused_kernel<28" 2
+  find /tmp/kt_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -40 {} > '$OUT'/rocprofv3_kernel_stats_head.csv'
+  cd $R; head -8 $OUT/cfg2_step_kernel_trace.md | cut -c1-200
+}
+t_pmc5() {
+  cd /tmp && export TMPDIR=/tmp
+  for only in "s2 Swin" "s3 Pool"; do
+    tag=$(echo "$only" | tr " " "_")
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc5_$tag/$c -o pmc -- python $R/tools/kernel_bench.py --cfg 5 --iters 3 --only "$only" > $OUT/pmc5_${tag}_$c.log 2>&1 || tail -3 $OUT/pmc5_${tag}_$c.log
+    done
+    python $R/tools/pmc_table.py $OUT/pmc5_$tag/FETCH_SIZE $OUT/pmc5_$tag/WRITE_SIZE > $OUT/pmc5_$tag.md 2>&1
+    cat $OUT/pmc5_$tag.md | cut -c1-260
+    find $OUT/pmc5_$tag -name "*.csv" -size +2M -delete
+  done
+  cd $R
+}
+t_cpusurvey() {
+  python bench.py --steps 5 --warmup 3 --cpu-protocol survey > $OUT/bench_cfg2_cpu_survey.json 2> $OUT/bench_cfg2_cpu_survey.log
+  python -c "import json;d=json.load(open('$OUT/bench_cfg2_cpu_survey.json'));print(d['cpu_baseline'])"
+}
+case $TASK in
+  closing) for t in tests margins bench configs stages kernels trace pmc5; do echo "== $t"; t_$t; done ;;
+  *) for t in ${TASK//,/ }; do echo "== $t"; t_$t; done ;;
+esac
+du -sh $OUT | tail -1
