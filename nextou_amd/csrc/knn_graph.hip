@@ -707,6 +707,7 @@ static FusedPlan plan_fused(int B, int N, int M, int K, bool self = false) {
     FusedPlan p;
     const int need = cdiv(N, 32);
     p.nw = need <= 6 ? (need < 1 ? 1 : need) : 4;
+    if (const char* e = getenv("NEXTOU_KNN_NW")) { const int v = atoi(e); if (v >= 1 && v <= 6) p.nw = v; }                 // experiments
     const long long waves = (long long)B * cdiv(N, 32 * p.nw) * p.nw;
     const bool small = waves < 1024;
     const long long ww = (long long)cdiv(M, 192) * 192, w2 = (long long)cdiv(M, 64) * 64;
@@ -726,17 +727,19 @@ static FusedPlan plan_fused(int B, int N, int M, int K, bool self = false) {
     static const bool window_plan = [] { const char* e = getenv("NEXTOU_KNN_WINDOW"); return !(e && e[0] == '0'); }();
     const bool window = window_plan && small && waves >= 512 && N <= 192 && M <= 192;
     if (window) p.tiles = 6;
-    if (const char* e = getenv("NEXTOU_KNN_TILES")) p.tiles = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : (atoi(e) == 6 ? 6 : p.tiles));   // experiments
+    if (const char* e = getenv("NEXTOU_KNN_TILES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 6) p.tiles = v; }   // experiments
     const int tm = 32 * p.tiles;
     const int chunks = cdiv(M, tm);
     long long want = cdiv64(2048, waves);
     if (want > chunks) want = chunks;
     if (want > kMaxSplits) want = kMaxSplits;
     if (want < 1 || window) want = 1;
+    if (const char* e = getenv("NEXTOU_KNN_SPLITS")) { const int v = atoi(e); if (v >= 1 && v <= kMaxSplits) want = v < chunks ? v : chunks; }   // experiments
     const int chunks_per_split = cdiv(chunks, (int)want);
     p.splits = cdiv(chunks, chunks_per_split);
     p.m_per_split = chunks_per_split * tm;
     p.ks = (waves * p.splits < 2048) ? 64 : 32;
+    if (const char* e = getenv("NEXTOU_KNN_KS")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) p.ks = v; }                    // experiments
     // default dynamic-LDS limit; a self window covered by one workgroup stages ONE slab for both MFMA operands (launch_fused)
     const bool one_slab = self && p.splits == 1 && N <= tm && 32 * p.nw == tm;
     if ((size_t)p.ks * (one_slab ? tm : tm + 32 * p.nw) * sizeof(float) > 64 * 1024) p.ks = 32;
@@ -884,6 +887,7 @@ template <int KB>
 static int launch_fused_tiles(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
     // 192-wide chunks keep 96 accumulator registers per lane: beside 64 + 32 key registers that spills (54 VGPRs at
     // K = 32), so the network path is taken with 64-wide chunks only
+    if (p.tiles == 1) return launch_fused<KB, 1, false>(a, p, s);
     if (p.tiles == 2) return use_networks(KB) ? launch_fused<KB, 2, true>(a, p, s) : launch_fused<KB, 2, false>(a, p, s);
     if (p.tiles == 4) return launch_fused<KB, 4, false>(a, p, s);
     return launch_fused<KB, 6, false>(a, p, s);
