@@ -716,9 +716,9 @@ static FusedPlan plan_fused(int B, int N, int M, int K, bool self = false) {
     // SIMD; 64-wide chunks (133 VGPRs, 3 waves) are faster although they stage three times as often — cfg-5 Pool s3
     // 1850 -> 1591 us, Swin s3 268 -> 232 us (profiles/r02_knn_topk_ab.md)
     if (K > 16) p.tiles = 2;
-    // Round 4: 128-wide chunks (64 accumulator registers: ~150 VGPRs, still 3 waves per SIMD) for long lists on grids that fill the chip —
+    // Round 4: 128-wide chunks (64 accumulator registers: ~150 VGPRs, still 3 waves per SIMD) for long lists over long candidate sets —
     // each query slab is re-staged half as often: cfg-2 Pool s3 350 -> 316 us in one call (profiles/r04_k1_tiles4.md)
-    if (K > 16 && !small) p.tiles = 4;
+    if (K > 16 && M >= 512) p.tiles = 4;
     // Round 3: windows that ONE workgroup covers (N, M <= 192) on a grid of 512 ... 1023 waves (the stage-3 windows of cfg 2,
     // B' = 128) took 64-wide chunks, 3 candidate splits and a merge launch: 80 + 16 us; one 192-wide chunk per workgroup, no
     // split, no merge is 90 us in ONE launch (profiles/r03_kernel_bench_cfg2.md).  Below 512 waves (stage 4 / 5: B' = 16 / 2) the
