@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NEXTOU_ABI_VERSION 9
+#define NEXTOU_ABI_VERSION 10
 
 #define NEXTOU_EINVAL   (-1)  /* bad argument (null pointer, non-positive size, k > M ...) */
 #define NEXTOU_ENOSPACE (-2)  /* workspace too small */
@@ -142,6 +142,27 @@ int nextou_mr_aggregate_bwd(const float* gout, const float* x, const float* y,
                             float* dx, float* dy,
                             int B, int C, int N, int M, int K, int idx_stride, int idx_step,
                             nextou_stream_t stream);
+
+/* K2 + K7 fused: the max-relative aggregation of Swin windows feeding MRConv's grouped 1x1 convolution in one
+ * launch — reference NexToU_Encoder_Decoder.py:401-418 (MRConv.forward: aggregate, then BasicConv), torch_nn.py:66-92 (BasicConv's
+ * grouped conv), :766-818 (window partition / reverse around them).  Replaces nextou_mr_aggregate_fwd -> nextou_window_scatter ->
+ * nextou_pw_rows_fused(groups) for a self graph inside windows:
+ *   windows   (B * nWin, C, Nw) channel-major rows of the shifted windows (nextou_window_gather's output), Nw = wd * wh * ww
+ *   nn_idx    (B * nWin, Nw, idx_stride) neighbour ids inside the window; neighbours j * idx_step, j < K <= 32
+ *   weight    (2C, 2C / groups) the grouped convolution's weights, no bias (folded into the norm behind it)
+ *   a_rows    NULL or channels-last (B, D, H, W, 2C): the aggregate [x_0, mr_0, x_1, mr_1, ...] at the rows the window map assigns —
+ *             bit-identical to nextou_window_scatter(nextou_mr_aggregate_fwd(...)); the weight gradient's operand, not needed in eval
+ *   arg_out   NULL or (B * nWin, C, Nw) uint16: the arg-max tape of nextou_mr_aggregate_fwd (bit-identical)
+ *   h_rows    channels-last (B, D, H, W, 2C): conv1x1(a, weight, groups) — bit-identical to nextou_pw_rows_fused on a_rows
+ *   stats_partial  NULL or [2C][stats_tiles] (sum, sum of squares) float64 pairs of h per window, stats_tiles == B * nWin
+ *                  (nextou_norm_finalize's `partial`)
+ * C % groups == 0, C / groups even and <= 32, Nw <= 256: nextou_mr_grouped_rows_supported() says whether a shape is taken
+ * (NEXTOU_ENOTSUP otherwise; NEXTOU_MR_GROUPED=0 switches the kernel off).  HBM-bound: 12 B'C Nw + 4 B' Nw K bytes in eval. */
+int nextou_mr_grouped_rows_supported(int n_windows, int C, int groups, int Nw, int K);
+int nextou_mr_grouped_rows(const float* windows, const int32_t* nn_idx, int idx_stride, int idx_step, int K, const float* weight,
+                           float* a_rows, uint16_t* arg_out, float* h_rows, double* stats_partial, int stats_tiles,
+                           int B, int C, int D, int H, int W, int wd, int wh, int ww, int sd, int sh, int sw, int groups,
+                           nextou_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * batched_index_select (reference torch_nn.py:94-115):

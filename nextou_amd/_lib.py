@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("NEXTOU_HIP_LIB") or os.path.join(_PKG_DIR, "libnextou
 
 KNN_AUTO, KNN_FUSED, KNN_NAIVE = 0, 1, 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # name -> (restype, argtypes); mirrors include/nextou_hip.h one to one
 _SIGNATURES = {
@@ -41,6 +41,9 @@ _SIGNATURES = {
     "nextou_mr_aggregate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "nextou_mr_aggregate_has_arg": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "nextou_mr_grouped_rows_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "nextou_mr_grouped_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int] +
+                               [c_int] * 12 + [c_void_p]),
     "nextou_mr_aggregate_bwd_arg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                             c_void_p]),
     "nextou_mr_aggregate_bwd_wants_idx": (c_int, [c_int, c_int, c_int, c_int]),

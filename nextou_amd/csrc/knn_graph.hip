@@ -539,6 +539,218 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// Self graphs of at most 192 points (the windows of every Swin-GNN block and the stage-5 pooled graph: N = M = 168 at cfg 2) in ONE
+// launch, normalisation included (round 4).  Through the general path such a graph costs three launches — knn_prep (21-28 us: a chain of
+// 2 x C / 16 dependent round trips per point), knn_fused (60-90 us) and, when the candidates are split, knn_merge (7 us) — i.e. 90-120 us for
+// <= 2.3 GFLOP (profiles/r04_k1_small_graphs.md).  Here a workgroup owns a window (and one 32 * TILES-wide candidate range of it):
+//   pass A  the (C, 192) raw slab streams through LDS in KS-channel slabs, all loads of a slab in flight; lane n runs the c-ordered chain
+//           s = fmaf(x, x, s) out of LDS -> den[n] = max(sqrt(s), 1e-12)                     (the arithmetic of knn_prep_kernel, same order)
+//   pass B  the slabs stream again (L2-hot); every element is divided by its point's den on the way into LDS (IEEE division: xn = x / den),
+//           lane n continues the chain q = fmaf(xn, xn, q), and the MFMAs take BOTH operands from the one normalised slab
+//   then    the epilogue, the per-lane sorted lists and the half-wave merge of knn_fused_kernel, with the squared norms read from LDS.
+// Bit-identical to the general path by construction (same fmaf chains, same division, same MFMA k order); tests/test_gpu_parity.py holds
+// both to the oracle.  grid = (splits, B'), block = 64 * ceil(N / 32) threads, LDS = KS * 192 floats + 2 * 192 floats.
+// --------------------------------------------------------------------------------------------
+constexpr int kWinPts = 192;
+
+// One KS x 192 slab of the window kernel: EIGHT 16-byte loads in flight per thread before any is consumed (with one load per loop iteration
+// the staging of a slab was a chain of eight dependent round trips — the run time of a 2-window launch), optionally divided by the points'
+// norms on the way into LDS.  vec path only (N % 4 == 0, 16-byte aligned rows); pieces past C or N are zero.
+template <bool DIVIDE>
+__device__ __forceinline__ void win_stage(float* __restrict__ slab, const float* __restrict__ xb, const float* __restrict__ den_s, int c0,
+                                          int C, int N, int KS) {
+    constexpr int W = 192, U = 8;
+    const int w4 = W / 4, total = KS * w4;
+    for (int e0 = threadIdx.x; e0 < total; e0 += blockDim.x * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * blockDim.x;
+            const int r = e / w4, c4 = (e - r * w4) << 2;
+            const bool ok = e < total && c0 + r < C && c4 < N;
+            v[u] = *reinterpret_cast<const float4*>(xb + (size_t)(ok ? c0 + r : 0) * N + (ok ? c4 : 0));       // clamped, unconditional
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * blockDim.x;
+            if (e < total) {
+                const int r = e / w4, c4 = (e - r * w4) << 2;
+                const bool ok = c0 + r < C && c4 < N;
+                float4 t = v[u];
+                if (DIVIDE) {
+                    const float4 d = *reinterpret_cast<const float4*>(den_s + (ok ? c4 : 0));
+                    t = make_float4(t.x / d.x, t.y / d.y, t.z / d.z, t.w / d.w);
+                }
+                *reinterpret_cast<float4*>(slab + r * W + c4) = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+            }
+        }
+    }
+}
+
+
+
+template <int KB, int TILES>
+__global__ __launch_bounds__(384) void knn_window_kernel(const float* __restrict__ x, const float* __restrict__ relpos,
+                                                         int32_t* __restrict__ out, float* __restrict__ part_d,
+                                                         int32_t* __restrict__ part_i, int C, int N, int K, int KS, int ablate) {
+    // ablate (experiments, NEXTOU_KNN_WIN_ABLATE; wrong results with any bit set): 1 skip pass A, 2 skip the MFMAs, 4 skip the list pushes,
+    // 8 skip the chains of squares
+    constexpr int TM = 32 * TILES;
+    constexpr int W = kWinPts;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* slab = lds;                 // [KS][W]
+    float* den_s = lds + KS * W;       // [W]
+    float* sq_s = den_s + W;           // [W]  chain of xn^2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, split = blockIdx.x, n_splits = gridDim.x;
+    const float* xb = x + (size_t)b * C * N;
+    const int n = wave * 32 + lq;
+    const bool nvalid = n < N;
+    const int m_begin = split * TM;
+    const int m_end = min(m_begin + TM, N);
+    const bool vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+    const int w4 = W / 4;
+
+    // ---- pass A: den
+    float ssum = 0.f;
+    for (int c0 = 0; c0 < ((ablate & 1) ? 0 : C); c0 += KS) {
+        __syncthreads();
+        if (vec) win_stage<false>(slab, xb, den_s, c0, C, N, KS);
+        else stage_slab(slab, xb, N, c0, C, 0, N, W, false, KS);
+        __syncthreads();
+        if (tid < W) {
+            int kmax = C - c0;
+            if (kmax > KS) kmax = KS;
+#pragma unroll 8
+            for (int k = 0; k < kmax; ++k) { const float v = slab[k * W + tid]; ssum = fmaf(v, v, ssum); }
+        }
+    }
+    if (tid < W) den_s[tid] = fmaxf(sqrtf(ssum), kNormEps);
+    __syncthreads();
+
+    // ---- pass B: normalise while staging, chain of squares, distance tiles
+    f32x16 acc[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float qsum = 0.f;
+    for (int c0 = 0; c0 < C; c0 += KS) {
+        __syncthreads();               // the previous slab is fully consumed
+        if (vec) {
+            win_stage<true>(slab, xb, den_s, c0, C, N, KS);
+        } else {
+            for (int e = tid; e < KS * W; e += blockDim.x) {
+                const int r = e / W, c = e - r * W;
+                const int row = c0 + r;
+                slab[e] = (row < C && c < N) ? xb[(size_t)row * N + c] / den_s[c] : 0.f;
+            }
+        }
+        __syncthreads();
+        int kmax = C - c0;
+        if (kmax > KS) kmax = KS;
+        if (tid < W && !(ablate & 8)) {
+#pragma unroll 8
+            for (int k = 0; k < kmax; ++k) { const float v = slab[k * W + tid]; qsum = fmaf(v, v, qsum); }
+        }
+        kmax = (kmax + 1) & ~1;        // (an odd tail multiplies a zero row: the slab is zero-filled past C)
+        if (ablate & 2) kmax = 0;
+        for (int kp = 0; kp < kmax; kp += 2) {
+            const float bq = slab[(kp + h) * W + wave * 32 + lq];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                const float a = slab[(kp + h) * W + m_begin + t * 32 + lq];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    if (tid < W) sq_s[tid] = qsum;
+    __syncthreads();
+
+    // ---- epilogue: distances -> per-lane sorted list (candidates reach a lane in ascending index)
+    TopK<KB> top;
+    top.init();
+    const float xsv = nvalid ? sq_s[n] : 0.f;
+    const float* rp_row = (relpos != nullptr && nvalid) ? relpos + (size_t)n * N : nullptr;
+    const bool rvec = vec && ((reinterpret_cast<uintptr_t>(relpos) & 15u) == 0);
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        f32x16 v = acc[t];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int mbase = m_begin + t * 32 + 8 * g + 4 * h;
+            float yv[4], rv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[r] = mbase + r < W ? sq_s[mbase + r] : 0.f;
+            if (rp_row != nullptr && rvec && mbase + 3 < m_end) {
+                const float4 r4 = *reinterpret_cast<const float4*>(rp_row + mbase);
+                rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rv[r] = (rp_row != nullptr && mbase + r < m_end) ? rp_row[mbase + r] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mbase + r;
+                float dist = INFINITY;
+                if (nvalid && m < m_end) {
+                    dist = (xsv + (-2.0f * v[4 * g + r])) + yv[r];
+                    if (rp_row != nullptr) dist = dist + rv[r];
+                }
+                if (__any(dist < top.d[KB - 1]) && !(ablate & 4)) top.push_ascending(dist, m);
+            }
+        }
+    }
+
+    // ---- merge the two half-waves' lists (bitonic, (dist, index) order) and emit — as knn_fused_kernel
+    constexpr int KP = KB <= 8 ? 8 : (KB <= 16 ? 16 : 32);
+    float md[KP];
+    int mi[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const int pj = KP - 1 - j;
+        const float ad = (j < KB) ? top.d[j < KB ? j : 0] : INFINITY;
+        const int ai = (j < KB) ? top.i[j < KB ? j : 0] : kSentinelIdx;
+        float bd = INFINITY;
+        int bi = kSentinelIdx;
+        if (pj < KB) {
+            bd = __shfl_xor(top.d[pj < KB ? pj : 0], 32);
+            bi = __shfl_xor(top.i[pj < KB ? pj : 0], 32);
+        }
+        const bool take_b = (bd < ad) || (bd == ad && bi < ai);
+        md[j] = take_b ? bd : ad;
+        mi[j] = take_b ? bi : ai;
+    }
+#pragma unroll
+    for (int stride = KP / 2; stride >= 1; stride >>= 1) {
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            if ((j & stride) == 0) {
+                const int q = j + stride;
+                const bool sw = (md[q] < md[j]) || (md[q] == md[j] && mi[q] < mi[j]);
+                const float lo = sw ? md[q] : md[j], hi = sw ? md[j] : md[q];
+                const int li = sw ? mi[q] : mi[j], hi_i = sw ? mi[j] : mi[q];
+                md[j] = lo; md[q] = hi; mi[j] = li; mi[q] = hi_i;
+            }
+        }
+    }
+    if (nvalid && h == 0) {
+        if (n_splits == 1) {
+            int32_t* o = out + ((size_t)b * N + n) * K;
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+                if (j < K) o[j] = mi[j];
+        } else {
+            const size_t base = (((size_t)b * N + n) * n_splits + split) * K;
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+                if (j < K) { part_d[base + j] = md[j]; part_i[base + j] = mi[j]; }
+        }
+    }
+}
+
 // S sorted partial lists per query -> the K best overall, by (dist, index).  One thread per partial
 // entry: its final position is its own position plus the number of entries of the OTHER lists that
 // sort before it (binary search; every candidate lives in exactly one list, so ranks are unique).
@@ -746,6 +958,29 @@ static FusedPlan plan_fused(int B, int N, int M, int K, bool self = false) {
     return p;
 }
 
+// ---- the single-launch window path (knn_window_kernel): self graphs of <= 192 points, normalisation inside
+struct WindowPlan { bool ok; int nw, tiles, splits, ks; size_t lds; };
+static WindowPlan plan_window(int B, int N, int M, int K, bool has_y) {
+    WindowPlan w{};
+    w.ok = false;
+    static const bool enabled = [] { const char* e = getenv("NEXTOU_KNN_WINDOW_FUSED"); return !(e && e[0] == '0'); }();
+    if (!enabled || has_y || N != M || N > kWinPts || K > 32 || N < 1) return w;
+    w.nw = cdiv(N, 32);
+    // enough windows to fill the chip (>= 512 waves): one workgroup per window, every candidate in registers, no merge launch;
+    // fewer: the candidates are split in 64-wide ranges over workgroups (the window's MFMAs on one CU would be the run time)
+    const bool whole = (long long)B * w.nw >= 512 || N <= 64;
+    // a handful of windows (stage 5: B' = 2): measured 102 us here against 101 us for prep + fused + merge with its wider split; the
+    // kernel's serial floor (staging + epilogue, 66 us with every arithmetic phase ablated) is not amortised — profiles/r04_k1_small_graphs.md
+    if (!whole && (long long)B * w.nw < 64) return w;
+    w.tiles = whole ? (N <= 64 ? 2 : 6) : 2;
+    w.splits = whole ? 1 : cdiv(N, 64);
+    w.ks = 64;
+    if (const char* e = getenv("NEXTOU_KNN_WIN_KS")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128 || v == 192) w.ks = v; }   // experiments
+    w.lds = (size_t)(w.ks * kWinPts + 2 * kWinPts) * sizeof(float);
+    w.ok = true;
+    return w;
+}
+
 static int resolve_algo(int algo, int K) {
     if (algo == NEXTOU_KNN_AUTO) return K <= 32 ? NEXTOU_KNN_FUSED : NEXTOU_KNN_NAIVE;
     return algo;
@@ -766,9 +1001,11 @@ static KnnWorkspace knn_layout(int B, int C, int N, int M, int K, int has_y, int
         w.dist = off; off += align256((size_t)B * N * M * sizeof(float));
     } else {
         const FusedPlan p = plan_fused(B, N, M, K);
-        if (p.splits > 1) {
-            w.part_d = off; off += align256((size_t)B * N * p.splits * K * sizeof(float));
-            w.part_i = off; off += align256((size_t)B * N * p.splits * K * sizeof(int32_t));
+        const WindowPlan wp = plan_window(B, N, M, K, has_y != 0);
+        const int splits = (wp.ok && wp.splits > p.splits) ? wp.splits : p.splits;
+        if (splits > 1) {
+            w.part_d = off; off += align256((size_t)B * N * splits * K * sizeof(float));
+            w.part_i = off; off += align256((size_t)B * N * splits * K * sizeof(int32_t));
         }
     }
     w.total = off;
@@ -839,6 +1076,51 @@ static bool use_networks(int KB) {
     return mode == 1 && KB >= 8;
 }
 
+// S sorted partial lists per query -> final ids (shared by the general and the window path)
+static int launch_merge(const FusedArgs& a, int splits, hipStream_t s) {
+    const long long rows = (long long)a.B * a.N;
+    ProfScope prof(s, kBoundHbm, 8.0 * rows * splits * a.K + 4.0 * rows * a.K, "knn_merge_kernel[B%d N%d S%d K%d]",
+                   a.B, a.N, splits, a.K);       // (both merge kernels report under this label)
+    // LDS-staged merge for up to 4 partial lists (cfg-2 Pool s3 53.9 -> 41.9 us, Swin / Pool s4-s5 9 -> 7 us, cfg-5 S = 2
+    // 37 -> 32 us); with 6-11 lists it is level or behind the global one (64 -> 81 us at S = 11 on 2 688 rows, 108 -> 88 us
+    // on 6 144): profiles/r03_k1_prep_merge.md.  NEXTOU_KNN_MERGE=v1 / lds forces one of them.
+    static const int merge_mode = [] { const char* e = getenv("NEXTOU_KNN_MERGE"); return !e ? 0 : (e[0] == 'v' ? 1 : 2); }();
+    if (merge_mode == 1 || (merge_mode == 0 && splits > 4)) {
+        hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)cdiv64(rows * splits * a.K, 256)), dim3(256), 0, s,
+                           a.part_d, a.part_i, a.out, rows, splits, a.K);
+        return check_launch("knn_merge_kernel");
+    }
+    const int per_row = splits * a.K;
+    int rows_per_wg = 2048 / per_row;          // <= 16 KB of LDS; at least 4 entries per thread
+    if (rows_per_wg < 1) rows_per_wg = 1;
+    // small problems: fewer rows per workgroup until ~2 workgroups sit on every CU
+    while (rows_per_wg > 1 && cdiv64(rows, rows_per_wg) < 512) rows_per_wg = (rows_per_wg + 1) / 2;
+    hipLaunchKernelGGL(knn_merge_lds_kernel, dim3((unsigned)cdiv64(rows, rows_per_wg)), dim3(256),
+                       (size_t)rows_per_wg * per_row * 8, s, a.part_d, a.part_i, a.out, rows, splits, a.K, rows_per_wg);
+    return check_launch("knn_merge_lds_kernel");
+}
+
+template <int KB>
+static int launch_window(const FusedArgs& a, const float* x, const WindowPlan& w, hipStream_t s) {
+    {
+        ProfScope prof(s, kBoundMfma, 2.0 * a.B * (double)a.N * a.N * a.C, "knn_window_kernel<%d,%d>[B%d C%d N%d K%d]", KB, w.tiles, a.B, a.C,
+                       a.N, a.K);
+        const dim3 grid(w.splits, a.B), block(64 * w.nw);
+        int ablate = 0;
+        if (const char* e = getenv("NEXTOU_KNN_WIN_ABLATE")) ablate = atoi(e);
+        if (w.lds > 64 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_window_kernel<KB, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_window_kernel<KB, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds);
+        }
+        if (w.tiles == 2)
+            hipLaunchKernelGGL((knn_window_kernel<KB, 2>), grid, block, w.lds, s, x, a.relpos, a.out, a.part_d, a.part_i, a.C, a.N, a.K, w.ks, ablate);
+        else
+            hipLaunchKernelGGL((knn_window_kernel<KB, 6>), grid, block, w.lds, s, x, a.relpos, a.out, a.part_d, a.part_i, a.C, a.N, a.K, w.ks, ablate);
+    }
+    if (int e = check_launch("knn_window_kernel")) return e;
+    return w.splits > 1 ? launch_merge(a, w.splits, s) : 0;
+}
+
 template <int KB, int TILES, bool BITONIC>
 static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
     const int QW = 32 * p.nw;
@@ -858,29 +1140,7 @@ static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
                            a.relpos, a.out, a.part_d, a.part_i, a.C, a.N, a.M, a.K, p.m_per_split, vec_ok, p.ks);
     }
     if (int e = check_launch("knn_fused_kernel")) return e;
-    if (p.splits > 1) {
-        const long long rows = (long long)a.B * a.N;
-        ProfScope prof(s, kBoundHbm, 8.0 * rows * p.splits * a.K + 4.0 * rows * a.K, "knn_merge_kernel[B%d N%d S%d K%d]",
-                       a.B, a.N, p.splits, a.K);       // (both merge kernels report under this label)
-        // LDS-staged merge for up to 4 partial lists (cfg-2 Pool s3 53.9 -> 41.9 us, Swin / Pool s4-s5 9 -> 7 us, cfg-5 S = 2
-        // 37 -> 32 us); with 6-11 lists it is level or behind the global one (64 -> 81 us at S = 11 on 2 688 rows, 108 -> 88 us
-        // on 6 144): profiles/r03_k1_prep_merge.md.  NEXTOU_KNN_MERGE=v1 / lds forces one of them.
-        static const int merge_mode = [] { const char* e = getenv("NEXTOU_KNN_MERGE"); return !e ? 0 : (e[0] == 'v' ? 1 : 2); }();
-        if (merge_mode == 1 || (merge_mode == 0 && p.splits > 4)) {
-            hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)cdiv64(rows * p.splits * a.K, 256)), dim3(256), 0, s,
-                               a.part_d, a.part_i, a.out, rows, p.splits, a.K);
-            return check_launch("knn_merge_kernel");
-        }
-        const int per_row = p.splits * a.K;
-        int rows_per_wg = 2048 / per_row;          // <= 16 KB of LDS; at least 4 entries per thread
-        if (rows_per_wg < 1) rows_per_wg = 1;
-        // small problems: fewer rows per workgroup until ~2 workgroups sit on every CU
-        while (rows_per_wg > 1 && cdiv64(rows, rows_per_wg) < 512) rows_per_wg = (rows_per_wg + 1) / 2;
-        hipLaunchKernelGGL(knn_merge_lds_kernel, dim3((unsigned)cdiv64(rows, rows_per_wg)), dim3(256),
-                           (size_t)rows_per_wg * per_row * 8, s, a.part_d, a.part_i, a.out, rows, p.splits, a.K, rows_per_wg);
-        return check_launch("knn_merge_lds_kernel");
-    }
-    return 0;
+    return p.splits > 1 ? launch_merge(a, p.splits, s) : 0;
 }
 
 template <int KB>
@@ -930,6 +1190,16 @@ extern "C" int nextou_knn_graph(const float* x, const float* y, const float* rel
     float* yn = (float*)(base + w.yn);
     float* ys = (float*)(base + w.ys);
 
+    if (algo == NEXTOU_KNN_FUSED && normalize) {
+        const WindowPlan wp = plan_window(B, N, M, K, has_y != 0);
+        if (wp.ok) {       // <= 192-point self graph: normalisation, distances, selection in one launch
+            FusedArgs a{nullptr, nullptr, nullptr, nullptr, relpos, nn_idx, (float*)(base + w.part_d), (int32_t*)(base + w.part_i), B, C, N, M, K};
+            if (K <= 7) return launch_window<7>(a, x, wp, s);
+            if (K <= 14) return launch_window<14>(a, x, wp, s);
+            if (K <= 28) return launch_window<28>(a, x, wp, s);
+            return launch_window<32>(a, x, wp, s);
+        }
+    }
     if (int e = launch_prep_pair(x, xn, xs, N, has_y ? y : nullptr, yn, ys, M, B, C, normalize != 0, s)) return e;
     if (!normalize) {  // the un-normalised copies are the inputs themselves
         xn = const_cast<float*>(x);

@@ -25,26 +25,7 @@ constexpr int kLayThreads = 256;
 constexpr int kTileChannels = 64;   // channels per tile (LDS row = 65 floats)
 constexpr int kTilePoints = 64;     // points per tile of the pool / unpool kernels
 
-struct Vol {
-    int D, H, W;    // channels-last volume
-};
-struct Win {
-    int wd, wh, ww, sd, sh, sw;   // window size, cyclic shift
-};
-
-// row index (without batch) of point p of window `win` after the cyclic shift: the partitioned tensor is roll(x, -shift),
-// i.e. window coordinate (d, h, w) reads x at ((d + sd) mod D, ...)
-__device__ __forceinline__ long long window_point_row(int win, int p, const Vol& v, const Win& w, int nH, int nW) {
-    const int wi_w = win % nW, t = win / nW;
-    const int wi_h = t % nH, wi_d = t / nH;
-    const int pw = p % w.ww, t2 = p / w.ww;
-    const int ph = t2 % w.wh, pd = t2 / w.wh;
-    int d = wi_d * w.wd + pd + w.sd, h = wi_h * w.wh + ph + w.sh, x = wi_w * w.ww + pw + w.sw;
-    if (d >= v.D) d -= v.D;
-    if (h >= v.H) h -= v.H;
-    if (x >= v.W) x -= v.W;
-    return ((long long)d * v.H + h) * v.W + x;
-}
+// (Vol, Win and window_point_row live in common.h: the window map is shared with mr_aggregate.hip)
 
 // grid = (windows per sample, channel tiles, B); LDS = Nw * 65 floats (tile) + Nw ints (row of every window point)
 // GATHER:  out_cm[(b * nWin + win), c, p] = x_cl[b, row(win, p), c]

@@ -878,6 +878,267 @@ static int check_mr_args(const char* who, const void* a, const void* b, const vo
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K2 + K7 in one launch — SURVEY.md §8(f)-1 taken literally: the max-relative aggregation of a Swin window feeds MRConv's grouped
+// 1x1 convolution from LDS (reference NexToU_Encoder_Decoder.py:401-418 MRConv.forward = aggregate -> BasicConv; torch_nn.py:66-92
+// BasicConv = grouped conv -> norm -> act; :766-818 the window partition / reverse around it).
+//
+// Op by op the stage-2 Swin block of cfg 2 (1 024 windows x 168 points, C = 132 -> 2C = 264 in 6 groups of 44) moved the
+// (B', 2C, Nw) aggregate four times: mr_fwd_qb wrote it (182 MB), window_scatter read it and wrote it again as channels-last
+// rows, pw_rows_grp read the rows for the grouped GEMM.  Here one workgroup owns (window, group):
+//   0. the group's Cg = C / groups source channels of the window -> LDS as channel quads (the float4 tile of mr_fwd_qb_kernel);
+//   1. lane n gathers its K neighbours per quad, same subtract / first-max arithmetic as mr_fwd_qb_kernel (bit-identical values
+//      and arg tape), and writes the interleaved [x_c, mr_c] row n of the GEMM's A operand into an LDS slab [Nw][2 Cg];
+//   2. (training) the slab goes out ONCE, as the 16-byte pieces of the channels-last rows the window map assigns (what
+//      window_scatter produced: the weight gradient's operand); the group's 2Cg x 2Cg weights sit in registers and
+//      v_mfma_f32_16x16x4_f32 forms the product over the slab in place, the same k-ordered chain per element as
+//      pw_rows_grp_kernel (bit-identical h); (sum, sum of squares) per output channel in float64 -> one statistics partial per
+//      window (nextou_norm_finalize's input, tiles = windows);
+//   3. the product rows go out through the same window map.
+// HBM: 4 B'C Nw (x) + 4 B' Nw K (ids) + 8 B'C Nw (h) [+ 8 B'C Nw (a) + 2 B'C Nw (arg) when a gradient is needed] — the
+// aggregate is written at most once and never read back in the forward.
+// grid = 8-window blocks x groups x 8 (ids differing by 8 = the groups of one window land on one XCD back to back, so that the
+// 176-byte segments they write into the same rows meet in one L2); block = 64 * ceil(Nw / 64).
+// ---------------------------------------------------------------------------------------------
+// LDS-only workgroup barrier: __syncthreads() also waits for the wave's outstanding global stores (its release fence is
+// s_waitcnt vmcnt(0)), which would put a store round trip into every phase boundary of the kernel below.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// e / d for 0 <= e < 65 536, 1 <= d < 65 536 by one v_mul_hi_u32: m = ceil(2^32 / d) (exact: e * (m * d - 2^32) < 2^32); d = 1 -> m = 0
+struct GrpDiv { unsigned nw, k, kp; };
+inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
+__device__ __forceinline__ int fdiv(int e, int d, unsigned magic) { return d == 1 ? e : (int)__umulhi((unsigned)e, magic); }
+
+template <int KT, int NT, int KSTEPS, bool EXACT>
+__global__ __launch_bounds__(512) void mr_grp_rows_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ idx, const float* __restrict__ w, float* __restrict__ a_rows,
+    float* __restrict__ h_rows, uint16_t* __restrict__ arg, double2* __restrict__ partial, Vol v, Win wn, int nH, int nW, int n_win,
+    int n_windows, int C, int Cg, int Nw, int K, int idx_stride, int idx_step, int groups, int ld, long ld_rows, GrpDiv dv, int ablate) {
+    extern __shared__ __attribute__((aligned(16))) float4 grp_tile4[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = blockDim.x, nwv = T >> 6;
+    const int blk = blockIdx.x / (8 * groups), rem = blockIdx.x - blk * 8 * groups;
+    const int g = rem >> 3, bw = blk * 8 + (rem & 7);
+    if (bw >= n_windows) return;
+    const int Kg = 2 * Cg, Q = (Cg + 3) >> 2, MT = (Nw + 15) >> 4;
+    // LDS: [tile4: Nw x Q float4 | later the statistics' cross-wave buffer][slab: MT * 16 rows x ld][rows: Nw int][ids: Nw x K u16]
+    const int tile_f4 = max(Nw * Q, nwv * NT * 16 + ((Kg * Kg) >> 2));
+    float* slab = reinterpret_cast<float*>(grp_tile4 + tile_f4);
+    int* rows = reinterpret_cast<int*>(slab + (size_t)MT * 16 * ld);
+    uint16_t* ids = reinterpret_cast<uint16_t*>(rows + ((Nw + 3) & ~3));
+    double2* red = reinterpret_cast<double2*>(grp_tile4);
+    const int ln = lane & 15, lk = lane >> 4;
+    // ---- 0: window map, neighbour ids, the group's channel quads and weights: the first round of every global load of the
+    // workgroup is in flight before anything is stored (one memory round trip for the cfg-2 shapes), divisions by multiplication
+    const int b = bw / n_win, win = bw - b * n_win;             // (uniform)
+    const float* xb = x + ((size_t)bw * C + (size_t)g * Cg) * Nw;
+    const int32_t* ib = idx + (size_t)bw * Nw * idx_stride;
+    const f32x4* wg = reinterpret_cast<const f32x4*>(w + (size_t)g * Kg * Kg);
+    const int items = Q * Nw, n_ids = Nw * K, w4 = (Kg * Kg) >> 2;
+    constexpr int UX = 2, UI = 4, UW = 2;
+    f32x4 wpre[UW];
+    {
+        float4 t[UX];
+        int iv[UI];
+#pragma unroll
+        for (int u = 0; u < UX; ++u) {
+            const int e = tid + u * T;
+            const int ec = e < items ? e : items - 1;
+            const int q = fdiv(ec, Nw, dv.nw), m = ec - q * Nw, c = 4 * q;
+            const float* p = xb + (size_t)c * Nw + m;
+            t[u].x = p[0];
+            t[u].y = c + 1 < Cg ? p[(size_t)Nw] : 0.f;
+            t[u].z = c + 2 < Cg ? p[(size_t)2 * Nw] : 0.f;
+            t[u].w = c + 3 < Cg ? p[(size_t)3 * Nw] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UI; ++u) {
+            const int e = tid + u * T;
+            const int ec = e < n_ids ? e : n_ids - 1;
+            const int n = fdiv(ec, K, dv.k), j = ec - n * K;
+            iv[u] = ib[(size_t)n * idx_stride + (size_t)j * idx_step];
+        }
+#pragma unroll
+        for (int u = 0; u < UW; ++u) wpre[u] = wg[min(tid + u * T, w4 - 1)];
+        for (int p = tid; p < Nw; p += T) rows[p] = (int)window_point_row(win, p, v, wn, nH, nW);
+#pragma unroll
+        for (int u = 0; u < UX; ++u) {
+            const int e = tid + u * T;
+            if (e < items) { const int q = fdiv(e, Nw, dv.nw), m = e - q * Nw; grp_tile4[m * Q + q] = t[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < UI; ++u) {
+            const int e = tid + u * T;
+            if (e < n_ids) ids[e] = (uint16_t)iv[u];
+        }
+        for (int e = tid + UX * T; e < items; e += T) {          // (larger windows / fewer threads: the remaining rounds)
+            const int q = fdiv(e, Nw, dv.nw), m = e - q * Nw, c = 4 * q;
+            const float* p = xb + (size_t)c * Nw + m;
+            float4 r;
+            r.x = p[0];
+            r.y = c + 1 < Cg ? p[(size_t)Nw] : 0.f;
+            r.z = c + 2 < Cg ? p[(size_t)2 * Nw] : 0.f;
+            r.w = c + 3 < Cg ? p[(size_t)3 * Nw] : 0.f;
+            grp_tile4[m * Q + q] = r;
+        }
+        for (int e = tid + UI * T; e < n_ids; e += T) {
+            const int n = fdiv(e, K, dv.k), j = e - n * K;
+            ids[e] = (uint16_t)ib[(size_t)n * idx_stride + (size_t)j * idx_step];
+        }
+    }
+    __syncthreads();
+    // ---- 1: max-relative rows; a lane owns (query point, channel quad)
+    if (!(ablate & 1)) {
+        const f32x4* t4 = reinterpret_cast<const f32x4*>(grp_tile4);
+        for (int e = tid; e < Nw * Q; e += T) {
+            const int q = fdiv(e, Nw, dv.nw), n = e - q * Nw;
+            unsigned id[KT];
+#pragma unroll
+            for (int j = 0; j < KT; ++j) id[j] = ids[n * K + (j < K ? j : 0)];
+            const f32x4 xv = t4[n * Q + q];
+            const f32x2 xlo = xv.lo, xhi = xv.hi;
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+            unsigned a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int j0 = 0; j0 < KT; j0 += 8) {         // eight gathers in flight
+                f32x4 sv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sv[u] = t4[id[j0 + u] * (unsigned)Q + q];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u;
+                    const f32x2 dlo = sv[u].lo - xlo, dhi = sv[u].hi - xhi;
+                    if (j == 0) {                        // the first neighbour initialises the maximum (NaN included)
+                        m0 = dlo.x; m1 = dlo.y; m2 = dhi.x; m3 = dhi.y;
+                        a0 = a1 = a2 = a3 = id[0];
+                    } else if (j < K) {                  // (uniform) strict >: the first maximum of the rounded differences wins
+                        mr_update4<true>(m0, m1, m2, m3, a0, a1, a2, a3, dlo.x, dlo.y, dhi.x, dhi.y, id[j]);
+                    }
+                }
+            }
+            const bool hi_ok = 4 * q + 2 < Cg;           // Cg is even: channels come in pairs
+            float* arow = slab + (size_t)n * ld + 8 * q;
+            *reinterpret_cast<f32x4*>(arow) = f32x4{xv.x, m0, xv.y, m1};
+            if (hi_ok) *reinterpret_cast<f32x4*>(arow + 4) = f32x4{xv.z, m2, xv.w, m3};
+            if (arg != nullptr && !(ablate & 16)) {
+                uint16_t* ap = arg + ((size_t)bw * C + (size_t)g * Cg + 4 * q) * Nw + n;
+                ap[0] = (uint16_t)a0;
+                ap[(size_t)Nw] = (uint16_t)a1;
+                if (hi_ok) { ap[(size_t)2 * Nw] = (uint16_t)a2; ap[(size_t)3 * Nw] = (uint16_t)a3; }
+            }
+        }
+    }
+    lds_barrier();
+    // ---- 2a: the aggregate's rows (the weight gradient's operand), 16-byte pieces through the window map
+    const int kp = Kg >> 2;
+    const size_t row_base = (size_t)b * ((size_t)v.D * v.H * v.W);
+    if (a_rows != nullptr && !(ablate & 2)) {
+        for (int e = tid; e < Nw * kp; e += T) {
+            const int r = fdiv(e, kp, dv.kp), pc = e - r * kp;
+            *reinterpret_cast<f32x4*>(a_rows + (row_base + rows[r]) * ld_rows + (size_t)g * Kg + 4 * pc) =
+                *reinterpret_cast<const f32x4*>(slab + (size_t)r * ld + 4 * pc);
+        }
+    }
+    // the group's Kg x Kg weights -> LDS over the dead quad tile (behind `red`), 16-byte pieces; then every wave's B operands:
+    // tile (nt, ks) = w[g * Kg + nt * 16 + ln][4 * ks + lk].  (Read straight from global by every wave — 4-byte reads of 16 rows
+    // per instruction — they were 40 % of the kernel's time.)
+    float* wl = reinterpret_cast<float*>(red + nwv * NT * 16);
+#pragma unroll
+    for (int u = 0; u < UW; ++u)
+        if (tid + u * T < w4) reinterpret_cast<f32x4*>(wl)[tid + u * T] = wpre[u];
+    for (int e = tid + UW * T; e < w4; e += T) reinterpret_cast<f32x4*>(wl)[e] = wg[e];
+    lds_barrier();
+    float wreg[NT][KSTEPS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int n = nt * 16 + ln, k = 4 * ks + lk;
+            const int nc = n < Kg ? n : Kg - 1, kc = k < Kg ? k : Kg - 1;
+            const float t = wl[nc * Kg + kc];
+            wreg[nt][ks] = (n < Kg && k < Kg) ? t : 0.f;
+        }
+    // ---- 2b: rows x W_g^T in place, statistics
+    double s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.0;
+#pragma unroll 1
+    for (int mt = wave; mt < MT && !(ablate & 4); mt += nwv) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* arow = slab + (size_t)(mt * 16 + ln) * ld + lk;
+        float a[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) a[ks] = arow[(EXACT || 4 * ks + lk < Kg) ? 4 * ks : 0];      // (a clamped read meets a zero weight)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], wreg[nt][ks], acc[nt], 0, 0, 0);
+        float* orow = slab + (size_t)(mt * 16 + 4 * lk) * ld + ln;
+        const bool full = mt * 16 + 16 <= Nw;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt * 16 + ln < Kg) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) orow[(size_t)r * ld + nt * 16] = acc[nt][r];
+            }
+            if (partial != nullptr) {
+                f32x4 t = acc[nt];
+                if (!full) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] = (mt * 16 + 4 * lk + r < Nw) ? t[r] : 0.f;
+                }
+                const float u = (t[0] + t[1]) + (t[2] + t[3]);
+                const float q2 = fmaf(t[3], t[3], fmaf(t[2], t[2], fmaf(t[1], t[1], t[0] * t[0])));
+                s1[nt] += (double)u;
+                s2[nt] += (double)q2;
+            }
+        }
+    }
+    if (partial != nullptr) {                            // (the quad tile is dead since phase 1: `red` lies over it)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            double u = s1[nt], q2 = s2[nt];
+            u += __shfl_xor(u, 16); q2 += __shfl_xor(q2, 16);
+            u += __shfl_xor(u, 32); q2 += __shfl_xor(q2, 32);
+            if (lk == 0) red[(wave * NT + nt) * 16 + ln] = make_double2(u, q2);
+        }
+    }
+    lds_barrier();
+    if (partial != nullptr && tid < NT * 16 && tid < Kg) {
+        double u = 0.0, q2 = 0.0;
+        for (int wv = 0; wv < nwv; ++wv) { const double2 t = red[wv * NT * 16 + tid]; u += t.x; q2 += t.y; }
+        partial[(size_t)(g * Kg + tid) * n_windows + bw] = make_double2(u, q2);
+    }
+    // ---- 3: the product's rows
+    for (int e = tid; e < Nw * kp && !(ablate & 8); e += T) {
+        const int r = fdiv(e, kp, dv.kp), pc = e - r * kp;
+        *reinterpret_cast<f32x4*>(h_rows + (row_base + rows[r]) * ld_rows + (size_t)g * Kg + 4 * pc) =
+            *reinterpret_cast<const f32x4*>(slab + (size_t)r * ld + 4 * pc);
+    }
+}
+
+struct MrGrpPlan { bool ok; int threads, ld, grid; size_t lds; };
+static MrGrpPlan plan_mr_grp(int n_windows, int C, int groups, int Nw, int K) {
+    MrGrpPlan q{};
+    const char* env = getenv("NEXTOU_MR_GROUPED");            // read per call (tests / A-B)
+    if ((env && env[0] == '0') || n_windows < 1 || groups < 1 || groups > 64 || C < 1 || C % groups != 0 || Nw < 1 || Nw > 256 || K < 1 || K > 32) return q;
+    const int Cg = C / groups, Kg = 2 * Cg;
+    if ((Cg & 1) || Kg > 64) return q;
+    const int Q = (Cg + 3) / 4, MT = cdiv(Nw, 16);
+    q.threads = 64 * cdiv(Nw * Q, 64);                         // a lane per (point, channel quad), two rounds from 512 items on
+    if (q.threads > 512) q.threads = 512;
+    if (const char* e = getenv("NEXTOU_MRG_THREADS")) { const int t = atoi(e); if (t >= 64 && t <= 512 && t % 64 == 0) q.threads = t; }
+    q.ld = Kg + ((Kg % 8 == 4) ? 0 : 4);                       // row stride = 4 mod 8 floats (pw_rows_grp_kernel's slab)
+    const int tile_f4 = std::max(Nw * Q, (q.threads / 64) * 4 * 16 + Kg * Kg / 4);
+    q.lds = (size_t)tile_f4 * 16 + (size_t)MT * 16 * q.ld * 4 + (size_t)((Nw + 3) & ~3) * 4 + (((size_t)Nw * K * 2 + 15) & ~(size_t)15);
+    if (q.lds > 150 * 1024) return q;
+    q.grid = cdiv(n_windows, 8) * 8 * groups;
+    q.ok = true;
+    return q;
+}
+
 }  // namespace nextou
 
 using namespace nextou;
@@ -1147,4 +1408,64 @@ extern "C" int nextou_gather_bwd(const float* gout, const int32_t* idx, float* d
     hipLaunchKernelGGL(gather_bwd_kernel, dim3((unsigned)cdiv64(NK, 256), C, B), dim3(256), 0, s, gout,
                        idx, dsrc, C, M, NK);
     return check_launch("gather_bwd_kernel");
+}
+
+// ---- K2 + K7: window aggregation feeding the grouped 1x1 convolution (mr_grp_rows_kernel) ----
+extern "C" int nextou_mr_grouped_rows_supported(int n_windows, int C, int groups, int Nw, int K) {
+    return plan_mr_grp(n_windows, C, groups, Nw, K).ok ? 1 : 0;
+}
+
+extern "C" int nextou_mr_grouped_rows(const float* windows, const int32_t* nn_idx, int idx_stride, int idx_step, int K,
+                                      const float* weight, float* a_rows, uint16_t* arg_out, float* h_rows, double* stats_partial,
+                                      int stats_tiles, int B, int C, int D, int H, int W, int wd, int wh, int ww, int sd, int sh,
+                                      int sw, int groups, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(windows && nn_idx && weight && h_rows, "mr_grouped_rows: null pointer");
+    NEXTOU_REQUIRE(B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && (long long)D * H * W < (1ll << 31), "mr_grouped_rows: bad volume");
+    NEXTOU_REQUIRE(wd > 0 && wh > 0 && ww > 0 && D % wd == 0 && H % wh == 0 && W % ww == 0,
+                   "mr_grouped_rows: window (%d,%d,%d) does not tile the volume (%d,%d,%d)", wd, wh, ww, D, H, W);
+    NEXTOU_REQUIRE(sd >= 0 && sd < D && sh >= 0 && sh < H && sw >= 0 && sw < W, "mr_grouped_rows: shift (%d,%d,%d) out of range", sd, sh, sw);
+    const int Nw = wd * wh * ww, nD = D / wd, nH = H / wh, nW = W / ww, n_win = nD * nH * nW;
+    const long long n_windows = (long long)B * n_win;
+    NEXTOU_REQUIRE(n_windows < (1ll << 24), "mr_grouped_rows: %lld windows", n_windows);
+    NEXTOU_REQUIRE(idx_step > 0 && idx_stride >= (K - 1) * idx_step + 1, "mr_grouped_rows: idx_stride=%d too small for K=%d step=%d",
+                   idx_stride, K, idx_step);
+    const MrGrpPlan q = plan_mr_grp((int)n_windows, C, groups, Nw, K);
+    if (!q.ok)
+        return fail(NEXTOU_ENOTSUP, "mr_grouped_rows: unsupported shape (windows %lld, C %d, groups %d, Nw %d, K %d)", n_windows, C, groups, Nw, K);
+    NEXTOU_REQUIRE(stats_partial == nullptr || stats_tiles == (int)n_windows,
+                   "mr_grouped_rows: stats_partial sized for %d partials per channel, this launch writes %lld (one per window)", stats_tiles, n_windows);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(h_rows) | reinterpret_cast<uintptr_t>(a_rows) | reinterpret_cast<uintptr_t>(stats_partial) |
+                         reinterpret_cast<uintptr_t>(weight);
+    NEXTOU_REQUIRE((al & 15u) == 0, "mr_grouped_rows: weight / row / partial buffers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int Cg = C / groups, Kg = 2 * Cg;
+    const double pts = (double)n_windows * Nw;
+    ProfScope prof(s, kBoundHbm, 4.0 * C * pts + 4.0 * pts * K + 8.0 * C * pts + (a_rows ? 8.0 * C * pts : 0.0) + (arg_out ? 2.0 * C * pts : 0.0),
+                   "mr_grp_rows_kernel<%s>[B%lld C%d N%d K%d g%d]", a_rows || arg_out ? "train" : "eval", n_windows, C, Nw, K, groups);
+    const Vol v{D, H, W};
+    const Win wn{wd, wh, ww, sd, sh, sw};
+    double2* part = reinterpret_cast<double2*>(stats_partial);
+    int ablate = 0;
+    if (const char* e = getenv("NEXTOU_MRG_ABLATE")) ablate = atoi(e);
+    const GrpDiv dv{div_magic(Nw), div_magic(K), div_magic(Kg >> 2)};
+#define NEXTOU_MR_GRP(KT, NT, KS, EX)                                                                                                  \
+    do {                                                                                                                             \
+        if (q.lds > 64 * 1024)                                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_grp_rows_kernel<KT, NT, KS, EX>),                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds);                                       \
+        hipLaunchKernelGGL((mr_grp_rows_kernel<KT, NT, KS, EX>), dim3(q.grid), dim3(q.threads), q.lds, s, windows, nn_idx, weight, a_rows,   \
+                           h_rows, arg_out, part, v, wn, nH, nW, n_win, (int)n_windows, C, Cg, Nw, K, idx_stride, idx_step, groups, q.ld,  \
+                           (long)2 * C, dv, ablate);                                                                                             \
+    } while (0)
+#define NEXTOU_MR_GRP_K(NT, KS, EX)                     \
+    do {                                                \
+        if (K <= 8) NEXTOU_MR_GRP(8, NT, KS, EX);       \
+        else if (K <= 16) NEXTOU_MR_GRP(16, NT, KS, EX); \
+        else NEXTOU_MR_GRP(32, NT, KS, EX);             \
+    } while (0)
+    if (Kg == 44) NEXTOU_MR_GRP_K(3, 11, true);
+    else NEXTOU_MR_GRP_K(4, 16, false);
+#undef NEXTOU_MR_GRP_K
+#undef NEXTOU_MR_GRP
+    return check_launch("mr_grp_rows_kernel");
 }

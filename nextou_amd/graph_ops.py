@@ -155,6 +155,33 @@ class _HipBackend:
         return dx, dy
 
     @staticmethod
+    def mr_grouped_rows_supported(n_windows, C, groups, Nw, K):
+        return bool(_lib.lib().nextou_mr_grouped_rows_supported(n_windows, C, groups, Nw, K))
+
+    @staticmethod
+    def mr_grouped_rows(windows, nn_idx, K, idx_step, w2, groups, batch, spatial, window, shift, want_a, want_arg, want_stats):
+        """K2 + K7 in one launch (csrc/mr_aggregate.hip mr_grp_rows_kernel).  windows (B * nWin, C, Nw), w2 (2C, 2C / groups) ->
+        (a, arg, h, partial): the aggregate as a channels-last (B, 2C, *spatial) volume (None unless ``want_a``), the uint16 arg-max
+        tape (None unless ``want_arg``), the grouped convolution of the aggregate (channels-last volume) and its (2C, B * nWin, 2)
+        float64 statistics partials (None unless ``want_stats``)."""
+        L_ = _lib.lib()
+        n_windows, C, Nw = windows.shape
+        D, H, W = _dhw(spatial)
+        wd, wh, ww = _dhw(window)
+        sd, sh, sw = _dhw(shift, fill=0)
+        shape = (batch, 2 * C) + tuple(spatial)
+        h = _empty_channels_last(shape, windows.device)
+        a = _empty_channels_last(shape, windows.device) if want_a else None
+        arg = torch.empty((n_windows, C, Nw), dtype=torch.int16, device=windows.device) if want_arg else None
+        partial = torch.empty((2 * C, n_windows, 2), dtype=torch.float64, device=windows.device) if want_stats else None
+        with torch.cuda.device(windows.device):
+            rc = L_.nextou_mr_grouped_rows(windows.data_ptr(), nn_idx.data_ptr(), nn_idx.shape[2], idx_step, K, w2.data_ptr(), _ptr(a),
+                                           _ptr(arg), h.data_ptr(), _ptr(partial), n_windows if want_stats else 0, batch, C, D, H, W,
+                                           wd, wh, ww, sd, sh, sw, groups, _stream_ptr(windows.device))
+        _lib.check(rc, "mr_grouped_rows")
+        return a, arg, h, partial
+
+    @staticmethod
     def mr_bwd_wants_idx(B, C, N, K):
         return bool(_lib.lib().nextou_mr_aggregate_bwd_wants_idx(B, C, N, K))
 
@@ -1248,12 +1275,15 @@ class _PointwiseChain(torch.autograd.Function):
     normalisation is K6's fmaf, the statistics are float64 sums of the same values in another order)."""
 
     @staticmethod
-    def forward(ctx, x, residual, w1, g1, b1, cb1, w2, g2, b2, cb2, groups1, n1, n2, fuse_bwd):
+    def forward(ctx, x, residual, w1, g1, b1, cb1, w2, g2, b2, cb2, groups1, n1, n2, fuse_bwd, pre=None):
         dev = x.device
         P = x.numel() // x.shape[1]
         c1 = w1.shape[0]
-        w1m = w1.reshape(c1, w1.shape[1]).contiguous()
-        h, part1 = _HIP.pw_rows_fused(x, w1m, groups1, want_stats=n1.batch_stats)
+        if pre is not None:             # (h, partials) of GEMM1 from the kernel that produced x (mr_grouped_chain): same values
+            h, part1 = pre
+        else:
+            w1m = w1.reshape(c1, w1.shape[1]).contiguous()
+            h, part1 = _HIP.pw_rows_fused(x, w1m, groups1, want_stats=n1.batch_stats)
         m1, i1, sc1, sh1 = _HIP.norm_finalize(part1, P, c1, dev, g1, b1, cb1, n1.running_mean, n1.running_var, n1.batch_stats,
                                               n1.momentum, n1.eps)
         if w2 is not None:
@@ -1308,7 +1338,7 @@ class _PointwiseChain(torch.autograd.Function):
         if cb1 is not None and ctx.needs_input_grad[5]:
             gcb1 = torch.zeros_like(cb1) if n1.batch_stats else (gb1 * i1 * (g1 if g1 is not None else 1.0))
         return (gx, g if has_res else None, gw1, gg1 if ctx.needs_input_grad[3] else None, gb1 if ctx.needs_input_grad[4] else None, gcb1,
-                gw2, gg2 if ctx.needs_input_grad[7] else None, gb2 if ctx.needs_input_grad[8] else None, gcb2, None, None, None, None)
+                gw2, gg2 if ctx.needs_input_grad[7] else None, gb2 if ctx.needs_input_grad[8] else None, gcb2, None, None, None, None, None)
 
 
 def pointwise_chain(x, residual, conv1, norm1, conv2=None, norm2=None):
@@ -1326,6 +1356,69 @@ def pointwise_chain(x, residual, conv1, norm1, conv2=None, norm2=None):
     return _PointwiseChain.apply(x, res, conv1.weight, norm1.weight, norm1.bias, cb1,
                                  None if conv2 is None else conv2.weight, None if norm2 is None else norm2.weight,
                                  None if norm2 is None else norm2.bias, cb2, int(conv1.groups), n1, n2, mode != "fwd")
+
+
+class _MRAggregateRows(torch.autograd.Function):
+    """Max-relative aggregation of Swin windows written straight into the channels-last volume (``window_scatter(mr_aggregate(x))``)
+    by the K2 + K7 kernel, which also leaves the grouped convolution of those rows and its statistics partials in ``box`` for the
+    point-wise chain behind it.  Backward = the two ops' own backwards (window gather of the gradient rows, arg-tape scatter)."""
+
+    @staticmethod
+    def forward(ctx, windows, nn_idx, K, idx_step, w1m, groups, batch, spatial, window, shift, want_stats, box):
+        need_x = windows.requires_grad
+        a, arg, h, part = _HIP.mr_grouped_rows(windows, nn_idx, K, idx_step, w1m, groups, batch, spatial, window, shift,
+                                               want_a=True, want_arg=need_x, want_stats=want_stats)
+        box["pre"] = (h, part)
+        ctx.conf = (window, shift, windows.shape[2])
+        if need_x:
+            ctx.save_for_backward(arg)
+        return a
+
+    @staticmethod
+    def backward(ctx, ga):
+        window, shift, Nw = ctx.conf
+        (arg,) = ctx.saved_tensors
+        mf = {4: torch.channels_last, 5: torch.channels_last_3d}[ga.dim()]
+        gw = _HIP.window_gather(ga.contiguous(memory_format=mf), window, shift)
+        dx, _ = _HIP.mr_bwd_arg(gw, arg, Nw, False)
+        return (dx,) + (None,) * 11
+
+
+def mr_grouped_chain(windows, nn_idx, residual, conv1, norm1, conv2, norm2, spatial, window, shift):
+    """SwinGrapher's ``fc2(BasicConv(mr_aggregate(windows)))  + residual`` with the aggregation, the window reverse and the grouped
+    1x1 convolution in ONE kernel (reference NexToU_Encoder_Decoder.py:401-418, torch_nn.py:66-92), followed by the
+    rest of the fused point-wise chain (:class:`_PointwiseChain`) — or ``None`` when a piece does not qualify (the caller then runs
+    mr_aggregate -> window_scatter -> pointwise_chain).  ``windows``: (B * nWin, C, Nw) float32 from :func:`window_gather`;
+    ``nn_idx``: (B * nWin, Nw, K) int32; ``residual``: the block's channels-last input."""
+    mode = _pw_fuse_mode()
+    if mode == "0" or not windows.is_cuda or windows.dtype != torch.float32 or torch.is_autocast_enabled("cuda"):
+        return None
+    n_windows, C, Nw = windows.shape
+    K = nn_idx.shape[2]
+    groups = int(conv1.groups)
+    batch = residual.shape[0]
+    shape = (batch, 2 * C) + tuple(int(v) for v in spatial)
+    if nn_idx.dtype != torch.int32 or conv1.weight.shape[0] != 2 * C or not _chain_modules_eligible(shape, residual, conv1, norm1, conv2, norm2):
+        return None
+    if not _HIP.mr_grouped_rows_supported(n_windows, C, groups, Nw, K):
+        return None
+    n1, n2 = _norm_state(norm1), _norm_state(norm2)
+    w1 = conv1.weight
+    w1m = w1.detach().reshape(w1.shape[0], w1.shape[1]).contiguous()
+    window, shift = tuple(int(v) for v in window), tuple(int(v) for v in shift)
+    needs_grad = torch.is_grad_enabled() and (windows.requires_grad or w1.requires_grad)
+    res = as_channels_last_rows(residual)
+    if needs_grad:
+        box = {}
+        a = _MRAggregateRows.apply(_f32c(windows), nn_idx.contiguous(), K, 1, w1m, groups, batch, shape[2:], window, shift,
+                                   n1.batch_stats, box)
+        pre = box["pre"]
+    else:               # eval / no_grad: the aggregate itself is never written
+        _, _, h, part = _HIP.mr_grouped_rows(_f32c(windows), nn_idx.contiguous(), K, 1, w1m, groups, batch, shape[2:], window, shift,
+                                             want_a=False, want_arg=False, want_stats=n1.batch_stats)
+        a, pre = h, (h, part)       # (x is only the chain's shape carrier here)
+    return _PointwiseChain.apply(a, res, w1, norm1.weight, norm1.bias, conv1.bias, conv2.weight, norm2.weight, norm2.bias, conv2.bias,
+                                 groups, n1, n2, mode != "fwd", pre)
 
 
 def _norm_state(norm) -> _NormState:
@@ -1353,11 +1446,19 @@ def pointwise_chain_eligible(x, residual, conv1, norm1, conv2=None, norm2=None) 
     or none; fused BatchNorm modules (batch or running statistics) without internal channel padding."""
     if not x.is_cuda or x.dtype != torch.float32 or torch.is_autocast_enabled("cuda") or _dense_channels_last(x) is None:
         return False
-    if x.numel() // x.shape[1] < _pw_fuse_min_points():
+    return _chain_modules_eligible(tuple(x.shape), residual, conv1, norm1, conv2, norm2)
+
+
+def _chain_modules_eligible(shape, residual, conv1, norm1, conv2=None, norm2=None) -> bool:
+    """:func:`pointwise_chain_eligible` without the input tensor: ``shape`` = (B, C_in, *spatial) of the channels-last input."""
+    points = 1
+    for v in shape[2:]:
+        points *= int(v)
+    if shape[0] * points < _pw_fuse_min_points():
         return False
-    if residual is not None and (residual.dtype != torch.float32 or residual.shape[0] != x.shape[0] or residual.shape[2:] != x.shape[2:]):
+    if residual is not None and (residual.dtype != torch.float32 or residual.shape[0] != shape[0] or tuple(residual.shape[2:]) != tuple(shape[2:])):
         return False
-    cin = x.shape[1]
+    cin = shape[1]
     for conv, norm in ((conv1, norm1), (conv2, norm2)):
         if conv is None:
             continue

@@ -502,10 +502,15 @@ def _swin_forward_channels_last(self, x, size_tuple, dim):
     h = _conv_norm(self.fc1, x)
     windows = graph_ops.window_gather(h, self.window_size, shift)                      # (B * nW, C, Nw)
     nn_idx = gc.dilated_knn_graph.neighbor_ids(windows, None, self._get_relative_pos(self.relative_pos, tuple(self.window_size)))
+    basic = gc.gconv.nn                                                                # grouped 1x1 conv -> norm (-> absorbed LeakyReLU)
+    chain = len(basic) == 3 and isinstance(basic[2], nn.Identity) and len(self.fc2) == 2
+    if chain:       # K2 + K7: aggregation, window reverse and the grouped convolution in one kernel, then the fused chain
+        y = graph_ops.mr_grouped_chain(windows, nn_idx, x, basic[0], basic[1], self.fc2[0], self.fc2[1], size_tuple, self.window_size, shift)
+        if y is not None:
+            return y
     agg = graph_ops.mr_aggregate(windows, nn_idx)                                      # (B * nW, 2C, Nw)
     vol = graph_ops.window_scatter(agg, size_tuple, self.window_size, shift)           # NDHWC (B, 2C, *size)
-    basic = gc.gconv.nn                                                                # grouped 1x1 conv -> norm (-> absorbed LeakyReLU)
-    if len(basic) == 3 and isinstance(basic[2], nn.Identity) and len(self.fc2) == 2:
+    if chain:
         y = graph_ops.pointwise_chain(vol, x, basic[0], basic[1], self.fc2[0], self.fc2[1])
         if y is not None:
             return y

@@ -246,6 +246,99 @@ def test_graph_blocks_fused_vs_op_by_op(ops, monkeypatch, mode):
             assert torch.allclose(r1[k], r0[k], rtol=1e-5, atol=1e-6), (name, k)
 
 
+@pytest.mark.parametrize("B,C,spatial,window,shift,groups,k", [
+    (2, 132, (4, 12, 28), (2, 6, 14), (1, 3, 7), 6, 7),      # cfg-2 stage-2 Swin windows (168 points, 6 groups of 44): the 3 x 11 instance
+    (1, 132, (2, 6, 14), (2, 6, 14), (0, 0, 0), 6, 14),      # one window, K = 14
+    (2, 12, (4, 8, 8), (2, 4, 4), (1, 2, 2), 6, 4),          # groups of 4 channels (generic instance), 32-point windows
+    (3, 64, (1, 12, 10), (1, 4, 5), (0, 2, 0), 4, 9),        # 2-D (D = 1), groups of 32, 20-point windows (less than one wave)
+    (1, 48, (6, 6, 6), (3, 6, 6), (1, 0, 3), 2, 32),         # 108-point windows, groups of 48, the longest list
+])
+def test_mr_aggregate_fused_with_grouped_conv(ops, B, C, spatial, window, shift, groups, k):
+    """K2 + K7 in one launch (nextou_mr_grouped_rows): aggregate rows and arg tape bit-identical to
+    window_scatter(mr_aggregate(windows)), the product equal to the grouped 1x1 convolution of those rows (bit-identical to
+    pw_rows_grp_kernel where that kernel takes the shape), statistics partials = float64 sums of the product."""
+    be = ops._HIP
+    g = torch.Generator().manual_seed(C + k)
+    vol = _cl(torch.randn((B, C) + spatial, generator=g).to(DEV))
+    windows = ops.window_gather(vol, window, shift)
+    n_windows, _, Nw = windows.shape
+    assert be.mr_grouped_rows_supported(n_windows, C, groups, Nw, k)
+    nn_idx = ops.knn_graph(windows, None, None, k)
+    w = (torch.randn((2 * C, 2 * C // groups), generator=g) * 0.2).to(DEV)
+    a, arg, h, part = be.mr_grouped_rows(windows, nn_idx, k, 1, w, groups, B, spatial, window, shift, True, True, True)
+    agg, arg0 = be.mr_fwd(windows, None, nn_idx, None, k, 1, want_arg=True)
+    a0 = be.window_scatter(agg, None, spatial, window, shift)
+    assert torch.equal(a, a0) and torch.equal(arg, arg0)
+    h0, _ = be.pw_rows_fused(a0, w, groups, want_stats=True)
+    want = F.conv3d(a0.double(), w.double().reshape(2 * C, -1, 1, 1, 1), groups=groups)
+    scale = float(want.abs().max())
+    assert float((h.double() - want).abs().max()) <= 2e-6 * scale
+    if a0.numel() // (2 * C) >= 64 * 2 * 256 and 2 * C // groups <= 64:
+        assert torch.equal(h, h0)
+    hs = _rows(h)
+    got = part.sum(1)
+    assert torch.allclose(got[:, 0], hs.sum(0), rtol=0, atol=1e-5 * scale * hs.shape[0] ** 0.5)
+    assert torch.allclose(got[:, 1], (hs * hs).sum(0), rtol=1e-5, atol=1e-6 * scale * scale)
+    # eval: no aggregate, no tape, no statistics — the same product
+    _, _, h_eval, _ = be.mr_grouped_rows(windows, nn_idx, k, 1, w, groups, B, spatial, window, shift, False, False, False)
+    assert torch.equal(h_eval, h)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_swin_block_with_fused_aggregate_vs_three_launches(ops, monkeypatch, mode):
+    """SwinGrapher at the cfg-2 stage-2 width: the K2 + K7 kernel in front of the fused chain against mr_aggregate -> window_scatter ->
+    chain (NEXTOU_MR_GROUPED=0) — same output, gradients and running statistics (the two differ only in the statistics' summation
+    order); the launch labels prove which path ran."""
+    import ctypes
+    import json
+    from nextou_amd import _lib, graph_ops
+    from nextou_amd.network_architecture import NexToU_Encoder_Decoder as encdec
+    from nextou_amd.network_architecture.norm_act import fuse_norm_act
+    monkeypatch.setenv("NEXTOU_PW_FUSE_MIN_POINTS", "0")
+    kw = dict(conv_op=nn.Conv3d, norm_op=nn.BatchNorm3d, norm_op_kwargs={'eps': 1e-5, 'affine': True})
+    torch.manual_seed(11)
+    blk = encdec.SwinGrapher(132, (4, 12, 28), 7, 1, 'mr', 'leakyrelu', 'instance', True, True, 0.2, 1, n=168, relative_pos=True,
+                             window_size=(2, 6, 14), shift_size=[1, 3, 7], dropout_op=None, **kw)
+    fuse_norm_act(blk)
+    blk = blk.to(DEV).train(mode == "train")
+    shape = (2, 132, 4, 12, 28)
+    x0 = torch.randn(shape, device=DEV).contiguous(memory_format=CL)
+    gy = torch.randn(shape, device=DEV).contiguous(memory_format=CL)
+    L_ = _lib.lib()
+    results = {}
+    for setting in ("1", "0"):
+        monkeypatch.setenv("NEXTOU_MR_GROUPED", setting)
+        m = copy.deepcopy(blk)
+        x = x0.clone().requires_grad_(True)
+        L_.nextou_profile_enable(512)
+        y = m(x)
+        grads = torch.autograd.grad(y, [x] + [p for p in m.parameters() if p.requires_grad], gy, allow_unused=True)
+        with torch.no_grad():
+            y_ng = copy.deepcopy(blk)(x0)
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = L_.nextou_profile_report(buf, len(buf))
+        L_.nextou_profile_enable(0)
+        names = [r["kernel"] for r in json.loads(buf.value[:n].decode())]
+        results[setting] = (y.detach(), grads, {k: v.clone() for k, v in m.state_dict().items() if "running" in k}, names, y_ng)
+    assert sum(k.startswith("mr_grp_rows_kernel<train>") for k in results["1"][3]) == 1
+    assert sum(k.startswith("mr_grp_rows_kernel<eval>") for k in results["1"][3]) == 1
+    assert not any(k.startswith(("mr_fwd", "window_scatter")) for k in results["1"][3][:results["1"][3].index(
+        next(k for k in results["1"][3] if k.startswith("mr_grp_rows_kernel")))]), results["1"][3]
+    assert not any(k.startswith("mr_grp_rows_kernel") for k in results["0"][3])
+    (y1, g1, r1, _, n1), (y0, g0, r0, _, n0) = results["1"], results["0"]
+    assert float((y1 - y0).abs().max()) <= 1e-6 * float(y0.abs().max())
+    assert float((n1 - n0).abs().max()) <= 1e-6 * float(n0.abs().max())
+    assert float((n1 - y1).abs().max()) <= 1e-6 * float(y1.abs().max())       # (no_grad takes the eval kernel variant)
+    gscale = max(float(b.abs().max()) for b in g0 if b is not None)
+    for a, b in zip(g1, g0):
+        assert (a is None) == (b is None)
+        if a is not None:   # (analytically zero gradients — a bias in front of a batch-statistics norm — are round-off of the largest ones)
+            assert float((a - b).abs().max()) <= max(1e-5 * float(b.abs().max()), 5e-7 * gscale)
+    for k in r0:
+        assert torch.allclose(r1[k], r0[k], rtol=1e-6, atol=1e-7), k
+
+
 @pytest.mark.parametrize("ci,co", [(132, 528), (132, 264), (132, 132), (264, 132), (528, 132)])
 def test_stationary_weights_rows_kernel(ops, monkeypatch, ci, co):
     """pw_rows_sw_kernel (weights in registers, x streamed once; the stage-2 shapes, >= 65 536 points) against pw_rows_kernel and the

@@ -95,6 +95,30 @@ def test_knn_shape_sweep_bit_exact(ops, ora, B, C, N, M, k, relpos):
     _knn_case(ops, ora, B, C, N, M, k, relpos, seed=1000 + N + (M or 0) + k)
 
 
+@pytest.mark.parametrize("B,C,N,k,relpos", [
+    (600, 12, 168, 7, True),     # whole window per workgroup (B * ceil(N/32) >= 512), list bucket 7
+    (100, 33, 191, 14, True),    # whole window, ragged N and C, bucket 14
+    (90, 8, 192, 28, False),     # whole window at the 192-point limit, bucket 28
+    (3, 5, 64, 32, True),        # N <= 64: one 64-wide tile pair, K = 32
+    (2, 3, 1, 1, False),         # a single point
+    (1, 4, 33, 9, True),         # N <= 64 ragged, K bucketed into 14
+    (16, 324, 168, 14, True),    # cfg-2 stage-4 Swin windows: candidate ranges split over workgroups + merge
+    (12, 40, 130, 32, True),     # split, ragged last range, K = 32
+    (11, 17, 97, 20, False),     # split, odd everything, K bucketed into 28
+    (2, 324, 168, 28, True),     # cfg-2 stage 5 (too few windows: stays on prep + fused + merge)
+])
+def test_knn_single_launch_window_kernel_bit_exact(ops, ora, B, C, N, k, relpos):
+    """Self graphs of <= 192 points take knn_window_kernel (normalisation, squared norms, MFMA distances and selection in one launch;
+    knn_graph.hip plan_window); the same ids as the oracle and as the three-launch path it replaces."""
+    _knn_case(ops, ora, B, C, N, None, k, relpos, seed=4000 + N + k, algos=("fused",))
+    x = _rand((B, C, N), 4000 + N + k).to(DEV)
+    rp = _rand((N, N), 4002 + N + k, 0.05).to(DEV) if relpos else None
+    one = ops.knn_graph(x, None, rp, k, algo="fused")
+    # (the switch is read once per process by the library: the three-launch path is reached through an explicit y = x graph)
+    three = ops.knn_graph(x, x.clone(), rp, k, algo="fused")
+    assert torch.equal(one, three)
+
+
 def test_knn_auto_selects_and_rejects(ops):
     x = _rand((1, 8, 40), 3).to(DEV)
     assert ops.knn_graph(x, k=33).shape == (1, 40, 33)           # auto -> naive

@@ -156,6 +156,42 @@ def bench_bti(args, dev, L):
         json.dump(rows, open(args.json, "w"), indent=1)
 
 
+def bench_mrg(args, dev, L):
+    """K2 + K7 (nextou_mr_grouped_rows) at the cfg-2 stage-2 Swin shape, train and eval variants, against the three launches it replaces."""
+    from torch import nn
+    from nextou_amd.network_architecture import NexToU_Encoder_Decoder as encdec
+    patch, strides = (64, 224, 192), [[1, 1, 1], [1, 2, 2]] + [[2, 2, 2]] * 4
+    shapes, _ = encdec._stage_shapes(nn.Conv3d, patch, strides)
+    _, _, window = encdec.gnn_stage_hyperparameters(nn.Conv3d, shapes[-1], 6)
+    spatial, C, k, groups, B = tuple(shapes[2]), 132, 7, 6, 2
+    shift = tuple(w // 2 for w in window)
+    be = graph_ops._HIP
+    g = torch.Generator(device=dev).manual_seed(1)
+    vol = torch.randn((B, C) + spatial, generator=g, device=dev).contiguous(memory_format=torch.channels_last_3d)
+    windows = graph_ops.window_gather(vol, window, shift)
+    idx = graph_ops.knn_graph(windows, None, None, k)
+    w = torch.randn((2 * C, 2 * C // groups), generator=g, device=dev) * 0.1
+    print("windows", tuple(windows.shape), "volume", spatial, "window", tuple(window))
+    for it in range(2 + args.iters):
+        if it == 2:
+            torch.cuda.synchronize()
+            L.nextou_profile_enable(64 * args.iters)
+        be.mr_grouped_rows(windows, idx, k, 1, w, groups, B, spatial, window, shift, True, True, True)
+        be.mr_grouped_rows(windows, idx, k, 1, w, groups, B, spatial, window, shift, False, False, True)
+        be.mr_grouped_rows(windows, idx, k, 1, w, groups, B, spatial, window, shift, False, False, False)
+        agg, _ = be.mr_fwd(windows, None, idx, None, k, 1, want_arg=True)
+        a0 = be.window_scatter(agg, None, spatial, window, shift)
+        be.pw_rows_fused(a0, w, groups, want_stats=True)
+    torch.cuda.synchronize()
+    buf = ctypes.create_string_buffer(1 << 20)
+    L.nextou_profile_report(buf, len(buf))
+    L.nextou_profile_enable(0)
+    for r in json.loads(buf.value.decode()):
+        per_s = r["ms"] / r["launches"] / 1e3
+        ach = r["work"] / r["launches"] / per_s
+        print("%-70s %8.1f us %8.1f GB/s %5.1f%%  x%d" % (r["kernel"][:70], per_s * 1e6, ach / 1e9, 100 * ach / PEAK[r["bound"]], r["launches"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg", type=int, default=2)
@@ -164,6 +200,7 @@ def main():
     ap.add_argument("--only", default=None, help="substring filter on the call label")
     ap.add_argument("--norm", action="store_true", help="bench K6 (norm + LeakyReLU) instead of K1/K2")
     ap.add_argument("--cl", action="store_true", help="with --norm: channels-last tensors")
+    ap.add_argument("--mrg", action="store_true", help="bench the K2 + K7 kernel (aggregate + grouped conv) at the cfg-2 stage-2 Swin shape")
     ap.add_argument("--bti", action="store_true", help="bench K5 (arg-max labels, critical map, critical-voxel CE) at the cfg-4 scales")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -172,6 +209,8 @@ def main():
         return bench_norm(args, dev, L)
     if args.bti:
         return bench_bti(args, dev, L)
+    if args.mrg:
+        return bench_mrg(args, dev, L)
     calls = CFG2 if args.cfg == 2 else CFG5
     rows = []
     for label, B, C, N, M, k in calls:

@@ -9,8 +9,9 @@
 #   kernels    tools/kernel_bench.py at the cfg-2 and cfg-5 shapes, K5 (--bti), K6 (--norm --cl)
 #   trace      rocprofv3 --kernel-trace --stats of the eager cfg-2 step -> one steady-state step as a markdown table
 #   pmc5       PMC FETCH_SIZE / WRITE_SIZE (separate passes) of the graph kernels at the cfg-5 shapes "s2 Swin" and "s3 Pool"
+#   pmcmrg     the same two PMC passes over the K2 + K7 kernel and the three launches it replaces (tools/kernel_bench.py --mrg)
 #   cpusurvey  bench.py --cpu-protocol survey (batch 2, 1 + 3 steps, all physical cores; ~10 min of host time)
-#   closing    tests margins bench configs stages kernels trace pmc5 in that order
+#   closing    tests margins bench configs stages kernels trace pmc5 pmcmrg in that order
 TASK=${1:-closing}
 TAG=${2:-r04}
 R=$PWD
@@ -49,6 +50,7 @@ t_kernels() {
   python tools/kernel_bench.py --cfg 5 --iters 5 > $OUT/kernel_bench_cfg5.txt 2>&1
   python tools/kernel_bench.py --bti --iters 10 > $OUT/kernel_bench_k5.txt 2>&1
   python tools/kernel_bench.py --norm --cl --iters 10 > $OUT/kernel_bench_norm_cl.txt 2>&1
+  python tools/kernel_bench.py --mrg --iters 10 > $OUT/kernel_bench_mrg.txt 2>&1
   grep -E "knn_fused|mr_" $OUT/kernel_bench_cfg2.txt | head -24
 }
 t_trace() {
@@ -72,12 +74,22 @@ t_pmc5() {
   done
   cd $R
 }
+t_pmcmrg() {
+  cd /tmp && export TMPDIR=/tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcmrg/$c -o pmc -- python $R/tools/kernel_bench.py --mrg --iters 3 > $OUT/pmcmrg_$c.log 2>&1 || tail -3 $OUT/pmcmrg_$c.log
+  done
+  python $R/tools/pmc_table.py $OUT/pmcmrg/FETCH_SIZE $OUT/pmcmrg/WRITE_SIZE > $OUT/pmcmrg.md 2>&1
+  cat $OUT/pmcmrg.md | cut -c1-400
+  find $OUT/pmcmrg -name "*.csv" -size +2M -delete
+  cd $R
+}
 t_cpusurvey() {
   python bench.py --steps 5 --warmup 3 --cpu-protocol survey > $OUT/bench_cfg2_cpu_survey.json 2> $OUT/bench_cfg2_cpu_survey.log
   python -c "import json;d=json.load(open('$OUT/bench_cfg2_cpu_survey.json'));print(d['cpu_baseline'])"
 }
 case $TASK in
-  closing) for t in tests margins bench configs stages kernels trace pmc5; do echo "== $t"; t_$t; done ;;
+  closing) for t in tests margins bench configs stages kernels trace pmc5 pmcmrg; do echo "== $t"; t_$t; done ;;
   *) for t in ${TASK//,/ }; do echo "== $t"; t_$t; done ;;
 esac
 du -sh $OUT | tail -1
