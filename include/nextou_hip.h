@@ -159,10 +159,18 @@ int nextou_mr_aggregate_bwd(const float* gout, const float* x, const float* y,
  * C % groups == 0, C / groups even and <= 32, Nw <= 256: nextou_mr_grouped_rows_supported() says whether a shape is taken
  * (NEXTOU_ENOTSUP otherwise; NEXTOU_MR_GROUPED=0 switches the kernel off).  HBM-bound: 12 B'C Nw + 4 B' Nw K bytes in eval. */
 int nextou_mr_grouped_rows_supported(int n_windows, int C, int groups, int Nw, int K);
+/* nextou_mr_grouped_rows_bwd: the window tensor's gradient in one launch — autograd of the three ops above (grouped data-gradient
+ * GEMM, window gather of the gradient rows, arg-tape scatter of nextou_mr_aggregate_bwd_arg):
+ *   dh_rows  channels-last (B, D, H, W, 2C): gradient of h_rows;  weight, arg: as in the forward
+ *   dx       (B * nWin, C, Nw) float32, overwritten: dx[c][n] = ga[n][2c] - ga[n][2c+1] + sum_{n': arg[c][n'] == n} ga[n'][2c+1],
+ *            ga = dh W_g per group; sums in 64-bit fixed point (bit-reproducible), NaN-poisoned per (window, group) tile when a
+ *            gradient in it is not finite.  (The weight gradient is nextou_pw_wgrad on (dh_rows, a_rows).) */
 int nextou_mr_grouped_rows(const float* windows, const int32_t* nn_idx, int idx_stride, int idx_step, int K, const float* weight,
                            float* a_rows, uint16_t* arg_out, float* h_rows, double* stats_partial, int stats_tiles,
                            int B, int C, int D, int H, int W, int wd, int wh, int ww, int sd, int sh, int sw, int groups,
                            nextou_stream_t stream);
+int nextou_mr_grouped_rows_bwd(const float* dh_rows, const float* weight, const uint16_t* arg, float* dx, int B, int C,
+                               int D, int H, int W, int wd, int wh, int ww, int sd, int sh, int sw, int groups, nextou_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * batched_index_select (reference torch_nn.py:94-115):

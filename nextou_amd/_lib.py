@@ -42,6 +42,7 @@ _SIGNATURES = {
                                         c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "nextou_mr_aggregate_has_arg": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "nextou_mr_grouped_rows_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "nextou_mr_grouped_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),
     "nextou_mr_grouped_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int] +
                                [c_int] * 12 + [c_void_p]),
     "nextou_mr_aggregate_bwd_arg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

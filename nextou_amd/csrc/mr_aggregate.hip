@@ -1119,6 +1119,155 @@ __global__ __launch_bounds__(512) void mr_grp_rows_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward of the K2 + K7 launch for the window tensor: grouped data-gradient GEMM -> window gather -> arg-tape scatter, one
+// workgroup per (window, group).  Op by op: pw_rows(dh, W^T, groups) wrote the aggregate's gradient as channels-last rows,
+// window_gather re-wrote it channel-major per window, mr_bwd_fix_kernel read it back — 1 046 MB at the cfg-2 stage-2 Swin shape,
+// 318 MB here (dh rows in, arg tape in, dx out):
+//   0. the window's rows of dh (the gradient of the grouped convolution's output, channels-last volume) come in through the window
+//      map as 16-byte pieces -> LDS slab [Nw][2 Cg]; the group's weights -> LDS -> registers as B[o][k] = W[g * Kg + o][k];
+//   1. v_mfma_f32_16x16x4_f32 forms ga = dh W_g in place (the same o-ordered chain per element as pw_rows_grp_kernel on W^T):
+//      ga[n][2j] = d/dx_j of the pass-through half, ga[n][2j + 1] = the gradient of the max-relative half;
+//   2. mr_bwd_fix_kernel's scheme on the slab: tile maximum exponent, 64-bit fixed-point LDS atomics routed by the arg tape
+//      (exact integer sums: bit-reproducible), dx[c][n] = scattered + (ga[n][2j] - ga[n][2j + 1]) written channel-major.
+// ---------------------------------------------------------------------------------------------
+template <int NT, int KSTEPS, bool EXACT>
+__global__ __launch_bounds__(512) void mr_grp_rows_bwd_kernel(
+    const float* __restrict__ dh_rows, const float* __restrict__ w, const uint16_t* __restrict__ arg, float* __restrict__ dx, Vol v,
+    Win wn, int nH, int nW, int n_win, int n_windows, int C, int Cg, int Nw, int groups, int ld, long ld_rows, GrpDiv dv, int S) {
+    extern __shared__ __attribute__((aligned(16))) float4 grp_tile4[];
+    __shared__ unsigned wave_max[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = blockDim.x, nwv = T >> 6;
+    const int blk = blockIdx.x / (8 * groups), rem = blockIdx.x - blk * 8 * groups;
+    const int g = rem >> 3, bw = blk * 8 + (rem & 7);
+    if (bw >= n_windows) return;
+    const int Kg = 2 * Cg, MT = (Nw + 15) >> 4, kp = Kg >> 2;
+    // LDS: [facc: Cg x Nw int64 | before that the weights Kg x Kg][slab: MT * 16 rows x ld][rows: Nw int]
+    long long* facc = reinterpret_cast<long long*>(grp_tile4);
+    float* wl = reinterpret_cast<float*>(grp_tile4);
+    const int acc_f4 = max((Cg * Nw + 1) >> 1, (Kg * Kg) >> 2);
+    float* slab = reinterpret_cast<float*>(grp_tile4 + acc_f4);
+    int* rows = reinterpret_cast<int*>(slab + (size_t)MT * 16 * ld);
+    const int ln = lane & 15, lk = lane >> 4;
+    const int b = bw / n_win, win = bw - b * n_win;                 // (uniform)
+    const size_t row_base = (size_t)b * ((size_t)v.D * v.H * v.W);
+    const uint16_t* ab = arg + ((size_t)bw * C + (size_t)g * Cg) * Nw;
+    const int items = Cg * Nw;
+    constexpr int UA = 8;
+    unsigned short apre[UA];
+    // ---- 0: the window map (LDS-only barrier), then the rows of dh through it as 16-byte pieces; the weights' loads are in flight
+    // from the start and reach LDS with the first batch of rows: one memory round trip for the cfg-2 shapes
+    {
+        const f32x4* wg = reinterpret_cast<const f32x4*>(w + (size_t)g * Kg * Kg);
+        const int w4 = (Kg * Kg) >> 2;
+        constexpr int UW = 2, U = 4;
+        f32x4 wpre[UW];
+#pragma unroll
+        for (int u = 0; u < UW; ++u) wpre[u] = wg[min(tid + u * T, w4 - 1)];
+#pragma unroll
+        for (int u = 0; u < UA; ++u) apre[u] = ab[min(tid + u * T, items - 1)];      // the arg tape of phase 2: no round trip there
+        for (int p = tid; p < Nw; p += T) rows[p] = (int)window_point_row(win, p, v, wn, nH, nW);
+        lds_barrier();
+        const int pieces = Nw * kp;
+        for (int e0 = tid; e0 < pieces; e0 += U * T) {
+            f32x4 t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = min(e0 + u * T, pieces - 1);
+                const int r = fdiv(e, kp, dv.kp), pc = e - r * kp;
+                t[u] = *reinterpret_cast<const f32x4*>(dh_rows + (row_base + rows[r]) * ld_rows + (size_t)g * Kg + 4 * pc);
+            }
+            if (e0 == tid) {
+#pragma unroll
+                for (int u = 0; u < UW; ++u)
+                    if (tid + u * T < w4) reinterpret_cast<f32x4*>(wl)[tid + u * T] = wpre[u];
+                for (int e = tid + UW * T; e < w4; e += T) reinterpret_cast<f32x4*>(wl)[e] = wg[e];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * T;
+                if (e < pieces) { const int r = fdiv(e, kp, dv.kp), pc = e - r * kp; *reinterpret_cast<f32x4*>(slab + (size_t)r * ld + 4 * pc) = t[u]; }
+            }
+        }
+        __syncthreads();
+    }
+    // B operand of tile (nt, ks) = W[g * Kg + 4 * ks + lk][nt * 16 + ln]
+    float wreg[NT][KSTEPS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int k = nt * 16 + ln, o = 4 * ks + lk;
+            const int kc = k < Kg ? k : Kg - 1, oc = o < Kg ? o : Kg - 1;
+            const float t = wl[oc * Kg + kc];
+            wreg[nt][ks] = (k < Kg && o < Kg) ? t : 0.f;
+        }
+    __syncthreads();
+    // ---- 1: ga = dh W_g in place; the tile's largest |g_mr| on the way
+    for (int e = tid; e < Cg * Nw; e += T) facc[e] = 0ll;          // (the weights are in registers)
+    unsigned mx = 0u;
+#pragma unroll 1
+    for (int mt = wave; mt < MT; mt += nwv) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* arow = slab + (size_t)(mt * 16 + ln) * ld + lk;
+        float a[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) a[ks] = arow[(EXACT || 4 * ks + lk < Kg) ? 4 * ks : 0];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], wreg[nt][ks], acc[nt], 0, 0, 0);
+        float* orow = slab + (size_t)(mt * 16 + 4 * lk) * ld + ln;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt * 16 + ln < Kg) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    orow[(size_t)r * ld + nt * 16] = acc[nt][r];
+                    if ((ln & 1) && mt * 16 + 4 * lk + r < Nw) mx = max(mx, __float_as_uint(acc[nt][r]) & 0x7fffffffu);   // odd column: g_mr
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+    if (lane == 0) wave_max[wave] = mx;
+    __syncthreads();
+    mx = 0u;
+    for (int wv = 0; wv < nwv; ++wv) mx = max(mx, wave_max[wv]);
+    const int e_raw = (int)(mx >> 23);
+    const bool bad = e_raw == 255;                                  // inf / NaN somewhere in the tile
+    const int e_max = e_raw ? e_raw : 1;
+    // ---- 2: scatter by the arg tape (lanes along the points of one channel)
+    if (!bad) {
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            const int e = tid + u * T;
+            if (e < items) {
+                const int j = fdiv(e, Nw, dv.nw), n = e - j * Nw;
+                atomicAdd(reinterpret_cast<unsigned long long*>(facc) + j * Nw + apre[u],
+                          (unsigned long long)fix_from_float(slab[(size_t)n * ld + 2 * j + 1], e_max, S));
+            }
+        }
+        for (int e = tid + UA * T; e < items; e += T) {
+            const int j = fdiv(e, Nw, dv.nw), n = e - j * Nw;
+            const unsigned a = ab[e];
+            atomicAdd(reinterpret_cast<unsigned long long*>(facc) + j * Nw + a,
+                      (unsigned long long)fix_from_float(slab[(size_t)n * ld + 2 * j + 1], e_max, S));
+        }
+    }
+    __syncthreads();
+    const float poison = __uint_as_float(0x7fc00000u);
+    float* dxb = dx + ((size_t)bw * C + (size_t)g * Cg) * Nw;
+    for (int e = tid; e < items; e += T) {
+        const int j = fdiv(e, Nw, dv.nw), n = e - j * Nw;
+        const f32x2 gp = *reinterpret_cast<const f32x2*>(slab + (size_t)n * ld + 2 * j);
+        dxb[e] = (bad ? poison : fix_to_float(facc[e], e_max, S)) + (gp.x - gp.y);
+    }
+}
+
 struct MrGrpPlan { bool ok; int threads, ld, grid; size_t lds; };
 static MrGrpPlan plan_mr_grp(int n_windows, int C, int groups, int Nw, int K) {
     MrGrpPlan q{};
@@ -1468,4 +1617,49 @@ extern "C" int nextou_mr_grouped_rows(const float* windows, const int32_t* nn_id
 #undef NEXTOU_MR_GRP_K
 #undef NEXTOU_MR_GRP
     return check_launch("mr_grp_rows_kernel");
+}
+
+/* data gradient of nextou_mr_grouped_rows for the window tensor (see include/nextou_hip.h) */
+extern "C" int nextou_mr_grouped_rows_bwd(const float* dh_rows, const float* weight, const uint16_t* arg, float* dx, int B, int C,
+                                          int D, int H, int W, int wd, int wh, int ww, int sd, int sh, int sw, int groups,
+                                          nextou_stream_t stream) {
+    NEXTOU_REQUIRE(dh_rows && weight && arg && dx, "mr_grouped_rows_bwd: null pointer");
+    NEXTOU_REQUIRE(B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && (long long)D * H * W < (1ll << 31), "mr_grouped_rows_bwd: bad volume");
+    NEXTOU_REQUIRE(wd > 0 && wh > 0 && ww > 0 && D % wd == 0 && H % wh == 0 && W % ww == 0,
+                   "mr_grouped_rows_bwd: window (%d,%d,%d) does not tile the volume (%d,%d,%d)", wd, wh, ww, D, H, W);
+    NEXTOU_REQUIRE(sd >= 0 && sd < D && sh >= 0 && sh < H && sw >= 0 && sw < W, "mr_grouped_rows_bwd: shift (%d,%d,%d) out of range", sd, sh, sw);
+    const int Nw = wd * wh * ww, nD = D / wd, nH = H / wh, nW = W / ww, n_win = nD * nH * nW;
+    const long long n_windows = (long long)B * n_win;
+    NEXTOU_REQUIRE(n_windows < (1ll << 24), "mr_grouped_rows_bwd: %lld windows", n_windows);
+    const MrGrpPlan q = plan_mr_grp((int)n_windows, C, groups, Nw, 1);
+    if (!q.ok)
+        return fail(NEXTOU_ENOTSUP, "mr_grouped_rows_bwd: unsupported shape (windows %lld, C %d, groups %d, Nw %d)", n_windows, C, groups, Nw);
+    NEXTOU_REQUIRE(((reinterpret_cast<uintptr_t>(dh_rows) | reinterpret_cast<uintptr_t>(weight)) & 15u) == 0,
+                   "mr_grouped_rows_bwd: weight / row buffers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int Cg = C / groups, Kg = 2 * Cg, MT = cdiv(Nw, 16);
+    const double pts = (double)n_windows * Nw;
+    ProfScope prof(s, kBoundHbm, 8.0 * C * pts + 2.0 * C * pts + 4.0 * C * pts, "mr_grp_rows_bwd_kernel[B%lld C%d N%d g%d]", n_windows, C, Nw, groups);
+    const Vol v{D, H, W};
+    const Win wn{wd, wh, ww, sd, sh, sw};
+    const GrpDiv dv{div_magic(Nw), 0u, div_magic(Kg >> 2)};
+    const int acc_f4 = std::max((Cg * Nw + 1) / 2, Kg * Kg / 4);
+    const size_t lds = (size_t)acc_f4 * 16 + (size_t)MT * 16 * q.ld * 4 + (size_t)((Nw + 3) & ~3) * 4;
+    if (lds > 150 * 1024) return fail(NEXTOU_ENOTSUP, "mr_grouped_rows_bwd: %zu bytes of LDS", lds);
+    int threads = 64 * cdiv(Cg * Nw, 64 * 4);                      // ~4 scatter items per lane
+    if (threads > 512) threads = 512;
+    if (threads < 64) threads = 64;
+    const int S = 47;                                              // (a tile is one window: Nw <= 256 addends per accumulator)
+#define NEXTOU_MR_GRP_BWD(NT, KS, EX)                                                                                              \
+    do {                                                                                                                         \
+        if (lds > 64 * 1024)                                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_grp_rows_bwd_kernel<NT, KS, EX>),                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+        hipLaunchKernelGGL((mr_grp_rows_bwd_kernel<NT, KS, EX>), dim3(q.grid), dim3(threads), lds, s, dh_rows, weight, arg, dx, v, wn, nH, \
+                           nW, n_win, (int)n_windows, C, Cg, Nw, groups, q.ld, (long)2 * C, dv, S);                              \
+    } while (0)
+    if (Kg == 44) NEXTOU_MR_GRP_BWD(3, 11, true);
+    else NEXTOU_MR_GRP_BWD(4, 16, false);
+#undef NEXTOU_MR_GRP_BWD
+    return check_launch("mr_grp_rows_bwd_kernel");
 }

@@ -182,6 +182,20 @@ class _HipBackend:
         return a, arg, h, partial
 
     @staticmethod
+    def mr_grouped_rows_bwd(dh, w2, arg, groups, spatial, window, shift):
+        """dh channels-last (B, 2C, *spatial), arg (B * nWin, C, Nw) -> dx (B * nWin, C, Nw): csrc/mr_aggregate.hip mr_grp_rows_bwd_kernel."""
+        L_ = _lib.lib()
+        D, H, W = _dhw(spatial)
+        wd, wh, ww = _dhw(window)
+        sd, sh, sw = _dhw(shift, fill=0)
+        dx = torch.empty(arg.shape, dtype=torch.float32, device=dh.device)
+        with torch.cuda.device(dh.device):
+            rc = L_.nextou_mr_grouped_rows_bwd(dh.data_ptr(), w2.data_ptr(), arg.data_ptr(), dx.data_ptr(), dh.shape[0], arg.shape[1],
+                                               D, H, W, wd, wh, ww, sd, sh, sw, groups, _stream_ptr(dh.device))
+        _lib.check(rc, "mr_grouped_rows_bwd")
+        return dx
+
+    @staticmethod
     def mr_bwd_wants_idx(B, C, N, K):
         return bool(_lib.lib().nextou_mr_aggregate_bwd_wants_idx(B, C, N, K))
 
@@ -1275,12 +1289,13 @@ class _PointwiseChain(torch.autograd.Function):
     normalisation is K6's fmaf, the statistics are float64 sums of the same values in another order)."""
 
     @staticmethod
-    def forward(ctx, x, residual, w1, g1, b1, cb1, w2, g2, b2, cb2, groups1, n1, n2, fuse_bwd, pre=None):
+    def forward(ctx, x, residual, w1, g1, b1, cb1, w2, g2, b2, cb2, groups1, n1, n2, fuse_bwd, pre_h=None, pre_part=None):
         dev = x.device
         P = x.numel() // x.shape[1]
         c1 = w1.shape[0]
-        if pre is not None:             # (h, partials) of GEMM1 from the kernel that produced x (mr_grouped_chain): same values
-            h, part1 = pre
+        ctx.pre = pre_h is not None
+        if ctx.pre:     # GEMM1's output and statistics partials come from the kernel that produced x (mr_grouped_chain): that kernel
+            h, part1 = pre_h, pre_part      # owns GEMM1's data gradient too — the gradient goes to pre_h (dh), none to x
         else:
             w1m = w1.reshape(c1, w1.shape[1]).contiguous()
             h, part1 = _HIP.pw_rows_fused(x, w1m, groups1, want_stats=n1.batch_stats)
@@ -1330,7 +1345,7 @@ class _PointwiseChain(torch.autograd.Function):
             dh, gg1, gb1 = _HIP.norm_act_bwd(h, g, g1, b1, m1, i1, n1.batch_stats, n1.slope, 0, channels_last=True)
         gx = gw1 = gcb1 = None
         n, k = c1 // groups1, w1.shape[1]
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and not ctx.pre:
             w1t = w1.reshape(groups1, n, k).transpose(1, 2).reshape(groups1 * k, n).contiguous()
             gx = _HIP.pw_rows(dh, w1t, None, groups1)
         if ctx.needs_input_grad[2]:
@@ -1338,7 +1353,8 @@ class _PointwiseChain(torch.autograd.Function):
         if cb1 is not None and ctx.needs_input_grad[5]:
             gcb1 = torch.zeros_like(cb1) if n1.batch_stats else (gb1 * i1 * (g1 if g1 is not None else 1.0))
         return (gx, g if has_res else None, gw1, gg1 if ctx.needs_input_grad[3] else None, gb1 if ctx.needs_input_grad[4] else None, gcb1,
-                gw2, gg2 if ctx.needs_input_grad[7] else None, gb2 if ctx.needs_input_grad[8] else None, gcb2, None, None, None, None, None)
+                gw2, gg2 if ctx.needs_input_grad[7] else None, gb2 if ctx.needs_input_grad[8] else None, gcb2, None, None, None, None,
+                dh if ctx.pre else None, None)
 
 
 def pointwise_chain(x, residual, conv1, norm1, conv2=None, norm2=None):
@@ -1359,28 +1375,38 @@ def pointwise_chain(x, residual, conv1, norm1, conv2=None, norm2=None):
 
 
 class _MRAggregateRows(torch.autograd.Function):
-    """Max-relative aggregation of Swin windows written straight into the channels-last volume (``window_scatter(mr_aggregate(x))``)
-    by the K2 + K7 kernel, which also leaves the grouped convolution of those rows and its statistics partials in ``box`` for the
-    point-wise chain behind it.  Backward = the two ops' own backwards (window gather of the gradient rows, arg-tape scatter)."""
+    """K2 + K7 (csrc/mr_aggregate.hip): max-relative aggregation of Swin windows, window reverse and MRConv's grouped 1x1 convolution in
+    one launch.  Returns ``(a, h)``: the aggregate as a channels-last volume (``window_scatter(mr_aggregate(windows))``; data for the
+    weight gradient, not differentiable here) and the convolution's output; the statistics partials of ``h`` go to ``box``.
+    Backward (gradient of ``h`` -> gradient of ``windows``): one launch as well; NEXTOU_MR_GROUPED_BWD=0 or an unsupported shape runs
+    the three ops' own backwards (grouped data-gradient GEMM, window gather, arg-tape scatter)."""
 
     @staticmethod
     def forward(ctx, windows, nn_idx, K, idx_step, w1m, groups, batch, spatial, window, shift, want_stats, box):
         need_x = windows.requires_grad
         a, arg, h, part = _HIP.mr_grouped_rows(windows, nn_idx, K, idx_step, w1m, groups, batch, spatial, window, shift,
                                                want_a=True, want_arg=need_x, want_stats=want_stats)
-        box["pre"] = (h, part)
-        ctx.conf = (window, shift, windows.shape[2])
+        box["part"] = part
+        ctx.conf = (window, shift, tuple(spatial), windows.shape[2], groups)
         if need_x:
-            ctx.save_for_backward(arg)
-        return a
+            ctx.save_for_backward(arg, w1m)
+        ctx.mark_non_differentiable(a)
+        return a, h
 
     @staticmethod
-    def backward(ctx, ga):
-        window, shift, Nw = ctx.conf
-        (arg,) = ctx.saved_tensors
-        mf = {4: torch.channels_last, 5: torch.channels_last_3d}[ga.dim()]
-        gw = _HIP.window_gather(ga.contiguous(memory_format=mf), window, shift)
-        dx, _ = _HIP.mr_bwd_arg(gw, arg, Nw, False)
+    def backward(ctx, _ga, dh):
+        import os
+        window, shift, spatial, Nw, groups = ctx.conf
+        arg, w1m = ctx.saved_tensors
+        mf = {4: torch.channels_last, 5: torch.channels_last_3d}[dh.dim()]
+        dh = dh.contiguous(memory_format=mf)
+        if os.environ.get("NEXTOU_MR_GROUPED_BWD", "1") != "0":
+            dx = _HIP.mr_grouped_rows_bwd(dh, w1m, arg, groups, spatial, window, shift)
+        else:
+            n, k = w1m.shape[0] // groups, w1m.shape[1]
+            w1t = w1m.reshape(groups, n, k).transpose(1, 2).reshape(groups * k, n).contiguous()
+            ga = _HIP.pw_rows(dh, w1t, None, groups)
+            dx, _ = _HIP.mr_bwd_arg(_HIP.window_gather(ga, window, shift), arg, Nw, False)
         return (dx,) + (None,) * 11
 
 
@@ -1410,15 +1436,15 @@ def mr_grouped_chain(windows, nn_idx, residual, conv1, norm1, conv2, norm2, spat
     res = as_channels_last_rows(residual)
     if needs_grad:
         box = {}
-        a = _MRAggregateRows.apply(_f32c(windows), nn_idx.contiguous(), K, 1, w1m, groups, batch, shape[2:], window, shift,
-                                   n1.batch_stats, box)
-        pre = box["pre"]
+        a, h = _MRAggregateRows.apply(_f32c(windows), nn_idx.contiguous(), K, 1, w1m, groups, batch, shape[2:], window, shift,
+                                      n1.batch_stats, box)
+        part = box["part"]
     else:               # eval / no_grad: the aggregate itself is never written
         _, _, h, part = _HIP.mr_grouped_rows(_f32c(windows), nn_idx.contiguous(), K, 1, w1m, groups, batch, shape[2:], window, shift,
                                              want_a=False, want_arg=False, want_stats=n1.batch_stats)
-        a, pre = h, (h, part)       # (x is only the chain's shape carrier here)
+        a = h           # (x is only the chain's shape carrier here)
     return _PointwiseChain.apply(a, res, w1, norm1.weight, norm1.bias, conv1.bias, conv2.weight, norm2.weight, norm2.bias, conv2.bias,
-                                 groups, n1, n2, mode != "fwd", pre)
+                                 groups, n1, n2, mode != "fwd", h, part)
 
 
 def _norm_state(norm) -> _NormState:

@@ -282,6 +282,23 @@ def test_mr_aggregate_fused_with_grouped_conv(ops, B, C, spatial, window, shift,
     # eval: no aggregate, no tape, no statistics — the same product
     _, _, h_eval, _ = be.mr_grouped_rows(windows, nn_idx, k, 1, w, groups, B, spatial, window, shift, False, False, False)
     assert torch.equal(h_eval, h)
+    # backward for the window tensor in one launch: grouped data-gradient GEMM + window gather + arg-tape scatter
+    dh = _cl(torch.randn(h.shape, generator=g).to(DEV))
+    dx = be.mr_grouped_rows_bwd(dh, w, arg, groups, spatial, window, shift)
+    n_, k_ = w.shape[0] // groups, w.shape[1]
+    wt = w.reshape(groups, n_, k_).transpose(1, 2).reshape(groups * k_, n_).contiguous()
+    ga = be.pw_rows(dh, wt, None, groups)
+    dx0, _ = be.mr_bwd_arg(be.window_gather(ga, window, shift), arg, Nw, False)
+    ga64 = F.conv_transpose3d(dh.double(), w.double().reshape(2 * C, -1, 1, 1, 1), groups=groups)
+    gw64 = ops.window_gather(ga64.float(), window, shift).double()          # (layout only; the float32 round trip is checked below)
+    tol = 2e-6 * float(dx0.abs().max())
+    assert float((dx - dx0).abs().max()) <= tol
+    assert torch.equal(dx, be.mr_grouped_rows_bwd(dh, w, arg, groups, spatial, window, shift))      # fixed-point sums: bit-reproducible
+    want_dx = torch.zeros((n_windows, C, Nw), dtype=torch.float64, device=DEV)
+    gx64, gm64 = gw64[:, 0::2], gw64[:, 1::2]
+    want_dx.scatter_add_(2, arg.long() & 0xffff, gm64)
+    want_dx += gx64 - gm64
+    assert float((dx.double() - want_dx).abs().max()) <= 1e-5 * float(want_dx.abs().max())
 
 
 @pytest.mark.parametrize("mode", ["train", "eval"])
@@ -321,6 +338,7 @@ def test_swin_block_with_fused_aggregate_vs_three_launches(ops, monkeypatch, mod
         L_.nextou_profile_enable(0)
         names = [r["kernel"] for r in json.loads(buf.value[:n].decode())]
         results[setting] = (y.detach(), grads, {k: v.clone() for k, v in m.state_dict().items() if "running" in k}, names, y_ng)
+    assert sum(k.startswith("mr_grp_rows_bwd_kernel") for k in results["1"][3]) == 1
     assert sum(k.startswith("mr_grp_rows_kernel<train>") for k in results["1"][3]) == 1
     assert sum(k.startswith("mr_grp_rows_kernel<eval>") for k in results["1"][3]) == 1
     assert not any(k.startswith(("mr_fwd", "window_scatter")) for k in results["1"][3][:results["1"][3].index(

@@ -171,6 +171,8 @@ def bench_mrg(args, dev, L):
     windows = graph_ops.window_gather(vol, window, shift)
     idx = graph_ops.knn_graph(windows, None, None, k)
     w = torch.randn((2 * C, 2 * C // groups), generator=g, device=dev) * 0.1
+    n_, k_ = w.shape[0] // groups, w.shape[1]
+    wt = w.reshape(groups, n_, k_).transpose(1, 2).reshape(groups * k_, n_).contiguous()
     print("windows", tuple(windows.shape), "volume", spatial, "window", tuple(window))
     for it in range(2 + args.iters):
         if it == 2:
@@ -179,9 +181,12 @@ def bench_mrg(args, dev, L):
         be.mr_grouped_rows(windows, idx, k, 1, w, groups, B, spatial, window, shift, True, True, True)
         be.mr_grouped_rows(windows, idx, k, 1, w, groups, B, spatial, window, shift, False, False, True)
         be.mr_grouped_rows(windows, idx, k, 1, w, groups, B, spatial, window, shift, False, False, False)
-        agg, _ = be.mr_fwd(windows, None, idx, None, k, 1, want_arg=True)
+        agg, arg = be.mr_fwd(windows, None, idx, None, k, 1, want_arg=True)
         a0 = be.window_scatter(agg, None, spatial, window, shift)
-        be.pw_rows_fused(a0, w, groups, want_stats=True)
+        h0, _ = be.pw_rows_fused(a0, w, groups, want_stats=True)
+        be.mr_grouped_rows_bwd(h0, w, arg, groups, spatial, window, shift)
+        ga = be.pw_rows(h0, wt, None, groups)
+        be.mr_bwd_arg(be.window_gather(ga, window, shift), arg, windows.shape[2], False)
     torch.cuda.synchronize()
     buf = ctypes.create_string_buffer(1 << 20)
     L.nextou_profile_report(buf, len(buf))
