@@ -86,8 +86,10 @@ def build_trainer(workload, device, is_ddp, seed=0):
 def move_to(trainer, device):
     trainer.network.to(device)
     trainer.device = device
-    trainer.optimizer = torch.optim.SGD(trainer.network.parameters(), trainer.initial_lr,
-                                        weight_decay=trainer.weight_decay, momentum=trainer.momentum, nesterov=True)
+    # NEXTOU_SGD_FUSED=1: torch's multi-tensor fused SGD (A/B; see DESIGN_HISTORY.md section 5 — off by default)
+    fused = os.environ.get("NEXTOU_SGD_FUSED", "0") == "1" and device.type == "cuda"
+    trainer.optimizer = torch.optim.SGD(trainer.network.parameters(), trainer.initial_lr, weight_decay=trainer.weight_decay,
+                                        momentum=trainer.momentum, nesterov=True, **({"fused": True} if fused else {}))
     if hasattr(trainer.loss, "loss") and hasattr(trainer.loss.loss, "ti"):
         trainer.loss = trainer._build_loss()      # interaction tensors follow the device
 
@@ -143,6 +145,7 @@ def roofline_graph_from(report):
         return min(rows, key=lambda e: e["frac"]) if rows else None
     return {"K1_knn": pick(("knn_fused_kernel", "knn_window_kernel")), "K2_mr_forward": pick(("mr_fwd",)), "K2_mr_backward": pick(("mr_bwd",)),
             "K1_knn_worst_shape": worst(("knn_fused_kernel", "knn_window_kernel")), "K2_mr_forward_worst_shape": worst(("mr_fwd",)),
+            "K2K7_mr_grouped_forward": pick(("mr_grp_rows_kernel",)), "K2K7_mr_grouped_backward": pick(("mr_grp_rows_bwd_kernel",)),
             "K5_argmax_labels": pick(("argmax_labels_kernel",)), "K5_bti_critical": pick(("bti_critical_kernel",)),
             "K5_bti_ce_forward": pick(("bti_ce_fwd_kernel",)), "K5_bti_ce_backward": pick(("bti_ce_bwd_kernel",)),
             "K5_ce_mean_forward": pick(("ce_mean_fwd_kernel",)), "K5_ce_mean_backward": pick(("ce_mean_bwd_kernel",)),
