@@ -83,11 +83,14 @@ def build_trainer(workload, device, is_ddp, seed=0):
     return trainer, cfg, batch, classes
 
 
-def move_to(trainer, device):
+def move_to(trainer, device, fused_sgd=False):
     trainer.network.to(device)
     trainer.device = device
-    # NEXTOU_SGD_FUSED=1: torch's multi-tensor fused SGD (A/B; see DESIGN_HISTORY.md section 5 — off by default)
-    fused = os.environ.get("NEXTOU_SGD_FUSED", "0") == "1" and device.type == "cuda"
+    # fused_sgd: torch's single-launch multi-tensor SGD (same update rule; -0.5 ms per cfg-2 step).  Only without the gradient averager:
+    # with p.grad pointing into the averager's flat buckets the fused kernel takes a GPU memory fault in the EAGER step (single process,
+    # RCCL and gloo alike; the captured step runs) — reproduced with `NEXTOU_SGD_FUSED=1 bench.py --workload tiny --force-averager
+    # --graph off`, cause not found (profiles/r04_sgd_fused.md), so the averaged step keeps the foreach implementation.
+    fused = fused_sgd and device.type == "cuda" and os.environ.get("NEXTOU_SGD_FUSED", "1") != "0"
     trainer.optimizer = torch.optim.SGD(trainer.network.parameters(), trainer.initial_lr, weight_decay=trainer.weight_decay,
                                         momentum=trainer.momentum, nesterov=True, **({"fused": True} if fused else {}))
     if hasattr(trainer.loss, "loss") and hasattr(trainer.loss.loss, "ti"):
@@ -348,7 +351,7 @@ def main():
 
     trainer, cfg, batch, classes = build_trainer(args.workload, device, world > 1)
     cpu_copy_ok = (rank == 0 and world == 1 and not args.no_cpu_baseline)
-    move_to(trainer, device)
+    move_to(trainer, device, fused_sgd=(world == 1 and not args.force_averager) or os.environ.get("NEXTOU_SGD_FUSED") == "force")
     if args.channels_last:
         trainer.network.to(memory_format=torch.channels_last_3d)
     if args.force_averager and world == 1:
@@ -455,6 +458,9 @@ def main():
                        "layout": "channels-last stages %s" % sorted(trainer.network.encoder.channels_last_stages),
                        "internal_channel_padding_modules": getattr(trainer.network, "padded_modules", 0),
                        "gradient_averager": averager is not None,
+                       "optimizer": "SGD(nesterov, momentum %g, weight_decay %g, %s)" % (
+                           trainer.momentum, trainer.weight_decay,
+                           "fused" if trainer.optimizer.defaults.get("fused") else "foreach"),
                        "step_replayed_as_hipgraph": graphed is not None, "graph_capture_error": capture_error,
                        "parallelism": "dp%d" % world, "final_loss": float(loss.detach())},
             "roofline": roof,

@@ -28,6 +28,12 @@ class _Bucket:
     whether any rank produced a gradient for it this step (summed by the same collective — no extra launch)."""
     __slots__ = ("flat", "params", "offsets", "views", "flags", "pending", "filled", "work", "n_grad")
 
+    @staticmethod
+    def _view_like(flat: torch.Tensor, offset: int, p: torch.Tensor) -> torch.Tensor:
+        if _dense_strides(p) and not p.is_contiguous():
+            return flat.as_strided(p.shape, p.stride(), flat.storage_offset() + offset)
+        return flat[offset:offset + p.numel()].view_as(p)
+
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = params
         self.offsets, total = [], 0
@@ -36,11 +42,27 @@ class _Bucket:
             total += p.numel()
         self.n_grad = total
         self.flat = torch.zeros(total + len(params), dtype=params[0].dtype, device=params[0].device)
-        self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, params)]
+        # views with the PARAMETER's strides (a channels-last convolution weight keeps its permuted layout): what autograd's
+        # AccumulateGrad hands over has them too, so the multi-tensor copy takes its fast route, and optimizers that walk
+        # parameter, gradient and momentum as flat arrays (torch.optim.SGD(fused=True)) pair the right elements
+        self.views = [self._view_like(self.flat, o, p) for o, p in zip(self.offsets, params)]
         self.flags = self.flat[total:]
         self.pending = len(params)
         self.filled = [False] * len(params)
         self.work = None
+
+
+def _dense_strides(p: torch.Tensor) -> bool:
+    """True when ``p``'s elements occupy exactly ``numel`` consecutive slots in some dimension order (contiguous, channels-last ...)."""
+    if p.numel() == 0:
+        return False
+    dims = sorted((d for d in range(p.dim()) if p.shape[d] > 1), key=lambda d: p.stride(d))
+    expect = 1
+    for d in dims:
+        if p.stride(d) != expect:
+            return False
+        expect *= p.shape[d]
+    return True
 
 
 class BucketedGradientAverager:
