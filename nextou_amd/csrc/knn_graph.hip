@@ -968,7 +968,8 @@ static WindowPlan plan_window(int B, int N, int M, int K, bool has_y) {
     w.nw = cdiv(N, 32);
     // enough windows to fill the chip (>= 512 waves): one workgroup per window, every candidate in registers, no merge launch;
     // fewer: the candidates are split in 64-wide ranges over workgroups (the window's MFMAs on one CU would be the run time)
-    const bool whole = (long long)B * w.nw >= 512 || N <= 64;
+    bool whole = (long long)B * w.nw >= 512 || N <= 64;
+    if (const char* e = getenv("NEXTOU_KNN_WIN_SPLIT")) { if (e[0] == '1' && N > 64) whole = false; }   // experiments
     // a handful of windows (stage 5: B' = 2): measured 102 us here against 101 us for prep + fused + merge with its wider split; the
     // kernel's serial floor (staging + epilogue, 66 us with every arithmetic phase ablated) is not amortised — profiles/r04_k1_small_graphs.md
     if (!whole && (long long)B * w.nw < 64) return w;
