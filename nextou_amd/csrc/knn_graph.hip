@@ -590,28 +590,45 @@ __device__ __forceinline__ void win_stage(float* __restrict__ slab, const float*
 
 
 
-template <int KB, int TILES>
-__global__ __launch_bounds__(384) void knn_window_kernel(const float* __restrict__ x, const float* __restrict__ relpos,
+// G = 2 (whole windows of more than 64 points): TWO groups of waves share a window — waves 0 .. nq-1 take the lower half of the candidate
+// tiles, waves nq .. 2nq-1 the upper half, for the same 32-query tiles — and the two sorted lists of a query meet through LDS.  With one
+// group a 168-point window is 6 waves of 6 accumulator tiles: 159 VGPRs, waves placed 2 / 2 / 1 / 1 on the CU's SIMDs, and (measured) ONE
+// resident workgroup per CU whatever the occupancy calculator says; two groups are 12 waves of 3 tiles, 3 per SIMD.
+template <int KB, int TILES, int G>
+__global__ __launch_bounds__(G == 2 ? 768 : 384) void knn_window_kernel(const float* __restrict__ x, const float* __restrict__ relpos,
                                                          int32_t* __restrict__ out, float* __restrict__ part_d,
                                                          int32_t* __restrict__ part_i, int C, int N, int K, int KS, int ablate) {
     // ablate (experiments, NEXTOU_KNN_WIN_ABLATE; wrong results with any bit set): 1 skip pass A, 2 skip the MFMAs, 4 skip the list pushes,
     // 8 skip the chains of squares
-    constexpr int TM = 32 * TILES;
+    constexpr int TM = 32 * TILES * G;     // candidates per workgroup
     constexpr int W = kWinPts;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* slab = lds;                 // [KS][W]
-    float* den_s = lds + KS * W;       // [W]
+    float* slab = lds;                 // [KS][W]  (G = 2: afterwards the upper group's lists, [W][KP] (dist, id) pairs)
+    float* den_s = lds + max(KS * W, G == 2 ? 2 * W * (KB <= 8 ? 8 : (KB <= 16 ? 16 : 32)) : 0);     // [W]
     float* sq_s = den_s + W;           // [W]  chain of xn^2
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, h = lane >> 5;
+    const int nq = (int)(blockDim.x >> 6) / G;              // query tiles = waves per group
+    const int wq = G == 2 ? (wave >= nq ? wave - nq : wave) : wave, gq = G == 2 ? (wave >= nq ? 1 : 0) : 0;
     const int b = blockIdx.y, split = blockIdx.x, n_splits = gridDim.x;
     const float* xb = x + (size_t)b * C * N;
-    const int n = wave * 32 + lq;
+    const int n = wq * 32 + lq;
     const bool nvalid = n < N;
     const int m_begin = split * TM;
     const int m_end = min(m_begin + TM, N);
+    const int mw_begin = m_begin + gq * 32 * TILES;          // this wave's candidates
     const bool vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
     const int w4 = W / 4;
+    // stagger (bits 8+ of `ablate`, microseconds): the workgroups that take the SECOND slot of a CU (ids 256 ... 511 of the first wave of
+    // dispatches) start late, so that co-resident workgroups run different phases instead of the same ones in lockstep
+    if (const int stagger_us = ablate >> 8) {
+        const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
+        if ((id >> 8) & 1u) {
+            const long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < 100ll * stagger_us) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    ablate &= 255;
 
     // ---- pass A: den
     float ssum = 0.f;
@@ -658,10 +675,10 @@ __global__ __launch_bounds__(384) void knn_window_kernel(const float* __restrict
         kmax = (kmax + 1) & ~1;        // (an odd tail multiplies a zero row: the slab is zero-filled past C)
         if (ablate & 2) kmax = 0;
         for (int kp = 0; kp < kmax; kp += 2) {
-            const float bq = slab[(kp + h) * W + wave * 32 + lq];
+            const float bq = slab[(kp + h) * W + wq * 32 + lq];
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
-                const float a = slab[(kp + h) * W + m_begin + t * 32 + lq];
+                const float a = slab[(kp + h) * W + mw_begin + t * 32 + lq];
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc[t], 0, 0, 0);
             }
         }
@@ -680,7 +697,7 @@ __global__ __launch_bounds__(384) void knn_window_kernel(const float* __restrict
         f32x16 v = acc[t];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int mbase = m_begin + t * 32 + 8 * g + 4 * h;
+            const int mbase = mw_begin + t * 32 + 8 * g + 4 * h;
             float yv[4], rv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) yv[r] = mbase + r < W ? sq_s[mbase + r] : 0.f;
@@ -733,6 +750,39 @@ __global__ __launch_bounds__(384) void knn_window_kernel(const float* __restrict
                 const float lo = sw ? md[q] : md[j], hi = sw ? md[j] : md[q];
                 const int li = sw ? mi[q] : mi[j], hi_i = sw ? mi[j] : mi[q];
                 md[j] = lo; md[q] = hi; mi[j] = li; mi[q] = hi_i;
+            }
+        }
+    }
+    if (G == 2) {
+        // the upper group's list of every query -> LDS (over the slab: the last MFMA read it before the barrier above); the lower group
+        // takes the KP best of the two sorted lists with the same bitonic step (all of the upper group's ids are larger)
+        float* xd = slab;
+        int* xi = reinterpret_cast<int*>(slab + W * KP);
+        if (gq == 1 && h == 0) {
+#pragma unroll
+            for (int j = 0; j < KP; ++j) { xd[n * KP + j] = md[j]; xi[n * KP + j] = mi[j]; }
+        }
+        __syncthreads();
+        if (gq == 1) return;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const float bd = xd[n * KP + (KP - 1 - j)];
+            const int bi = xi[n * KP + (KP - 1 - j)];
+            const bool take_b = (bd < md[j]) || (bd == md[j] && bi < mi[j]);
+            md[j] = take_b ? bd : md[j];
+            mi[j] = take_b ? bi : mi[j];
+        }
+#pragma unroll
+        for (int stride = KP / 2; stride >= 1; stride >>= 1) {
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                if ((j & stride) == 0) {
+                    const int q = j + stride;
+                    const bool sw = (md[q] < md[j]) || (md[q] == md[j] && mi[q] < mi[j]);
+                    const float lo = sw ? md[q] : md[j], hi = sw ? md[j] : md[q];
+                    const int li = sw ? mi[q] : mi[j], hi_i = sw ? mi[j] : mi[q];
+                    md[j] = lo; md[q] = hi; mi[j] = li; mi[q] = hi_i;
+                }
             }
         }
     }
@@ -959,7 +1009,7 @@ static FusedPlan plan_fused(int B, int N, int M, int K, bool self = false) {
 }
 
 // ---- the single-launch window path (knn_window_kernel): self graphs of <= 192 points, normalisation inside
-struct WindowPlan { bool ok; int nw, tiles, splits, ks; size_t lds; };
+struct WindowPlan { bool ok; int nw, tiles, groups, splits, ks; size_t lds; };
 static WindowPlan plan_window(int B, int N, int M, int K, bool has_y) {
     WindowPlan w{};
     w.ok = false;
@@ -973,11 +1023,17 @@ static WindowPlan plan_window(int B, int N, int M, int K, bool has_y) {
     // a handful of windows (stage 5: B' = 2): measured 102 us here against 101 us for prep + fused + merge with its wider split; the
     // kernel's serial floor (staging + epilogue, 66 us with every arithmetic phase ablated) is not amortised — profiles/r04_k1_small_graphs.md
     if (!whole && (long long)B * w.nw < 64) return w;
-    w.tiles = whole ? (N <= 64 ? 2 : 6) : 2;
+    // whole windows of more than 64 points: two wave groups of three candidate tiles each (knn_window_kernel, G = 2); NEXTOU_KNN_WIN_G=1
+    // keeps the one-group kernel with six tiles per wave for A/B
+    w.groups = 1;
+    if (whole && N > 64) { const char* e = getenv("NEXTOU_KNN_WIN_G"); w.groups = (e && e[0] == '1') ? 1 : 2; }
+    w.tiles = whole ? (N <= 64 ? 2 : 6 / w.groups) : 2;        // per wave
     w.splits = whole ? 1 : cdiv(N, 64);
     w.ks = 64;
     if (const char* e = getenv("NEXTOU_KNN_WIN_KS")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128 || v == 192) w.ks = v; }   // experiments
-    w.lds = (size_t)(w.ks * kWinPts + 2 * kWinPts) * sizeof(float);
+    const int kp = K <= 7 ? 8 : (K <= 14 ? 16 : 32);           // padded list length of the kernel's bucket (KB 7 | 14 | 28 | 32)
+    const size_t slab = (size_t)w.ks * kWinPts, lists = w.groups == 2 ? (size_t)2 * kWinPts * kp : 0;
+    w.lds = ((slab > lists ? slab : lists) + 2 * kWinPts) * sizeof(float);
     w.ok = true;
     return w;
 }
@@ -1104,19 +1160,24 @@ static int launch_merge(const FusedArgs& a, int splits, hipStream_t s) {
 template <int KB>
 static int launch_window(const FusedArgs& a, const float* x, const WindowPlan& w, hipStream_t s) {
     {
-        ProfScope prof(s, kBoundMfma, 2.0 * a.B * (double)a.N * a.N * a.C, "knn_window_kernel<%d,%d>[B%d C%d N%d K%d]", KB, w.tiles, a.B, a.C,
+        ProfScope prof(s, kBoundMfma, 2.0 * a.B * (double)a.N * a.N * a.C, "knn_window_kernel<%d,%dx%d>[B%d C%d N%d K%d]", KB, w.groups, w.tiles, a.B, a.C,
                        a.N, a.K);
-        const dim3 grid(w.splits, a.B), block(64 * w.nw);
+        const dim3 grid(w.splits, a.B), block(64 * w.nw * w.groups);
         int ablate = 0;
         if (const char* e = getenv("NEXTOU_KNN_WIN_ABLATE")) ablate = atoi(e);
-        if (w.lds > 64 * 1024) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_window_kernel<KB, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_window_kernel<KB, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds);
-        }
-        if (w.tiles == 2)
-            hipLaunchKernelGGL((knn_window_kernel<KB, 2>), grid, block, w.lds, s, x, a.relpos, a.out, a.part_d, a.part_i, a.C, a.N, a.K, w.ks, ablate);
-        else
-            hipLaunchKernelGGL((knn_window_kernel<KB, 6>), grid, block, w.lds, s, x, a.relpos, a.out, a.part_d, a.part_i, a.C, a.N, a.K, w.ks, ablate);
+        if (const char* e = getenv("NEXTOU_KNN_WIN_STAGGER")) ablate |= atoi(e) << 8;
+#define NEXTOU_KNN_WIN(T, G_)                                                                                                          \
+    do {                                                                                                                             \
+        if (w.lds > 64 * 1024)                                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_window_kernel<KB, T, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)w.lds);                                                                                   \
+        hipLaunchKernelGGL((knn_window_kernel<KB, T, G_>), grid, block, w.lds, s, x, a.relpos, a.out, a.part_d, a.part_i, a.C, a.N, a.K, w.ks, \
+                           ablate);                                                                                                  \
+    } while (0)
+        if (w.groups == 2) NEXTOU_KNN_WIN(3, 2);
+        else if (w.tiles == 2) NEXTOU_KNN_WIN(2, 1);
+        else NEXTOU_KNN_WIN(6, 1);
+#undef NEXTOU_KNN_WIN
     }
     if (int e = check_launch("knn_window_kernel")) return e;
     return w.splits > 1 ? launch_merge(a, w.splits, s) : 0;
