@@ -316,3 +316,50 @@ def test_rows_gemm_view_algebra_and_cpu_fallbacks():
     from nextou_amd.loss.nnunet_losses import HAVE_NNUNET, RobustCrossEntropyLoss
     if not HAVE_NNUNET:
         assert torch.allclose(RobustCrossEntropyLoss()(logits, target.unsqueeze(1).float()), F.cross_entropy(logits, target))
+
+
+def test_gradient_bucket_views_carry_the_parameter_strides():
+    """ddp._Bucket: a bucket view of a channels-last (or otherwise permuted-dense) parameter has the parameter's strides, aliases the
+    flat buffer at its offset, and round-trips values; contiguous and non-dense parameters take the plain reshaped slice."""
+    from nextou_amd.ddp import _Bucket, _dense_strides
+    a = torch.nn.Parameter(torch.randn(6, 4, 3, 3, 3).contiguous(memory_format=torch.channels_last_3d))
+    b = torch.nn.Parameter(torch.randn(5, 7))
+    c = torch.nn.Parameter(torch.randn(4, 2, 3, 3).contiguous(memory_format=torch.channels_last))
+    d = torch.nn.Parameter(torch.randn(3))
+    assert _dense_strides(a) and _dense_strides(b) and _dense_strides(c) and _dense_strides(d)
+    assert not _dense_strides(torch.randn(4, 6)[:, ::2]) and not _dense_strides(torch.empty(0))
+    bucket = _Bucket([a, b, c, d])
+    assert bucket.flat.numel() == a.numel() + b.numel() + c.numel() + d.numel() + 4 and bucket.flags.numel() == 4
+    for p, v, off in zip(bucket.params, bucket.views, bucket.offsets):
+        assert v.shape == p.shape and v.stride() == p.stride()
+        assert v.data_ptr() == bucket.flat.data_ptr() + 4 * off
+        v.copy_(p.detach())
+        assert torch.equal(v, p.detach())
+        # the view covers exactly its numel() slots of the flat buffer
+        span = bucket.flat[off:off + p.numel()]
+        assert torch.equal(span.sort().values, p.detach().reshape(-1).sort().values)
+    assert bucket.offsets == [0, a.numel(), a.numel() + b.numel(), a.numel() + b.numel() + c.numel()]
+
+
+def test_fused_graph_chain_declines_what_it_cannot_take():
+    """graph_ops.mr_grouped_chain / pointwise_chain return None (the caller then runs the op-by-op path) for CPU tensors — the product has
+    no CPU kernels — and _chain_modules_eligible applies the point threshold to the volume's shape alone."""
+    import os
+    from torch import nn
+    from nextou_amd import graph_ops
+    conv1, conv2 = nn.Conv3d(24, 24, 1, groups=6, bias=False), nn.Conv3d(24, 12, 1, bias=False)
+    windows = torch.randn(4, 12, 8)
+    idx = torch.zeros(4, 8, 3, dtype=torch.int32)
+    res = torch.randn(1, 12, 2, 4, 4)
+    assert graph_ops.mr_grouped_chain(windows, idx, res, conv1, nn.BatchNorm3d(24), conv2, nn.BatchNorm3d(12), (2, 4, 4), (1, 2, 4),
+                                      (0, 0, 0)) is None
+    assert graph_ops.pointwise_chain(res.contiguous(memory_format=torch.channels_last_3d), None, conv2, nn.BatchNorm3d(12)) is None
+    old = os.environ.get("NEXTOU_PW_FUSE_MIN_POINTS")
+    try:
+        os.environ["NEXTOU_PW_FUSE_MIN_POINTS"] = "1000"
+        assert not graph_ops._chain_modules_eligible((1, 24, 2, 4, 4), None, conv1, nn.BatchNorm3d(24))       # 32 points < 1000
+    finally:
+        if old is None:
+            os.environ.pop("NEXTOU_PW_FUSE_MIN_POINTS", None)
+        else:
+            os.environ["NEXTOU_PW_FUSE_MIN_POINTS"] = old
