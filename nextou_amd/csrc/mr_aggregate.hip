@@ -1169,19 +1169,31 @@ __global__ __launch_bounds__(512) void mr_grp_rows_bwd_kernel(
         for (int p = tid; p < Nw; p += T) rows[p] = (int)window_point_row(win, p, v, wn, nH, nW);
         lds_barrier();
         const int pieces = Nw * kp;
-        for (int e0 = tid; e0 < pieces; e0 += U * T) {
+        {                                                    // first batch of rows in flight, then the weights (EVERY thread), then the rows
+            f32x4 t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = min(tid + u * T, pieces - 1);
+                const int r = fdiv(e, kp, dv.kp), pc = e - r * kp;
+                t[u] = *reinterpret_cast<const f32x4*>(dh_rows + (row_base + rows[r]) * ld_rows + (size_t)g * Kg + 4 * pc);
+            }
+#pragma unroll
+            for (int u = 0; u < UW; ++u)
+                if (tid + u * T < w4) reinterpret_cast<f32x4*>(wl)[tid + u * T] = wpre[u];
+            for (int e = tid + UW * T; e < w4; e += T) reinterpret_cast<f32x4*>(wl)[e] = wg[e];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = tid + u * T;
+                if (e < pieces) { const int r = fdiv(e, kp, dv.kp), pc = e - r * kp; *reinterpret_cast<f32x4*>(slab + (size_t)r * ld + 4 * pc) = t[u]; }
+            }
+        }
+        for (int e0 = tid + U * T; e0 < pieces; e0 += U * T) {
             f32x4 t[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int e = min(e0 + u * T, pieces - 1);
                 const int r = fdiv(e, kp, dv.kp), pc = e - r * kp;
                 t[u] = *reinterpret_cast<const f32x4*>(dh_rows + (row_base + rows[r]) * ld_rows + (size_t)g * Kg + 4 * pc);
-            }
-            if (e0 == tid) {
-#pragma unroll
-                for (int u = 0; u < UW; ++u)
-                    if (tid + u * T < w4) reinterpret_cast<f32x4*>(wl)[tid + u * T] = wpre[u];
-                for (int e = tid + UW * T; e < w4; e += T) reinterpret_cast<f32x4*>(wl)[e] = wg[e];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {

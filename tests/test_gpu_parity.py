@@ -119,6 +119,18 @@ def test_knn_single_launch_window_kernel_bit_exact(ops, ora, B, C, N, k, relpos)
     assert torch.equal(one, three)
 
 
+@pytest.mark.parametrize("B,C,N,k", [(600, 12, 168, 7), (90, 8, 192, 28), (100, 33, 191, 14)])
+def test_knn_window_kernel_one_group_variant_bit_exact(ops, ora, monkeypatch, B, C, N, k):
+    """Whole windows run as two wave groups of three candidate tiles by default; NEXTOU_KNN_WIN_G=1 (read per call) keeps the one-group
+    kernel with six tiles per wave for A/B — same ids."""
+    monkeypatch.setenv("NEXTOU_KNN_WIN_G", "1")
+    _knn_case(ops, ora, B, C, N, None, k, True, seed=5000 + N + k, algos=("fused",))
+    x = _rand((B, C, N), 5000 + N + k).to(DEV)
+    one = ops.knn_graph(x, None, None, k, algo="fused")
+    monkeypatch.delenv("NEXTOU_KNN_WIN_G")
+    assert torch.equal(one, ops.knn_graph(x, None, None, k, algo="fused"))
+
+
 def test_knn_auto_selects_and_rejects(ops):
     x = _rand((1, 8, 40), 3).to(DEV)
     assert ops.knn_graph(x, k=33).shape == (1, 40, 33)           # auto -> naive

@@ -72,3 +72,57 @@ def test_bti_any_shape(B, D, H, W, L, conn3d, full, thick, seed):
     assert torch.equal(got.cpu(), want)
     logits = torch.randn((B, L) + shape[1:], generator=g)
     assert torch.equal(ops.argmax_labels(logits.to(DEV)).cpu(), ora.argmax_labels(logits))
+
+
+@settings(max_examples=12, deadline=None, derandomize=True)
+@given(B=st.integers(86, 160), C=st.integers(1, 40), N=st.integers(65, 192), k=st.integers(1, 32), relpos=st.booleans(),
+       seed=st.integers(0, 10 ** 6))
+def test_knn_whole_window_kernel_any_shape_bit_exact(B, C, N, k, relpos, seed):
+    """Self graphs of 65 ... 192 points in batches large enough for the whole-window plan of knn_window_kernel (two wave groups, lists
+    merged through LDS): ragged last tiles in both groups, every list bucket."""
+    ops, ora = _ops_ora()
+    x = _rand((B, C, N), seed)
+    rp = _rand((N, N), seed + 2, 0.05) if relpos else None
+    want = ora.knn_graph(x, None, rp, k)
+    got = ops.knn_graph(x.to(DEV), None, None if rp is None else rp.to(DEV), k)
+    assert torch.equal(got.cpu(), want)
+
+
+@settings(max_examples=20, deadline=None, derandomize=True)
+@given(B=st.integers(1, 2), cg2=st.integers(1, 16), groups=st.integers(1, 6), win=st.tuples(st.integers(1, 4), st.integers(1, 5), st.integers(1, 6)),
+       cnt=st.tuples(st.integers(1, 2), st.integers(1, 3), st.integers(1, 3)), k=st.integers(1, 32), shifted=st.booleans(),
+       seed=st.integers(0, 10 ** 6))
+def test_mr_grouped_rows_any_shape(B, cg2, groups, win, cnt, k, shifted, seed):
+    """K2 + K7 forward / backward in one launch each against the launches they replace, on random window / group / list shapes."""
+    ops, _ = _ops_ora()
+    be = ops._HIP
+    C = 2 * cg2 * groups
+    Nw = win[0] * win[1] * win[2]
+    k = min(k, Nw)
+    spatial = tuple(w * c for w, c in zip(win, cnt))
+    shift = tuple((s // 2) if shifted else 0 for s in win)
+    n_windows = B * cnt[0] * cnt[1] * cnt[2]
+    if not be.mr_grouped_rows_supported(n_windows, C, groups, Nw, k):
+        return
+    g = torch.Generator().manual_seed(seed)
+    vol = torch.randn((B, C) + spatial, generator=g).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    windows = ops.window_gather(vol, win, shift)
+    idx = torch.randint(0, Nw, (n_windows, Nw, k), generator=g, dtype=torch.int32).to(DEV)
+    w = (torch.randn((2 * C, 2 * C // groups), generator=g) * 0.3).to(DEV)
+    a, arg, h, part = be.mr_grouped_rows(windows, idx, k, 1, w, groups, B, spatial, win, shift, True, True, True)
+    agg, arg0 = be.mr_fwd(windows, None, idx, None, k, 1, want_arg=True)
+    a0 = be.window_scatter(agg, None, spatial, win, shift)
+    assert torch.equal(a, a0) and torch.equal(arg, arg0)
+    want = torch.nn.functional.conv3d(a0.double(), w.double().reshape(2 * C, -1, 1, 1, 1), groups=groups)
+    scale = max(float(want.abs().max()), 1e-6)
+    assert float((h.double() - want).abs().max()) <= 3e-6 * scale
+    hs = h.permute(0, 2, 3, 4, 1).reshape(-1, 2 * C).double()
+    got = part.sum(1)
+    assert torch.allclose(got[:, 0], hs.sum(0), rtol=0, atol=1e-5 * scale * max(hs.shape[0], 1) ** 0.5 + 1e-9)
+    assert torch.allclose(got[:, 1], (hs * hs).sum(0), rtol=1e-5, atol=1e-6 * scale * scale)
+    dh = torch.randn(h.shape, generator=g).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    dx = be.mr_grouped_rows_bwd(dh, w, arg, groups, spatial, win, shift)
+    n_, k_ = w.shape[0] // groups, w.shape[1]
+    wt = w.reshape(groups, n_, k_).transpose(1, 2).reshape(groups * k_, n_).contiguous()
+    dx0, _ = be.mr_bwd_arg(be.window_gather(be.pw_rows(dh, wt, None, groups), win, shift), arg, Nw, False)
+    assert float((dx - dx0).abs().max()) <= 3e-6 * max(float(dx0.abs().max()), 1e-6)
