@@ -149,8 +149,13 @@ def test_pointwise_chain_autograd_vs_float64_reference(ops, monkeypatch, trainin
     restatement of the reference's op sequence, in training (batch statistics) and inference (running statistics + the folded conv
     bias), with the gradient statistics fused into the data-gradient GEMM ("1") and with K6's own backward reduce ("fwd")."""
     monkeypatch.setenv("NEXTOU_PW_FUSE", mode)
-    gen = torch.Generator().manual_seed(ci + cm + g + int(two))
     co = (132 if (two and g == 6) else ci) if two else cm
+    check_pointwise_chain(ops, training, B, sp, ci, cm, co, g, two, with_res, mode)
+
+
+def check_pointwise_chain(ops, training, B, sp, ci, cm, co, g, two, with_res, mode):
+    """(shared with the randomised sweep in tests/test_gpu_property.py; NEXTOU_PW_FUSE must already be ``mode``)"""
+    gen = torch.Generator().manual_seed(ci + cm + g + int(two))
     x = _cl(torch.randn((B, ci) + sp, generator=gen)).requires_grad_(True)
     res = _cl(torch.randn((B, co) + sp, generator=gen)).requires_grad_(True) if with_res else None
 

@@ -71,7 +71,23 @@ def test_bti_any_shape(B, D, H, W, L, conn3d, full, thick, seed):
     got = ops.bti_critical_map(labels.to(DEV), lut_a.to(DEV), lut_c.to(DEV), conn, thick)
     assert torch.equal(got.cpu(), want)
     logits = torch.randn((B, L) + shape[1:], generator=g)
-    assert torch.equal(ops.argmax_labels(logits.to(DEV)).cpu(), ora.argmax_labels(logits))
+    want_lab = ora.argmax_labels(logits)
+    assert torch.equal(ops.argmax_labels(logits.to(DEV)).cpu(), want_lab)
+    # the same logits stored channels-last (the layout the network's heads produce): the rows kernels read them in place
+    mf = torch.channels_last_3d if conn3d else torch.channels_last
+    xcl = logits.to(DEV).contiguous(memory_format=mf)
+    assert torch.equal(ops.argmax_labels(xcl).cpu(), want_lab)
+    target = torch.randint(0, L, shape, generator=g, dtype=torch.uint8)
+    crit = (torch.rand(shape, generator=g) < 0.3).to(torch.uint8)
+    want_ce = ora.bti_ce_fwd(logits, target, crit)
+    for xin in (logits.to(DEV), xcl):
+        xin = xin.clone().requires_grad_(True)
+        got_ce = ops.critical_cross_entropy(xin, target.to(DEV), crit.to(DEV))
+        np.testing.assert_allclose(got_ce.detach().cpu().numpy(), want_ce.numpy(), rtol=1e-12, atol=1e-300)
+        wgt = torch.rand(B, generator=torch.Generator().manual_seed(seed + 5), dtype=torch.float64) + 0.5
+        (grad,) = torch.autograd.grad((got_ce * wgt.to(DEV)).sum(), xin)
+        ref = ora.bti_ce_bwd(logits, target, crit, wgt)
+        assert float((grad.cpu() - ref).abs().max()) <= 1e-6 * max(float(ref.abs().max()), 1e-30)
 
 
 @settings(max_examples=12, deadline=None, derandomize=True)
@@ -126,3 +142,117 @@ def test_mr_grouped_rows_any_shape(B, cg2, groups, win, cnt, k, shifted, seed):
     wt = w.reshape(groups, n_, k_).transpose(1, 2).reshape(groups * k_, n_).contiguous()
     dx0, _ = be.mr_bwd_arg(be.window_gather(be.pw_rows(dh, wt, None, groups), win, shift), arg, Nw, False)
     assert float((dx - dx0).abs().max()) <= 3e-6 * max(float(dx0.abs().max()), 1e-6)
+
+
+def _logits(shape, seed, channels_last):
+    x = (_rand(shape, seed) * 3).to(DEV)
+    mf = {4: torch.channels_last, 5: torch.channels_last_3d}.get(len(shape))
+    if channels_last and mf is not None:
+        x = x.contiguous(memory_format=mf)
+    return x
+
+
+@settings(max_examples=25, deadline=None, derandomize=True)
+@given(B=st.integers(1, 3), L=st.integers(2, 24), sp=st.lists(st.integers(1, 19), min_size=1, max_size=3), channels_last=st.booleans(),
+       masked=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_dice_statistics_any_shape(B, L, sp, channels_last, masked, seed):
+    """K5d: the three soft-Dice sums per (sample, class) and the logit gradient through them against their float64 definition — odd class
+    counts, one-voxel volumes, channels-last and NCDHW logits, optional loss mask."""
+    ops, _ = _ops_ora()
+    shape = (B, L) + tuple(sp)
+    x = _logits(shape, seed, channels_last).requires_grad_(True)
+    g = torch.Generator().manual_seed(seed + 1)
+    y = torch.randint(0, L, (B, 1) + tuple(sp), generator=g).float().to(DEV)
+    mask = (torch.rand((B, 1) + tuple(sp), generator=g) > 0.3).to(DEV) if masked else None
+    if not ops.dice_stats_eligible(x, y):
+        return
+    inter, pred, gt = ops.dice_stats(x, y, mask)
+    x64 = x.detach().double().contiguous().requires_grad_(True)
+    p = torch.softmax(x64, 1)
+    oh = torch.zeros_like(p).scatter_(1, y.long(), 1.0)
+    w = mask.double() if masked else torch.ones_like(y, dtype=torch.float64)
+    axes = tuple(range(2, x.dim()))
+    wi, wp, wg = (p * oh * w).sum(axes), (p * w).sum(axes), (oh * w).sum(axes)
+    for got, want in ((inter, wi), (pred, wp), (gt, wg)):
+        assert float((got.detach().double() - want.detach()).abs().max()) <= 2e-6 * max(1.0, float(want.detach().abs().max()))
+    ci = torch.rand(inter.shape, generator=g, dtype=torch.float64).to(DEV)
+    cp = torch.rand(inter.shape, generator=g, dtype=torch.float64).to(DEV)
+    gx, = torch.autograd.grad((inter.double() * ci).sum() + (pred.double() * cp).sum(), x)
+    gw, = torch.autograd.grad((wi * ci).sum() + (wp * cp).sum(), x64)
+    # (float32 products of O(1) coefficients: a few 1e-8 of absolute round-off whatever the gradient's own size)
+    assert float((gx.double() - gw).abs().max()) <= 5e-6 * float(gw.abs().max()) + 2e-7
+
+
+@settings(max_examples=25, deadline=None, derandomize=True)
+@given(B=st.integers(1, 3), L=st.integers(2, 24), sp=st.lists(st.integers(1, 23), min_size=1, max_size=3), channels_last=st.booleans(),
+       ignore_every=st.integers(0, 5), seed=st.integers(0, 10 ** 6))
+def test_mean_cross_entropy_any_shape(B, L, sp, channels_last, ignore_every, seed):
+    """K5c: mean cross-entropy and its logit gradient against torch's float64 cross_entropy on random class counts, volumes and layouts,
+    with ignored voxels (down to every voxel but one)."""
+    import torch.nn.functional as F
+    ops, _ = _ops_ora()
+    shape = (B, L) + tuple(sp)
+    x = _logits(shape, seed, channels_last).requires_grad_(True)
+    t = torch.randint(0, L, (B,) + tuple(sp), generator=torch.Generator().manual_seed(seed + 1)).to(DEV)
+    if ignore_every:
+        flat = t.view(-1)
+        flat[::ignore_every + 1] = -100
+        flat[-1] = 0
+    if not ops.cross_entropy_mean_eligible(x, t):
+        return
+    loss = ops.cross_entropy_mean(x, t)
+    gx, = torch.autograd.grad(loss * 1.7, x)
+    x64 = x.detach().double().requires_grad_(True)
+    want = F.cross_entropy(x64, t)
+    gw, = torch.autograd.grad(want * 1.7, x64)
+    assert abs(float(loss) - float(want)) <= 2e-6 * max(abs(float(want)), 1e-6)
+    assert float((gx.double() - gw).abs().max()) <= 2e-6 * float(gw.abs().max()) + 1e-7
+
+
+@settings(max_examples=20, deadline=None, derandomize=True)
+@given(n=st.integers(1, 5000), L=st.integers(1, 255), dtype=st.sampled_from(["f32", "i64", "u8"]), bad=st.sampled_from([None, "low", "high"]),
+       seed=st.integers(0, 10 ** 6))
+def test_label_map_conversion_and_range_flag(n, L, dtype, bad, seed):
+    """nextou_labels_u8: uint8 copy of a float32 / int64 / uint8 label map with the out-of-range flag OR-ed on the device."""
+    ops, _ = _ops_ora()
+    t = torch.randint(0, L, (n,), generator=torch.Generator().manual_seed(seed))
+    pos = seed % n
+    if bad == "high":
+        t[pos] = L if L < 255 or dtype != "u8" else 255
+    elif bad == "low" and dtype != "u8":
+        t[pos] = -1
+    expect_bad = (bad == "high" and (L <= 255 and int(t[pos]) >= L)) or (bad == "low" and dtype != "u8")
+    src = {"f32": t.float(), "i64": t.long(), "u8": t.clamp(0, 255).to(torch.uint8)}[dtype].to(DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out = ops.checked_label_map(src, L, flag)
+    assert out.dtype == torch.uint8 and out.shape == src.shape
+    assert bool(flag.item()) == bool(expect_bad)
+    ok = (t >= 0) & (t < L)
+    assert torch.equal(out.cpu()[ok], t[ok].to(torch.uint8))
+
+
+@settings(max_examples=16, deadline=None, derandomize=True)
+@given(B=st.integers(1, 2), sp=st.tuples(st.integers(1, 5), st.integers(1, 9), st.integers(1, 11)), g=st.sampled_from([1, 1, 2, 4, 6]),
+       a=st.integers(1, 12), b=st.integers(1, 16), c=st.integers(1, 12), two=st.booleans(), with_res=st.booleans(), training=st.booleans(),
+       mode=st.sampled_from(["1", "fwd"]))
+def test_pointwise_chain_any_shape(B, sp, g, a, b, c, two, with_res, training, mode):
+    """The fused point-wise chain (K7 GEMMs with K6 in their prologue / epilogue, forward and backward) on random channel counts, group
+    counts and ragged point counts against the float64 ATen restatement of the reference's op sequence."""
+    import os
+    import test_gpu_fused as tf
+    from hypothesis import assume
+    ops, _ = _ops_ora()
+    ci, cm = 4 * a * g, 4 * b * g
+    co = 4 * c if two else cm
+    # (batch statistics over a handful of points are ill-conditioned — and torch.batch_norm refuses a single one; the product only takes
+    # the chain from NEXTOU_PW_FUSE_MIN_POINTS = 65 536 points on)
+    assume(B * sp[0] * sp[1] * sp[2] >= 16)
+    old = os.environ.get("NEXTOU_PW_FUSE")
+    os.environ["NEXTOU_PW_FUSE"] = mode
+    try:
+        tf.check_pointwise_chain(ops, training, B, tuple(sp), ci, cm, co, g, two, with_res, mode)
+    finally:
+        if old is None:
+            os.environ.pop("NEXTOU_PW_FUSE", None)
+        else:
+            os.environ["NEXTOU_PW_FUSE"] = old
