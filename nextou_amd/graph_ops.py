@@ -1480,7 +1480,7 @@ def _chain_modules_eligible(shape, residual, conv1, norm1, conv2=None, norm2=Non
     points = 1
     for v in shape[2:]:
         points *= int(v)
-    if shape[0] * points < _pw_fuse_min_points():
+    if shape[0] * points < max(_pw_fuse_min_points(), 2):       # (one value per channel: the norm modules raise torch's ValueError)
         return False
     if residual is not None and (residual.dtype != torch.float32 or residual.shape[0] != shape[0] or tuple(residual.shape[2:]) != tuple(shape[2:])):
         return False

@@ -146,6 +146,21 @@ _OWN_BIAS = {nn.Conv2d: ConvOwnBias2d, nn.Conv3d: ConvOwnBias3d, nn.ConvTranspos
              nn.ConvTranspose3d: ConvTransposeOwnBias3d}
 
 
+def _verify_batch_size(x: torch.Tensor) -> None:
+    """torch.nn.functional.batch_norm's guard for batch statistics (the reference's modules raise the same ValueError)."""
+    if x.numel() // max(x.shape[1], 1) == 1:
+        raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (x.size(),))
+
+
+def _verify_spatial_size(x: torch.Tensor) -> None:
+    """torch.nn.functional.instance_norm's guard (statistics over the spatial elements of one sample)."""
+    n = 1
+    for v in x.shape[2:]:
+        n *= int(v)
+    if n == 1:
+        raise ValueError("Expected more than 1 spatial element when training, got input size %s" % (x.size(),))
+
+
 class _BatchNormAct:
     negative_slope: float = 1.0
 
@@ -163,6 +178,8 @@ class _BatchNormAct:
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._check_input_dim(x)
+        if self.training:
+            _verify_batch_size(x)
         use_batch_stats, factor, keep_running = self._step()
         return graph_ops.norm_act(x, self.weight, self.bias, self.running_mean if keep_running else None,
                                   self.running_var if keep_running else None, use_batch_stats, factor, self.eps,
@@ -182,6 +199,7 @@ class _InstanceNormAct:
             raise NotImplementedError("InstanceNormAct: track_running_stats=True is not on the NexToU path")
         if x.dim() == self._get_no_batch_dim():
             return self.forward(x.unsqueeze(0)).squeeze(0)
+        _verify_spatial_size(x)
         return graph_ops.norm_act(x, self.weight, self.bias, None, None, True, 0.0, self.eps, self.negative_slope,
                                   instance=True, pre_bias=_pre_bias(self))
 

@@ -363,3 +363,25 @@ def test_fused_graph_chain_declines_what_it_cannot_take():
             os.environ.pop("NEXTOU_PW_FUSE_MIN_POINTS", None)
         else:
             os.environ["NEXTOU_PW_FUSE_MIN_POINTS"] = old
+
+
+def test_fused_norms_keep_torchs_size_guards(cpu_checker):
+    """Batch statistics over one value per channel / instance statistics over one spatial element raise torch's ValueError in the fused
+    norm modules as they do in nn.BatchNorm3d / nn.InstanceNorm3d (the reference's modules)."""
+    from torch import nn
+    from nextou_amd.network_architecture.norm_act import fuse_norm_act
+    blk = nn.Sequential(nn.Conv3d(2, 4, 1), nn.BatchNorm3d(4), nn.LeakyReLU(0.01))
+    ins = nn.Sequential(nn.Conv3d(2, 4, 1), nn.InstanceNorm3d(4, affine=True), nn.LeakyReLU(0.01))
+    x = torch.randn(1, 2, 1, 1, 1)
+    for m in (blk, ins):
+        ref = None
+        try:
+            m.train()(x)
+        except ValueError as e:
+            ref = str(e)
+        assert ref is not None
+        fuse_norm_act(m)
+        with pytest.raises(ValueError) as got:
+            m.train()(x)
+        assert str(got.value) == ref
+    blk.eval()(x)                                   # running statistics: no guard
