@@ -219,11 +219,21 @@ __global__ __launch_bounds__(kLayThreads) void cell_gather_kernel(const float* _
     fill_cell_rows(rows, n0, tn, cells, v, q);
     __syncthreads();
     const float* base = x_cl + (size_t)b * vol_rows * C2;
-    for (int i = wave; i < tn; i += n_waves) {          // lanes along the channels: every lane its own cell of the point
-        if (lane >= cc) continue;
+    if (lane < cc) {                                    // lanes along the channels: every lane its own cell of the point
         const int c2 = c0 + lane;
-        const int k = cell[((size_t)b * N + n0 + i) * C + (c2 >= C ? c2 - C : c2)];
-        tile[i * ld + lane] = base[(size_t)rows[i * cells + k] * C2 + c2];
+        const uint8_t* cb = cell + ((size_t)b * N + n0) * C + (c2 >= C ? c2 - C : c2);
+        constexpr int U = 8;                            // eight points of the wave in flight: cell bytes first, then the values they select
+        for (int i0 = wave; i0 < tn; i0 += U * n_waves) {
+            int k[U];
+            float val[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) k[u] = cb[(size_t)min(i0 + u * n_waves, tn - 1) * C];
+#pragma unroll
+            for (int u = 0; u < U; ++u) val[u] = base[(size_t)rows[min(i0 + u * n_waves, tn - 1) * cells + k[u]] * C2 + c2];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (i0 + u * n_waves < tn) tile[(i0 + u * n_waves) * ld + lane] = val[u];
+        }
     }
     __syncthreads();
     for (int c = wave; c < cc; c += n_waves)
@@ -243,8 +253,17 @@ __global__ __launch_bounds__(kLayThreads) void cell_scatter_kernel(const float* 
     const long long vol_rows = (long long)v.D * v.H * v.W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = kLayThreads >> 6;
     fill_cell_rows(rows, n0, tn, cells, v, q);
-    for (int c = wave; c < cc; c += n_waves)
-        if (lane < tn) tile[lane * ld + c] = src_cm[((size_t)b * C2 + c0 + c) * N + n0 + lane];
+    if (lane < tn) {
+        constexpr int U = 8;                            // eight channel rows of the wave in flight
+        for (int cb = wave; cb < cc; cb += U * n_waves) {
+            float val[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) val[u] = src_cm[((size_t)b * C2 + c0 + min(cb + u * n_waves, cc - 1)) * N + n0 + lane];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (cb + u * n_waves < cc) tile[lane * ld + cb + u * n_waves] = val[u];
+        }
+    }
     __syncthreads();
     float* base = out_cl + (size_t)b * vol_rows * C2 + c0;
     if (VEC) {      // tile channel blocks never straddle C (C % 64 == 0 is not needed: c2 mod C is taken per 4-channel group)
