@@ -901,8 +901,9 @@ static int check_mr_args(const char* who, const void* a, const void* b, const vo
 // grid = 8-window blocks x groups x 8 (ids differing by 8 = the groups of one window land on one XCD back to back, so that the
 // 176-byte segments they write into the same rows meet in one L2); block = 64 * ceil(Nw / 64).
 // ---------------------------------------------------------------------------------------------
-// LDS-only workgroup barrier: __syncthreads() also waits for the wave's outstanding global stores (its release fence is
-// s_waitcnt vmcnt(0)), which would put a store round trip into every phase boundary of the kernel below.
+// LDS-only workgroup barrier between the phases of the kernel below: the hazards there are LDS hazards, and a wait on vmcnt would put
+// the previous phase's global stores (the in-order counter holds them too) into every phase boundary.  This is what __syncthreads()
+// compiles to on gfx950 today (s_waitcnt lgkmcnt(0); s_barrier — checked in the ISA); written out so that it stays that way.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // e / d for 0 <= e < 65 536, 1 <= d < 65 536 by one v_mul_hi_u32: m = ceil(2^32 / d) (exact: e * (m * d - 2^32) < 2^32); d = 1 -> m = 0
