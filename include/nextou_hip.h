@@ -156,7 +156,7 @@ int nextou_mr_aggregate_bwd(const float* gout, const float* x, const float* y,
  *   h_rows    channels-last (B, D, H, W, 2C): conv1x1(a, weight, groups) — bit-identical to nextou_pw_rows_fused on a_rows
  *   stats_partial  NULL or [2C][stats_tiles] (sum, sum of squares) float64 pairs of h per window, stats_tiles == B * nWin
  *                  (nextou_norm_finalize's `partial`)
- * C % groups == 0, C / groups even and <= 32, Nw <= 256: nextou_mr_grouped_rows_supported() says whether a shape is taken
+ * C % groups == 0, C / groups even and <= 32 (or 44 / 54: the 264- / 324-channel stages), Nw <= 256: nextou_mr_grouped_rows_supported() says whether a shape is taken
  * (NEXTOU_ENOTSUP otherwise; NEXTOU_MR_GROUPED=0 switches the kernel off).  HBM-bound: 12 B'C Nw + 4 B' Nw K bytes in eval. */
 int nextou_mr_grouped_rows_supported(int n_windows, int C, int groups, int Nw, int K);
 /* nextou_mr_grouped_rows_bwd: the window tensor's gradient in one launch — autograd of the three ops above (grouped data-gradient

@@ -912,7 +912,7 @@ inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32)
 __device__ __forceinline__ int fdiv(int e, int d, unsigned magic) { return d == 1 ? e : (int)__umulhi((unsigned)e, magic); }
 
 template <int KT, int NT, int KSTEPS, bool EXACT>
-__global__ __launch_bounds__(512) void mr_grp_rows_kernel(
+__global__ __launch_bounds__(NT >= 7 ? 256 : 512) void mr_grp_rows_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ idx, const float* __restrict__ w, float* __restrict__ a_rows,
     float* __restrict__ h_rows, uint16_t* __restrict__ arg, double2* __restrict__ partial, Vol v, Win wn, int nH, int nW, int n_win,
     int n_windows, int C, int Cg, int Nw, int K, int idx_stride, int idx_step, int groups, int ld, long ld_rows, GrpDiv dv, int ablate) {
@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(512) void mr_grp_rows_kernel(
 //      (exact integer sums: bit-reproducible), dx[c][n] = scattered + (ga[n][2j] - ga[n][2j + 1]) written channel-major.
 // ---------------------------------------------------------------------------------------------
 template <int NT, int KSTEPS, bool EXACT>
-__global__ __launch_bounds__(512) void mr_grp_rows_bwd_kernel(
+__global__ __launch_bounds__(NT >= 7 ? 256 : 512) void mr_grp_rows_bwd_kernel(
     const float* __restrict__ dh_rows, const float* __restrict__ w, const uint16_t* __restrict__ arg, float* __restrict__ dx, Vol v,
     Win wn, int nH, int nW, int n_win, int n_windows, int C, int Cg, int Nw, int groups, int ld, long ld_rows, GrpDiv dv, int S) {
     extern __shared__ __attribute__((aligned(16))) float4 grp_tile4[];
@@ -1287,13 +1287,14 @@ static MrGrpPlan plan_mr_grp(int n_windows, int C, int groups, int Nw, int K) {
     const char* env = getenv("NEXTOU_MR_GROUPED");            // read per call (tests / A-B)
     if ((env && env[0] == '0') || n_windows < 1 || groups < 1 || groups > 64 || C < 1 || C % groups != 0 || Nw < 1 || Nw > 256 || K < 1 || K > 32) return q;
     const int Cg = C / groups, Kg = 2 * Cg;
-    if ((Cg & 1) || Kg > 64) return q;
+    if ((Cg & 1) || (Kg > 64 && Kg != 88 && Kg != 108)) return q;       // 88 / 108: the 264- / 324-channel stages (own instances)
     const int Q = (Cg + 3) / 4, MT = cdiv(Nw, 16);
     q.threads = 64 * cdiv(Nw * Q, 64);                         // a lane per (point, channel quad), two rounds from 512 items on
     if (q.threads > 512) q.threads = 512;
+    if (Kg > 96 && q.threads > 256) q.threads = 256;           // (the 7 x 27 weight tiles of a 108-channel group: 189 registers per lane)
     if (const char* e = getenv("NEXTOU_MRG_THREADS")) { const int t = atoi(e); if (t >= 64 && t <= 512 && t % 64 == 0) q.threads = t; }
     q.ld = Kg + ((Kg % 8 == 4) ? 0 : 4);                       // row stride = 4 mod 8 floats (pw_rows_grp_kernel's slab)
-    const int tile_f4 = std::max(Nw * Q, (q.threads / 64) * 4 * 16 + Kg * Kg / 4);
+    const int tile_f4 = std::max(Nw * Q, (q.threads / 64) * 8 * 16 + Kg * Kg / 4);        // (statistics buffer sized for NT <= 8)
     q.lds = (size_t)tile_f4 * 16 + (size_t)MT * 16 * q.ld * 4 + (size_t)((Nw + 3) & ~3) * 4 + (((size_t)Nw * K * 2 + 15) & ~(size_t)15);
     if (q.lds > 150 * 1024) return q;
     q.grid = cdiv(n_windows, 8) * 8 * groups;
@@ -1626,6 +1627,8 @@ extern "C" int nextou_mr_grouped_rows(const float* windows, const int32_t* nn_id
         else NEXTOU_MR_GRP(32, NT, KS, EX);             \
     } while (0)
     if (Kg == 44) NEXTOU_MR_GRP_K(3, 11, true);
+    else if (Kg == 88) NEXTOU_MR_GRP_K(6, 22, true);
+    else if (Kg == 108) NEXTOU_MR_GRP_K(7, 27, true);
     else NEXTOU_MR_GRP_K(4, 16, false);
 #undef NEXTOU_MR_GRP_K
 #undef NEXTOU_MR_GRP
@@ -1661,6 +1664,7 @@ extern "C" int nextou_mr_grouped_rows_bwd(const float* dh_rows, const float* wei
     if (lds > 150 * 1024) return fail(NEXTOU_ENOTSUP, "mr_grouped_rows_bwd: %zu bytes of LDS", lds);
     int threads = 64 * cdiv(Cg * Nw, 64 * 4);                      // ~4 scatter items per lane
     if (threads > 512) threads = 512;
+    if (Kg > 96 && threads > 256) threads = 256;
     if (threads < 64) threads = 64;
     const int S = 47;                                              // (a tile is one window: Nw <= 256 addends per accumulator)
 #define NEXTOU_MR_GRP_BWD(NT, KS, EX)                                                                                              \
@@ -1672,6 +1676,8 @@ extern "C" int nextou_mr_grouped_rows_bwd(const float* dh_rows, const float* wei
                            nW, n_win, (int)n_windows, C, Cg, Nw, groups, q.ld, (long)2 * C, dv, S);                              \
     } while (0)
     if (Kg == 44) NEXTOU_MR_GRP_BWD(3, 11, true);
+    else if (Kg == 88) NEXTOU_MR_GRP_BWD(6, 22, true);
+    else if (Kg == 108) NEXTOU_MR_GRP_BWD(7, 27, true);
     else NEXTOU_MR_GRP_BWD(4, 16, false);
 #undef NEXTOU_MR_GRP_BWD
     return check_launch("mr_grp_rows_bwd_kernel");

@@ -1410,6 +1410,58 @@ class _MRAggregateRows(torch.autograd.Function):
         return (dx,) + (None,) * 11
 
 
+class _MRGroupedConv(torch.autograd.Function):
+    """``conv1x1(window_scatter(mr_aggregate(windows)), weight, groups)`` as the K2 + K7 launch, for the stages whose blocks do not take
+    the fused point-wise chain (below NEXTOU_PW_FUSE_MIN_POINTS): returns the convolution's output as a channels-last volume; backward =
+    the fused backward launch for the window tensor + K7's weight-gradient GEMM on the saved aggregate rows."""
+
+    @staticmethod
+    def forward(ctx, windows, weight, nn_idx, K, groups, batch, spatial, window, shift):
+        w2 = weight.reshape(weight.shape[0], weight.shape[1]).contiguous()
+        need_x, need_w = windows.requires_grad, weight.requires_grad
+        a, arg, h, _ = _HIP.mr_grouped_rows(windows, nn_idx, K, 1, w2, groups, batch, spatial, window, shift,
+                                            want_a=need_w, want_arg=need_x, want_stats=False)
+        ctx.conf = (window, shift, tuple(spatial), groups, tuple(weight.shape))
+        ctx.save_for_backward(arg if need_x else None, a if need_w else None, w2 if need_x else None)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        window, shift, spatial, groups, wshape = ctx.conf
+        arg, a, w2 = ctx.saved_tensors
+        mf = {4: torch.channels_last, 5: torch.channels_last_3d}[dh.dim()]
+        dh = dh.contiguous(memory_format=mf)
+        dx = _HIP.mr_grouped_rows_bwd(dh, w2, arg, groups, spatial, window, shift) if ctx.needs_input_grad[0] else None
+        gw = _HIP.pw_wgrad(dh, a, groups).reshape(wshape) if ctx.needs_input_grad[1] else None
+        return (dx, gw) + (None,) * 7
+
+
+def mr_grouped_conv(windows, nn_idx, conv, norm, batch, spatial, window, shift):
+    """MRConv inside Swin windows up to its grouped 1x1 convolution in ONE launch (K2 + K7), for blocks outside the fused point-wise
+    chain: ``conv(window_scatter(mr_aggregate(windows, nn_idx)))`` as a channels-last volume, or ``None`` when the shape / module is not
+    taken (the caller runs the three ops).  ``conv``'s bias must be absent or folded into ``norm`` (norm_act._ConvBiasFolded)."""
+    import os
+    if os.environ.get("NEXTOU_MR_GROUPED", "1") == "0" or not windows.is_cuda or windows.dtype != torch.float32 or \
+            torch.is_autocast_enabled("cuda") or nn_idx.dtype != torch.int32:
+        return None
+    n_windows, C, Nw = windows.shape
+    w = conv.weight
+    if not _plain_1x1(conv, 2 * C) or w.shape[0] != 2 * C:
+        return None
+    if conv.bias is not None and getattr(norm, "_pre_bias_src", (None,))[0] is not conv:
+        return None
+    K, groups = nn_idx.shape[2], int(conv.groups)
+    # one workgroup per (window, group): with fewer than a workgroup per CU the three small launches win as replayed hipGraphs (cfg 2:
+    # stage 3, 768 workgroups, 967 vs 1 005 us per block forward + backward; stage 4, 96 workgroups, 406 vs 381; stage 5, 12 workgroups,
+    # 349 vs 296 — profiles/r04_k2_k7_fused.md)
+    if n_windows * groups < int(os.environ.get("NEXTOU_MR_GROUPED_MIN_WORKGROUPS", "256")):
+        return None
+    if not _HIP.mr_grouped_rows_supported(n_windows, C, groups, Nw, K):
+        return None
+    return _MRGroupedConv.apply(_f32c(windows), w, nn_idx.contiguous(), K, groups, int(batch), tuple(int(v) for v in spatial),
+                                tuple(int(v) for v in window), tuple(int(v) for v in shift))
+
+
 def mr_grouped_chain(windows, nn_idx, residual, conv1, norm1, conv2, norm2, spatial, window, shift):
     """SwinGrapher's ``fc2(BasicConv(mr_aggregate(windows)))  + residual`` with the aggregation, the window reverse and the grouped
     1x1 convolution in ONE kernel (reference NexToU_Encoder_Decoder.py:401-418, torch_nn.py:66-92), followed by the

@@ -508,6 +508,13 @@ def _swin_forward_channels_last(self, x, size_tuple, dim):
         y = graph_ops.mr_grouped_chain(windows, nn_idx, x, basic[0], basic[1], self.fc2[0], self.fc2[1], size_tuple, self.window_size, shift)
         if y is not None:
             return y
+    if len(basic) >= 2 and isinstance(basic[0], (nn.Conv2d, nn.Conv3d)):
+        # below the chain's point threshold: still one launch for aggregate + window reverse + grouped convolution, then the norm module
+        h = graph_ops.mr_grouped_conv(windows, nn_idx, basic[0], basic[1], x.shape[0], size_tuple, self.window_size, shift)
+        if h is not None:
+            for mod in list(basic)[1:]:         # the norm (with its absorbed activation) and whatever follows it in BasicConv
+                h = mod(h)
+            return self.fc2(h) + x
     agg = graph_ops.mr_aggregate(windows, nn_idx)                                      # (B * nW, 2C, Nw)
     vol = graph_ops.window_scatter(agg, size_tuple, self.window_size, shift)           # NDHWC (B, 2C, *size)
     if chain:

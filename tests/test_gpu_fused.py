@@ -257,6 +257,8 @@ def test_graph_blocks_fused_vs_op_by_op(ops, monkeypatch, mode):
     (2, 12, (4, 8, 8), (2, 4, 4), (1, 2, 2), 6, 4),          # groups of 4 channels (generic instance), 32-point windows
     (3, 64, (1, 12, 10), (1, 4, 5), (0, 2, 0), 4, 9),        # 2-D (D = 1), groups of 32, 20-point windows (less than one wave)
     (1, 48, (6, 6, 6), (3, 6, 6), (1, 0, 3), 2, 32),         # 108-point windows, groups of 48, the longest list
+    (1, 264, (4, 6, 14), (2, 6, 14), (1, 3, 7), 6, 14),      # cfg-2 stage 3: groups of 88 (the 6 x 22 instance)
+    (1, 324, (2, 6, 14), (2, 6, 14), (0, 0, 0), 6, 28),      # cfg-2 stages 4 / 5: groups of 108 (the 7 x 27 instance, 256 threads)
 ])
 def test_mr_aggregate_fused_with_grouped_conv(ops, B, C, spatial, window, shift, groups, k):
     """K2 + K7 in one launch (nextou_mr_grouped_rows): aggregate rows and arg tape bit-identical to
@@ -708,3 +710,54 @@ def test_up_convolution_bias_folded_into_the_concatenation(ops, monkeypatch, dim
     assert torch.equal(y1, y0) or float((y1 - y0).abs().max()) <= 1e-6 * float(y0.abs().max())
     for a, b in zip(g1, g0):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("C,k,mode", [(264, 14, "train"), (324, 28, "train"), (264, 14, "eval")])
+def test_swin_block_below_the_chain_threshold_with_fused_aggregate(ops, monkeypatch, C, k, mode):
+    """Stages 3-5 of cfg 2 (groups of 88 / 108 channels, blocks below NEXTOU_PW_FUSE_MIN_POINTS): SwinGrapher with aggregate + window
+    reverse + grouped convolution in ONE launch (graph_ops.mr_grouped_conv) and the norm / fc2 modules behind it, against the three
+    launches (NEXTOU_MR_GROUPED=0): same output, gradients and running statistics; the launch labels prove which path ran."""
+    import ctypes
+    import json
+    from nextou_amd import _lib
+    from nextou_amd.network_architecture import NexToU_Encoder_Decoder as encdec
+    from nextou_amd.network_architecture.norm_act import fuse_norm_act
+    kw = dict(conv_op=nn.Conv3d, norm_op=nn.BatchNorm3d, norm_op_kwargs={'eps': 1e-5, 'affine': True})
+    monkeypatch.setenv("NEXTOU_MR_GROUPED_MIN_WORKGROUPS", "0")     # (8 windows here; the product takes the launch from 256 workgroups on)
+    torch.manual_seed(C + k)
+    blk = encdec.SwinGrapher(C, (4, 12, 14), k, 1, 'mr', 'leakyrelu', 'instance', True, True, 0.2, 1, n=168, relative_pos=True,
+                             window_size=(2, 6, 14), shift_size=[1, 3, 7], dropout_op=None, **kw)
+    fuse_norm_act(blk)
+    blk = blk.to(DEV).train(mode == "train")
+    shape = (2, C, 4, 12, 14)
+    x0 = torch.randn(shape, device=DEV).contiguous(memory_format=CL)
+    gy = torch.randn(shape, device=DEV).contiguous(memory_format=CL)
+    L_ = _lib.lib()
+    results = {}
+    for setting in ("1", "0"):
+        monkeypatch.setenv("NEXTOU_MR_GROUPED", setting)
+        m = copy.deepcopy(blk)
+        x = x0.clone().requires_grad_(True)
+        L_.nextou_profile_enable(512)
+        y = m(x)
+        grads = torch.autograd.grad(y, [x] + [p for p in m.parameters() if p.requires_grad], gy, allow_unused=True)
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = L_.nextou_profile_report(buf, len(buf))
+        L_.nextou_profile_enable(0)
+        names = [r["kernel"] for r in json.loads(buf.value[:n].decode())]
+        results[setting] = (y.detach(), grads, {k_: v.clone() for k_, v in m.state_dict().items() if "running" in k_}, names)
+    assert sum(n_.startswith("mr_grp_rows_kernel<train>") for n_ in results["1"][3]) == 1
+    assert sum(n_.startswith("mr_grp_rows_bwd_kernel") for n_ in results["1"][3]) == 1
+    assert not any(n_.startswith(("mr_fwd", "mr_bwd")) for n_ in results["1"][3])      # (window_scatter stays: window_gather's backward)
+    assert not any(n_.startswith("mr_grp_rows") for n_ in results["0"][3])
+    (y1, g1, r1, _), (y0, g0, r0, _) = results["1"], results["0"]
+    assert float((y1 - y0).abs().max()) <= 2e-5 * float(y0.abs().max())
+    gscale = max(float(b.abs().max()) for b in g0 if b is not None)
+    for a, b in zip(g1, g0):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert float((a - b).abs().max()) <= max(1e-4 * float(b.abs().max()), 2e-6 * gscale)
+    for k_ in r0:
+        assert torch.allclose(r1[k_], r0[k_], rtol=1e-5, atol=1e-6), k_
+
