@@ -1107,10 +1107,12 @@ __global__ __launch_bounds__(NT >= 7 ? 256 : 512) void mr_grp_rows_kernel(
         }
     }
     lds_barrier();
-    if (partial != nullptr && tid < NT * 16 && tid < Kg) {
-        double u = 0.0, q2 = 0.0;
-        for (int wv = 0; wv < nwv; ++wv) { const double2 t = red[wv * NT * 16 + tid]; u += t.x; q2 += t.y; }
-        partial[(size_t)(g * Kg + tid) * n_windows + bw] = make_double2(u, q2);
+    if (partial != nullptr) {
+        for (int c = tid; c < Kg; c += T) {             // (a small window's block can be narrower than the group: 64 threads, 88 channels)
+            double u = 0.0, q2 = 0.0;
+            for (int wv = 0; wv < nwv; ++wv) { const double2 t = red[wv * NT * 16 + c]; u += t.x; q2 += t.y; }
+            partial[(size_t)(g * Kg + c) * n_windows + bw] = make_double2(u, q2);
+        }
     }
     // ---- 3: the product's rows
     for (int e = tid; e < Nw * kp && !(ablate & 8); e += T) {

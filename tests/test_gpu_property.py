@@ -105,7 +105,8 @@ def test_knn_whole_window_kernel_any_shape_bit_exact(B, C, N, k, relpos, seed):
 
 
 @settings(max_examples=20, deadline=None, derandomize=True)
-@given(B=st.integers(1, 2), cg2=st.integers(1, 16), groups=st.integers(1, 6), win=st.tuples(st.integers(1, 4), st.integers(1, 5), st.integers(1, 6)),
+@given(B=st.integers(1, 2), cg2=st.one_of(st.integers(1, 16), st.sampled_from([22, 27])), groups=st.integers(1, 6),
+       win=st.tuples(st.integers(1, 4), st.integers(1, 5), st.integers(1, 6)),
        cnt=st.tuples(st.integers(1, 2), st.integers(1, 3), st.integers(1, 3)), k=st.integers(1, 32), shifted=st.booleans(),
        seed=st.integers(0, 10 ** 6))
 def test_mr_grouped_rows_any_shape(B, cg2, groups, win, cnt, k, shifted, seed):

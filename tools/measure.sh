@@ -24,7 +24,8 @@ field() { python -c "import json,sys;d=json.load(open('$1'));print('$(basename $
 
 t_tests() {
   python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt
-  python -m pytest tests -q -m gpu --durations=10 2>&1 | grep -v "MIOpen\|GridwiseOp\|amdgpu.ids" | tail -26 > $OUT/pytest_gpu_full.txt; tail -4 $OUT/pytest_gpu_full.txt
+  python -m pytest tests -q -m gpu --durations=10 -rf 2>&1 | grep -v "MIOpen\|GridwiseOp\|amdgpu.ids" > $OUT/pytest_gpu_full_log.txt
+  (grep -E "^(FAILED|ERROR)|^E  " $OUT/pytest_gpu_full_log.txt | cut -c1-400 | head -60; tail -26 $OUT/pytest_gpu_full_log.txt) > $OUT/pytest_gpu_full.txt; tail -4 $OUT/pytest_gpu_full.txt
 }
 t_margins() {
   python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity2.py tests/test_gpu_fused_goldens.py -q -s -m gpu \
