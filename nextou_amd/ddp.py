@@ -30,7 +30,8 @@ class _Bucket:
 
     @staticmethod
     def _view_like(flat: torch.Tensor, offset: int, p: torch.Tensor) -> torch.Tensor:
-        if _dense_strides(p) and not p.is_contiguous():
+        import os
+        if os.environ.get("NEXTOU_DDP_STRIDED_VIEWS", "0") == "1" and _dense_strides(p) and not p.is_contiguous():
             return flat.as_strided(p.shape, p.stride(), flat.storage_offset() + offset)
         return flat[offset:offset + p.numel()].view_as(p)
 
@@ -42,9 +43,9 @@ class _Bucket:
             total += p.numel()
         self.n_grad = total
         self.flat = torch.zeros(total + len(params), dtype=params[0].dtype, device=params[0].device)
-        # views with the PARAMETER's strides (a channels-last convolution weight keeps its permuted layout): what autograd's
-        # AccumulateGrad hands over has them too, so the multi-tensor copy takes its fast route, and optimizers that walk
-        # parameter, gradient and momentum as flat arrays (torch.optim.SGD(fused=True)) pair the right elements
+        # plain reshaped slices of the flat buffer (the layout every round's runs used).  NEXTOU_DDP_STRIDED_VIEWS=1: views with the
+        # PARAMETER's strides (a channels-last convolution weight keeps its permuted layout), so that optimizers that walk parameter,
+        # gradient and momentum as flat arrays (torch.optim.SGD(fused=True)) pair the right elements — opt-in, see bench.move_to
         self.views = [self._view_like(self.flat, o, p) for o, p in zip(self.offsets, params)]
         self.flags = self.flat[total:]
         self.pending = len(params)

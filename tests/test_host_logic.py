@@ -318,10 +318,14 @@ def test_rows_gemm_view_algebra_and_cpu_fallbacks():
         assert torch.allclose(RobustCrossEntropyLoss()(logits, target.unsqueeze(1).float()), F.cross_entropy(logits, target))
 
 
-def test_gradient_bucket_views_carry_the_parameter_strides():
-    """ddp._Bucket: a bucket view of a channels-last (or otherwise permuted-dense) parameter has the parameter's strides, aliases the
-    flat buffer at its offset, and round-trips values; contiguous and non-dense parameters take the plain reshaped slice."""
+def test_gradient_bucket_views_carry_the_parameter_strides(monkeypatch):
+    """ddp._Bucket with NEXTOU_DDP_STRIDED_VIEWS=1 (opt-in): a bucket view of a channels-last (or otherwise permuted-dense) parameter has
+    the parameter's strides, aliases the flat buffer at its offset, and round-trips values; contiguous and non-dense parameters — and
+    every parameter by default — take the plain reshaped slice."""
     from nextou_amd.ddp import _Bucket, _dense_strides
+    plain = _Bucket([torch.nn.Parameter(torch.randn(6, 4, 3, 3, 3).contiguous(memory_format=torch.channels_last_3d))])
+    assert plain.views[0].is_contiguous() and plain.views[0].shape == (6, 4, 3, 3, 3)
+    monkeypatch.setenv("NEXTOU_DDP_STRIDED_VIEWS", "1")
     a = torch.nn.Parameter(torch.randn(6, 4, 3, 3, 3).contiguous(memory_format=torch.channels_last_3d))
     b = torch.nn.Parameter(torch.randn(5, 7))
     c = torch.nn.Parameter(torch.randn(4, 2, 3, 3).contiguous(memory_format=torch.channels_last))
