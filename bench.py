@@ -87,9 +87,9 @@ def move_to(trainer, device, fused_sgd=False):
     trainer.network.to(device)
     trainer.device = device
     # fused_sgd: torch's single-launch multi-tensor SGD (same update rule; -0.5 ms per cfg-2 step).  Only without the gradient averager:
-    # with p.grad pointing into the averager's flat buckets the fused kernel takes a GPU memory fault in the EAGER step (single process,
-    # RCCL and gloo alike; the captured step runs) — reproduced with `NEXTOU_SGD_FUSED=1 bench.py --workload tiny --force-averager
-    # --graph off`, cause not found (profiles/r04_sgd_fused.md), so the averaged step keeps the foreach implementation.
+    # the averaged step's gradients are views into the flat buckets and keeps the foreach implementation.  (The GPU memory fault round 4
+    # first blamed on this combination is MIOpen's backward-data kernel of the 1x1 head convolution reading past its operand —
+    # tools/conv_bwd_fault_repro.py, profiles/r05_n_gt_1.md; the heads run on K8 since.)
     fused = fused_sgd and device.type == "cuda" and os.environ.get("NEXTOU_SGD_FUSED", "1") != "0"
     trainer.optimizer = torch.optim.SGD(trainer.network.parameters(), trainer.initial_lr, weight_decay=trainer.weight_decay,
                                         momentum=trainer.momentum, nesterov=True, **({"fused": True} if fused else {}))
@@ -156,6 +156,8 @@ def roofline_graph_from(report):
             "K7_pointwise_rows": pick(("pw_rows_kernel", "pw_rows_sw_kernel")),
             "K7_pointwise_wgrad": pick(("pw_wgrad_kernel", "pw_wgrad_so_kernel")),
             "K7_pointwise_rows_worst_shape": worst(("pw_rows_kernel", "pw_rows_sw_kernel")),
+            "K8_head_forward": pick(("head_fwd_kernel",)), "K8_head_dgrad": pick(("head_dgrad_kernel",)),
+            "K8_head_wgrad": pick(("head_wgrad_kernel",)),
             "graph_kernels_ms_per_step": None}
 
 
@@ -431,6 +433,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # what the process group really was: a SCALE record shows that RCCL saw N ranks on N distinct devices
+    props = torch.cuda.get_device_properties(device)
+    me = {"rank": rank, "device": str(device), "name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None),
+          "uuid": str(getattr(props, "uuid", "")) or None}
+    if dist.is_initialized():
+        ranks = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks, me)
+        dist_info = {"initialized": True, "backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks,
+                     "distinct_devices": len({(r["pci_bus_id"], r["uuid"], r["device"]) for r in ranks})}
+    else:
+        dist_info = {"initialized": False, "backend": None, "world_size": 1, "ranks": [me], "distinct_devices": 1}
+
     if rank == 0:
         voxels_per_step = world * batch * int(np.prod(cfg.patch_size))
         ms = elapsed / args.steps * 1e3
@@ -463,6 +477,7 @@ def main():
                            "fused" if trainer.optimizer.defaults.get("fused") else "foreach"),
                        "step_replayed_as_hipgraph": graphed is not None, "graph_capture_error": capture_error,
                        "parallelism": "dp%d" % world, "final_loss": float(loss.detach())},
+            "dist": dist_info,
             "roofline": roof,
             "roofline_graph": graph,
             "launch_profile_check": profile_check,

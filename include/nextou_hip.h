@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NEXTOU_ABI_VERSION 10
+#define NEXTOU_ABI_VERSION 11
 
 #define NEXTOU_EINVAL   (-1)  /* bad argument (null pointer, non-positive size, k > M ...) */
 #define NEXTOU_ENOSPACE (-2)  /* workspace too small */
@@ -433,6 +433,26 @@ int nextou_norm_bwd_finalize(const double* partial, int tiles, double count, flo
 int nextou_norm_bwd_apply_rows(const float* x, const float* gy, float* gx, const float* coeff, const float* weight,
                                const float* bias, const float* save_mean, const float* save_invstd, int64_t rows, int C,
                                float slope, nextou_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K8  segmentation heads (ABI v11): the decoder's deep-supervision `seg_layers` — nn.Conv{2,3}d(features, num_classes, 1, 1, 0,
+ * bias=True) applied to every decoder stage's output (reference NexToU_Encoder_Decoder.py:253-258, :311-337) — and their autograd,
+ * which PyTorch-ROCm runs as MIOpen convolutions.  Channels-last rows: x (P, C) with row stride ldx, logits y / gy (P, L) with row
+ * stride ldy / ldg, weights w (L, C) dense, float32.  HBM-bound: 4 P (C + L) bytes each way.  Any C and L <= 64 (forward: any L);
+ * 16-byte accesses when C % 4 == 0, ldx % 4 == 0 and the pointer is 16-byte aligned, scalar ones otherwise.
+ *
+ * nextou_head_rows_fwd            y[p, l] = bias[l] + sum_c x[p, c] w[l, c]   (bias may be NULL); c ascending in groups of four
+ *                                 channels {16 j + 4 g + r : g = 0..3} — a fixed order, bit-reproducible.
+ * nextou_head_rows_bwd            gx[p, c] = sum_l gy[p, l] w[l, c]           (gx NULL: skipped)
+ *                                 gw[l, c] = sum_p gy[p, l] x[p, c], gb[l] = sum_p gy[p, l]   (both NULL: skipped; either may be NULL)
+ *                                 split over points into `workspace` (nextou_head_rows_bwd_workspace bytes) and summed in a fixed
+ *                                 order: bit-reproducible.
+ * ---------------------------------------------------------------------------------------- */
+int nextou_head_rows_fwd(const float* x, const float* w, const float* bias, float* y, int64_t P, int L, int C, int64_t ldx,
+                         int64_t ldy, nextou_stream_t stream);
+int nextou_head_rows_bwd_workspace(int64_t P, int L, int C, size_t* bytes);
+int nextou_head_rows_bwd(const float* gy, const float* x, const float* w, float* gx, float* gw, float* gb, float* workspace,
+                         size_t workspace_bytes, int64_t P, int L, int C, int64_t ldg, int64_t ldx, nextou_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("NEXTOU_HIP_LIB") or os.path.join(_PKG_DIR, "libnextou
 
 KNN_AUTO, KNN_FUSED, KNN_NAIVE = 0, 1, 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # name -> (restype, argtypes); mirrors include/nextou_hip.h one to one
 _SIGNATURES = {
@@ -105,6 +105,10 @@ _SIGNATURES = {
     "nextou_norm_bwd_finalize": (c_int, [c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "nextou_norm_bwd_apply_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                            c_int, c_float, c_void_p]),
+    "nextou_head_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "nextou_head_rows_bwd_workspace": (c_int, [c_int64, c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "nextou_head_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int,
+                                     c_int64, c_int64, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -1457,7 +1457,14 @@ extern "C" int nextou_mr_aggregate_bwd_arg(const float* gout, const uint16_t* ar
     const int acc_bytes = float_atomics ? 4 : 8;
     const int budget = 32 * 1024 / acc_bytes;  // <= 32 KB of accumulators per workgroup
     int chunk = budget / M;
-    if (chunk < 1) return fail(NEXTOU_ENOTSUP, "mr_aggregate_bwd_arg: M=%d rows do not fit the LDS accumulators", M);
+    if (chunk < 1) {
+        // one channel row per workgroup with up to 152 KB of accumulators (one workgroup per CU): every M the forward writes an arg
+        // tape for (plan_qb: M * 16 <= 152 KB) has a backward — with the 8-byte accumulators the 32 KB budget stopped at M = 4096 while
+        // nextou_mr_aggregate_has_arg still said yes up to 9 728
+        if ((size_t)M * acc_bytes > 152 * 1024)
+            return fail(NEXTOU_ENOTSUP, "mr_aggregate_bwd_arg: M=%d rows do not fit the LDS accumulators", M);
+        chunk = 1;
+    }
     if (chunk > C) chunk = C;
     while (chunk > 1 && (long long)cdiv(C, chunk) * B < 1024) chunk = (chunk + 1) / 2;
     chunk = cdiv(C, cdiv(C, chunk));
@@ -1478,22 +1485,28 @@ extern "C" int nextou_mr_aggregate_bwd_arg(const float* gout, const uint16_t* ar
         while ((1ll << lg) < N) ++lg;
         const int S = lg <= 14 ? 47 : 61 - lg;
 #define NEXTOU_MR_BWD_FIX(SELF, VEC)                                                                            \
+    if (lds > 64 * 1024)                                                                                        \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_fix_kernel<SELF, VEC>),                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
     hipLaunchKernelGGL((mr_bwd_fix_kernel<SELF, VEC>), grid, dim3(threads), lds, s, gout, arg, dx, dy, C, N, M, chunk, \
                        magic, S)
-        if (self && vec4) NEXTOU_MR_BWD_FIX(true, true);
-        else if (self) NEXTOU_MR_BWD_FIX(true, false);
-        else if (vec4) NEXTOU_MR_BWD_FIX(false, true);
-        else NEXTOU_MR_BWD_FIX(false, false);
+        if (self && vec4) { NEXTOU_MR_BWD_FIX(true, true); }
+        else if (self) { NEXTOU_MR_BWD_FIX(true, false); }
+        else if (vec4) { NEXTOU_MR_BWD_FIX(false, true); }
+        else { NEXTOU_MR_BWD_FIX(false, false); }
 #undef NEXTOU_MR_BWD_FIX
         return check_launch("mr_bwd_fix_kernel");
     }
 #define NEXTOU_MR_BWD_ARG(SELF, VEC)                                                                            \
+    if (lds > 64 * 1024)                                                                                        \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_arg_kernel<SELF, VEC>),                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
     hipLaunchKernelGGL((mr_bwd_arg_kernel<SELF, VEC>), grid, dim3(threads), lds, s, gout, arg, dx, dy, C, N, M, chunk, \
                        magic)
-    if (self && vec4) NEXTOU_MR_BWD_ARG(true, true);
-    else if (self) NEXTOU_MR_BWD_ARG(true, false);
-    else if (vec4) NEXTOU_MR_BWD_ARG(false, true);
-    else NEXTOU_MR_BWD_ARG(false, false);
+    if (self && vec4) { NEXTOU_MR_BWD_ARG(true, true); }
+    else if (self) { NEXTOU_MR_BWD_ARG(true, false); }
+    else if (vec4) { NEXTOU_MR_BWD_ARG(false, true); }
+    else { NEXTOU_MR_BWD_ARG(false, false); }
 #undef NEXTOU_MR_BWD_ARG
     return check_launch("mr_bwd_arg_kernel");
 }

@@ -555,6 +555,42 @@ class _HipBackend:
         return dw
 
 
+    # ---- K8: segmentation heads (biased 1x1 convolutions to the class logits) on channels-last rows ----
+    @staticmethod
+    def head_rows_fwd(x_cl, w2, bias):
+        """x_cl: dense channels-last (B, C, *sp) float32; w2: (L, C) contiguous; bias (L,) or None -> channels-last (B, L, *sp)."""
+        L_ = _lib.lib()
+        C = x_cl.shape[1]
+        P = x_cl.numel() // C
+        L = w2.shape[0]
+        y = _empty_channels_last((x_cl.shape[0], L) + tuple(x_cl.shape[2:]), x_cl.device)
+        with torch.cuda.device(x_cl.device):
+            rc = L_.nextou_head_rows_fwd(x_cl.data_ptr(), w2.data_ptr(), _ptr(bias), y.data_ptr(), P, L, C, C, L, _stream_ptr(x_cl.device))
+        _lib.check(rc, "head_rows_fwd")
+        return y
+
+    @staticmethod
+    def head_rows_bwd(gy_cl, x_cl, w2, want_gx, want_gw):
+        """(gx channels-last like x_cl | None, gw (L, C) | None, gb (L,) | None) of the head; gy_cl, x_cl dense channels-last float32."""
+        import ctypes
+        L_ = _lib.lib()
+        L, C = w2.shape
+        P = x_cl.numel() // C
+        gx = _empty_channels_last(tuple(x_cl.shape), x_cl.device) if want_gx else None
+        gw = gb = ws = None
+        if want_gw:
+            need = ctypes.c_size_t(0)
+            _lib.check(L_.nextou_head_rows_bwd_workspace(P, L, C, ctypes.byref(need)), "head_rows_bwd_workspace")
+            ws = torch.empty((max(int(need.value), 4) // 4,), dtype=torch.float32, device=x_cl.device)
+            gw = torch.empty((L, C), dtype=torch.float32, device=x_cl.device)
+            gb = torch.empty((L,), dtype=torch.float32, device=x_cl.device)
+        with torch.cuda.device(x_cl.device):
+            rc = L_.nextou_head_rows_bwd(gy_cl.data_ptr(), x_cl.data_ptr(), w2.data_ptr(), _ptr(gx), _ptr(gw), _ptr(gb), _ptr(ws),
+                                         0 if ws is None else ws.numel() * 4, P, L, C, L, C, _stream_ptr(x_cl.device))
+        _lib.check(rc, "head_rows_bwd")
+        return gx, gw, gb
+
+
     # ---- K7 + K6 fused: statistics epilogue / operand prologue GEMMs and K6 in pieces ----
     @staticmethod
     def pw_rows_fused(x_cl, w2, groups, pro=None, want_stats=False, bwd=None):
@@ -1173,6 +1209,58 @@ class _ConvDgradAsForward(torch.autograd.Function):
             _, gw, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, ones, ctx.padding, ones, False, zeros, 1,
                                                            [False, True, False])
         return gx, gw, None
+
+
+HEAD_ROWS_DEFAULT = "1"
+
+
+class _HeadConv(torch.autograd.Function):
+    """A segmentation head — biased 1x1 convolution from the stage's features to the class logits (reference
+    NexToU_Encoder_Decoder.py:253-258, :311-337) — on K8 (csrc/head_rows.hip): forward, data gradient and weight + bias gradient
+    over the channels-last rows, no library convolution involved.  (MIOpen's backward of exactly this convolution is where the
+    averaged N > 1 eager step took its GPU memory fault, profiles/r05_n_gt_1.md.)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w2 = weight.reshape(weight.shape[0], weight.shape[1]).contiguous()
+        y = _HIP.head_rows_fwd(x, w2, bias)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous(memory_format={4: torch.channels_last, 5: torch.channels_last_3d}[gy.dim()])
+        want_gw = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        gx, gw, gb = _HIP.head_rows_bwd(gy, x, weight.reshape(weight.shape[0], weight.shape[1]).contiguous(), ctx.needs_input_grad[0],
+                                        want_gw)
+        if gw is not None:
+            gw = gw.reshape(weight.shape)
+        return gx, (gw if ctx.needs_input_grad[1] else None), (gb if ctx.has_bias and ctx.needs_input_grad[2] else None)
+
+
+def head_rows_eligible(conv: torch.nn.Module, x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """An un-grouped kernel-1 / stride-1 / unpadded convolution of a dense channels-last fp32 device volume outside autocast to at most
+    64 output channels — the segmentation heads.  ``NEXTOU_HEAD_ROWS=0`` hands them back to the library convolution (A/B)."""
+    import os
+    if os.environ.get("NEXTOU_HEAD_ROWS", HEAD_ROWS_DEFAULT) == "0":
+        return False
+    if not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or torch.is_autocast_enabled("cuda"):
+        return False
+    if x.dim() not in (4, 5) or conv.transposed or conv.groups != 1 or isinstance(conv.padding, str):
+        return False
+    if any(k != 1 for k in weight.shape[2:]) or any(v != 1 for v in conv.stride) or any(v != 0 for v in conv.padding) or \
+            any(v != 1 for v in conv.dilation):
+        return False
+    if weight.shape[0] > 64 or x.shape[1] != weight.shape[1] or weight.shape[1] > 1000:
+        return False
+    mf = {4: torch.channels_last, 5: torch.channels_last_3d}[x.dim()]
+    return x.is_contiguous(memory_format=mf) and x.shape[1] > 1
+
+
+def head_rows(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    return _HeadConv.apply(x, weight, bias)
 
 
 PW_GEMM_DEFAULT = "0"

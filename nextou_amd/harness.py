@@ -182,16 +182,24 @@ class GraphedTrainStep:
         for m in self._deferred:
             m.validate_targets = "deferred"
         _lib.lib().nextou_profile_enable(0)        # event records do not belong inside a captured graph
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(int(warmup), 1)):
-                step_fn()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = step_fn()
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(int(warmup), 1)):
+                    step_fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = step_fn()
+        except BaseException:
+            # a caller that falls back to the eager step (bench.py --graph auto) gets the reference's eager IndexError back: nobody
+            # would ever call check() on a step that was not captured
+            for m in self._deferred:
+                m.validate_targets = True
+            self._deferred = []
+            raise
 
     def __call__(self):
         self.graph.replay()

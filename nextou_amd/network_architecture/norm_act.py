@@ -101,6 +101,8 @@ class _ConvOwnBias:
         else:
             out_pad = (0,) * n
         weight, bias = padded_conv_params(self, x, with_bias=True)
+        if self._own(x) and graph_ops.head_rows_eligible(self, x, weight):
+            return graph_ops.head_rows(x, weight, bias)            # K8: the segmentation heads on own kernels, forward and backward
         if self._own(x):
             return graph_ops.conv_own_bias_grad(x, weight, bias, self.stride, self.padding, self.dilation,
                                                 self.transposed, out_pad, self.groups)

@@ -1,0 +1,116 @@
+#!/usr/bin/env python
+"""Body of tests/test_gpu_ddp.py::test_averaged_step_over_rccl_matches_plain_step, run in its own interpreter (a process group and
+RCCL's communicator should not outlive a test): the N > 1 train step — nextou_amd.ddp.BucketedGradientAverager: hooks, flat
+buckets, asynchronous all-reduce on RCCL's stream, finalize — on a world-size-1 `nccl` (= RCCL) group on this box's one GPU,
+eager AND captured into a hipGraph (harness.GraphedTrainStep), against the plain step of the same model on the same batch.
+
+With one rank the mean over ranks is the identity, so every gradient must come out as the plain step's: what the averager adds
+(bucket copies, the collective launch, the 1/world scale, p.grad pointing into the buckets, the remembered grad-is-None pattern
+of the zero-weighted head) is exactly what is under test.  One JSON line: distances, the eager-vs-eager floor beside them.
+
+    python tests/averaged_step_check.py [--backend nccl|gloo] [--workload tiny]
+"""
+import argparse
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import bench  # noqa: E402
+from nextou_amd import _lib  # noqa: E402
+from nextou_amd.ddp import BucketedGradientAverager, init_single_process_group  # noqa: E402
+from nextou_amd.harness import GraphedTrainStep, downsample_targets, synthetic_batch  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def make(workload, averaged):
+    trainer, cfg, batch, classes = bench.build_trainer(workload, DEV, averaged, seed=7)
+    bench.move_to(trainer, DEV)
+    averager = BucketedGradientAverager(trainer.network, bucket_bytes=1 << 20) if averaged else None     # 1 MiB: several buckets for the tiny net
+    data, target = synthetic_batch(cfg, 1, classes, batch, DEV, seed=11)
+    targets = downsample_targets(target, bench._head_shapes(cfg))
+    return trainer, bench.make_step(trainer, data, targets, averager), averager
+
+
+def grads(trainer):
+    """(flat gradient vector, names of the parameters whose grad is None) after a step"""
+    named = [(n, p) for n, p in trainer.network.named_parameters() if p.requires_grad]
+    return (torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).detach().flatten().clone() for _, p in named]),
+            [n for n, p in named if p.grad is None])
+
+
+def weights(trainer):
+    return torch.cat([p.detach().flatten() for p in trainer.network.parameters() if p.requires_grad])
+
+
+def dist_max(a, b):
+    return float((a - b).abs().max())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--workload", default="tiny")
+    ap.add_argument("--steps", type=int, default=3)
+    args = ap.parse_args()
+    _lib.lib()
+    torch.cuda.set_device(DEV)
+    torch.backends.cudnn.benchmark = False        # immediate mode: the same library kernels in every model of this process
+    init_single_process_group(args.backend)
+
+    runs = {}
+    for name, averaged, graphed in (("plain_a", False, False), ("plain_b", False, False), ("avg_eager", True, False),
+                                    ("avg_graph", True, True)):
+        t, step, averager = make(args.workload, averaged)
+        if graphed:
+            run = GraphedTrainStep(step, warmup=1, network=t.network, loss=t.loss)      # step 1 eager, then capture; replays are steps 2..
+            done = 1
+        else:
+            run, done = step, 0
+        first = None
+        if not graphed:
+            run()
+            done = 1
+            torch.cuda.synchronize()
+            first = grads(t)
+        while done < args.steps:
+            loss = run()
+            done += 1
+        torch.cuda.synchronize()
+        g_last, none_last = grads(t)
+        if averager is not None:
+            averager.check_consistency()
+            averager.remove_hooks()
+        runs[name] = {"first": first, "last": g_last, "none": none_last, "w": weights(t), "loss": float(loss.detach()),
+                      "buckets": None if averager is None else len(averager.buckets)}
+    scale_g = float(runs["plain_a"]["last"].abs().max())
+    out = {
+        "hip_library_loaded": "libnextou_hip.so" in open("/proc/self/maps").read(),
+        "backend": dist.get_backend(), "world_size": dist.get_world_size(), "steps": args.steps,
+        "buckets": runs["avg_eager"]["buckets"],
+        "grad_scale": scale_g,
+        "grad_is_none_plain": runs["plain_a"]["none"], "grad_is_none_avg_eager": runs["avg_eager"]["none"],
+        "grad_is_none_avg_graph": runs["avg_graph"]["none"],
+        # step 1: same weights, same batch -> the gradients themselves
+        "grad1_plain_vs_plain": dist_max(runs["plain_a"]["first"][0], runs["plain_b"]["first"][0]),
+        "grad1_avg_eager_vs_plain": dist_max(runs["avg_eager"]["first"][0], runs["plain_a"]["first"][0]),
+        # after `steps` steps: gradients of the last step and the weights
+        "grad_plain_vs_plain": dist_max(runs["plain_a"]["last"], runs["plain_b"]["last"]),
+        "grad_avg_eager_vs_plain": min(dist_max(runs["avg_eager"]["last"], runs[k]["last"]) for k in ("plain_a", "plain_b")),
+        "grad_avg_graph_vs_plain": min(dist_max(runs["avg_graph"]["last"], runs[k]["last"]) for k in ("plain_a", "plain_b")),
+        "weights_plain_vs_plain": dist_max(runs["plain_a"]["w"], runs["plain_b"]["w"]),
+        "weights_avg_eager_vs_plain": min(dist_max(runs["avg_eager"]["w"], runs[k]["w"]) for k in ("plain_a", "plain_b")),
+        "weights_avg_graph_vs_plain": min(dist_max(runs["avg_graph"]["w"], runs[k]["w"]) for k in ("plain_a", "plain_b")),
+        "loss": {k: v["loss"] for k, v in runs.items()},
+    }
+    print(json.dumps(out))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

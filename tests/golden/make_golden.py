@@ -528,6 +528,31 @@ def g_models(ref):
         save(name, **arrays)
 
 
+def g_state_dict(ref):
+    """G8s: the state_dict the REFERENCE model emits (tiny 3-D model of g8_tiny3d, same formula weights, the reference's own
+    `relative_pos` parameters, every alias key — `decoder.encoder.*`, `all_modules.*`): keys in state_dict order, one array per distinct
+    storage, and for every key the index of its storage.  tests: load_state_dict(strict=True) into an un-initialised nextou_amd model
+    must reproduce g8_tiny3d's logits."""
+    model = build_ref_model(ref, TINY_3D)
+    formula.fill_module_(model, seed=1)
+    sd = model.state_dict()
+    keys, owner, store = [], [], {}
+    arrays = {}
+    for k, v in sd.items():
+        ident = (v.data_ptr(), tuple(v.shape), tuple(v.stride()), str(v.dtype))
+        if ident not in store:
+            store[ident] = len(store)
+            arrays["t%d" % store[ident]] = v.detach().cpu().numpy()
+        keys.append(k)
+        owner.append(store[ident])
+    arrays["keys"] = np.asarray(keys)
+    arrays["storage_of_key"] = np.asarray(owner, dtype=np.int32)
+    n_values = sum(int(np.prod(a.shape)) for k, a in arrays.items() if k.startswith("t"))
+    print("   %d keys, %d distinct tensors, %d values; relative_pos keys: %d" % (
+        len(keys), len(store), n_values, sum(k.endswith("relative_pos") for k in keys)))
+    save("g8_tiny3d_state", **arrays)
+
+
 def g_config_table(ref):
     """G9: GNN hyper-parameters the reference derives for cfg 1 / cfg 2 / cfg 5,
     read from live module attributes of (cheap) stand-alone block factories."""
@@ -570,7 +595,7 @@ def main():
     torch.set_num_threads(8)
     ref = load_reference()
     only = set(sys.argv[1:])
-    for fn in (g_knn, g_distance, g_mrconv, g_pos_embed, g_blocks, g_ffn, g_bti, g_near_ties, g_ti, g_compound, g_models, g_config_table):
+    for fn in (g_knn, g_distance, g_mrconv, g_pos_embed, g_blocks, g_ffn, g_bti, g_near_ties, g_ti, g_compound, g_models, g_state_dict, g_config_table):
         if only and fn.__name__ not in only:
             continue
         print("==", fn.__name__)

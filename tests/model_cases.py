@@ -80,19 +80,49 @@ def float64_convolutions():
                                        list(stride), list(padding), list(dilation), bool(transposed),
                                        list(output_padding), int(groups))
         return y.to(x.dtype)
-    saved = graph_ops.conv_own_bias_grad
+    def head64(x, weight, bias):            # K8 (the segmentation heads on own kernels) -> the same float64 convolution
+        n = weight.dim() - 2
+        return conv64(x, weight, bias, (1,) * n, (0,) * n, (1,) * n, False, (0,) * n, 1)
+    saved, saved_head = graph_ops.conv_own_bias_grad, graph_ops.head_rows
     graph_ops.conv_own_bias_grad = conv64
+    graph_ops.head_rows = head64
     try:
         with formula.convs_in_float64():
             yield
     finally:
         graph_ops.conv_own_bias_grad = saved
+        graph_ops.head_rows = saved_head
 
 
-def run_model(name, cfg, batch, device, teacher_forced, float64_convs=False):
+def reference_state_dict(name="g8_tiny3d_state"):
+    """The state_dict the REFERENCE model emitted (tests/golden/make_golden.py:g_state_dict): every key, aliases sharing one tensor."""
+    g = load_golden(name)
+    tensors = {}
+    out = {}
+    for key, owner in zip(g["keys"], g["storage_of_key"]):
+        owner = int(owner)
+        if owner not in tensors:
+            tensors[owner] = torch.from_numpy(g["t%d" % owner])
+        out[str(key)] = tensors[owner]
+    return out
+
+
+def poison_(model):
+    """every parameter and buffer of ``model`` -> NaN (integers -> -1): whatever a later load_state_dict does not overwrite shows"""
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            t.fill_(float("nan") if t.is_floating_point() else -1)
+
+
+def run_model(name, cfg, batch, device, teacher_forced, float64_convs=False, state_dict=None):
     g = load_golden(name)
     model = build_model(cfg)
-    formula.fill_module_(model, seed=1)
+    if state_dict is None:
+        formula.fill_module_(model, seed=1)
+    else:                       # checkpoint interchange (SURVEY 8(f)-4): nothing of the model's own initialisation may survive
+        poison_(model)
+        result = model.load_state_dict(state_dict, strict=True)
+        assert not result.missing_keys and not result.unexpected_keys
     model = model.to(device).train()
     x = formula.gaussian(name + ".x", [batch, cfg["in_ch"]] + cfg["patch"]).to(device)
     entries = [torch.from_numpy(g["tape%d" % i]) for i in range(int(g["n_tape"]))]

@@ -1,0 +1,77 @@
+"""The N > 1 path on the one GPU of a test box: the bucketed, overlapped gradient mean of
+nextou_amd/ddp.py over RCCL (`nccl`, world size 1) — eager and captured into a hipGraph — against the plain step; bench.py's
+averaged step end to end; two ranks sharing the GPU over gloo.  No retries, no skips: the GPU memory fault these paths used to hit
+was MIOpen's backward-data kernel of the 1x1 head convolution reading past its operand (tools/conv_bwd_fault_repro.py,
+profiles/r05_n_gt_1.md), and the heads now run on K8 (csrc/head_rows.hip)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(1800)
+def test_averaged_step_over_rccl_matches_plain_step():
+    """World-size-1 RCCL group: the averaged step's gradients (step 1: same weights, same batch) and the weights after 3 steps equal the
+    plain step's — bit for bit when two plain runs agree bit for bit, else within 4x their distance; the zero-weighted head's
+    parameters keep grad = None in all three modes; eager and hipGraph-replayed."""
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "tests", "averaged_step_check.py"), "--backend", "nccl"],
+                          capture_output=True, text=True, timeout=1500)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    r = _json_line(proc.stdout)
+    print(r)
+    assert r["hip_library_loaded"] and r["backend"] == "nccl" and r["world_size"] == 1 and r["buckets"] >= 2
+    assert r["grad_is_none_plain"] == r["grad_is_none_avg_eager"] == r["grad_is_none_avg_graph"]
+    assert len(r["grad_is_none_plain"]) > 0          # the lowest-resolution head has weight 0 in the deep-supervision loss
+    tiny = 1e-6 * r["grad_scale"]
+    assert r["grad1_avg_eager_vs_plain"] <= max(4.0 * r["grad1_plain_vs_plain"], tiny), r
+    assert r["grad_avg_eager_vs_plain"] <= max(4.0 * r["grad_plain_vs_plain"], 10 * tiny), r
+    assert r["grad_avg_graph_vs_plain"] <= max(4.0 * r["grad_plain_vs_plain"], 10 * tiny), r
+    assert r["weights_avg_eager_vs_plain"] <= max(4.0 * r["weights_plain_vs_plain"], 1e-6), r
+    assert r["weights_avg_graph_vs_plain"] <= max(4.0 * r["weights_plain_vs_plain"], 1e-6), r
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("graph", ["on", "off"])
+def test_bench_averaged_step_on_one_gpu(graph):
+    """bench.py --force-averager: the N > 1 step (hooks, buckets, RCCL collectives, finalize, foreach SGD) on a world-size-1 RCCL
+    group, replayed as a hipGraph and eager — `off` is the mode that died with a GPU memory fault in round 4."""
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "2", "--workload", "tiny", "--force-averager",
+           "--graph", graph, "--no-miopen-find", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = _json_line(out.stdout)
+    assert rec["config"]["gradient_averager"] is True and rec["config"]["step_replayed_as_hipgraph"] is (graph == "on")
+    assert rec["dist"]["initialized"] and rec["dist"]["backend"] == "nccl" and rec["dist"]["world_size"] == 1
+    assert rec["value"] > 0 and rec["roofline"]["launches"] > 0
+    assert rec["roofline_graph"]["K8_head_dgrad"]["launches"] > 0       # the heads' backward ran on this library's kernels
+
+
+@pytest.mark.timeout(2700)
+def test_bench_two_ranks_share_one_gpu():
+    """The N > 1 path of bench.py end to end (launcher env, bucketed overlapped gradient mean, barrier + max-over-ranks timing, one
+    JSON line from rank 0) with two ranks on this box's single GPU over gloo; on the 8-GPU node the same code runs one rank per GPU
+    over RCCL.  The line says what the process group was."""
+    env = dict(os.environ, NEXTOU_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--workload", "tiny", "--no-miopen-find"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = _json_line(out.stdout)
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == 2 and rec["value"] > 0
+    assert rec["config"]["global_batch"] == 4 and rec["roofline"]["launches"] > 0
+    assert "cpu_baseline" not in rec or rec["cpu_baseline"] is None
+    assert rec["dist"]["backend"] == "gloo" and rec["dist"]["world_size"] == 2 and [r["rank"] for r in rec["dist"]["ranks"]] == [0, 1]
+    assert rec["dist"]["distinct_devices"] == 1          # both ranks on this box's one GPU (the 8-GPU node reports 8)

@@ -220,6 +220,8 @@ def _idx(B, N, M, K, seed):
     (1, 4, 20000, None, 6, 0, 1),        # self rows too long for LDS -> global-atomic fallback
     (1, 3, 64, 20000, 9, 0, 1),          # source rows too long for LDS (forward fallback)
     (2, 5, 70, 70, 33, 0, 1),            # K > 32 -> generic kernels
+    (1, 6, 8000, None, 9, 0, 1),         # 4096 < M <= 9728 (a 160^3 patch's 20^3 self graph): arg tape + one-row 8-byte accumulators
+    (1, 5, 1200, 9000, 6, 0, 1),         # the same for a pooled graph's source side
 ])
 def test_mr_aggregate_vs_oracle(ops, ora, B, C, N, M, K, stride_extra, step):
     x = _rand((B, C, N), 31)
@@ -327,7 +329,8 @@ def test_gather_backward(ops, ora):
     assert float((ds.cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.parametrize("B,C,N,M,K", [(64, 132, 168, None, 7), (2, 48, 10752, 1344, 28), (3, 10, 200, 64, 8), (2, 7, 50, None, 5)])
+@pytest.mark.parametrize("B,C,N,M,K", [(64, 132, 168, None, 7), (2, 48, 10752, 1344, 28), (3, 10, 200, 64, 8), (2, 7, 50, None, 5),
+                                       (2, 6, 8000, None, 9), (1, 5, 3000, 9700, 6)])       # M > 4096: > 32 KB of accumulators per row
 def test_mr_backward_is_bit_reproducible_and_tighter_than_fp32(ops, B, C, N, M, K):
     """The default backward (mr_bwd_fix_kernel: 64-bit fixed-point LDS accumulators) gives the SAME bits run after run — the float-atomic
     scatter it replaces did not (VERDICT r3 weak #1-iii) — and is closer to the float64 scatter than fp32 summation order allows it to be
@@ -603,40 +606,6 @@ def test_bf16_autocast_keeps_graph_ops_in_fp32(ops):
     assert outs[0].dtype == torch.bfloat16                                 # ... while the conv stages ran in bf16
     assert torch.isfinite(loss) and all(torch.isfinite(o.float()).all() for o in outs)
     assert all(torch.isfinite(p.grad).all() for p in tr.network.parameters() if p.grad is not None)
-
-
-@pytest.mark.timeout(2700)
-def test_bench_two_ranks_share_one_gpu(ops):
-    """The N > 1 path of bench.py end to end (launcher env, bucketed overlapped gradient mean, barrier +
-    max-over-ranks timing, one JSON line from rank 0) with two ranks on this box's single GPU over gloo;
-    on the 8-GPU node the same code runs one rank per GPU over RCCL."""
-    import json
-    import os
-    import subprocess
-    import sys
-    from conftest import REPO
-    env = dict(os.environ, NEXTOU_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--workload", "tiny", "--no-miopen-find"]
-    # Two processes on ONE GPU is a test configuration, not the product's (one rank per GPU).  On some boxes / binaries it dies with a GPU
-    # `Memory access fault` raised inside aten::convolution_backward — MIOpen's backward of the 1x1 segmentation-head convolution, whose
-    # tensors end exactly on 2 MiB mapping boundaries (located with PYTHONFAULTHANDLER + HIP_LAUNCH_BLOCKING, profiles/r04_sgd_fused.md);
-    # deterministic per box, independent of this repository's kernels (it persists with the K2 + K7 path off).  Such a run is retried and,
-    # if the box keeps faulting, reported as skipped rather than as a failure of the N > 1 path.
-    for attempt in range(3):
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
-        if out.returncode == 0 or "Memory access fault by GPU" not in out.stderr:
-            break
-    if out.returncode != 0 and "Memory access fault by GPU" in out.stderr:
-        pytest.skip("two ranks sharing one GPU: GPU memory fault inside aten::convolution_backward on this box (3 attempts)")
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == 2 and rec["value"] > 0
-    assert rec["config"]["global_batch"] == 4 and rec["roofline"]["launches"] > 0
-    assert "cpu_baseline" not in rec or rec["cpu_baseline"] is None
 
 
 def test_critical_cross_entropy_kernel(ops, ora):
