@@ -142,16 +142,19 @@ def test_model_heads_run_on_k8(ops, monkeypatch):
     loss = tr.loss(outs, downsample_targets(target, outs))
     loss.backward()
     heads = len(outs)
-    assert calls == {"fwd": heads, "bwd": heads}, calls
-    g_own = [p.grad.clone() for p in tr.network.decoder.seg_layers.parameters()]
+    # the lowest-resolution head has weight 0 in the deep-supervision loss: autograd never reaches its backward
+    assert calls == {"fwd": heads, "bwd": heads - 1}, calls
+    g_own = [None if p.grad is None else p.grad.clone() for p in tr.network.decoder.seg_layers.parameters()]
     # A/B against the library convolution on the same weights and running statistics
     monkeypatch.setenv("NEXTOU_HEAD_ROWS", "0")
     tr.network.load_state_dict(state)
     tr.network.zero_grad(set_to_none=True)
     outs_lib = tr.network(data)
     tr.loss(outs_lib, downsample_targets(target, outs_lib)).backward()
-    assert calls == {"fwd": heads, "bwd": heads}
+    assert calls == {"fwd": heads, "bwd": heads - 1}          # unchanged: the second pass ran on the library convolution
     for a, b in zip(outs, outs_lib):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
     for a, p in zip(g_own, tr.network.decoder.seg_layers.parameters()):
-        assert float((a - p.grad).abs().max()) <= 1e-4 * (float(p.grad.abs().max()) + 1e-12)
+        assert (a is None) == (p.grad is None)
+        if a is not None:
+            assert float((a - p.grad).abs().max()) <= 1e-4 * (float(p.grad.abs().max()) + 1e-12)
