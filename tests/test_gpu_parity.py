@@ -330,7 +330,7 @@ def test_gather_backward(ops, ora):
 
 
 @pytest.mark.parametrize("B,C,N,M,K", [(64, 132, 168, None, 7), (2, 48, 10752, 1344, 28), (3, 10, 200, 64, 8), (2, 7, 50, None, 5),
-                                       (2, 6, 8000, None, 9), (1, 5, 3000, 9700, 6)])       # M > 4096: > 32 KB of accumulators per row
+                                       (2, 6, 8000, None, 9), (2, 5, 3000, 9700, 6)])       # M > 4096: > 32 KB of accumulators per row
 def test_mr_backward_is_bit_reproducible_and_tighter_than_fp32(ops, B, C, N, M, K):
     """The default backward (mr_bwd_fix_kernel: 64-bit fixed-point LDS accumulators) gives the SAME bits run after run — the float-atomic
     scatter it replaces did not (VERDICT r3 weak #1-iii) — and is closer to the float64 scatter than fp32 summation order allows it to be
