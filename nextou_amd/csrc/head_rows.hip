@@ -21,6 +21,7 @@
 //             of a workgroup are summed through LDS in wave order, workgroups through `workspace` by a fixed-order reduce
 //             kernel: bit-reproducible.
 #include "common.h"
+#include <cstdlib>
 
 namespace nextou {
 namespace {
@@ -246,13 +247,190 @@ __global__ __launch_bounds__(kHeadThreads) void head_wgrad_kernel(const float* _
     }
 }
 
-// gw[l, c] = sum_blocks part[b][l][c] (c < C), gb[l] = sum_blocks part[b][l][C]; blocks in ascending order per slice, slices
-// (mod 4) combined as (s0 + s1) + (s2 + s3): the order pw_wgrad_reduce_kernel uses
+// ---------------------------------------------------------------------------------------------
+// LDS-staged variants for dense rows (ldx == C, ldy == L, C % 4 == 0, L <= 16, C + 1 <= 160): the direct kernels above touch every
+// 128-byte line of x / gx in 64-byte pieces from different instructions (forward 0.65, data gradient 0.41 of 8 TB/s at cfg 2's
+// full-resolution head, profiles/r05_head_bench_v1.txt).  Here a wave copies a tile of 32 WHOLE rows — one contiguous range of
+// global memory — into its private LDS region with 16-byte accesses, the MFMA operands come from LDS in whatever order they need,
+// and results leave the same way.  Wave-private regions: LDS instructions of one wave execute in order, so no barrier is needed
+// inside the tile loop, and a result tile may overwrite the operand tile it was computed from.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHeadTileRows = 32;      // rows per wave and iteration (two MFMA point tiles)
+constexpr int kHeadMaxCT = 10;         // channel tiles incl. the bias column: C + 1 <= 160
+
+// copy `n_floats` (a multiple of 4 except possibly at the very end of the tensor) from global to LDS; 16-byte pieces, scalar tail
+__device__ __forceinline__ void tile_in(float* dst, const float* __restrict__ src, int n_floats, int lane) {
+    const int n4 = n_floats >> 2;
+    for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    const int rest = n_floats & 3;
+    if (lane < rest) dst[4 * n4 + lane] = src[4 * n4 + lane];
+}
+__device__ __forceinline__ void tile_out(float* __restrict__ dst, const float* src, int n_floats, int lane) {
+    const int n4 = n_floats >> 2;
+    for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    const int rest = n_floats & 3;
+    if (lane < rest) dst[4 * n4 + lane] = src[4 * n4 + lane];
+}
+
+__global__ __launch_bounds__(kHeadThreads) void head_fwd_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, float* __restrict__ y, long P, int L,
+                                                                    int C, int KT, long tiles) {
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    const int ldw = KT * 16 + 4;
+    float* wl = hsm;                                                    // [16][ldw]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* xt = hsm + 16 * ldw + (size_t)wave * kHeadTileRows * (C > 16 ? C : 16);      // [32][C], later [32][L]
+    for (int e = threadIdx.x; e < 16 * ldw; e += kHeadThreads) {
+        const int l = e / ldw, c = e % ldw;
+        wl[e] = (l < L && c < C) ? w[(long)l * C + c] : 0.f;
+    }
+    __syncthreads();
+    const int q = lane & 15, g = lane >> 4;
+    f32x4 binit;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) binit[r] = (bias != nullptr && 4 * g + r < L) ? bias[4 * g + r] : 0.f;
+    const long n_waves = (long)gridDim.x * kHeadWaves;
+    for (long t = (long)blockIdx.x * kHeadWaves + wave; t < tiles; t += n_waves) {
+        const long p0 = t * kHeadTileRows;
+        const int rows = (int)((P - p0) < kHeadTileRows ? (P - p0) : kHeadTileRows);
+        tile_in(xt, x + p0 * C, rows * C, lane);
+        __builtin_amdgcn_wave_barrier();                    // (compiler only: the LDS itself runs a wave's instructions in order)
+        f32x4 acc[2] = {binit, binit};
+        for (int j = 0; j < KT; ++j) {
+            const int c = 16 * j + 4 * g;
+            const float4 wv = *reinterpret_cast<const float4*>(&wl[q * ldw + c]);
+            float4 xv[2];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                xv[pt] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < C && pt * 16 + q < rows) xv[pt] = *reinterpret_cast<const float4*>(&xt[(pt * 16 + q) * C + c]);
+            }
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                acc[pt] = mfma4(wv.x, xv[pt].x, acc[pt]);
+                acc[pt] = mfma4(wv.y, xv[pt].y, acc[pt]);
+                acc[pt] = mfma4(wv.z, xv[pt].z, acc[pt]);
+                acc[pt] = mfma4(wv.w, xv[pt].w, acc[pt]);
+            }
+        }
+        // the logits of the tile over the (dead) operand tile, rows of L floats, then out in one contiguous piece
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * g + r < L) xt[(pt * 16 + q) * L + 4 * g + r] = acc[pt][r];
+        __builtin_amdgcn_wave_barrier();
+        tile_out(y + p0 * L, xt, rows * L, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// gx = gy W (rows), part[block] = [gy^T x | gy^T 1] of this workgroup's rows: the data gradient and the weight + bias gradient
+// from ONE read of gy and x
+__global__ __launch_bounds__(kHeadThreads) void head_bwd_lds_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                    const float* __restrict__ w, float* __restrict__ gx,
+                                                                    float* __restrict__ part, long P, int L, int C, int CT, int CTtot,
+                                                                    long tiles) {
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    const int ldw = CT * 16 + 4;
+    float* wl = hsm;                                                    // [16][ldw]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* gt = hsm + 16 * ldw + (size_t)wave * kHeadTileRows * (C + 16);   // [32][L] (<= 32 x 16)
+    float* xt = gt + kHeadTileRows * 16;                                    // [32][C]: x, then gx
+    for (int e = threadIdx.x; e < 16 * ldw; e += kHeadThreads) {
+        const int l = e / ldw, c = e % ldw;
+        wl[e] = (l < L && c < C) ? w[(long)l * C + c] : 0.f;
+    }
+    __syncthreads();
+    const int q = lane & 15, g = lane >> 4;
+    f32x4 wacc[kHeadMaxCT];
+#pragma unroll
+    for (int j = 0; j < kHeadMaxCT; ++j) wacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long n_waves = (long)gridDim.x * kHeadWaves;
+    for (long t = (long)blockIdx.x * kHeadWaves + wave; t < tiles; t += n_waves) {
+        const long p0 = t * kHeadTileRows;
+        const int rows = (int)((P - p0) < kHeadTileRows ? (P - p0) : kHeadTileRows);
+        tile_in(gt, gy + p0 * L, rows * L, lane);
+        tile_in(xt, x + p0 * C, rows * C, lane);
+        __builtin_amdgcn_wave_barrier();
+        // weight + bias gradient: A[i = class q][k = point], B[k = point][j = channel q]; MFMA r of a point tile sums the points {4g + r}
+        float a[2][4];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = pt * 16 + 4 * g + r;
+                a[pt][r] = (row < rows && q < L) ? gt[row * L + q] : 0.f;
+            }
+#pragma unroll
+        for (int j = 0; j < kHeadMaxCT; ++j) {
+            if (j < CTtot) {
+                const int c = j * 16 + q;
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = pt * 16 + 4 * g + r;
+                        const float b = row < rows ? (c < C ? xt[row * C + c] : (c == C ? 1.f : 0.f)) : 0.f;
+                        wacc[j] = mfma4(a[pt][r], b, wacc[j]);
+                    }
+            }
+        }
+        // data gradient: A[i = channel q][k = class 4g + r] = W[4g + r][ct * 16 + q], B[k][j = point q] = gy[q][4g + r]
+        float gv[2][4];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gv[pt][r] = (pt * 16 + q < rows && 4 * g + r < L) ? gt[(pt * 16 + q) * L + 4 * g + r] : 0.f;
+        __builtin_amdgcn_wave_barrier();
+        for (int ct = 0; ct < CT; ++ct) {
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float wv = wl[(4 * g + r) * ldw + ct * 16 + q];
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) acc[pt] = mfma4(wv, gv[pt][r], acc[pt]);
+            }
+            const int c0 = ct * 16 + 4 * g;
+            if (c0 < C) {
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)          // over the x tile: every read of it by this wave has been issued (in-order LDS)
+                    *reinterpret_cast<float4*>(&xt[(pt * 16 + q) * C + c0]) = make_float4(acc[pt][0], acc[pt][1], acc[pt][2], acc[pt][3]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        tile_out(gx + p0 * C, xt, rows * C, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // waves in wave order, then one partial per workgroup (the layout head_wgrad_reduce_kernel sums)
+    __syncthreads();
+    float* red = hsm;                                                   // [waves][CTtot][4][64] over everything (all tiles are dead)
+#pragma unroll
+    for (int j = 0; j < kHeadMaxCT; ++j)
+        if (j < CTtot) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((wave * CTtot + j) * 4 + r) * 64 + lane] = wacc[j][r];
+        }
+    __syncthreads();
+    const int CW = CTtot * 16;
+    for (int e = threadIdx.x; e < CTtot * 4 * 64; e += kHeadThreads) {
+        const int ln = e & 63, r = (e >> 6) & 3, j = e >> 8;
+        float s = red[((0 * CTtot + j) * 4 + r) * 64 + ln];
+#pragma unroll
+        for (int wv = 1; wv < kHeadWaves; ++wv) s += red[((wv * CTtot + j) * 4 + r) * 64 + ln];
+        const int row = 4 * (ln >> 4) + r, col = j * 16 + (ln & 15);
+        part[((long)blockIdx.x * 16 + row) * CW + col] = s;
+    }
+}
+
+// gw[l, c] = sum_blocks part[b][l][c] (c < C), gb[l] = sum_blocks part[b][l][C]: 16 slices of blocks (mod 16), each in ascending
+// order with four loads in flight, combined by a fixed tree — bit-reproducible
 __global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gb,
                                                                 int blocks, int L, int C, int LT, int CW) {
-    __shared__ float partial[4][64];
-    const int slice = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long e = (long)blockIdx.x * 64 + lane;            // over L x (C + 1)
+    __shared__ float partial[16][16];
+    const int slice = threadIdx.x >> 4, ln = threadIdx.x & 15;
+    const long e = (long)blockIdx.x * 16 + ln;              // over L x (C + 1)
     const long elems = (long)L * (C + 1);
     float s = 0.f;
     int l = 0, c = 0;
@@ -261,16 +439,28 @@ __global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(const float* __r
         c = (int)(e % (C + 1));
         const long stride = (long)LT * 16 * CW;
         const float* src = part + (long)l * CW + c;
-        for (int i = slice; i < blocks; i += 4) s += src[(long)i * stride];
+        int i = slice;
+        for (; i + 48 < blocks; i += 64) {
+            const float v0 = src[(long)i * stride], v1 = src[(long)(i + 16) * stride], v2 = src[(long)(i + 32) * stride],
+                        v3 = src[(long)(i + 48) * stride];
+            s = (((s + v0) + v1) + v2) + v3;
+        }
+        for (; i < blocks; i += 16) s += src[(long)i * stride];
     }
-    partial[slice][lane] = s;
+    partial[slice][ln] = s;
     __syncthreads();
     if (slice == 0 && e < elems) {
-        const float t = (partial[0][lane] + partial[1][lane]) + (partial[2][lane] + partial[3][lane]);
+        float t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = partial[k][ln];
+#pragma unroll
+        for (int h = 8; h >= 1; h >>= 1)
+#pragma unroll
+            for (int k = 0; k < h; ++k) t[k] = t[k] + t[k + h];
         if (c < C) {
-            if (gw != nullptr) gw[(long)l * C + c] = t;
+            if (gw != nullptr) gw[(long)l * C + c] = t[0];
         } else if (gb != nullptr) {
-            gb[l] = t;
+            gb[l] = t[0];
         }
     }
 }
@@ -302,6 +492,37 @@ int wgrad_blocks(int64_t tiles) {
     return (int)(want < 1 ? 1 : (want > cap ? cap : want));
 }
 
+// LDS-staged kernels: bytes of dynamic LDS (0 = shape not eligible) and the grid
+struct LdsPlan { size_t lds; int blocks; };
+LdsPlan plan_fwd_lds(int64_t P, int L, int C) {
+    if (C % 4 != 0 || L > 16) return {0, 0};
+    const size_t lds = ((size_t)16 * (cdiv(C, 16) * 16 + 4) + (size_t)kHeadWaves * kHeadTileRows * (C > 16 ? C : 16)) * sizeof(float);
+    if (lds > 64 * 1024) return {0, 0};
+    const int64_t tiles = cdiv64(P, kHeadTileRows);
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 6) per_cu = 6;
+    const int64_t want = cdiv64(tiles, kHeadWaves), cap = (int64_t)per_cu * head_cus();
+    return {lds, (int)(want > cap ? cap : want)};
+}
+LdsPlan plan_bwd_lds(int64_t P, int L, int C) {
+    const int CTtot = cdiv(C + 1, 16);
+    if (C % 4 != 0 || L > 16 || CTtot > kHeadMaxCT) return {0, 0};
+    size_t lds = ((size_t)16 * (cdiv(C, 16) * 16 + 4) + (size_t)kHeadWaves * kHeadTileRows * (C + 16)) * sizeof(float);
+    const size_t red = (size_t)kHeadWaves * CTtot * 4 * 64 * sizeof(float);
+    if (red > lds) lds = red;
+    if (lds > 64 * 1024) return {0, 0};
+    const int64_t tiles = cdiv64(P, kHeadTileRows);
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 4) per_cu = 4;
+    // every wave should see >= 4 tiles of 32 rows (the partials cost a reduce pass)
+    const int64_t want = cdiv64(tiles, 4 * kHeadWaves), cap = (int64_t)per_cu * head_cus();
+    return {lds, (int)(want < 1 ? 1 : (want > cap ? cap : want))};
+}
+bool lds_path_off() {
+    static const bool off = [] { const char* e = getenv("NEXTOU_HEAD_LDS"); return e != nullptr && e[0] == '0'; }();
+    return off;
+}
+
 }  // namespace
 }  // namespace nextou
 
@@ -320,6 +541,13 @@ extern "C" int nextou_head_rows_fwd(const float* x, const float* w, const float*
     const dim3 grid((unsigned)(want > cap ? cap : want), (unsigned)LT);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = C % 4 == 0 && ldx % 4 == 0 && aligned16(x);
+    const LdsPlan lp = plan_fwd_lds(P, L, C);
+    if (lp.lds != 0 && !lds_path_off() && ldx == C && ldy == L && aligned16(x) && aligned16(y)) {
+        ProfScope prof(s, kBoundHbm, 4.0 * (double)P * (C + L), "head_fwd_lds_kernel[P%lld C%d L%d]", (long long)P, C, L);
+        hipLaunchKernelGGL(head_fwd_lds_kernel, dim3((unsigned)lp.blocks), dim3(kHeadThreads), lp.lds, s, x, w, bias, y, (long)P, L, C, KT,
+                           (long)cdiv64(P, kHeadTileRows));
+        return check_launch("head_rows_fwd");
+    }
     ProfScope prof(s, kBoundHbm, 4.0 * (double)P * (C + L), "head_fwd_kernel[P%lld C%d L%d]", (long long)P, C, L);
     if (vec)
         hipLaunchKernelGGL(head_fwd_kernel<true>, grid, dim3(kHeadThreads), lds, s, x, w, bias, y, (long)P, L, C, (long)ldx, (long)ldy, KT,
@@ -334,7 +562,10 @@ extern "C" int nextou_head_rows_bwd_workspace(int64_t P, int L, int C, size_t* b
     NEXTOU_REQUIRE(bytes != nullptr, "head_rows_bwd_workspace: null pointer");
     if (int e = check_head("head_rows_bwd_workspace", P, L, C, L, C)) return e;
     const int CTtot = cdiv(C + 1, 16), LT = cdiv(L, 16);
-    *bytes = (size_t)wgrad_blocks(cdiv64(P, 16)) * LT * 16 * CTtot * 16 * sizeof(float);
+    int blocks = wgrad_blocks(cdiv64(P, 16));
+    const LdsPlan lp = plan_bwd_lds(P, L, C);                // the caller's strides / alignment decide later: room for either plan
+    if (lp.lds != 0 && lp.blocks > blocks) blocks = lp.blocks;
+    *bytes = (size_t)blocks * LT * 16 * CTtot * 16 * sizeof(float);
     return 0;
 }
 
@@ -345,6 +576,25 @@ extern "C" int nextou_head_rows_bwd(const float* gy, const float* x, const float
     hipStream_t s = (hipStream_t)stream;
     const int64_t tiles = cdiv64(P, 16);
     const int LT = cdiv(L, 16);
+    const LdsPlan lp = plan_bwd_lds(P, L, C);
+    if (gx != nullptr && (gw != nullptr || gb != nullptr) && lp.lds != 0 && !lds_path_off() && ldg == L && ldx == C && x != nullptr &&
+        w != nullptr && workspace != nullptr && aligned16(gy) && aligned16(x) && aligned16(gx)) {
+        // both gradients from one read of gy and x
+        const int CT = cdiv(C, 16), CTtot = cdiv(C + 1, 16);
+        const size_t need = (size_t)lp.blocks * 16 * CTtot * 16 * sizeof(float);
+        if (workspace_bytes < need) return fail(NEXTOU_ENOSPACE, "head_rows_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+        {
+            ProfScope prof(s, kBoundHbm, 4.0 * (double)P * (2 * C + L), "head_bwd_lds_kernel[P%lld C%d L%d]", (long long)P, C, L);
+            hipLaunchKernelGGL(head_bwd_lds_kernel, dim3((unsigned)lp.blocks), dim3(kHeadThreads), lp.lds, s, gy, x, w, gx, workspace, (long)P, L, C,
+                               CT, CTtot, (long)cdiv64(P, kHeadTileRows));
+            if (int e = check_launch("head_rows_bwd (fused)")) return e;
+        }
+        const long elems = (long)L * (C + 1);
+        ProfScope prof(s, kBoundHbm, (double)need, "head_wgrad_reduce_kernel[L%d C%d x%d]", L, C, lp.blocks);
+        hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((unsigned)cdiv64(elems, 16)), dim3(256), 0, s, workspace, gw, gb, lp.blocks, L, C, 1,
+                           CTtot * 16);
+        return check_launch("head_rows_bwd (reduce)");
+    }
     if (gx != nullptr) {
         NEXTOU_REQUIRE(w != nullptr, "head_rows_bwd: the data gradient needs the weights");
         const int CT = cdiv(C, 16);
@@ -378,7 +628,7 @@ extern "C" int nextou_head_rows_bwd(const float* gy, const float* x, const float
         }
         const long elems = (long)L * (C + 1);
         ProfScope prof(s, kBoundHbm, (double)need, "head_wgrad_reduce_kernel[L%d C%d x%d]", L, C, blocks);
-        hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((unsigned)cdiv64(elems, 64)), dim3(256), 0, s, workspace, gw, gb, blocks, L, C, LT,
+        hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((unsigned)cdiv64(elems, 16)), dim3(256), 0, s, workspace, gw, gb, blocks, L, C, LT,
                            CTtot * 16);
         if (int e = check_launch("head_rows_bwd (reduce)")) return e;
     }

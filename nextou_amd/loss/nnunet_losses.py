@@ -142,7 +142,11 @@ class _FusedDiceMixin:
 
     def forward(self, x, y, loss_mask=None):
         from .. import graph_ops
-        if self.apply_nonlin is softmax_helper_dim1 and graph_ops.dice_stats_eligible(x, y):
+        # the kernel uses the mask as a 0 / 1 flag and knows nothing of nnunetv2's `clip_tp`: a fractional (float) mask or a clip
+        # takes the base class, whose arithmetic it is
+        mask_ok = loss_mask is None or loss_mask.dtype in (torch.bool, torch.uint8)
+        if self.apply_nonlin is softmax_helper_dim1 and getattr(self, "clip_tp", None) is None and mask_ok and \
+                graph_ops.dice_stats_eligible(x, y):
             intersect, sum_pred, sum_gt = graph_ops.dice_stats(x, y, loss_mask)
             if not self.do_bg:
                 intersect, sum_pred, sum_gt = intersect[:, 1:], sum_pred[:, 1:], sum_gt[:, 1:]

@@ -67,7 +67,10 @@ class NexToU(nn.Module):
             self.padded_modules = pad_plain_stage_channels(self, pad_multiple())
             # reduced-precision autocast keeps NDHWC only when the plain stages really run multiple-of-8 channel counts
             plain = list(self.encoder.output_channels)[:self.encoder.n_conv_stages]
-            self.encoder.reduced_precision_layout_ok = bool(self.padded_modules) or all(f % max(pad_multiple(), 1) == 0 for f in plain)
+            # (the hardware requirement is fixed — 16-byte bf16 / fp16 rows = multiples of 8 channels — whatever NEXTOU_PAD_CHANNELS says:
+            # with padding switched off, or to a multiple of 4, the 33 / 66-channel stages must NOT claim it)
+            runs_padded_to_8 = bool(self.padded_modules) and pad_multiple() % 8 == 0
+            self.encoder.reduced_precision_layout_ok = runs_padded_to_8 or all(f % 8 == 0 for f in plain)
 
     def forward(self, x):
         return self.decoder(self.encoder(x))

@@ -113,14 +113,19 @@ def test_head_rows_never_touch_memory_outside_their_operands(ops, B, C, sp, L):
     gy0 = gy0.contiguous(memory_format=_mf(gy0))
     want_y = ops._HIP.head_rows_fwd(x0, w0, b0)
     want = ops._HIP.head_rows_bwd(gy0, x0, w0, True, True)
-    for flush in ("end", "start"):
-        x, w, b, gy = (guarded_like(t, flush=flush, align=16 if t is x0 else 4) for t in (x0, w0, b0, gy0))
+    for flush, align in (("end", 16), ("start", 16), ("end", 4)):
+        # align 16: the kernels the plain tensors took (LDS-staged where the shape allows) -> the same bits; align 4: operands that may start
+        # off a 16-byte boundary take the direct kernels (another, equally fixed, summation order for the weight gradient)
+        x, w, b, gy = (guarded_like(t, flush=flush, align=16 if t is x0 else align) for t in (x0, w0, b0, gy0))
         y = ops._HIP.head_rows_fwd(x, w, b)
         got = ops._HIP.head_rows_bwd(gy, x, w, True, True)
         torch.cuda.synchronize()
         assert torch.equal(y, want_y)
         for a, e in zip(got, want):
-            assert torch.equal(a, e)
+            if align == 16:
+                assert torch.equal(a, e)
+            else:
+                assert float((a - e).abs().max()) <= 1e-5 * (float(e.abs().max()) + 1e-20)
 
 
 def test_model_heads_run_on_k8(ops, monkeypatch):

@@ -389,3 +389,16 @@ def test_fused_norms_keep_torchs_size_guards(cpu_checker):
             m.train()(x)
         assert str(got.value) == ref
     blk.eval()(x)                                   # running statistics: no guard
+
+
+def test_reduced_precision_layout_flag_follows_the_hardware_rule(monkeypatch):
+    """encoder.reduced_precision_layout_ok (bf16 / fp16 autocast keeps NDHWC only then): true iff the plain stages really run
+    multiple-of-8 channel counts — with the padding switched off or set to 4 the 33 / 66-channel stages must not claim it."""
+    import model_cases as mc
+    from torch import nn
+    cfg = dict(mc.TINY_3D, features=[33, 66, 24, 48, 48, 48])
+    for spec, want in (("auto", True), ("8", True), ("16", True), ("0", False), ("4", False)):
+        monkeypatch.setenv("NEXTOU_PAD_CHANNELS", spec)
+        assert mc.build_model(cfg).encoder.reduced_precision_layout_ok is want, spec
+    monkeypatch.setenv("NEXTOU_PAD_CHANNELS", "0")
+    assert mc.build_model(dict(mc.TINY_3D, features=[32, 64, 24, 48, 48, 48])).encoder.reduced_precision_layout_ok is True
