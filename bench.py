@@ -156,8 +156,9 @@ def roofline_graph_from(report):
             "K7_pointwise_rows": pick(("pw_rows_kernel", "pw_rows_sw_kernel")),
             "K7_pointwise_wgrad": pick(("pw_wgrad_kernel", "pw_wgrad_so_kernel")),
             "K7_pointwise_rows_worst_shape": worst(("pw_rows_kernel", "pw_rows_sw_kernel")),
-            "K8_head_forward": pick(("head_fwd_kernel",)), "K8_head_dgrad": pick(("head_dgrad_kernel",)),
-            "K8_head_wgrad": pick(("head_wgrad_kernel",)),
+            "K8_head_forward": pick(("head_fwd_kernel", "head_fwd_lds_kernel")),
+            "K8_head_backward": pick(("head_bwd_lds_kernel", "head_dgrad_kernel", "head_wgrad_kernel")),
+            "K2K7_pool_grouped_forward": pick(("mr_grp_cm_kernel",)),
             "graph_kernels_ms_per_step": None}
 
 

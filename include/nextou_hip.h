@@ -454,6 +454,30 @@ int nextou_head_rows_bwd_workspace(int64_t P, int L, int C, size_t* bytes);
 int nextou_head_rows_bwd(const float* gy, const float* x, const float* w, float* gx, float* gw, float* gb, float* workspace,
                          size_t workspace_bytes, int64_t P, int L, int C, int64_t ldg, int64_t ldx, nextou_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K2 + K7 for the pooled graphs (ABI v11): MRConv of a Pool-GNN block in one launch — max-relative aggregation
+ * of a pooled (y != NULL, M candidates) or self (y == NULL, M == N) graph -> grouped 1x1 convolution -> InstanceNorm statistics
+ * (reference NexToU_Encoder_Decoder.py:401-418 inside PoolDyGraphConv :516-551; torch_nn.py:66-92).  Channel-major tensors:
+ * x (B, C, N), y (B, C, M), nn_idx (B, N, >= K) int32 with the row stride / element step of nextou_mr_aggregate_fwd, weight
+ * (groups * Ng, 2C / groups) dense, h (B, groups * Ng, N) = the convolution of the interleaved aggregate [x_c, max_j(y_j - x)_c].
+ * a_out (B, 2C, N): the aggregate itself (the weight gradient's operand), arg_out (B, C, N) uint16: the arg-max tape of
+ * nextou_mr_aggregate_bwd_arg — both optional, both bit-identical to nextou_mr_aggregate_fwd's.  stats_partial: per (sample,
+ * output channel) and 128-query tile one (sum, sum of squares) in float64, laid out [(b * groups * Ng + channel)][tile] — what
+ * nextou_norm_act_fwd_partials consumes with B = 1, C = B * groups * Ng, param_period = groups * Ng (instance statistics);
+ * stats_tiles must equal nextou_mr_grouped_cm_tiles(...), which returns 0 for a shape the kernel does not take (K > 32,
+ * 2C / groups > 108, Ng > 112, a source too long for LDS; NEXTOU_MR_GROUPED_CM=0 switches it off).
+ *
+ * nextou_norm_act_fwd_partials   K6's forward (normalise + LeakyReLU, fp32, channel-major (B, C, S)) from ready-made statistics
+ *     partials: n_partial per channel at partial[c * n_partial + t].  param_period as in nextou_norm_act_fwd.
+ * ---------------------------------------------------------------------------------------- */
+int nextou_mr_grouped_cm_tiles(int B, int C, int groups, int Ng, int N, int M, int K);
+int nextou_mr_grouped_cm(const float* x, const float* y, const int32_t* nn_idx, int idx_stride, int idx_step, int K,
+                         const float* weight, float* a_out, uint16_t* arg_out, float* h, double* stats_partial, int stats_tiles,
+                         int B, int C, int N, int M, int groups, int Ng, nextou_stream_t stream);
+int nextou_norm_act_fwd_partials(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
+                                 float* y, float* save_mean, float* save_invstd, const double* partial, int n_partial, int B, int C,
+                                 int64_t S, int param_period, float momentum, float eps, float slope, nextou_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

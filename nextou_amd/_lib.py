@@ -105,6 +105,11 @@ _SIGNATURES = {
     "nextou_norm_bwd_finalize": (c_int, [c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "nextou_norm_bwd_apply_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                            c_int, c_float, c_void_p]),
+    "nextou_mr_grouped_cm_tiles": (c_int, [c_int] * 7),
+    "nextou_mr_grouped_cm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "nextou_norm_act_fwd_partials": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_int, c_int, c_int, c_int64, c_int, c_float, c_float, c_float, c_void_p]),
     "nextou_head_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_void_p]),
     "nextou_head_rows_bwd_workspace": (c_int, [c_int64, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "nextou_head_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int,

@@ -256,14 +256,37 @@ __global__ __launch_bounds__(kHeadThreads) void head_wgrad_kernel(const float* _
 // inside the tile loop, and a result tile may overwrite the operand tile it was computed from.
 // ---------------------------------------------------------------------------------------------
 constexpr int kHeadTileRows = 32;      // rows per wave and iteration (two MFMA point tiles)
-constexpr int kHeadMaxCT = 10;         // channel tiles incl. the bias column: C + 1 <= 160
+constexpr int kHeadMaxCT = 7;          // channel tiles incl. the bias column: C + 1 <= 112
 
-// copy `n_floats` (a multiple of 4 except possibly at the very end of the tensor) from global to LDS; 16-byte pieces, scalar tail
-__device__ __forceinline__ void tile_in(float* dst, const float* __restrict__ src, int n_floats, int lane) {
+// A wave's view of one tile of whole rows: NV 16-byte pieces per lane, fetched into REGISTERS one iteration ahead (the loads of
+// tile t + 1 are in flight while tile t multiplies — written as "load the tile, then use it" every tile cost the wave one exposed HBM
+// round trip per piece: 662 us for the first head_bwd_lds_kernel where the two direct kernels it replaces took 637) and committed to
+// the wave's private LDS region at the top of the next iteration.  `base`: start of the tensor (a valid 16-byte read for lanes that
+// have no piece), n_floats: floats of this tile (a multiple of 4 except possibly in the tensor's last tile: scalar tail).
+__device__ __forceinline__ int head_rows_of(long P, long tt) {
+    const long left = P - tt * kHeadTileRows;
+    return (int)(left < kHeadTileRows ? left : kHeadTileRows);
+}
+template <int NV>
+__device__ __forceinline__ void tile_fetch(f32x4 (&v)[NV], const float* __restrict__ base, const float* __restrict__ src, int n_floats, int lane) {
     const int n4 = n_floats >> 2;
-    for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int i = u * 64 + lane;
+        const long off = i < n4 ? (src - base) + 4 * (long)i : 0;        // (an offset, not a select of two pointers)
+        v[u] = *reinterpret_cast<const f32x4*>(base + off);
+    }
+}
+template <int NV>
+__device__ __forceinline__ void tile_commit(const f32x4 (&v)[NV], float* dst, const float* __restrict__ src, int n_floats, int lane) {
+    const int n4 = n_floats >> 2;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int i = u * 64 + lane;
+        if (i < n4) reinterpret_cast<f32x4*>(dst)[i] = v[u];
+    }
     const int rest = n_floats & 3;
-    if (lane < rest) dst[4 * n4 + lane] = src[4 * n4 + lane];
+    if (lane < rest) dst[4 * n4 + lane] = src[4 * n4 + lane];       // (the tensor's last, ragged tile only)
 }
 __device__ __forceinline__ void tile_out(float* __restrict__ dst, const float* src, int n_floats, int lane) {
     const int n4 = n_floats >> 2;
@@ -272,6 +295,7 @@ __device__ __forceinline__ void tile_out(float* __restrict__ dst, const float* s
     if (lane < rest) dst[4 * n4 + lane] = src[4 * n4 + lane];
 }
 
+template <int NXV>
 __global__ __launch_bounds__(kHeadThreads) void head_fwd_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                     const float* __restrict__ bias, float* __restrict__ y, long P, int L,
                                                                     int C, int KT, long tiles) {
@@ -290,11 +314,16 @@ __global__ __launch_bounds__(kHeadThreads) void head_fwd_lds_kernel(const float*
 #pragma unroll
     for (int r = 0; r < 4; ++r) binit[r] = (bias != nullptr && 4 * g + r < L) ? bias[4 * g + r] : 0.f;
     const long n_waves = (long)gridDim.x * kHeadWaves;
-    for (long t = (long)blockIdx.x * kHeadWaves + wave; t < tiles; t += n_waves) {
+    long t = (long)blockIdx.x * kHeadWaves + wave;
+    f32x4 xr[NXV];
+    if (t < tiles) tile_fetch(xr, x, x + t * kHeadTileRows * C, head_rows_of(P, t) * C, lane);
+    for (; t < tiles; t += n_waves) {
         const long p0 = t * kHeadTileRows;
-        const int rows = (int)((P - p0) < kHeadTileRows ? (P - p0) : kHeadTileRows);
-        tile_in(xt, x + p0 * C, rows * C, lane);
-        __builtin_amdgcn_wave_barrier();                    // (compiler only: the LDS itself runs a wave's instructions in order)
+        const int rows = head_rows_of(P, t);
+        tile_commit(xr, xt, x + p0 * C, rows * C, lane);
+        const long nx = t + n_waves < tiles ? t + n_waves : t;          // no next tile: a re-read nobody uses
+        tile_fetch(xr, x, x + nx * kHeadTileRows * C, head_rows_of(P, nx) * C, lane);
+        __builtin_amdgcn_wave_barrier();                                // (compiler only: the LDS itself runs a wave's instructions in order)
         f32x4 acc[2] = {binit, binit};
         for (int j = 0; j < KT; ++j) {
             const int c = 16 * j + 4 * g;
@@ -328,6 +357,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_fwd_lds_kernel(const float*
 
 // gx = gy W (rows), part[block] = [gy^T x | gy^T 1] of this workgroup's rows: the data gradient and the weight + bias gradient
 // from ONE read of gy and x
+template <int NXV>
 __global__ __launch_bounds__(kHeadThreads) void head_bwd_lds_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                                     const float* __restrict__ w, float* __restrict__ gx,
                                                                     float* __restrict__ part, long P, int L, int C, int CT, int CTtot,
@@ -348,11 +378,20 @@ __global__ __launch_bounds__(kHeadThreads) void head_bwd_lds_kernel(const float*
 #pragma unroll
     for (int j = 0; j < kHeadMaxCT; ++j) wacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const long n_waves = (long)gridDim.x * kHeadWaves;
-    for (long t = (long)blockIdx.x * kHeadWaves + wave; t < tiles; t += n_waves) {
+    long t = (long)blockIdx.x * kHeadWaves + wave;
+    f32x4 xr[NXV], gr[2];
+    if (t < tiles) {
+        tile_fetch(gr, gy, gy + t * kHeadTileRows * L, head_rows_of(P, t) * L, lane);
+        tile_fetch(xr, x, x + t * kHeadTileRows * C, head_rows_of(P, t) * C, lane);
+    }
+    for (; t < tiles; t += n_waves) {
         const long p0 = t * kHeadTileRows;
-        const int rows = (int)((P - p0) < kHeadTileRows ? (P - p0) : kHeadTileRows);
-        tile_in(gt, gy + p0 * L, rows * L, lane);
-        tile_in(xt, x + p0 * C, rows * C, lane);
+        const int rows = head_rows_of(P, t);
+        tile_commit(gr, gt, gy + p0 * L, rows * L, lane);
+        tile_commit(xr, xt, x + p0 * C, rows * C, lane);
+        const long nx = t + n_waves < tiles ? t + n_waves : t;
+        tile_fetch(gr, gy, gy + nx * kHeadTileRows * L, head_rows_of(P, nx) * L, lane);
+        tile_fetch(xr, x, x + nx * kHeadTileRows * C, head_rows_of(P, nx) * C, lane);
         __builtin_amdgcn_wave_barrier();
         // weight + bias gradient: A[i = class q][k = point], B[k = point][j = channel q]; MFMA r of a point tile sums the points {4g + r}
         float a[2][4];
@@ -495,7 +534,7 @@ int wgrad_blocks(int64_t tiles) {
 // LDS-staged kernels: bytes of dynamic LDS (0 = shape not eligible) and the grid
 struct LdsPlan { size_t lds; int blocks; };
 LdsPlan plan_fwd_lds(int64_t P, int L, int C) {
-    if (C % 4 != 0 || L > 16) return {0, 0};
+    if (C % 4 != 0 || L > 16 || C > 104 || P < 4) return {0, 0};
     const size_t lds = ((size_t)16 * (cdiv(C, 16) * 16 + 4) + (size_t)kHeadWaves * kHeadTileRows * (C > 16 ? C : 16)) * sizeof(float);
     if (lds > 64 * 1024) return {0, 0};
     const int64_t tiles = cdiv64(P, kHeadTileRows);
@@ -506,7 +545,7 @@ LdsPlan plan_fwd_lds(int64_t P, int L, int C) {
 }
 LdsPlan plan_bwd_lds(int64_t P, int L, int C) {
     const int CTtot = cdiv(C + 1, 16);
-    if (C % 4 != 0 || L > 16 || CTtot > kHeadMaxCT) return {0, 0};
+    if (C % 4 != 0 || L > 16 || C > 104 || CTtot > kHeadMaxCT || P < 4) return {0, 0};
     size_t lds = ((size_t)16 * (cdiv(C, 16) * 16 + 4) + (size_t)kHeadWaves * kHeadTileRows * (C + 16)) * sizeof(float);
     const size_t red = (size_t)kHeadWaves * CTtot * 4 * 64 * sizeof(float);
     if (red > lds) lds = red;
@@ -544,8 +583,12 @@ extern "C" int nextou_head_rows_fwd(const float* x, const float* w, const float*
     const LdsPlan lp = plan_fwd_lds(P, L, C);
     if (lp.lds != 0 && !lds_path_off() && ldx == C && ldy == L && aligned16(x) && aligned16(y)) {
         ProfScope prof(s, kBoundHbm, 4.0 * (double)P * (C + L), "head_fwd_lds_kernel[P%lld C%d L%d]", (long long)P, C, L);
-        hipLaunchKernelGGL(head_fwd_lds_kernel, dim3((unsigned)lp.blocks), dim3(kHeadThreads), lp.lds, s, x, w, bias, y, (long)P, L, C, KT,
-                           (long)cdiv64(P, kHeadTileRows));
+        const long t32 = (long)cdiv64(P, kHeadTileRows);
+        const dim3 grid((unsigned)lp.blocks), block(kHeadThreads);
+        if (C <= 16) hipLaunchKernelGGL(head_fwd_lds_kernel<2>, grid, block, lp.lds, s, x, w, bias, y, (long)P, L, C, KT, t32);
+        else if (C <= 40) hipLaunchKernelGGL(head_fwd_lds_kernel<5>, grid, block, lp.lds, s, x, w, bias, y, (long)P, L, C, KT, t32);
+        else if (C <= 72) hipLaunchKernelGGL(head_fwd_lds_kernel<9>, grid, block, lp.lds, s, x, w, bias, y, (long)P, L, C, KT, t32);
+        else hipLaunchKernelGGL(head_fwd_lds_kernel<13>, grid, block, lp.lds, s, x, w, bias, y, (long)P, L, C, KT, t32);
         return check_launch("head_rows_fwd");
     }
     ProfScope prof(s, kBoundHbm, 4.0 * (double)P * (C + L), "head_fwd_kernel[P%lld C%d L%d]", (long long)P, C, L);
@@ -585,8 +628,12 @@ extern "C" int nextou_head_rows_bwd(const float* gy, const float* x, const float
         if (workspace_bytes < need) return fail(NEXTOU_ENOSPACE, "head_rows_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
         {
             ProfScope prof(s, kBoundHbm, 4.0 * (double)P * (2 * C + L), "head_bwd_lds_kernel[P%lld C%d L%d]", (long long)P, C, L);
-            hipLaunchKernelGGL(head_bwd_lds_kernel, dim3((unsigned)lp.blocks), dim3(kHeadThreads), lp.lds, s, gy, x, w, gx, workspace, (long)P, L, C,
-                               CT, CTtot, (long)cdiv64(P, kHeadTileRows));
+            const long t32 = (long)cdiv64(P, kHeadTileRows);
+            const dim3 grid((unsigned)lp.blocks), block(kHeadThreads);
+            if (C <= 16) hipLaunchKernelGGL(head_bwd_lds_kernel<2>, grid, block, lp.lds, s, gy, x, w, gx, workspace, (long)P, L, C, CT, CTtot, t32);
+            else if (C <= 40) hipLaunchKernelGGL(head_bwd_lds_kernel<5>, grid, block, lp.lds, s, gy, x, w, gx, workspace, (long)P, L, C, CT, CTtot, t32);
+            else if (C <= 72) hipLaunchKernelGGL(head_bwd_lds_kernel<9>, grid, block, lp.lds, s, gy, x, w, gx, workspace, (long)P, L, C, CT, CTtot, t32);
+            else hipLaunchKernelGGL(head_bwd_lds_kernel<13>, grid, block, lp.lds, s, gy, x, w, gx, workspace, (long)P, L, C, CT, CTtot, t32);
             if (int e = check_launch("head_rows_bwd (fused)")) return e;
         }
         const long elems = (long)L * (C + 1);

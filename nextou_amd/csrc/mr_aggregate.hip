@@ -1283,6 +1283,244 @@ __global__ __launch_bounds__(NT >= 7 ? 256 : 512) void mr_grp_rows_bwd_kernel(
     }
 }
 
+
+// sum over the 16 lanes of a DPP row (lanes that share lane >> 4), result in every lane; fixed tree
+__device__ __forceinline__ float row16_sum_mr(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 + K7 for the POOLED graphs (round 5, SURVEY.md §8(f)-1, the channel-major half): the max-relative aggregation of a pooled
+// (xy) or self graph feeds MRConv's grouped 1x1 convolution from LDS and the InstanceNorm statistics leave with it (reference
+// NexToU_Encoder_Decoder.py:401-418 MRConv.forward inside PoolDyGraphConv :516-551; torch_nn.py:66-92 BasicConv = grouped conv ->
+// InstanceNorm -> act).  Op by op: mr_fwd_qb_kernel wrote the (B, 2C, N) aggregate, a strided-batched BLAS GEMM read it and wrote
+// h, K6's bn_stats_kernel read h again.  Here one workgroup owns (128-query tile, group, sample):
+//   0. neighbour ids of the tile -> LDS (uint16);
+//   1. per chunk of QC channel quads: the group's source channels of y (all M candidate points) -> LDS as float4 quads; a lane
+//      per (query, quad) gathers its K neighbours — mr_fwd_qb_kernel's subtract / first-max arithmetic: aggregate and arg tape are
+//      bit-identical to it — and writes the interleaved [x_c, mr_c] row of the GEMM's operand into a slab [128][Kg] (the
+//      aggregate itself goes out only when a weight gradient will need it);
+//   2. H_g^T (Ng x 128) = W_g (Ng x Kg) . slab^T on v_mfma_f32_16x16x4_f32 with the group's weights in registers: a lane ends up
+//      with 4 output channels of ONE point, i.e. 64-byte row segments of the channel-major h; per (sample, channel) sum and sum of
+//      squares of the tile in float64 -> partial[(b, channel)][tile] (fixed order: bit-reproducible).
+// HBM: 4 B C (N + M) + 4 B N K (ids) + 8 B C N (h) [+ 8 B C N (a) + 2 B C N (arg) when a gradient is needed].
+// ---------------------------------------------------------------------------------------------
+constexpr int kCmTQ = 128;
+
+template <int KT, int NT, int KSTEPS>
+__global__ __launch_bounds__(256) void mr_grp_cm_kernel(const float* __restrict__ x, const float* __restrict__ src,
+                                                        const int32_t* __restrict__ idx, const float* __restrict__ w,
+                                                        float* __restrict__ a_out, float* __restrict__ h, uint16_t* __restrict__ arg,
+                                                        double2* __restrict__ partial, int C, int Cg, int Ng, int N, int M, int K,
+                                                        int idx_stride, int idx_step, int QC, int ld, int tile_f4, unsigned m_magic) {
+    extern __shared__ __attribute__((aligned(16))) float4 cm_tile4[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qt = blockIdx.x, g = blockIdx.y, b = blockIdx.z, QT = gridDim.x, groups = gridDim.y;
+    const int Kg = 2 * Cg, Q = (Cg + 3) >> 2, n0 = qt * kCmTQ;
+    const int nq = min(kCmTQ, N - n0);                           // queries of this tile
+    float* slab = reinterpret_cast<float*>(cm_tile4 + tile_f4);  // [128][ld]
+    uint16_t* ids = reinterpret_cast<uint16_t*>(slab + (size_t)kCmTQ * ld);
+    const int ln = lane & 15, lk = lane >> 4;
+    // ---- 0: ids (clamped rows for the tail tile: their results are never stored)
+    {
+        const int32_t* ib = idx + ((size_t)b * N + n0) * idx_stride;
+        for (int e = tid; e < kCmTQ * K; e += 256) {
+            const int n = e / K, j = e - n * K;
+            ids[e] = (uint16_t)ib[(size_t)min(n, nq - 1) * idx_stride + (size_t)j * idx_step];
+        }
+    }
+    const float* xg = x + ((size_t)b * C + (size_t)g * Cg) * N + n0;
+    const float* sg = src + ((size_t)b * C + (size_t)g * Cg) * M;
+    // ---- 1: chunks of QC quads
+    for (int q0 = 0; q0 < Q; q0 += QC) {
+        const int qc = min(QC, Q - q0);
+        __syncthreads();                                        // ids visible / the previous chunk's gathers done
+        for (int e = tid; e < qc * M; e += 256) {
+            const int q = (int)__umulhi((unsigned)e, m_magic), m = e - q * M;       // e / M (m_magic = 0 for M = 1 is handled by the host: M >= 2)
+            const int c = 4 * (q0 + q);
+            const float* p = sg + (size_t)c * M + m;
+            float4 t;
+            t.x = p[0];
+            t.y = c + 1 < Cg ? p[(size_t)M] : 0.f;
+            t.z = c + 2 < Cg ? p[(size_t)2 * M] : 0.f;
+            t.w = c + 3 < Cg ? p[(size_t)3 * M] : 0.f;
+            cm_tile4[m * QC + q] = t;
+        }
+        __syncthreads();
+        const f32x4* t4 = reinterpret_cast<const f32x4*>(cm_tile4);
+        for (int e = tid; e < qc * kCmTQ; e += 256) {
+            const int q = e >> 7, n = e & (kCmTQ - 1);          // consecutive lanes = consecutive queries: coalesced x / a / arg
+            const int c = 4 * (q0 + q);
+            const bool live = n < nq;
+            const int nr = live ? n : nq - 1;
+            const bool v1 = c + 1 < Cg, v2 = c + 2 < Cg, v3 = c + 3 < Cg;
+            f32x4 xv;
+            xv.x = xg[(size_t)c * N + nr];
+            xv.y = v1 ? xg[(size_t)(c + 1) * N + nr] : 0.f;
+            xv.z = v2 ? xg[(size_t)(c + 2) * N + nr] : 0.f;
+            xv.w = v3 ? xg[(size_t)(c + 3) * N + nr] : 0.f;
+            unsigned id[KT];
+#pragma unroll
+            for (int j = 0; j < KT; ++j) id[j] = ids[n * K + (j < K ? j : 0)];
+            const f32x2 xlo = xv.lo, xhi = xv.hi;
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+            unsigned a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int j0 = 0; j0 < KT; j0 += 8) {                // eight gathers in flight
+                f32x4 sv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sv[u] = t4[id[j0 + u] * (unsigned)QC + q];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u;
+                    const f32x2 dlo = sv[u].lo - xlo, dhi = sv[u].hi - xhi;
+                    if (j == 0) {                               // the first neighbour initialises the maximum (NaN included)
+                        m0 = dlo.x; m1 = dlo.y; m2 = dhi.x; m3 = dhi.y;
+                        a0 = a1 = a2 = a3 = id[0];
+                    } else if (j < K) {                         // (uniform) strict >: the first maximum of the rounded differences wins
+                        mr_update4<true>(m0, m1, m2, m3, a0, a1, a2, a3, dlo.x, dlo.y, dhi.x, dhi.y, id[j]);
+                    }
+                }
+            }
+            // the GEMM's operand row (zeros for the tail tile's dead rows and for channels past the group's)
+            float* arow = slab + (size_t)n * ld + 8 * (q0 + q);
+            const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(arow) = live ? f32x4{xv.x, m0, v1 ? xv.y : 0.f, v1 ? m1 : 0.f} : z4;
+            if (8 * (q0 + q) + 4 < ld) *reinterpret_cast<f32x4*>(arow + 4) = (live && v2) ? f32x4{xv.z, m2, v3 ? xv.w : 0.f, v3 ? m3 : 0.f} : z4;
+            if (live) {
+                if (a_out != nullptr) {
+                    float* o = a_out + ((size_t)b * 2 * C + (size_t)g * Kg + 2 * c) * N + n0 + n;
+                    o[0] = xv.x; o[(size_t)N] = m0;
+                    if (v1) { o[(size_t)2 * N] = xv.y; o[(size_t)3 * N] = m1; }
+                    if (v2) { o[(size_t)4 * N] = xv.z; o[(size_t)5 * N] = m2; }
+                    if (v3) { o[(size_t)6 * N] = xv.w; o[(size_t)7 * N] = m3; }
+                }
+                if (arg != nullptr) {
+                    uint16_t* ap = arg + ((size_t)b * C + (size_t)g * Cg + c) * N + n0 + n;
+                    ap[0] = (uint16_t)a0;
+                    if (v1) ap[(size_t)N] = (uint16_t)a1;
+                    if (v2) ap[(size_t)2 * N] = (uint16_t)a2;
+                    if (v3) ap[(size_t)3 * N] = (uint16_t)a3;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2: the group's weights -> LDS (over the dead source tile) -> every wave's A operands W[g Ng + nt 16 + ln][4 ks + lk]
+    float* wl = reinterpret_cast<float*>(cm_tile4);
+    const float* wgp = w + (size_t)g * Ng * Kg;
+    for (int e = tid; e < Ng * Kg; e += 256) wl[e] = wgp[e];
+    // columns of the slab between Kg and 4 KSTEPS that no quad wrote (Kg % 8 == 4 leaves none; a quad-padded group does)
+    for (int e = tid; e < kCmTQ * (4 * KSTEPS - 8 * Q > 0 ? 4 * KSTEPS - 8 * Q : 0); e += 256) {
+        const int wcols = 4 * KSTEPS - 8 * Q, n = e / wcols, col = 8 * Q + e - n * wcols;
+        if (col < ld) slab[(size_t)n * ld + col] = 0.f;
+    }
+    __syncthreads();
+    float wreg[NT][KSTEPS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int o = nt * 16 + ln, k = 4 * ks + lk;
+            const float t = wl[min(o, Ng - 1) * Kg + min(k, Kg - 1)];
+            wreg[nt][ks] = (o < Ng && k < Kg) ? t : 0.f;
+        }
+    double s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[nt][r] = s2[nt][r] = 0.0;
+    float* hb = h + ((size_t)b * groups * Ng + (size_t)g * Ng) * N + n0;
+#pragma unroll 1
+    for (int mt = wave; mt < kCmTQ / 16; mt += 4) {
+        if (mt * 16 >= nq) break;                               // (uniform)
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* arow = slab + (size_t)(mt * 16 + ln) * ld + lk;
+        float av[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) av[ks] = (4 * ks + lk < ld) ? arow[4 * ks] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[nt][ks], av[ks], acc[nt], 0, 0, 0);
+        const int n = mt * 16 + ln;
+        const bool live = n < nq;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = nt * 16 + 4 * lk + r;
+                const float v = live ? acc[nt][r] : 0.f;
+                if (live && o < Ng) hb[(size_t)o * N + n] = v;
+                if (partial != nullptr) {
+                    const float u = row16_sum_mr(v), q2 = row16_sum_mr(v * v);
+                    s1[nt][r] += (double)u;
+                    s2[nt][r] += (double)q2;
+                }
+            }
+    }
+    if (partial != nullptr) {
+        __syncthreads();                                        // every wave is done with wl: the reduction buffer goes over it
+        double2* red = reinterpret_cast<double2*>(cm_tile4);    // [4 waves][NT * 16]
+        if (ln == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * NT * 16 + nt * 16 + 4 * lk + r] = make_double2(s1[nt][r], s2[nt][r]);
+        }
+        __syncthreads();
+        for (int o = tid; o < Ng; o += 256) {
+            double u = 0.0, q2 = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) { const double2 t = red[wv * NT * 16 + o]; u += t.x; q2 += t.y; }
+            partial[((size_t)b * groups * Ng + (size_t)g * Ng + o) * QT + qt] = make_double2(u, q2);
+        }
+    }
+}
+
+// plan of mr_grp_cm_kernel: instance (KT neighbour bucket, NT x KSTEPS weight tiles), quads per source chunk, LDS
+struct CmPlan { bool ok; int kt, cfg, nt, ksteps, qc, ld, tile_f4, tiles; size_t lds; };
+static CmPlan plan_mr_grp_cm(int B, int C, int groups, int Ng, int N, int M, int K) {
+    CmPlan q{};
+    const char* env = getenv("NEXTOU_MR_GROUPED_CM");         // read per call (tests / A-B)
+    if ((env && env[0] == '0') || B < 1 || B > 65535 || groups < 1 || groups > 64 || C < 1 || C % groups != 0 || N < 1 || M < 2 ||
+        M > 65535 || K < 1 || K > 32 || Ng < 1)
+        return q;
+    const int Cg = C / groups, Kg = 2 * Cg;
+    static const int cfgs[4][2] = {{1, 4}, {3, 11}, {6, 22}, {7, 27}};     // (NT, KSTEPS): Ng <= 16 NT, Kg <= 4 KSTEPS
+    q.cfg = -1;
+    for (int i = 0; i < 4; ++i)
+        if (Ng <= 16 * cfgs[i][0] && Kg <= 4 * cfgs[i][1]) { q.cfg = i; break; }
+    if (q.cfg < 0) return q;
+    q.nt = cfgs[q.cfg][0];
+    q.ksteps = cfgs[q.cfg][1];
+    q.kt = K <= 8 ? 8 : (K <= 16 ? 16 : 32);
+    const int Q = (Cg + 3) / 4;
+    int ld4 = std::max(q.ksteps, 2 * Q);                      // row stride / 4: odd, so that 16 rows start in 16 different bank groups
+    if ((ld4 & 1) == 0) ++ld4;
+    q.ld = 4 * ld4;
+    const size_t slab = (size_t)kCmTQ * q.ld * 4, ids = (((size_t)kCmTQ * K * 2) + 15) & ~(size_t)15;
+    const size_t fixed_f4 = ((size_t)Ng * Kg * 4 + 15) / 16 + (size_t)4 * q.nt * 16;      // weights, then (over them) the reduction buffer
+    const size_t budget = 150 * 1024;
+    if (slab + ids + fixed_f4 * 16 > budget) return q;
+    size_t room_f4 = (budget - slab - ids) / 16;
+    int qc = (int)std::min<size_t>((size_t)Q, room_f4 / (size_t)M);
+    if (qc < 1) return q;
+    qc = cdiv(Q, cdiv(Q, qc));                                // even chunks
+    q.qc = qc;
+    q.tile_f4 = (int)std::max<size_t>((size_t)M * qc, fixed_f4);
+    q.lds = (size_t)q.tile_f4 * 16 + slab + ids;
+    q.tiles = cdiv(N, kCmTQ);
+    q.ok = q.tiles <= 65535;
+    return q;
+}
+
 struct MrGrpPlan { bool ok; int threads, ld, grid; size_t lds; };
 static MrGrpPlan plan_mr_grp(int n_windows, int C, int groups, int Nw, int K) {
     MrGrpPlan q{};
@@ -1589,6 +1827,56 @@ extern "C" int nextou_gather_bwd(const float* gout, const int32_t* idx, float* d
 }
 
 // ---- K2 + K7: window aggregation feeding the grouped 1x1 convolution (mr_grp_rows_kernel) ----
+// number of statistics partials per (sample, channel) a launch of this shape writes = query tiles; 0 = shape not supported
+extern "C" int nextou_mr_grouped_cm_tiles(int B, int C, int groups, int Ng, int N, int M, int K) {
+    const CmPlan q = plan_mr_grp_cm(B, C, groups, Ng, N, M, K);
+    return q.ok ? q.tiles : 0;
+}
+
+extern "C" int nextou_mr_grouped_cm(const float* x, const float* y, const int32_t* nn_idx, int idx_stride, int idx_step, int K,
+                                    const float* weight, float* a_out, uint16_t* arg_out, float* h, double* stats_partial,
+                                    int stats_tiles, int B, int C, int N, int M, int groups, int Ng, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(x && nn_idx && weight && h, "mr_grouped_cm: null pointer");
+    NEXTOU_REQUIRE(y != nullptr || M == N, "mr_grouped_cm: y == NULL (self graph) needs M == N (N=%d M=%d)", N, M);
+    NEXTOU_REQUIRE(idx_step > 0 && idx_stride >= (K - 1) * idx_step + 1, "mr_grouped_cm: idx_stride=%d too small for K=%d step=%d", idx_stride, K,
+                   idx_step);
+    const CmPlan q = plan_mr_grp_cm(B, C, groups, Ng, N, M, K);
+    if (!q.ok) return fail(NEXTOU_ENOTSUP, "mr_grouped_cm: shape B=%d C=%d groups=%d Ng=%d N=%d M=%d K=%d not supported", B, C, groups, Ng, N, M, K);
+    NEXTOU_REQUIRE(stats_partial == nullptr || stats_tiles == q.tiles, "mr_grouped_cm: stats_tiles=%d, this launch writes %d per channel", stats_tiles,
+                   q.tiles);
+    hipStream_t s = (hipStream_t)stream;
+    const int Cg = C / groups;
+    const float* src = y ? y : x;
+    const unsigned m_magic = (unsigned)(((1ull << 32) + (unsigned)M - 1) / (unsigned)M);
+    const double bytes = 4.0 * B * C * ((double)N + (y ? M : 0)) + 4.0 * B * (double)N * K + 4.0 * B * (double)groups * Ng * N +
+                         (a_out ? 8.0 * B * C * (double)N : 0.0) + (arg_out ? 2.0 * B * C * (double)N : 0.0);
+    ProfScope prof(s, kBoundHbm, bytes, "mr_grp_cm_kernel<%d,%d,%d|%s%s>[B%d C%d N%d M%d K%d g%d]", q.kt, q.nt, q.ksteps, y ? "xy" : "self",
+                   a_out ? ",train" : "", B, C, N, M, K, groups);
+    const dim3 grid(q.tiles, groups, B);
+#define NEXTOU_CM_LAUNCH(KT_, NT_, KS_)                                                                                              \
+    do {                                                                                                                              \
+        if (q.lds > 64 * 1024)                                                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_grp_cm_kernel<KT_, NT_, KS_>),                               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds);                                        \
+        hipLaunchKernelGGL((mr_grp_cm_kernel<KT_, NT_, KS_>), grid, dim3(256), q.lds, s, x, src, nn_idx, weight, a_out, h, arg_out,   \
+                           reinterpret_cast<double2*>(stats_partial), C, Cg, Ng, N, M, K, idx_stride, idx_step, q.qc, q.ld, q.tile_f4, \
+                           m_magic);                                                                                                  \
+    } while (0)
+#define NEXTOU_CM_CFG(KT_)                                      \
+    switch (q.cfg) {                                            \
+        case 0: NEXTOU_CM_LAUNCH(KT_, 1, 4); break;             \
+        case 1: NEXTOU_CM_LAUNCH(KT_, 3, 11); break;            \
+        case 2: NEXTOU_CM_LAUNCH(KT_, 6, 22); break;            \
+        default: NEXTOU_CM_LAUNCH(KT_, 7, 27); break;           \
+    }
+    if (q.kt == 8) { NEXTOU_CM_CFG(8) }
+    else if (q.kt == 16) { NEXTOU_CM_CFG(16) }
+    else { NEXTOU_CM_CFG(32) }
+#undef NEXTOU_CM_CFG
+#undef NEXTOU_CM_LAUNCH
+    return check_launch("mr_grp_cm_kernel");
+}
+
 extern "C" int nextou_mr_grouped_rows_supported(int n_windows, int C, int groups, int Nw, int K) {
     return plan_mr_grp(n_windows, C, groups, Nw, K).ok ? 1 : 0;
 }

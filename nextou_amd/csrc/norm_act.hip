@@ -320,10 +320,11 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const T* __restrict_
                                                             float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                             int B, int C, long long cols, int row_len, long long col_len,
                                                             int col_tiles, int tw_log2, int wmod, double count,
-                                                            int training, float momentum, float eps, float slope) {
+                                                            int training, float momentum, float eps, float slope, int n_partial) {
     const int c = C - 1 - blockIdx.y;
     double var;
-    const ChannelAffine a = channel_affine(partial, gridDim.x, c, wmod, count, weight, bias, pre_bias, running_mean,
+    // n_partial > 0: the statistics partials came from another kernel (mr_grp_cm_kernel's epilogue), n_partial per channel
+    const ChannelAffine a = channel_affine(partial, n_partial > 0 ? n_partial : (int)gridDim.x, c, wmod, count, weight, bias, pre_bias, running_mean,
                                            running_var, training, eps, &var);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (save_mean) save_mean[c] = a.mean;
@@ -835,6 +836,7 @@ struct NormArgs {
     long long S;
     int wmod, training;
     float momentum, eps, slope;
+    int n_partial;      // > 0: `partial` holds that many ready-made partials per channel (NCDHW forward only): no statistics launch
 };
 
 template <typename T, int VEC>
@@ -842,7 +844,7 @@ void launch_fwd(const NormArgs& a, const TilePlan& p, hipStream_t s, const char*
     const dim3 grid(p.tiles, a.C);
     const double bytes = (double)a.B * a.C * (double)a.S * sizeof(T);
     const double count = (double)a.B * (double)a.S;
-    if (a.training) {
+    if (a.training && a.n_partial == 0) {
         ProfScope prof(s, kBoundHbm, bytes, "bn_stats_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
         hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), grid, dim3(kThreads), 0, s, (const T*)a.x, a.partial, a.B, a.C, p.cols,
                            p.row_len, p.col_len, p.col_tiles, p.tw_log2);
@@ -850,7 +852,7 @@ void launch_fwd(const NormArgs& a, const TilePlan& p, hipStream_t s, const char*
     ProfScope prof(s, kBoundHbm, 2.0 * bytes, "bn_apply_kernel<%s>[B%d C%d S%lld]", tname, a.B, a.C, a.S);
     hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), grid, dim3(kThreads), 0, s, (const T*)a.x, (T*)a.y, a.partial, a.weight,
                        a.bias, a.pre_bias, a.running_mean, a.running_var, a.save_mean, a.save_invstd, a.B, a.C, p.cols, p.row_len,
-                       p.col_len, p.col_tiles, p.tw_log2, a.wmod, count, a.training, a.momentum, a.eps, a.slope);
+                       p.col_len, p.col_tiles, p.tw_log2, a.wmod, count, a.training, a.momentum, a.eps, a.slope, a.n_partial);
 }
 
 template <typename T, int VEC>
@@ -1368,6 +1370,27 @@ extern "C" int nextou_norm_act_bwd(const void* x, const void* gy, const float* w
         return fail(NEXTOU_ENOSPACE, "norm_act_bwd: workspace %zu < %zu bytes", ws_bytes, (size_t)C * p.tiles * sizeof(double2));
     norm_dispatch<false>(a, p, dtype, (hipStream_t)stream);
     return check_launch("bn_bwd_apply_kernel");
+}
+
+// K6's forward for a channel-major (B, C, S) fp32 tensor whose (sum, sum of squares) partials another kernel already wrote —
+// mr_grp_cm_kernel's epilogue (csrc/mr_aggregate.hip): finalize + normalise + LeakyReLU in the one apply launch, no statistics pass.
+// Batch statistics over (B, S) per channel (param_period = 0) or, with param_period = C_real > 0 and B = 1, instance statistics
+// per row of the (1, B' C_real, S) view; training mode semantics (the running statistics, if given, are updated).
+extern "C" int nextou_norm_act_fwd_partials(const float* x, const float* weight, const float* bias, float* running_mean,
+                                            float* running_var, float* y, float* save_mean, float* save_invstd, const double* partial,
+                                            int n_partial, int B, int C, int64_t S, int param_period, float momentum, float eps,
+                                            float slope, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(x && y && partial && n_partial > 0, "norm_act_fwd_partials: null pointer or no partials");
+    if (int rc = check_common("norm_act_fwd_partials", B, C, S, param_period, NEXTOU_DTYPE_F32, 0)) return rc;
+    NEXTOU_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "norm_act_fwd_partials: running_mean / running_var must come together");
+    NormArgs a{};
+    a.x = x; a.y = y; a.weight = weight; a.bias = bias; a.running_mean = running_mean; a.running_var = running_var;
+    a.save_mean = save_mean; a.save_invstd = save_invstd; a.partial = reinterpret_cast<double2*>(const_cast<double*>(partial));
+    a.B = B; a.C = C; a.S = S; a.wmod = param_period; a.training = 1; a.momentum = momentum; a.eps = eps; a.slope = slope;
+    a.n_partial = n_partial;
+    const TilePlan p = plan_tiles(B, C, S, 4, aligned16(x) && aligned16(y));
+    norm_dispatch<true>(a, p, NEXTOU_DTYPE_F32, (hipStream_t)stream);
+    return check_launch("bn_apply_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -196,6 +196,51 @@ class _HipBackend:
         return dx
 
     @staticmethod
+    def mr_grouped_cm_tiles(B, C, groups, Ng, N, M, K):
+        """statistics partials per (sample, channel) the channel-major K2 + K7 launch writes for this shape; 0 = shape not taken"""
+        return int(_lib.lib().nextou_mr_grouped_cm_tiles(B, C, groups, Ng, N, M, K))
+
+    @staticmethod
+    def mr_grouped_cm(x, y, nn_idx, K, idx_step, w2, groups, want_a, want_arg, want_stats):
+        """K2 + K7 for a pooled / self graph in one launch (csrc/mr_aggregate.hip mr_grp_cm_kernel).  x (B, C, N), y (B, C, M) | None,
+        w2 (groups * Ng, 2C / groups) -> (a (B, 2C, N) | None, arg (B, C, N) int16 | None, h (B, groups * Ng, N),
+        partial (B * groups * Ng, tiles, 2) float64 | None)."""
+        L_ = _lib.lib()
+        B, C, N = x.shape
+        M = N if y is None else y.shape[2]
+        Ng = w2.shape[0] // groups
+        tiles = int(L_.nextou_mr_grouped_cm_tiles(B, C, groups, Ng, N, M, K))
+        if tiles <= 0:
+            raise RuntimeError("mr_grouped_cm: shape not supported (check mr_grouped_cm_tiles first)")
+        h = torch.empty((B, groups * Ng, N), dtype=torch.float32, device=x.device)
+        a = torch.empty((B, 2 * C, N), dtype=torch.float32, device=x.device) if want_a else None
+        arg = torch.empty((B, C, N), dtype=torch.int16, device=x.device) if want_arg else None
+        partial = torch.empty((B * groups * Ng, tiles, 2), dtype=torch.float64, device=x.device) if want_stats else None
+        with torch.cuda.device(x.device):
+            rc = L_.nextou_mr_grouped_cm(x.data_ptr(), _ptr(y), nn_idx.data_ptr(), nn_idx.shape[2], idx_step, K, w2.data_ptr(), _ptr(a),
+                                         _ptr(arg), h.data_ptr(), _ptr(partial), tiles if want_stats else 0, B, C, N, M, groups, Ng,
+                                         _stream_ptr(x.device))
+        _lib.check(rc, "mr_grouped_cm")
+        return a, arg, h, partial
+
+    @staticmethod
+    def norm_act_fwd_partials(x, weight, bias, partial, period, eps, slope):
+        """K6's normalise + activate for a channel-major fp32 (B, C, S) tensor from ready-made statistics partials (C, n, 2) float64
+        -> (y, save_mean, save_invstd)."""
+        L_ = _lib.lib()
+        B, C = x.shape[:2]
+        S = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L_.nextou_norm_act_fwd_partials(x.data_ptr(), _ptr(weight), _ptr(bias), None, None, y.data_ptr(), save_mean.data_ptr(),
+                                                 save_invstd.data_ptr(), partial.data_ptr(), partial.shape[1], B, C, S, period, 0.0,
+                                                 float(eps), float(slope), _stream_ptr(x.device))
+        _lib.check(rc, "norm_act_fwd_partials")
+        return y, save_mean, save_invstd
+
+    @staticmethod
     def mr_bwd_wants_idx(B, C, N, K):
         return bool(_lib.lib().nextou_mr_aggregate_bwd_wants_idx(B, C, N, K))
 
@@ -997,7 +1042,7 @@ class _NormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, instance,
-                pre_bias, pad_holder=None):
+                pre_bias, pad_holder=None, stats_partial=None):
         shape = x.shape
         B, C = shape[0], shape[1]
         period = C if instance else 0
@@ -1033,8 +1078,11 @@ class _NormAct(torch.autograd.Function):
         else:
             x3 = x.contiguous()
             x3 = x3.view(1, B * C, -1) if instance else x3.view(B, C, -1)
-            y, mean, invstd = be.norm_act_fwd(x3, k_weight, k_bias, k_rm, k_rv, training, momentum, eps,
-                                              slope, period, k_pre)
+            if stats_partial is not None:       # instance statistics already summed by the producer (mr_grouped_cm): no statistics pass
+                y, mean, invstd = be.norm_act_fwd_partials(x3, k_weight, k_bias, stats_partial, period, eps, slope)
+            else:
+                y, mean, invstd = be.norm_act_fwd(x3, k_weight, k_bias, k_rm, k_rv, training, momentum, eps,
+                                                  slope, period, k_pre)
             y = y.view(shape)
         if stage is not None:
             if training and running_mean is not None and running_var is not None:
@@ -1072,7 +1120,7 @@ class _NormAct(torch.autograd.Function):
                 gpre = (gb * invstd * (weight if weight is not None else 1.0))[:c_real].to(ctx.pre_bias_like.dtype)
         gw = gw[:c_real].to(weight.dtype) if weight is not None and ctx.needs_input_grad[1] else None
         gb = gb[:c_real].to(bias.dtype) if bias is not None and ctx.needs_input_grad[2] else None
-        return gx, gw, gb, None, None, None, None, None, None, None, gpre, None
+        return gx, gw, gb, None, None, None, None, None, None, None, gpre, None, None
 
 
 def _pad_stage(holder, C: int, c_real: int, device) -> torch.Tensor:
@@ -1089,7 +1137,7 @@ def _pad_stage(holder, C: int, c_real: int, device) -> torch.Tensor:
 def norm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
              running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], training: bool,
              momentum: float, eps: float, negative_slope: float = 1.0, instance: bool = False,
-             pre_bias: Optional[torch.Tensor] = None, pad_holder=None) -> torch.Tensor:
+             pre_bias: Optional[torch.Tensor] = None, pad_holder=None, stats_partial: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``leaky_relu(batch_norm(x [+ pre_bias]) | instance_norm(x), negative_slope)`` on (B,C,*spatial) fp32 / bf16 / fp16
     (statistics and the normalisation itself are always computed in fp32 / fp64; only loads and stores are narrow).
 
@@ -1117,8 +1165,10 @@ def norm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[tor
         pre_bias = pre_bias.float()
     if pad_holder is not None and instance:
         raise ValueError("norm_act: channel padding is only defined for batch statistics")
+    if stats_partial is not None and not (instance and x.is_cuda and x.dtype == torch.float32 and pad_holder is None):
+        raise ValueError("norm_act: ready-made statistics are for fp32 instance norm on the device")
     return _NormAct.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum),
-                          float(eps), float(negative_slope), bool(instance), pre_bias, pad_holder)
+                          float(eps), float(negative_slope), bool(instance), pre_bias, pad_holder, stats_partial)
 
 
 def _dense_channels_last(x: torch.Tensor):
@@ -1522,6 +1572,70 @@ class _MRGroupedConv(torch.autograd.Function):
         dx = _HIP.mr_grouped_rows_bwd(dh, w2, arg, groups, spatial, window, shift) if ctx.needs_input_grad[0] else None
         gw = _HIP.pw_wgrad(dh, a, groups).reshape(wshape) if ctx.needs_input_grad[1] else None
         return (dx, gw) + (None,) * 7
+
+
+class _MRGroupedCM(torch.autograd.Function):
+    """MRConv of a pooled / self graph up to its grouped 1x1 convolution in ONE launch (K2 + K7, channel-major half: csrc/mr_aggregate.hip
+    mr_grp_cm_kernel): ``conv1x1(mr_aggregate(x, nn_idx, y), weight, groups)`` with the InstanceNorm (sum, sum of squares) partials of
+    the result.  Backward = the three ops' own backwards: the two strided-batched GEMMs of the grouped convolution (data gradient,
+    weight gradient on the saved aggregate) and the fixed-point arg-tape scatter (mr_bwd_fix_kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, y, nn_idx, weight, K, idx_step, groups, want_stats):
+        w2 = weight.reshape(weight.shape[0], weight.shape[1]).contiguous()
+        need_x = x.requires_grad or (y is not None and y.requires_grad)
+        need_w = weight.requires_grad
+        a, arg, h, partial = _HIP.mr_grouped_cm(x, y, nn_idx, K, idx_step, w2, groups, want_a=need_w, want_arg=need_x, want_stats=want_stats)
+        ctx.conf = (groups, tuple(weight.shape), x.shape[2] if y is None else y.shape[2], y is not None)
+        ctx.save_for_backward(arg if need_x else None, a if need_w else None, w2 if need_x else None)
+        if partial is None:
+            partial = h.new_empty(0)
+        ctx.mark_non_differentiable(partial)
+        return h, partial
+
+    @staticmethod
+    def backward(ctx, dh, _):
+        groups, wshape, M, has_y = ctx.conf
+        arg, a, w2 = ctx.saved_tensors
+        B, _, N = dh.shape
+        dh4 = dh.contiguous().view(B, groups, -1, N)
+        dx = dy = gw = None
+        if arg is not None:
+            ga = torch.matmul(w2.view(groups, dh4.shape[2], -1).transpose(1, 2), dh4)          # (B, groups, 2C / groups, N)
+            dx, dy = _HIP.mr_bwd_arg(ga.view(B, -1, N), arg, M, has_y)
+        if a is not None:
+            gw = torch.matmul(dh4, a.view(B, groups, -1, N).transpose(2, 3)).sum(0).reshape(wshape)
+        return dx, dy, None, gw, None, None, None, None
+
+
+def mr_grouped_cm_block(x, nn_idx, y, conv, norm):
+    """MRConv of a Pool-GNN block — ``norm(conv(mr_aggregate(x, nn_idx, y)))`` with ``norm`` = InstanceNorm + the absorbed LeakyReLU —
+    as the K2 + K7 launch followed by K6's apply on the launch's statistics partials (reference
+    NexToU_Encoder_Decoder.py:401-418 inside :516-551, torch_nn.py:66-92), or ``None`` when a piece does not qualify (the caller runs
+    mr_aggregate -> conv -> norm).  x (B, C, N), y (B, C, M) | None, nn_idx (B, N, K) int32 -> (B, 2C', N)."""
+    import os
+    if os.environ.get("NEXTOU_MR_GROUPED_CM", "1") == "0" or not x.is_cuda or x.dtype != torch.float32 or \
+            torch.is_autocast_enabled("cuda") or nn_idx.dtype != torch.int32 or x.dim() != 3:
+        return None
+    from .network_architecture.norm_act import _InstanceNormAct
+    if not isinstance(norm, _InstanceNormAct) or norm.track_running_stats:
+        return None
+    B, C, N = x.shape
+    M = N if y is None else y.shape[2]
+    w = conv.weight
+    groups = int(conv.groups)
+    if conv.transposed or isinstance(conv.padding, str) or w.dtype != torch.float32 or any(k != 1 for k in w.shape[2:]) or \
+            any(v != 1 for v in conv.stride) or any(v != 0 for v in conv.padding) or any(v != 1 for v in conv.dilation) or \
+            getattr(conv, "_pad_spec", None) is not None or w.shape[1] * groups != 2 * C or w.shape[0] % groups:
+        return None
+    if conv.bias is not None and getattr(norm, "_pre_bias_src", (None,))[0] is not conv:
+        return None               # a bias the norm does not absorb would have to be added to h
+    K = nn_idx.shape[2]
+    if _HIP.mr_grouped_cm_tiles(B, C, groups, w.shape[0] // groups, N, M, K) <= 0:
+        return None
+    h, partial = _MRGroupedCM.apply(_f32c(x), None if y is None else _f32c(y), nn_idx.contiguous(), w, K, 1, groups, True)
+    return norm_act(h, norm.weight, norm.bias, None, None, True, 0.0, norm.eps, norm.negative_slope, instance=True,
+                    stats_partial=partial)
 
 
 def mr_grouped_conv(windows, nn_idx, conv, norm, batch, spatial, window, shift):

@@ -252,6 +252,12 @@ class MRConv(nn.Module):
 
     def aggregate(self, x, nn_idx, y=None):
         """Fused path: x (B,C,N), y (B,C,M)|None, nn_idx int32 (B,N,k) -> (B,2C,N,1[,1])."""
+        basic = self.nn
+        if len(basic) >= 2 and isinstance(basic[0], (nn.Conv2d, nn.Conv3d)) and all(isinstance(m, nn.Identity) for m in list(basic)[2:]):
+            # K2 + K7 (channel-major): aggregation, grouped 1x1 convolution and the InstanceNorm statistics in one launch, then K6's apply
+            out = graph_ops.mr_grouped_cm_block(x, nn_idx, y, basic[0], basic[1])
+            if out is not None:
+                return out.reshape(out.shape[0], out.shape[1], out.shape[2], *([1] * (_conv_dim(self.conv_op) - 1)))
         return self._pointwise(graph_ops.mr_aggregate(x, nn_idx, y))
 
     def forward(self, x, edge_index, y=None):
