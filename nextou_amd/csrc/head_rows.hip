@@ -248,12 +248,14 @@ __global__ __launch_bounds__(kHeadThreads) void head_wgrad_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-staged variants for dense rows (ldx == C, ldy == L, C % 4 == 0, L <= 16, C + 1 <= 160): the direct kernels above touch every
-// 128-byte line of x / gx in 64-byte pieces from different instructions (forward 0.65, data gradient 0.41 of 8 TB/s at cfg 2's
-// full-resolution head, profiles/r05_head_bench_v1.txt).  Here a wave copies a tile of 32 WHOLE rows — one contiguous range of
-// global memory — into its private LDS region with 16-byte accesses, the MFMA operands come from LDS in whatever order they need,
-// and results leave the same way.  Wave-private regions: LDS instructions of one wave execute in order, so no barrier is needed
-// inside the tile loop, and a result tile may overwrite the operand tile it was computed from.
+// LDS-staged backward for dense rows (ldg == L, ldx == C, C % 4 == 0, L <= 16, C <= 104): the direct kernels above read gy twice and
+// touch every 128-byte line of gx in 64-byte pieces from different instructions (data gradient 0.41, weight gradient 0.54 of 8 TB/s
+// at cfg 2's full-resolution head, profiles/r05_head_bench_v1.txt).  Here a wave copies a tile of 32 WHOLE rows of gy and x — one
+// contiguous range of global memory each — into its private LDS region with 16-byte accesses, BOTH gradients' MFMA operands come
+// from LDS in whatever order they need, and gx leaves the same way: 637 -> 385 us at that head (0.67 of 8 TB/s on 376 B per point).
+// Wave-private regions: LDS instructions of one wave execute in order, so no barrier is needed inside the tile loop, and the gx
+// tile may overwrite the x tile it was computed beside.  (The same staging for the forward was measured and dropped: 243 us
+// against the direct kernel's 228 — the forward has one operand and its 64-byte pieces already merge in L2.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kHeadTileRows = 32;      // rows per wave and iteration (two MFMA point tiles)
 constexpr int kHeadMaxCT = 7;          // channel tiles incl. the bias column: C + 1 <= 112
@@ -293,66 +295,6 @@ __device__ __forceinline__ void tile_out(float* __restrict__ dst, const float* s
     for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
     const int rest = n_floats & 3;
     if (lane < rest) dst[4 * n4 + lane] = src[4 * n4 + lane];
-}
-
-template <int NXV>
-__global__ __launch_bounds__(kHeadThreads) void head_fwd_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                    const float* __restrict__ bias, float* __restrict__ y, long P, int L,
-                                                                    int C, int KT, long tiles) {
-    extern __shared__ __attribute__((aligned(16))) float hsm[];
-    const int ldw = KT * 16 + 4;
-    float* wl = hsm;                                                    // [16][ldw]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* xt = hsm + 16 * ldw + (size_t)wave * kHeadTileRows * (C > 16 ? C : 16);      // [32][C], later [32][L]
-    for (int e = threadIdx.x; e < 16 * ldw; e += kHeadThreads) {
-        const int l = e / ldw, c = e % ldw;
-        wl[e] = (l < L && c < C) ? w[(long)l * C + c] : 0.f;
-    }
-    __syncthreads();
-    const int q = lane & 15, g = lane >> 4;
-    f32x4 binit;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) binit[r] = (bias != nullptr && 4 * g + r < L) ? bias[4 * g + r] : 0.f;
-    const long n_waves = (long)gridDim.x * kHeadWaves;
-    long t = (long)blockIdx.x * kHeadWaves + wave;
-    f32x4 xr[NXV];
-    if (t < tiles) tile_fetch(xr, x, x + t * kHeadTileRows * C, head_rows_of(P, t) * C, lane);
-    for (; t < tiles; t += n_waves) {
-        const long p0 = t * kHeadTileRows;
-        const int rows = head_rows_of(P, t);
-        tile_commit(xr, xt, x + p0 * C, rows * C, lane);
-        const long nx = t + n_waves < tiles ? t + n_waves : t;          // no next tile: a re-read nobody uses
-        tile_fetch(xr, x, x + nx * kHeadTileRows * C, head_rows_of(P, nx) * C, lane);
-        __builtin_amdgcn_wave_barrier();                                // (compiler only: the LDS itself runs a wave's instructions in order)
-        f32x4 acc[2] = {binit, binit};
-        for (int j = 0; j < KT; ++j) {
-            const int c = 16 * j + 4 * g;
-            const float4 wv = *reinterpret_cast<const float4*>(&wl[q * ldw + c]);
-            float4 xv[2];
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                xv[pt] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < C && pt * 16 + q < rows) xv[pt] = *reinterpret_cast<const float4*>(&xt[(pt * 16 + q) * C + c]);
-            }
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                acc[pt] = mfma4(wv.x, xv[pt].x, acc[pt]);
-                acc[pt] = mfma4(wv.y, xv[pt].y, acc[pt]);
-                acc[pt] = mfma4(wv.z, xv[pt].z, acc[pt]);
-                acc[pt] = mfma4(wv.w, xv[pt].w, acc[pt]);
-            }
-        }
-        // the logits of the tile over the (dead) operand tile, rows of L floats, then out in one contiguous piece
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * g + r < L) xt[(pt * 16 + q) * L + 4 * g + r] = acc[pt][r];
-        __builtin_amdgcn_wave_barrier();
-        tile_out(y + p0 * L, xt, rows * L, lane);
-        __builtin_amdgcn_wave_barrier();
-    }
 }
 
 // gx = gy W (rows), part[block] = [gy^T x | gy^T 1] of this workgroup's rows: the data gradient and the weight + bias gradient
@@ -533,16 +475,6 @@ int wgrad_blocks(int64_t tiles) {
 
 // LDS-staged kernels: bytes of dynamic LDS (0 = shape not eligible) and the grid
 struct LdsPlan { size_t lds; int blocks; };
-LdsPlan plan_fwd_lds(int64_t P, int L, int C) {
-    if (C % 4 != 0 || L > 16 || C > 104 || P < 4) return {0, 0};
-    const size_t lds = ((size_t)16 * (cdiv(C, 16) * 16 + 4) + (size_t)kHeadWaves * kHeadTileRows * (C > 16 ? C : 16)) * sizeof(float);
-    if (lds > 64 * 1024) return {0, 0};
-    const int64_t tiles = cdiv64(P, kHeadTileRows);
-    int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 6) per_cu = 6;
-    const int64_t want = cdiv64(tiles, kHeadWaves), cap = (int64_t)per_cu * head_cus();
-    return {lds, (int)(want > cap ? cap : want)};
-}
 LdsPlan plan_bwd_lds(int64_t P, int L, int C) {
     const int CTtot = cdiv(C + 1, 16);
     if (C % 4 != 0 || L > 16 || C > 104 || CTtot > kHeadMaxCT || P < 4) return {0, 0};
@@ -580,17 +512,6 @@ extern "C" int nextou_head_rows_fwd(const float* x, const float* w, const float*
     const dim3 grid((unsigned)(want > cap ? cap : want), (unsigned)LT);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = C % 4 == 0 && ldx % 4 == 0 && aligned16(x);
-    const LdsPlan lp = plan_fwd_lds(P, L, C);
-    if (lp.lds != 0 && !lds_path_off() && ldx == C && ldy == L && aligned16(x) && aligned16(y)) {
-        ProfScope prof(s, kBoundHbm, 4.0 * (double)P * (C + L), "head_fwd_lds_kernel[P%lld C%d L%d]", (long long)P, C, L);
-        const long t32 = (long)cdiv64(P, kHeadTileRows);
-        const dim3 grid((unsigned)lp.blocks), block(kHeadThreads);
-        if (C <= 16) hipLaunchKernelGGL(head_fwd_lds_kernel<2>, grid, block, lp.lds, s, x, w, bias, y, (long)P, L, C, KT, t32);
-        else if (C <= 40) hipLaunchKernelGGL(head_fwd_lds_kernel<5>, grid, block, lp.lds, s, x, w, bias, y, (long)P, L, C, KT, t32);
-        else if (C <= 72) hipLaunchKernelGGL(head_fwd_lds_kernel<9>, grid, block, lp.lds, s, x, w, bias, y, (long)P, L, C, KT, t32);
-        else hipLaunchKernelGGL(head_fwd_lds_kernel<13>, grid, block, lp.lds, s, x, w, bias, y, (long)P, L, C, KT, t32);
-        return check_launch("head_rows_fwd");
-    }
     ProfScope prof(s, kBoundHbm, 4.0 * (double)P * (C + L), "head_fwd_kernel[P%lld C%d L%d]", (long long)P, C, L);
     if (vec)
         hipLaunchKernelGGL(head_fwd_kernel<true>, grid, dim3(kHeadThreads), lds, s, x, w, bias, y, (long)P, L, C, (long)ldx, (long)ldy, KT,

@@ -1634,8 +1634,10 @@ def mr_grouped_cm_block(x, nn_idx, y, conv, norm):
     if _HIP.mr_grouped_cm_tiles(B, C, groups, w.shape[0] // groups, N, M, K) <= 0:
         return None
     h, partial = _MRGroupedCM.apply(_f32c(x), None if y is None else _f32c(y), nn_idx.contiguous(), w, K, 1, groups, True)
+    # the convolution's folded bias rides along as the norm's `pre_bias` exactly as in the op-by-op block: instance statistics absorb it
+    # (no effect on the values), and it keeps its — exactly zero — gradient instead of `None`
     return norm_act(h, norm.weight, norm.bias, None, None, True, 0.0, norm.eps, norm.negative_slope, instance=True,
-                    stats_partial=partial)
+                    pre_bias=conv.bias, stats_partial=partial)
 
 
 def mr_grouped_conv(windows, nn_idx, conv, norm, batch, spatial, window, shift):
