@@ -177,6 +177,9 @@ def roofline_from(report):
     tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):   # HBM bytes per launch from a committed rocprofv3 --pmc run
         traffic = json.load(open(tpath)).get(top["kernel"])
+        if traffic is None:     # never silent: the committed counter table has no row for today's dominant label
+            print("bench.py: profiles/pmc_traffic.json has no entry for the dominant kernel label %r: roofline.traffic = null "
+                  "(regenerate with tools/pmc_traffic.sh)" % top["kernel"], file=sys.stderr)
     real = _real_channel_fraction(top["kernel"])
     return {"bound": top["bound"], "achieved": round(achieved, 3), "peak": peak, "unit": unit,
             "frac": round(achieved / peak, 4), "traffic": traffic,
@@ -496,6 +499,19 @@ def main():
                                         "kind": "port", "sample": "failed: %r" % (e,)}
         elif world == 1:
             line["cpu_baseline"] = None
+        if world == 1 and args.workload == "cfg2":
+            # both CPU numbers in the line: `cpu_baseline` is measured in THIS run on a bounded sample (batch 1, the
+            # sweep's best thread count — the faster of the two protocols, i.e. the fairer yardstick); `cpu_baseline_survey` is SURVEY.md
+            # 8(d) to the letter (batch 2, 1 warm-up + 3 timed, all physical cores), ~10 min of host time and therefore a COMMITTED run
+            # (`bench.py --cpu-protocol survey` reproduces it), not re-measured here
+            spath = os.path.join(REPO, "profiles", "r04_bench_cfg2_cpu_survey.json")
+            if os.path.exists(spath):
+                try:
+                    sv = json.load(open(spath))["cpu_baseline"]
+                    line["cpu_baseline_survey"] = dict(sv, source="committed run profiles/r04_bench_cfg2_cpu_survey.json (not measured in this run)",
+                                                       batch=2, timed_steps=3)
+                except (OSError, ValueError, KeyError):
+                    line["cpu_baseline_survey"] = None
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
     if dist.is_initialized():

@@ -1339,16 +1339,34 @@ __global__ __launch_bounds__(256) void mr_grp_cm_kernel(const float* __restrict_
     for (int q0 = 0; q0 < Q; q0 += QC) {
         const int qc = min(QC, Q - q0);
         __syncthreads();                                        // ids visible / the previous chunk's gathers done
-        for (int e = tid; e < qc * M; e += 256) {
-            const int q = (int)__umulhi((unsigned)e, m_magic), m = e - q * M;       // e / M (m_magic = 0 for M = 1 is handled by the host: M >= 2)
-            const int c = 4 * (q0 + q);
-            const float* p = sg + (size_t)c * M + m;
-            float4 t;
-            t.x = p[0];
-            t.y = c + 1 < Cg ? p[(size_t)M] : 0.f;
-            t.z = c + 2 < Cg ? p[(size_t)2 * M] : 0.f;
-            t.w = c + 3 < Cg ? p[(size_t)3 * M] : 0.f;
-            cm_tile4[m * QC + q] = t;
+        // four items (16 scalar row loads) in flight per lane before the first LDS store: with one or two workgroups on a CU nothing else
+        // hides a round trip per item (the first version staged a 86 KB chunk in 21 dependent rounds: Pool s3 forward 852 vs 686 us)
+        for (int e0 = tid; e0 < qc * M; e0 += 4 * 256) {
+            f32x4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + u * 256, qc * M - 1);
+                const int q = (int)__umulhi((unsigned)e, m_magic), m = e - q * M;   // e / M (the host guarantees M >= 2)
+                const int c = 4 * (q0 + q);
+                const float* p = sg + (size_t)c * M + m;
+                t[u].x = p[0];
+                t[u].y = p[c + 1 < Cg ? (size_t)M : 0];
+                t[u].z = p[c + 2 < Cg ? (size_t)2 * M : 0];
+                t[u].w = p[c + 3 < Cg ? (size_t)3 * M : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * 256;
+                if (e < qc * M) {
+                    const int q = (int)__umulhi((unsigned)e, m_magic), m = e - q * M;
+                    const int c = 4 * (q0 + q);
+                    f32x4 v = t[u];
+                    if (c + 1 >= Cg) v.y = 0.f;
+                    if (c + 2 >= Cg) v.z = 0.f;
+                    if (c + 3 >= Cg) v.w = 0.f;
+                    reinterpret_cast<f32x4*>(cm_tile4)[m * QC + q] = v;
+                }
+            }
         }
         __syncthreads();
         const f32x4* t4 = reinterpret_cast<const f32x4*>(cm_tile4);
@@ -1507,7 +1525,9 @@ static CmPlan plan_mr_grp_cm(int B, int C, int groups, int Ng, int N, int M, int
     q.ld = 4 * ld4;
     const size_t slab = (size_t)kCmTQ * q.ld * 4, ids = (((size_t)kCmTQ * K * 2) + 15) & ~(size_t)15;
     const size_t fixed_f4 = ((size_t)Ng * Kg * 4 + 15) / 16 + (size_t)4 * q.nt * 16;      // weights, then (over them) the reduction buffer
-    const size_t budget = 150 * 1024;
+    // two workgroups per CU (76 KB each) whenever a chunk of at least two quads still fits; else one (150 KB)
+    size_t budget = 76 * 1024;
+    if (slab + ids + fixed_f4 * 16 > budget || (budget - slab - ids) / 16 / (size_t)M < (size_t)std::min(Q, 2)) budget = 150 * 1024;
     if (slab + ids + fixed_f4 * 16 > budget) return q;
     size_t room_f4 = (budget - slab - ids) / 16;
     int qc = (int)std::min<size_t>((size_t)Q, room_f4 / (size_t)M);
@@ -1517,7 +1537,11 @@ static CmPlan plan_mr_grp_cm(int B, int C, int groups, int Ng, int N, int M, int
     q.tile_f4 = (int)std::max<size_t>((size_t)M * qc, fixed_f4);
     q.lds = (size_t)q.tile_f4 * 16 + slab + ids;
     q.tiles = cdiv(N, kCmTQ);
-    q.ok = q.tiles <= 65535;
+    // one workgroup per (128 queries, group, sample): below a workgroup per CU the three launches it replaces win as replayed graphs
+    // (cfg 2 Pool s4: 132 workgroups, 555 vs 487 us per block; s5: 12 workgroups, 366 vs 316 — profiles/r05_pool_fused.md)
+    int min_wg = 256;
+    if (const char* e = getenv("NEXTOU_MR_GROUPED_CM_MIN_WORKGROUPS")) min_wg = atoi(e);
+    q.ok = q.tiles <= 65535 && (long long)q.tiles * groups * B >= min_wg;
     return q;
 }
 

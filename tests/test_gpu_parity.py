@@ -418,7 +418,9 @@ def test_bti_kernels_vs_oracle_and_reference(ops, ora):
 
 
 @pytest.mark.parametrize("shape,conn,thick", [((2, 7, 9, 11), 26, 1), ((1, 5, 6, 7), 26, 2), ((2, 9, 10, 13), 6, 1),
-                                              ((3, 17, 19), 8, 1), ((3, 17, 19), 4, 1), ((1, 33, 21), 8, 2)])
+                                              ((3, 17, 19), 8, 1), ((3, 17, 19), 4, 1), ((1, 33, 21), 8, 2),
+                                              ((1, 9, 12, 10), 26, 3),      # the widest box the tiled kernel takes
+                                              ((2, 10, 11, 13), 26, 4), ((2, 40, 37), 8, 5)])      # min_thick > 3: bti_critical_naive_kernel
 def test_bti_ragged_shapes(ops, ora, shape, conn, thick):
     g = torch.Generator().manual_seed(sum(shape) + conn)
     labels = torch.randint(0, 6, shape, generator=g, dtype=torch.uint8)

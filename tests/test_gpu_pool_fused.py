@@ -21,7 +21,16 @@ def ops():
     return graph_ops
 
 
+@pytest.fixture(autouse=True)
+def _every_shape(monkeypatch):
+    """the product takes the launch only from a workgroup per CU on (NEXTOU_MR_GROUPED_CM_MIN_WORKGROUPS = 256, a measured crossover):
+    the tests want it at every size"""
+    monkeypatch.setenv("NEXTOU_MR_GROUPED_CM_MIN_WORKGROUPS", "0")
+
+
 def _ops():
+    import os
+    os.environ["NEXTOU_MR_GROUPED_CM_MIN_WORKGROUPS"] = "0"          # (hypothesis bodies run outside function-scoped fixtures)
     from nextou_amd import graph_ops
     return graph_ops
 
@@ -132,3 +141,11 @@ def test_pooled_mrconv_any_shape(B, cg, groups, N, M, K, seed):
     if ops._HIP.mr_grouped_cm_tiles(B, C, groups, 2 * cg, N, m, K) <= 0:
         return
     _check_forward(ops, B, C, N, M, K, groups, seed)
+
+
+def test_pooled_mrconv_is_taken_from_a_workgroup_per_cu_on(ops, monkeypatch):
+    """the default crossover: cfg 2's Pool s2 / s3 shapes (1 008 workgroups) take the launch, s4 (132) and s5 (12) keep the three launches"""
+    monkeypatch.delenv("NEXTOU_MR_GROUPED_CM_MIN_WORKGROUPS")
+    be = ops._HIP
+    assert be.mr_grouped_cm_tiles(2, 132, 6, 44, 10752, 168, 14) == 84 and be.mr_grouped_cm_tiles(2, 264, 6, 88, 10752, 1344, 28) == 84
+    assert be.mr_grouped_cm_tiles(2, 324, 6, 108, 1344, 1344, 32) == 0 and be.mr_grouped_cm_tiles(2, 324, 6, 108, 168, 168, 32) == 0

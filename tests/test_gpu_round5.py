@@ -38,3 +38,46 @@ def test_fused_dice_declines_fractional_masks_and_clip_tp(ops, monkeypatch):
     dice.clip_tp = 0.5
     dice(x, y)
     assert len(calls) == n, "a Dice module with clip_tp must take the base class"
+
+
+def test_float_atomic_aggregation_backward_variant(ops):
+    """NEXTOU_MR_BWD=float keeps round 1's LDS float-atomic scatter (mr_bwd_arg_kernel) reachable through nextou_mr_aggregate_bwd_arg for
+    A/B runs; the switch is read once per process, so the variant runs in its own interpreter (every kernel reachable
+    through the C-ABI has a test): dx / dy against the float64 scatter, pooled and self graphs."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from nextou_amd import _lib, graph_ops
+_lib.lib()
+dev = torch.device("cuda:0")
+worst = 0.0
+for (B, C, N, M) in ((2, 12, 300, 64), (2, 7, 168, None), (1, 5, 2000, 5000)):
+    g = torch.Generator().manual_seed(N)
+    m = M or N
+    gout = torch.randn(B, 2 * C, N, generator=g)
+    arg = torch.randint(0, m, (B, C, N), generator=g).to(torch.int16)
+    dx, dy = graph_ops._HIP.mr_bwd_arg(gout.to(dev), arg.to(dev), m, M is not None)
+    scat = torch.zeros(B, C, m, dtype=torch.float64).scatter_add_(2, arg.long() & 0xffff, gout[:, 1::2].double())
+    ident = (gout[:, 0::2] - gout[:, 1::2]).double()
+    want_dx, want_dy = (ident + scat, None) if M is None else (ident, scat)
+    worst = max(worst, float((dx.cpu().double() - want_dx).abs().max()) / float(want_dx.abs().max()))
+    if want_dy is not None:
+        worst = max(worst, float((dy.cpu().double() - want_dy).abs().max()) / float(want_dy.abs().max()))
+import ctypes, json
+L = _lib.lib()
+L.nextou_profile_enable(8)
+graph_ops._HIP.mr_bwd_arg(gout.to(dev), arg.to(dev), m, M is not None)
+torch.cuda.synchronize()
+buf = ctypes.create_string_buffer(1 << 16)
+L.nextou_profile_report(buf, len(buf))
+print("RESULT", worst, json.loads(buf.value.decode())[0]["kernel"])
+''' % REPO
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NEXTOU_MR_BWD="float"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    assert line[2].startswith("mr_bwd_arg_kernel"), line          # the float-atomic kernel really ran
+    assert float(line[1]) <= 1e-5

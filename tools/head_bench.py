@@ -40,6 +40,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--classes", type=int, default=14)
+    ap.add_argument("--only", default=None, help="substring filter on the head label")
+    ap.add_argument("--json", default=None, help="write the own kernels' rows (launch label, us, GB/s) here")
+    ap.add_argument("--own-only", action="store_true", help="skip the library route (counter runs)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     L_ = _lib.lib()
@@ -47,7 +50,10 @@ def main():
     nl = args.classes
     print("%-18s %-44s %10s %10s %7s" % ("head", "kernel", "us/launch", "GB/s", "frac"))
     rows = []
+    jrows = []
     for label, B, C, sp in HEADS:
+        if args.only and args.only not in label:
+            continue
         g = torch.Generator(device=dev).manual_seed(1)
         x = torch.randn((B, C) + sp, generator=g, device=dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
         w = (torch.randn((nl, C, 1, 1, 1), generator=g, device=dev) * 0.1).requires_grad_(True)
@@ -61,7 +67,7 @@ def main():
             y = graph_ops.conv_own_bias_grad(x, w, b, (1, 1, 1), (0, 0, 0), (1, 1, 1), False, (0, 0, 0), 1)
             torch.autograd.grad(y, (x, w, b), gy)
 
-        t_lib = wall(lib, args.iters)
+        t_lib = 0.0 if args.own_only else wall(lib, args.iters)
         t_own = wall(own, args.iters)
         L_.nextou_profile_enable(8 * args.iters)
         for _ in range(args.iters):
@@ -74,9 +80,12 @@ def main():
             us = r["ms"] / r["launches"] * 1e3
             gbs = r["work"] / r["launches"] / (us * 1e-6) / 1e9
             print("%-18s %-44s %10.1f %10.0f %7.3f" % (label, r["kernel"], us, gbs, gbs / 8000.0))
+            jrows.append({"call": label, "kernel": r["kernel"], "us": us, "achieved": gbs * 1e9, "frac": gbs / 8000.0})
         print("%-18s forward + backward wall: own %.1f us, library route %.1f us" % (label, t_own, t_lib))
         rows.append((label, t_own, t_lib))
     print("\nsum over the five heads: own %.1f us, library route %.1f us" % (sum(r[1] for r in rows), sum(r[2] for r in rows)))
+    if args.json:
+        json.dump(jrows, open(args.json, "w"), indent=1)
 
 
 if __name__ == "__main__":

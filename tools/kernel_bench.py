@@ -157,7 +157,8 @@ def bench_bti(args, dev, L):
 
 
 def bench_mrg(args, dev, L):
-    """K2 + K7 (nextou_mr_grouped_rows) at the cfg-2 stage-2 Swin shape, train and eval variants, against the three launches it replaces."""
+    """K2 + K7 (nextou_mr_grouped_rows) at the cfg-2 stage-2 Swin shape, train and eval variants, against the three launches it replaces;
+    the channel-major K2 + K7 of the pooled graphs (nextou_mr_grouped_cm) at Pool s2 / s3.  --only swin | pool | "pool s2" | "pool s3"."""
     from torch import nn
     from nextou_amd.network_architecture import NexToU_Encoder_Decoder as encdec
     patch, strides = (64, 224, 192), [[1, 1, 1], [1, 2, 2]] + [[2, 2, 2]] * 4
@@ -174,27 +175,46 @@ def bench_mrg(args, dev, L):
     n_, k_ = w.shape[0] // groups, w.shape[1]
     wt = w.reshape(groups, n_, k_).transpose(1, 2).reshape(groups * k_, n_).contiguous()
     print("windows", tuple(windows.shape), "volume", spatial, "window", tuple(window))
+    only = (args.only or "").lower()
+    pools = [p for p in (("pool s2", 132, 10752, 168, 14), ("pool s3", 264, 10752, 1344, 28)) if not only or only in p[0] or only == "pool"]
+    pool_data = []
+    for (_, pc, pn, pm, pk) in pools:      # Pool s2 / s3 of cfg 2: the channel-major K2 + K7 launch (mr_grp_cm_kernel)
+        gp = torch.Generator(device=dev).manual_seed(pc)
+        pool_data.append((torch.randn((2, pc, pn), generator=gp, device=dev), torch.randn((2, pc, pm), generator=gp, device=dev),
+                          torch.randint(0, pm, (2, pn, pk), generator=gp, device=dev, dtype=torch.int32),
+                          torch.randn((2 * pc, 2 * pc // 6), generator=gp, device=dev) * 0.1, pk))
     for it in range(2 + args.iters):
         if it == 2:
             torch.cuda.synchronize()
             L.nextou_profile_enable(64 * args.iters)
-        be.mr_grouped_rows(windows, idx, k, 1, w, groups, B, spatial, window, shift, True, True, True)
-        be.mr_grouped_rows(windows, idx, k, 1, w, groups, B, spatial, window, shift, False, False, True)
-        be.mr_grouped_rows(windows, idx, k, 1, w, groups, B, spatial, window, shift, False, False, False)
-        agg, arg = be.mr_fwd(windows, None, idx, None, k, 1, want_arg=True)
-        a0 = be.window_scatter(agg, None, spatial, window, shift)
-        h0, _ = be.pw_rows_fused(a0, w, groups, want_stats=True)
-        be.mr_grouped_rows_bwd(h0, w, arg, groups, spatial, window, shift)
-        ga = be.pw_rows(h0, wt, None, groups)
-        be.mr_bwd_arg(be.window_gather(ga, window, shift), arg, windows.shape[2], False)
+        if not only or "swin" in only:
+            _, arg, h0, _ = be.mr_grouped_rows(windows, idx, k, 1, w, groups, B, spatial, window, shift, True, True, True)
+            be.mr_grouped_rows_bwd(h0, w, arg, groups, spatial, window, shift)
+            if not only:        # (a counter run wants ONE launch shape per kernel name: --only swin stops here)
+                be.mr_grouped_rows(windows, idx, k, 1, w, groups, B, spatial, window, shift, False, False, True)
+                be.mr_grouped_rows(windows, idx, k, 1, w, groups, B, spatial, window, shift, False, False, False)
+                agg, arg = be.mr_fwd(windows, None, idx, None, k, 1, want_arg=True)
+                a0 = be.window_scatter(agg, None, spatial, window, shift)
+                h0, _ = be.pw_rows_fused(a0, w, groups, want_stats=True)
+                ga = be.pw_rows(h0, wt, None, groups)
+                be.mr_bwd_arg(be.window_gather(ga, window, shift), arg, windows.shape[2], False)
+        for (px, py, pidx, pw, pk) in pool_data:
+            be.mr_grouped_cm(px, py, pidx, pk, 1, pw, 6, True, True, True)        # training: aggregate + arg tape written too
+            if not only:
+                be.mr_grouped_cm(px, py, pidx, pk, 1, pw, 6, False, False, True)  # eval
+                be.mr_fwd(px, py, pidx, None, pk, 1, want_arg=True)               # what it replaces, first launch of three
     torch.cuda.synchronize()
     buf = ctypes.create_string_buffer(1 << 20)
     L.nextou_profile_report(buf, len(buf))
     L.nextou_profile_enable(0)
+    rows = []
     for r in json.loads(buf.value.decode()):
         per_s = r["ms"] / r["launches"] / 1e3
         ach = r["work"] / r["launches"] / per_s
         print("%-70s %8.1f us %8.1f GB/s %5.1f%%  x%d" % (r["kernel"][:70], per_s * 1e6, ach / 1e9, 100 * ach / PEAK[r["bound"]], r["launches"]))
+        rows.append({"call": "mrg", "kernel": r["kernel"], "bound": r["bound"], "us": per_s * 1e6, "achieved": ach, "frac": ach / PEAK[r["bound"]]})
+    if args.json:
+        json.dump(rows, open(args.json, "w"), indent=1)
 
 
 def main():

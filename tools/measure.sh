@@ -10,10 +10,11 @@
 #   trace      rocprofv3 --kernel-trace --stats of the eager cfg-2 step -> one steady-state step as a markdown table
 #   pmc5       PMC FETCH_SIZE / WRITE_SIZE (separate passes) of the graph kernels at the cfg-5 shapes "s2 Swin" and "s3 Pool"
 #   pmcmrg     the same two PMC passes over the K2 + K7 kernel and the three launches it replaces (tools/kernel_bench.py --mrg)
+#   pmcjson    regenerate profiles/pmc_traffic.json (-> <out>/pmc_traffic.json) for the labels that launch today
 #   cpusurvey  bench.py --cpu-protocol survey (batch 2, 1 + 3 steps, all physical cores; ~10 min of host time)
 #   closing    tests margins bench configs stages kernels trace pmc5 pmcmrg in that order
 TASK=${1:-closing}
-TAG=${2:-r04}
+TAG=${2:-r05}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -83,6 +84,28 @@ t_pmcmrg() {
   python $R/tools/pmc_table.py $OUT/pmcmrg/FETCH_SIZE $OUT/pmcmrg/WRITE_SIZE > $OUT/pmcmrg.md 2>&1
   cat $OUT/pmcmrg.md | cut -c1-400
   find $OUT/pmcmrg -name "*.csv" -size +2M -delete
+  cd $R
+}
+t_pmcjson() {
+  # profiles/pmc_traffic.json for the launch labels of today's kernels: two counter passes (FETCH_SIZE, WRITE_SIZE: separate, counters only
+  # with --kernel-trace) + one plain run that writes the labels, per probe; tools/pmc_traffic_json.py pairs label and kernel by name
+  cd /tmp && export TMPDIR=/tmp
+  cp $R/profiles/pmc_traffic.json $OUT/pmc_traffic.json
+  probe() {   # <tag> <command ...>
+    local tag=$1; shift
+    "$@" --json $OUT/pmcjson_$tag.json > $OUT/pmcjson_$tag.log 2>&1 || tail -3 $OUT/pmcjson_$tag.log
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcjson_$tag/$c -o pmc -- "$@" > $OUT/pmcjson_${tag}_$c.log 2>&1 || tail -3 $OUT/pmcjson_${tag}_$c.log
+    done
+    python $R/tools/pmc_traffic_json.py --labels $OUT/pmcjson_$tag.json --fetch $OUT/pmcjson_$tag/FETCH_SIZE --write $OUT/pmcjson_$tag/WRITE_SIZE \
+        --merge $OUT/pmc_traffic.json --drop "knn_fused_kernel<28,2>" "knn_fused_kernel<7,6>" | cut -c1-200
+    find $OUT/pmcjson_$tag -name "*.csv" -size +2M -delete
+  }
+  probe s3pool python $R/tools/kernel_bench.py --cfg 2 --iters 3 --only "s3 Pool"
+  probe s2swin python $R/tools/kernel_bench.py --cfg 2 --iters 3 --only "s2 Swin"
+  probe mrgswin python $R/tools/kernel_bench.py --mrg --iters 3 --only swin
+  probe mrgpool3 python $R/tools/kernel_bench.py --mrg --iters 3 --only "pool s3"
+  probe head python $R/tools/head_bench.py --iters 3 --own-only --only "full res"
   cd $R
 }
 t_cpusurvey() {
