@@ -618,7 +618,6 @@ __global__ __launch_bounds__(G == 2 ? 768 : 384) void knn_window_kernel(const fl
     const int m_end = min(m_begin + TM, N);
     const int mw_begin = m_begin + gq * 32 * TILES;          // this wave's candidates
     const bool vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
-    const int w4 = W / 4;
     // stagger (bits 8+ of `ablate`, microseconds): the workgroups that take the SECOND slot of a CU (ids 256 ... 511 of the first wave of
     // dispatches) start late, so that co-resident workgroups run different phases instead of the same ones in lockstep
     if (const int stagger_us = ablate >> 8) {
@@ -907,6 +906,61 @@ __device__ __forceinline__ unsigned long long knn_key(float d, int m) {
     return ((unsigned long long)u << 32) | (unsigned int)m;
 }
 
+// Round 5: the merge as a TOURNAMENT of list heads.  Both kernels above rank every partial entry by binary searches through the other
+// S - 1 lists — (S - 1) log2 K dependent LDS / global probes per entry: 63 us for the 2 688 rows of cfg 2's stage-4 pooled graph
+// (S = 11, K = 32: a 7.5 MB problem), 40 us at Pool s3 — pure latency.  Here 16 lanes own a row, lane l walks list l (the lists
+// are sorted, so the K best overall are K pops of the smallest head): a 64-bit (distance, index) key per head (knn_key: the
+// (dist, index) order, -0 == +0), the minimum over the 16 lanes by four DPP steps, the one lane that holds it advances.  K
+// sequential steps per row, but four rows per wave and every row of the problem in flight at once.  Same result as the rank merge
+// (keys are unique: every candidate lives in exactly one list).  grid = ceil(rows / 16); LDS = 16 rows x S x K keys.
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    return o < v ? o : v;
+}
+
+__global__ __launch_bounds__(256) void knn_merge_heads_kernel(const float* __restrict__ part_d, const int32_t* __restrict__ part_i,
+                                                              int32_t* __restrict__ out, long long rows, int S, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long merge_keys[];
+    const int per_row = S * K;
+    const long long row0 = (long long)blockIdx.x * 16;
+    const long long left = rows - row0;
+    const int nrows = left < 16 ? (int)left : 16;
+    const int total = nrows * per_row;
+    const size_t base = (size_t)row0 * per_row;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int i = part_i[base + e];
+        merge_keys[e] = i == kSentinelIdx ? ~0ull : knn_key(part_d[base + e], i);      // (a list shorter than K ends in sentinels)
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, l = lane & 15;
+    const int r = (threadIdx.x >> 6) * 4 + (lane >> 4);
+    const bool walks = r < nrows && l < S;
+    const unsigned long long* lk = merge_keys + (size_t)(walks ? r : 0) * per_row + (walks ? l : 0) * K;
+    int pos = 0;
+    unsigned long long head = walks ? lk[0] : ~0ull;
+    int res0 = 0, res1 = 0;
+    for (int k = 0; k < K; ++k) {
+        unsigned long long m = head;
+        m = dpp_min_u64<0xB1>(m);      // quad_perm [1,0,3,2]
+        m = dpp_min_u64<0x4E>(m);      // quad_perm [2,3,0,1]
+        m = dpp_min_u64<0x141>(m);     // row_half_mirror
+        m = dpp_min_u64<0x140>(m);     // row_mirror
+        if (walks && head == m && m != ~0ull) {
+            ++pos;
+            head = pos < K ? lk[pos] : ~0ull;
+        }
+        if (l == (k & 15)) { if (k < 16) res0 = (int)(unsigned)m; else res1 = (int)(unsigned)m; }
+    }
+    if (r < nrows) {
+        int32_t* o = out + (size_t)(row0 + r) * K;
+        if (l < K) o[l] = res0;
+        if (16 + l < K) o[16 + l] = res1;
+    }
+}
+
 __global__ __launch_bounds__(256) void knn_select_naive_kernel(const float* __restrict__ dist,
                                                                int32_t* __restrict__ out,
                                                                long long rows, int M, int K) {
@@ -1141,7 +1195,14 @@ static int launch_merge(const FusedArgs& a, int splits, hipStream_t s) {
     // LDS-staged merge for up to 4 partial lists (cfg-2 Pool s3 53.9 -> 41.9 us, Swin / Pool s4-s5 9 -> 7 us, cfg-5 S = 2
     // 37 -> 32 us); with 6-11 lists it is level or behind the global one (64 -> 81 us at S = 11 on 2 688 rows, 108 -> 88 us
     // on 6 144): profiles/r03_k1_prep_merge.md.  NEXTOU_KNN_MERGE=v1 / lds forces one of them.
-    static const int merge_mode = [] { const char* e = getenv("NEXTOU_KNN_MERGE"); return !e ? 0 : (e[0] == 'v' ? 1 : 2); }();
+    static const int merge_mode = [] { const char* e = getenv("NEXTOU_KNN_MERGE"); return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'l' ? 2 : 0)); }();
+    // Round 5 default: the tournament of list heads (knn_merge_heads_kernel) for every split count (S <= 16 = kMaxSplits lanes of a
+    // row group, K <= 32); NEXTOU_KNN_MERGE=v1 / lds keep the two rank merges for A/B
+    if (merge_mode == 0 && splits <= 16 && a.K <= 32 && (size_t)16 * splits * a.K * 8 <= 64 * 1024) {
+        hipLaunchKernelGGL(knn_merge_heads_kernel, dim3((unsigned)cdiv64(rows, 16)), dim3(256), (size_t)16 * splits * a.K * 8, s, a.part_d,
+                           a.part_i, a.out, rows, splits, a.K);
+        return check_launch("knn_merge_heads_kernel");
+    }
     if (merge_mode == 1 || (merge_mode == 0 && splits > 4)) {
         hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)cdiv64(rows * splits * a.K, 256)), dim3(256), 0, s,
                            a.part_d, a.part_i, a.out, rows, splits, a.K);

@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(256) void mr_grp_cm_kernel(const float* __restrict_
                     if (c + 1 >= Cg) v.y = 0.f;
                     if (c + 2 >= Cg) v.z = 0.f;
                     if (c + 3 >= Cg) v.w = 0.f;
-                    reinterpret_cast<f32x4*>(cm_tile4)[m * QC + q] = v;
+                    reinterpret_cast<f32x4*>(cm_tile4)[q * M + m] = v;      // quad-major: random ids of one quad spread over ALL banks
                 }
             }
         }
@@ -1391,7 +1391,7 @@ __global__ __launch_bounds__(256) void mr_grp_cm_kernel(const float* __restrict_
             for (int j0 = 0; j0 < KT; j0 += 8) {                // eight gathers in flight
                 f32x4 sv[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sv[u] = t4[id[j0 + u] * (unsigned)QC + q];
+                for (int u = 0; u < 8; ++u) sv[u] = t4[(unsigned)q * (unsigned)M + id[j0 + u]];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int j = j0 + u;
@@ -1533,6 +1533,12 @@ static CmPlan plan_mr_grp_cm(int B, int C, int groups, int Ng, int N, int M, int
     int qc = (int)std::min<size_t>((size_t)Q, room_f4 / (size_t)M);
     if (qc < 1) return q;
     qc = cdiv(Q, cdiv(Q, qc));                                // even chunks
+    // Measured crossover (profiles/r05_pool_fused.md): when the group's source does not fit LDS in one piece (cfg 2 Pool s3: M = 1 344
+    // x 44 channels = 236 KB) every workgroup streams it in chunks, two barriers and a latency-bound staging round each, at 8 waves per
+    // CU — 228 us against 89 us for mr_fwd_qb (which spreads the quads over workgroups) + BLAS GEMM + K6 statistics.  The launch is
+    // therefore taken for single-chunk shapes only; NEXTOU_MR_GROUPED_CM_CHUNKS=1 lifts the rule (tests, A/B).
+    const char* ce = getenv("NEXTOU_MR_GROUPED_CM_CHUNKS");
+    if (qc < Q && !(ce && ce[0] == '1')) return q;
     q.qc = qc;
     q.tile_f4 = (int)std::max<size_t>((size_t)M * qc, fixed_f4);
     q.lds = (size_t)q.tile_f4 * 16 + slab + ids;

@@ -26,11 +26,13 @@ def _every_shape(monkeypatch):
     """the product takes the launch only from a workgroup per CU on (NEXTOU_MR_GROUPED_CM_MIN_WORKGROUPS = 256, a measured crossover):
     the tests want it at every size"""
     monkeypatch.setenv("NEXTOU_MR_GROUPED_CM_MIN_WORKGROUPS", "0")
+    monkeypatch.setenv("NEXTOU_MR_GROUPED_CM_CHUNKS", "1")          # ... and for sources that stream through LDS in chunks
 
 
 def _ops():
     import os
     os.environ["NEXTOU_MR_GROUPED_CM_MIN_WORKGROUPS"] = "0"          # (hypothesis bodies run outside function-scoped fixtures)
+    os.environ["NEXTOU_MR_GROUPED_CM_CHUNKS"] = "1"
     from nextou_amd import graph_ops
     return graph_ops
 
@@ -144,8 +146,11 @@ def test_pooled_mrconv_any_shape(B, cg, groups, N, M, K, seed):
 
 
 def test_pooled_mrconv_is_taken_from_a_workgroup_per_cu_on(ops, monkeypatch):
-    """the default crossover: cfg 2's Pool s2 / s3 shapes (1 008 workgroups) take the launch, s4 (132) and s5 (12) keep the three launches"""
+    """the default, measured crossovers: cfg 2's Pool s2 shape (1 008 workgroups, the group's source in LDS in one piece) takes the launch;
+    s3 (the source streams in chunks), s4 (132 workgroups) and s5 (12) keep the three launches"""
     monkeypatch.delenv("NEXTOU_MR_GROUPED_CM_MIN_WORKGROUPS")
+    monkeypatch.delenv("NEXTOU_MR_GROUPED_CM_CHUNKS")
     be = ops._HIP
-    assert be.mr_grouped_cm_tiles(2, 132, 6, 44, 10752, 168, 14) == 84 and be.mr_grouped_cm_tiles(2, 264, 6, 88, 10752, 1344, 28) == 84
+    assert be.mr_grouped_cm_tiles(2, 132, 6, 44, 10752, 168, 14) == 84
+    assert be.mr_grouped_cm_tiles(2, 264, 6, 88, 10752, 1344, 28) == 0
     assert be.mr_grouped_cm_tiles(2, 324, 6, 108, 1344, 1344, 32) == 0 and be.mr_grouped_cm_tiles(2, 324, 6, 108, 168, 168, 32) == 0
