@@ -9,6 +9,7 @@
 // which is one pass over the label volume.  HBM-bound: 1 B read + 1 B written per voxel for the
 // map, 4*L B per voxel for the arg-max that produces the labels.
 #include "common.h"
+#include <cstdlib>
 
 namespace nextou {
 
@@ -232,7 +233,7 @@ constexpr int kCritTX = 64, kCritTY = 8, kCritTZ = 14, kCritG = 4;     // TZ + 2
 template <int R, bool BOX>
 __global__ __launch_bounds__(256) void bti_critical_kernel(const uint8_t* __restrict__ labels, const uint32_t* __restrict__ lut_a,
                                                           const uint32_t* __restrict__ lut_c, int n_labels,
-                                                          uint8_t* __restrict__ critical, int D, int H, int W, int z_chunks) {
+                                                          uint8_t* __restrict__ critical, int D, int H, int W, int z_chunks, int tz) {
     constexpr int HX = kCritTX + 2 * R, HY = kCritTY + 2 * R;
     __shared__ uint2 lut[256];
     __shared__ uint2 M[HY][HX];              // masks of the halo plane
@@ -240,8 +241,8 @@ __global__ __launch_bounds__(256) void bti_critical_kernel(const uint8_t* __rest
     const int tid = threadIdx.x;
     for (int i = tid; i < 256; i += 256) lut[i] = i < n_labels ? make_uint2(lut_a[i], lut_c[i]) : make_uint2(0u, 0u);
     const int b = blockIdx.z / z_chunks, zc = blockIdx.z - b * z_chunks;
-    const int x0 = blockIdx.x * kCritTX, y0 = blockIdx.y * kCritTY, z0 = zc * kCritTZ;
-    const int z1 = min(D, z0 + kCritTZ);
+    const int x0 = blockIdx.x * kCritTX, y0 = blockIdx.y * kCritTY, z0 = zc * tz;
+    const int z1 = min(D, z0 + tz);
     const long long HW = (long long)H * W;
     const uint8_t* lb = labels + (size_t)b * HW * D;
     uint8_t* cb = critical + (size_t)b * HW * D;
@@ -887,7 +888,17 @@ extern "C" int nextou_bti_critical_map(const uint8_t* labels, const uint32_t* lu
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(s, kBoundHbm, 2.0 * B * (double)V, "bti_critical_kernel[B%d %dx%dx%d c%d]", B, D, H, W, connectivity);
     const int rad = full_box ? min_thick : 1;
-    const int z_chunks = cdiv(D, kCritTZ);
+    // depth per workgroup: kCritTZ planes for volumes that fill the chip; a low-resolution deep-supervision scale (cfg 4: 32x56x48 and
+    // smaller, a few dozen workgroups) is a chain of tz + 2R dependent plane steps (~1 us each: 17-19 us whatever the volume, round 4's
+    // floor) — shorter columns (6, then 2 planes) trade a little halo work for a chain of 8 / 4 steps on 3-7x the workgroups
+    int tz = kCritTZ;
+    {
+        const long long per_z = (long long)cdiv(W, kCritTX) * cdiv(H, kCritTY) * B;
+        if (per_z * cdiv(D, tz) < 512) tz = 6;
+        if (per_z * cdiv(D, tz) < 512) tz = 2;
+        if (const char* e = getenv("NEXTOU_BTI_TZ")) { const int v = atoi(e); if (v >= 1 && v <= kCritTZ) tz = v; }      // experiments
+    }
+    const int z_chunks = cdiv(D, tz);
     const dim3 grid(cdiv(W, kCritTX), cdiv(H, kCritTY), (unsigned)(B * z_chunks));
     if (rad > 3 || (long long)B * z_chunks > 65535 || cdiv(H, kCritTY) > 65535) {
         hipLaunchKernelGGL(bti_critical_naive_kernel, dim3((unsigned)cdiv64(V, 256), 1, B), dim3(256), 0, s, labels, lut_a, lut_c, n_labels,
@@ -895,7 +906,7 @@ extern "C" int nextou_bti_critical_map(const uint8_t* labels, const uint32_t* lu
         return check_launch("bti_critical_naive_kernel");
     }
 #define NEXTOU_CRIT(R_, BOX_)                                                                                                      \
-    hipLaunchKernelGGL((bti_critical_kernel<R_, BOX_>), grid, dim3(256), 0, s, labels, lut_a, lut_c, n_labels, critical, D, H, W, z_chunks)
+    hipLaunchKernelGGL((bti_critical_kernel<R_, BOX_>), grid, dim3(256), 0, s, labels, lut_a, lut_c, n_labels, critical, D, H, W, z_chunks, tz)
     if (!full_box) NEXTOU_CRIT(1, false);
     else if (rad == 1) NEXTOU_CRIT(1, true);
     else if (rad == 2) NEXTOU_CRIT(2, true);

@@ -11,6 +11,9 @@
 #   pmc5       PMC FETCH_SIZE / WRITE_SIZE (separate passes) of the graph kernels at the cfg-5 shapes "s2 Swin" and "s3 Pool"
 #   pmcmrg     the same two PMC passes over the K2 + K7 kernel and the three launches it replaces (tools/kernel_bench.py --mrg)
 #   pmcjson    regenerate profiles/pmc_traffic.json (-> <out>/pmc_traffic.json) for the labels that launch today
+#   convtable  per-layer table of the library convolutions at the model's own routing (tools/conv_layer_table.py)
+#   heads      K8 against the library route at the cfg-2 head shapes
+#   repro      the guard-page reproducer of MIOpen's backward-data over-read (+ K8 on the same operands)
 #   cpusurvey  bench.py --cpu-protocol survey (batch 2, 1 + 3 steps, all physical cores; ~10 min of host time)
 #   closing    tests margins bench configs stages kernels trace pmc5 pmcmrg in that order
 TASK=${1:-closing}
@@ -29,8 +32,8 @@ t_tests() {
   (grep -E "^(FAILED|ERROR)|^E  " $OUT/pytest_gpu_full_log.txt | cut -c1-400 | head -60; tail -26 $OUT/pytest_gpu_full_log.txt) > $OUT/pytest_gpu_full.txt; tail -4 $OUT/pytest_gpu_full.txt
 }
 t_margins() {
-  python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity2.py tests/test_gpu_fused_goldens.py -q -s -m gpu \
-      -k "tiny_models or forward_parity or equal_conv" 2>&1 | grep -E "max \|dlogit\||teacher-forced|full-size forward|equal \(fp64\)|passed|failed" > $OUT/parity_margins.txt
+  python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity2.py tests/test_gpu_fused_goldens.py tests/test_gpu_parity_r5.py -q -s -m gpu \
+      -k "tiny_models or forward_parity or equal_conv or reference_state_dict or reduced_precision or graph_stack or batch2" 2>&1 | grep -E "max \|dlogit\||mean \|dlogit\||teacher-forced|full-size forward|equal \(fp64\)|passed|failed" > $OUT/parity_margins.txt
   cat $OUT/parity_margins.txt
 }
 t_bench() {
@@ -108,12 +111,21 @@ t_pmcjson() {
   probe head python $R/tools/head_bench.py --iters 3 --own-only --only "full res"
   cd $R
 }
+t_convtable() {
+  python tools/conv_layer_table.py --iters 5 --md $OUT/conv_layer_table.md > $OUT/conv_layer_table.log 2>&1; tail -3 $OUT/conv_layer_table.md | cut -c1-300
+}
+t_heads() {
+  python tools/head_bench.py 2>&1 | grep -v "GridwiseOp\|amdgpu.ids\|MIOpen" > $OUT/head_bench.txt; tail -1 $OUT/head_bench.txt
+}
+t_repro() {
+  python tools/conv_bwd_fault_repro.py --own --repeat 3 --log-dir $OUT/repro_logs 2>&1 | cut -c1-420 > $OUT/conv_bwd_fault_repro.txt; tail -20 $OUT/conv_bwd_fault_repro.txt | cut -c1-160
+}
 t_cpusurvey() {
   python bench.py --steps 5 --warmup 3 --cpu-protocol survey > $OUT/bench_cfg2_cpu_survey.json 2> $OUT/bench_cfg2_cpu_survey.log
   python -c "import json;d=json.load(open('$OUT/bench_cfg2_cpu_survey.json'));print(d['cpu_baseline'])"
 }
 case $TASK in
-  closing) for t in tests margins bench configs stages kernels trace pmc5 pmcmrg; do echo "== $t"; t_$t; done ;;
+  closing) for t in tests margins bench configs stages kernels heads trace convtable pmcjson repro; do echo "== $t"; t_$t; done ;;
   *) for t in ${TASK//,/ }; do echo "== $t"; t_$t; done ;;
 esac
 du -sh $OUT | tail -1
