@@ -39,11 +39,13 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // --------------------------------------------------------------------------------------------
 // NORMALIZE = false: inputs are used as they are (dense_knn_matrix / *_pairwise_distance called
 // directly, torch_edge.py:58-110 do not normalise); only the squared norms are produced.
-template <bool NORMALIZE>
+// U = loads in flight per lane (the fma chain itself stays strictly c-ordered whatever U): 16 when the grid fills the chip; 64 for the
+// few-hundred-point graphs of stages 4 / 5 (B' x N <= 8 192: one or two waves per CU), where the kernel is nothing but 2 C / U dependent
+// round trips to memory — 22-27 us at C = 324 with U = 16 (round 5)
+template <bool NORMALIZE, int U>
 __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__ x,
                                                        float* __restrict__ xn,
                                                        float* __restrict__ sq, int C, int N) {
-    constexpr int U = 16;  // loads in flight per lane; the fma chain itself stays strictly c-ordered
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (n >= N) return;
@@ -1128,10 +1130,14 @@ static int launch_prep(const float* x, float* xn, float* sq, int B, int C, int N
     // reads x twice (second pass L2-hot: counted once), writes xn and the norms
     ProfScope prof(s, kBoundHbm, 4.0 * B * (double)N * ((normalize ? 2.0 : 1.0) * C + 1), "knn_prep_kernel[B%d C%d N%d]",
                    B, C, N);
-    if (normalize)
-        hipLaunchKernelGGL(knn_prep_kernel<true>, dim3(cdiv(N, 256), B), dim3(256), 0, s, x, xn, sq, C, N);
-    else
-        hipLaunchKernelGGL(knn_prep_kernel<false>, dim3(cdiv(N, 256), B), dim3(256), 0, s, x, xn, sq, C, N);
+    const bool small = (long long)B * N <= 8192;
+    if (normalize) {
+        if (small) hipLaunchKernelGGL((knn_prep_kernel<true, 64>), dim3(cdiv(N, 64), B), dim3(64), 0, s, x, xn, sq, C, N);
+        else hipLaunchKernelGGL((knn_prep_kernel<true, 16>), dim3(cdiv(N, 256), B), dim3(256), 0, s, x, xn, sq, C, N);
+    } else {
+        if (small) hipLaunchKernelGGL((knn_prep_kernel<false, 64>), dim3(cdiv(N, 64), B), dim3(64), 0, s, x, xn, sq, C, N);
+        else hipLaunchKernelGGL((knn_prep_kernel<false, 16>), dim3(cdiv(N, 256), B), dim3(256), 0, s, x, xn, sq, C, N);
+    }
     return check_launch("knn_prep_kernel");
 }
 

@@ -178,6 +178,7 @@ def bench_mrg(args, dev, L):
     only = (args.only or "").lower()
     pools = [p for p in (("pool s2", 132, 10752, 168, 14), ("pool s3", 264, 10752, 1344, 28)) if not only or only in p[0] or only == "pool"]
     pool_data = []
+    pools = [p for p in pools if be.mr_grouped_cm_tiles(2, p[1], 6, 2 * p[1] // 6, p[2], p[3], p[4]) > 0]     # (Pool s3 streams its source in chunks: not taken by default)
     for (_, pc, pn, pm, pk) in pools:      # Pool s2 / s3 of cfg 2: the channel-major K2 + K7 launch (mr_grp_cm_kernel)
         gp = torch.Generator(device=dev).manual_seed(pc)
         pool_data.append((torch.randn((2, pc, pn), generator=gp, device=dev), torch.randn((2, pc, pm), generator=gp, device=dev),

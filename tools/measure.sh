@@ -107,7 +107,7 @@ t_pmcjson() {
   probe s3pool python $R/tools/kernel_bench.py --cfg 2 --iters 3 --only "s3 Pool"
   probe s2swin python $R/tools/kernel_bench.py --cfg 2 --iters 3 --only "s2 Swin"
   probe mrgswin python $R/tools/kernel_bench.py --mrg --iters 3 --only swin
-  probe mrgpool3 python $R/tools/kernel_bench.py --mrg --iters 3 --only "pool s3"
+  probe mrgpool2 python $R/tools/kernel_bench.py --mrg --iters 3 --only "pool s2"
   probe head python $R/tools/head_bench.py --iters 3 --own-only --only "full res"
   cd $R
 }
