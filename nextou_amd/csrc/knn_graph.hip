@@ -1057,10 +1057,14 @@ static FusedPlan plan_fused(int B, int N, int M, int K, bool self = false) {
     p.splits = cdiv(chunks, chunks_per_split);
     p.m_per_split = chunks_per_split * tm;
     p.ks = (waves * p.splits < 2048) ? 64 : 32;
+    // (round 5: 128-channel slabs for the handful-of-workgroups launches of stages 4 / 5 — half the staging round trips — measured: no
+    // change, 72.0 / 95.7 us either way; NEXTOU_KNN_KS=128 keeps the experiment, launch_fused raises the LDS limit for it)
     if (const char* e = getenv("NEXTOU_KNN_KS")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) p.ks = v; }                    // experiments
-    // default dynamic-LDS limit; a self window covered by one workgroup stages ONE slab for both MFMA operands (launch_fused)
+    // a self window covered by one workgroup stages ONE slab for both MFMA operands (launch_fused)
     const bool one_slab = self && p.splits == 1 && N <= tm && 32 * p.nw == tm;
-    if ((size_t)p.ks * (one_slab ? tm : tm + 32 * p.nw) * sizeof(float) > 64 * 1024) p.ks = 32;
+    const size_t per_k = (size_t)(one_slab ? tm : tm + 32 * p.nw) * sizeof(float);
+    if (p.ks == 128 && p.ks * per_k > 150 * 1024) p.ks = 64;
+    if (p.ks == 64 && p.ks * per_k > 64 * 1024) p.ks = 32;          // (the default dynamic-LDS limit for everything but the tiny grids)
     return p;
 }
 
@@ -1265,6 +1269,9 @@ static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
         // algorithmic work of the distance contraction: 2*B*N*M*C flops
         ProfScope prof(s, kBoundMfma, 2.0 * a.B * (double)a.N * a.M * a.C,
                        "knn_fused_kernel<%d,%d>[B%d C%d N%d M%d K%d]", KB, TILES, a.B, a.C, a.N, a.M, a.K);
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_fused_kernel<KB, TILES, BITONIC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
         hipLaunchKernelGGL((knn_fused_kernel<KB, TILES, BITONIC>), grid, dim3(64 * p.nw), lds, s, a.xn, a.yn, a.xs, a.ys,
                            a.relpos, a.out, a.part_d, a.part_i, a.C, a.N, a.M, a.K, p.m_per_split, vec_ok, p.ks);
     }

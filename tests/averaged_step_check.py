@@ -8,6 +8,13 @@ With one rank the mean over ranks is the identity, so every gradient must come o
 (bucket copies, the collective launch, the 1/world scale, p.grad pointing into the buckets, the remembered grad-is-None pattern
 of the zero-weighted head) is exactly what is under test.  One JSON line: distances, the eager-vs-eager floor beside them.
 
+The learning rate is ZERO in every run: two PLAIN runs of this tiny random-label network agree to ~1e-7 of the gradient scale in step 1
+(the library's atomics) and then fall into different discrete outcomes — a neighbour or pooling tie decided the other way — that differ by
+1e-3 of the weights one step later (measured: loss 3.55645 vs 3.55720 at step 2, either outcome in any mode), so trained weights cannot be
+compared run to run.  With lr = 0 the weights stay put, every step's gradient must equal step 1's, and the optimizer's MOMENTUM BUFFERS —
+a deterministic function of the gradients it was handed through `p.grad`, i.e. through the bucket views under capture — show that the
+update consumed the right numbers.
+
     python tests/averaged_step_check.py [--backend nccl|gloo] [--workload tiny]
 """
 import argparse
@@ -31,6 +38,8 @@ DEV = torch.device("cuda:0")
 def make(workload, averaged):
     trainer, cfg, batch, classes = bench.build_trainer(workload, DEV, averaged, seed=7)
     bench.move_to(trainer, DEV)
+    for group in trainer.optimizer.param_groups:
+        group["lr"] = 0.0            # see the module docstring
     averager = BucketedGradientAverager(trainer.network, bucket_bytes=1 << 20) if averaged else None     # 1 MiB: several buckets for the tiny net
     data, target = synthetic_batch(cfg, 1, classes, batch, DEV, seed=11)
     targets = downsample_targets(target, bench._head_shapes(cfg))
@@ -48,6 +57,15 @@ def weights(trainer):
     return torch.cat([p.detach().flatten() for p in trainer.network.parameters() if p.requires_grad])
 
 
+def momentum(trainer):
+    bufs = []
+    for p in trainer.network.parameters():
+        st = trainer.optimizer.state.get(p, {})
+        if p.requires_grad and st.get("momentum_buffer") is not None:
+            bufs.append(st["momentum_buffer"].detach().flatten())
+    return torch.cat(bufs)
+
+
 def dist_max(a, b):
     return float((a - b).abs().max())
 
@@ -56,7 +74,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--workload", default="tiny")
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     args = ap.parse_args()
     _lib.lib()
     torch.cuda.set_device(DEV)
@@ -65,7 +83,7 @@ def main():
 
     runs = {}
     for name, averaged, graphed in (("plain_a", False, False), ("plain_b", False, False), ("avg_eager", True, False),
-                                    ("avg_graph", True, True)):
+                                    ("avg_graph", True, True), ("plain_graph", False, True)):
         t, step, averager = make(args.workload, averaged)
         if graphed:
             # step 1 eager, then capture (executes nothing); the replays are steps 2..  — with the default 2 steps the comparison is
@@ -89,7 +107,7 @@ def main():
         if averager is not None:
             averager.check_consistency()
             averager.remove_hooks()
-        runs[name] = {"first": first, "last": g_last, "none": none_last, "w": weights(t), "loss": float(loss.detach()),
+        runs[name] = {"first": first, "last": g_last, "none": none_last, "w": weights(t), "m": momentum(t), "loss": float(loss.detach()),
                       "buckets": None if averager is None else len(averager.buckets)}
     scale_g = float(runs["plain_a"]["last"].abs().max())
     out = {
@@ -102,17 +120,22 @@ def main():
         # step 1: same weights, same batch -> the gradients themselves
         "grad1_plain_vs_plain": dist_max(runs["plain_a"]["first"][0], runs["plain_b"]["first"][0]),
         "grad1_avg_eager_vs_plain": dist_max(runs["avg_eager"]["first"][0], runs["plain_a"]["first"][0]),
-        # after `steps` steps: gradients of the last step and the weights
+        # last step (lr = 0: still the same weights): gradients and the optimizer's momentum buffers
         "grad_plain_vs_plain": dist_max(runs["plain_a"]["last"], runs["plain_b"]["last"]),
         "grad_avg_eager_vs_plain": min(dist_max(runs["avg_eager"]["last"], runs[k]["last"]) for k in ("plain_a", "plain_b")),
         "grad_avg_graph_vs_plain": min(dist_max(runs["avg_graph"]["last"], runs[k]["last"]) for k in ("plain_a", "plain_b")),
-        "weights_plain_vs_plain": dist_max(runs["plain_a"]["w"], runs["plain_b"]["w"]),
-        "weights_avg_eager_vs_plain": min(dist_max(runs["avg_eager"]["w"], runs[k]["w"]) for k in ("plain_a", "plain_b")),
-        "weights_avg_graph_vs_plain": min(dist_max(runs["avg_graph"]["w"], runs[k]["w"]) for k in ("plain_a", "plain_b")),
+        "grad_plain_graph_vs_plain": min(dist_max(runs["plain_graph"]["last"], runs[k]["last"]) for k in ("plain_a", "plain_b")),
+        "momentum_scale": float(runs["plain_a"]["m"].abs().max()),
+        "momentum_plain_vs_plain": dist_max(runs["plain_a"]["m"], runs["plain_b"]["m"]),
+        "momentum_avg_eager_vs_plain": min(dist_max(runs["avg_eager"]["m"], runs[k]["m"]) for k in ("plain_a", "plain_b")),
+        "momentum_avg_graph_vs_plain": min(dist_max(runs["avg_graph"]["m"], runs[k]["m"]) for k in ("plain_a", "plain_b")),
+        "momentum_plain_graph_vs_plain": min(dist_max(runs["plain_graph"]["m"], runs[k]["m"]) for k in ("plain_a", "plain_b")),
+        "weights_moved": max(dist_max(runs[k]["w"], runs["plain_a"]["w"]) for k in runs),
         "loss": {k: v["loss"] for k, v in runs.items()},
     }
-    print(json.dumps(out))
     dist.destroy_process_group()
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)       # (the last line: RCCL prints its banner when the communicator comes up, not after)
 
 
 if __name__ == "__main__":

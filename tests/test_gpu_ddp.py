@@ -23,25 +23,24 @@ def _json_line(stdout):
 
 @pytest.mark.timeout(1800)
 def test_averaged_step_over_rccl_matches_plain_step():
-    """World-size-1 RCCL group: the averaged step's gradients (step 1: same weights, same batch; step 2: after one update) and the weights
-    after 2 steps equal the plain step's — bit for bit when two plain runs agree bit for bit, else within 4x their distance (two PLAIN
-    runs of this tiny random-label network drift apart by ~1e-7 of the gradient scale in step 1 and by orders of magnitude more a few
-    steps later, which is why the comparison stops at step 2); the zero-weighted head's parameters keep grad = None in all three modes;
-    eager and hipGraph-replayed."""
+    """World-size-1 RCCL group, learning rate 0 (tests/averaged_step_check.py says why): after three steps — eager, and one eager + two
+    replayed — the averaged step's gradients and the optimizer's momentum buffers (what it was handed through `p.grad`, i.e. the bucket
+    views) equal the plain step's: bit for bit when two plain runs agree bit for bit, else within 4x their distance; the zero-weighted
+    head's parameters keep grad = None in every mode; the weights did not move."""
     proc = subprocess.run([sys.executable, os.path.join(REPO, "tests", "averaged_step_check.py"), "--backend", "nccl"],
                           capture_output=True, text=True, timeout=1500)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
     r = _json_line(proc.stdout)
     print(r)
-    assert r["hip_library_loaded"] and r["backend"] == "nccl" and r["world_size"] == 1 and r["buckets"] >= 2
+    assert r["hip_library_loaded"] and r["backend"] == "nccl" and r["world_size"] == 1 and r["buckets"] >= 2 and r["steps"] == 3
     assert r["grad_is_none_plain"] == r["grad_is_none_avg_eager"] == r["grad_is_none_avg_graph"]
     assert len(r["grad_is_none_plain"]) > 0          # the lowest-resolution head has weight 0 in the deep-supervision loss
-    tiny = 1e-6 * r["grad_scale"]
-    assert r["grad1_avg_eager_vs_plain"] <= max(4.0 * r["grad1_plain_vs_plain"], tiny), r
-    assert r["grad_avg_eager_vs_plain"] <= max(4.0 * r["grad_plain_vs_plain"], 10 * tiny), r
-    assert r["grad_avg_graph_vs_plain"] <= max(4.0 * r["grad_plain_vs_plain"], 10 * tiny), r
-    assert r["weights_avg_eager_vs_plain"] <= max(4.0 * r["weights_plain_vs_plain"], 1e-6), r
-    assert r["weights_avg_graph_vs_plain"] <= max(4.0 * r["weights_plain_vs_plain"], 1e-6), r
+    assert r["weights_moved"] == 0.0
+    tiny_g, tiny_m = 2e-6 * r["grad_scale"], 2e-6 * r["momentum_scale"]
+    assert r["grad1_avg_eager_vs_plain"] <= max(4.0 * r["grad1_plain_vs_plain"], tiny_g), r
+    for mode in ("avg_eager", "avg_graph", "plain_graph"):
+        assert r["grad_%s_vs_plain" % mode] <= max(4.0 * r["grad_plain_vs_plain"], tiny_g), (mode, r)
+        assert r["momentum_%s_vs_plain" % mode] <= max(4.0 * r["momentum_plain_vs_plain"], tiny_m), (mode, r)
 
 
 @pytest.mark.timeout(1800)
