@@ -661,6 +661,162 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// pw_rows, K-SPLIT stationary weights (round 5): the K = 528 direction of the stage-2 FFN (fc2 forward 528 -> 132 and the data gradient of
+// fc1), which the kernel above cannot hold — 132 x 528 weights are 279 KB, more than a wave's registers — and which therefore ran on the
+// LDS-tiled pw_rows_kernel at 0.53-0.57 of the fp32 MFMA peak (weights re-staged for every tile, two barriers per 16 k).  Here the FOUR
+// waves of a workgroup split K: wave w keeps W[:, 132 w .. 132 w + 131] for all nine 16-channel tiles in registers (297 VGPRs, one
+// wave per SIMD) for the whole launch, the workgroup streams 16-point tiles of x (16 x 528 floats) through a double-buffered LDS slab,
+// every wave multiplies ITS k slice of the tile (297 MFMAs, nine independent accumulators), the four partial products meet in a
+// double-buffered LDS area and are summed in the fixed order (w0 + w1) + (w2 + w3) by threads that own (point, channel quad) pairs laid
+// out so that the 16 points of a quad sit in one DPP row — the statistics epilogue is a row reduction, no extra barrier.  ONE barrier
+// per tile.  x is read once, weights never touch LDS.  Another (fixed) order of the fp32 sum than pw_rows_kernel's: the chain is cut at
+// multiples of 132.  PRO / EPI as above (EPI = 2 is not instantiated: the K = 528 direction never carries it).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kKsPts = 16, kKsK = 4 * kSwSk, kKsLdk = kKsK + 4, kKsTn = 9, kKsN4 = kKsTn * 4;
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) void pw_rows_ks_kernel(const float* __restrict__ X, const float* __restrict__ Wt, float* __restrict__ Y, int P,
+                                                        int N, long ldx, long ldy, int tiles16, PwFuse fz) {
+    constexpr int K = kKsK, LDK = kKsLdk, TN = kKsTn, NCH = kSwNch, SK = kSwSk, ROW4 = K / 4;
+    constexpr int NV = (kKsPts * ROW4 + 255) / 256;                        // float4 per thread per tile (9)
+    extern __shared__ float4 pw_smem4[];
+    float* xs = reinterpret_cast<float*>(pw_smem4);                        // [2][16][LDK]
+    f32x4* red = reinterpret_cast<f32x4*>(xs + 2 * kKsPts * LDK);          // [2][4 waves][16 points][36 quads]
+    float* psc = reinterpret_cast<float*>(red + 2 * 4 * kKsPts * kKsN4);   // PRO: [K] scale, [K] shift
+    float* psh = psc + (PRO ? K : 0);
+    double2* wg_stats = reinterpret_cast<double2*>(psh + (PRO ? K : 0));   // EPI: [144] per-channel (sum, sum of squares) of this workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+
+    // ---- the wave's weights: wreg[j][c] = W[16 j + r16][132 wave + 16 c + 4 kg + {0..3}], wtail[j] = W[..][132 wave + 128 + kg]
+    f32x4 wreg[TN][NCH];
+    float wtail[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = j * 16 + r16;
+        const float* wp = Wt + (long)min(n, N - 1) * K + wave * SK;
+        const bool ok = n < N;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const float4 v = ld4(wp + 16 * c + 4 * kg);
+            wreg[j][c] = ok ? f32x4{v.x, v.y, v.z, v.w} : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        wtail[j] = ok ? wp[16 * NCH + kg] : 0.f;
+    }
+    if constexpr (PRO == 1) {
+        for (int k = tid; k < K; k += 256) { psc[k] = fz.pro_scale[k]; psh[k] = fz.pro_shift[k]; }
+    }
+    if constexpr (EPI != 0) {
+        for (int c = tid; c < TN * 16; c += 256) wg_stats[c] = make_double2(0.0, 0.0);
+    }
+
+    float4 xr[NV];
+    auto load_tile = [&](int tile) __attribute__((always_inline)) {
+        const long p0 = (long)tile * kKsPts;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = min(tid + i * 256, kKsPts * ROW4 - 1), row = f / ROW4, c4 = f - row * ROW4;
+            const long p = min(p0 + row, (long)P - 1);
+            xr[i] = ld4(X + p * ldx + c4 * 4);
+        }
+    };
+    auto store_tile = [&](int buf, int tile) __attribute__((always_inline)) {
+        float* dst = xs + buf * kKsPts * LDK;
+        const long p0 = (long)tile * kKsPts;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + i * 256;
+            if (f < kKsPts * ROW4) {
+                const int row = f / ROW4, c4 = f - row * ROW4;
+                float4 v = xr[i];
+                if constexpr (PRO == 1) {
+                    const float4 sc = *reinterpret_cast<const float4*>(psc + c4 * 4), sh = *reinterpret_cast<const float4*>(psh + c4 * 4);
+                    v = make_float4(leaky_f(fmaf(v.x, sc.x, sh.x), fz.pro_slope), leaky_f(fmaf(v.y, sc.y, sh.y), fz.pro_slope),
+                                    leaky_f(fmaf(v.z, sc.z, sh.z), fz.pro_slope), leaky_f(fmaf(v.w, sc.w, sh.w), fz.pro_slope));
+                }
+                *reinterpret_cast<float4*>(dst + row * LDK + c4 * 4) = keep_if(p0 + row < P, v);
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < tiles16) load_tile(tile);
+    __syncthreads();                                                        // psc / psh / wg_stats visible
+    if (tile < tiles16) store_tile(0, tile);
+    __syncthreads();
+    int buf = 0, rb = 0;
+    const int n4s = N >> 2;
+    for (; tile < tiles16; tile += gridDim.x) {
+        const int next = tile + gridDim.x < tiles16 ? tile + gridDim.x : tile;           // no next tile: a re-read nobody uses
+        load_tile(next);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- this wave's k slice of the tile
+        f32x4 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* base = xs + buf * kKsPts * LDK + r16 * LDK + wave * SK + 4 * kg;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const float4 b = ld4(base + 16 * c);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][c][0], b.x, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][c][1], b.y, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][c][2], b.z, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][c][3], b.w, acc[j], 0, 0, 0);
+        }
+        {
+            const float bt = base[16 * NCH - 3 * kg];                       // column 128 + kg of the slice
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wtail[j], bt, acc[j], 0, 0, 0);
+        }
+        // ---- partial products of (point r16, channels 16 j + 4 kg ..) -> LDS; the next tile -> the other x buffer
+        f32x4* mine = red + ((rb * 4 + wave) * kKsPts + r16) * kKsN4 + kg;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mine[4 * j] = acc[j];
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(buf ^ 1, next);
+        __syncthreads();
+        // ---- (w0 + w1) + (w2 + w3), rows out, statistics: thread = (point tid & 15, quad 16 round + (tid >> 4))
+        const long p = (long)tile * kKsPts + (tid & 15);
+        const f32x4* rbase = red + (rb * 4 * kKsPts + (tid & 15)) * kKsN4;
+#pragma unroll
+        for (int round = 0; round < 3; ++round) {
+            const int n4 = 16 * round + (tid >> 4);
+            if (n4 < n4s) {                                                 // (uniform over a DPP row)
+                const f32x4 a0 = rbase[n4], a1 = rbase[kKsPts * kKsN4 + n4], a2 = rbase[2 * kKsPts * kKsN4 + n4],
+                            a3 = rbase[3 * kKsPts * kKsN4 + n4];
+                f32x4 v = (a0 + a1) + (a2 + a3);
+                if (p < P) *reinterpret_cast<float4*>(Y + p * ldy + 4 * n4) = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (EPI == 1) {
+                    if (p >= P) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    float sm[4], q[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(v[r]); q[r] = row16_sum(v[r] * v[r]); }
+                    if ((tid & 15) == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            double2 t = wg_stats[4 * n4 + r];
+                            t.x += (double)sm[r];
+                            t.y += (double)q[r];
+                            wg_stats[4 * n4 + r] = t;
+                        }
+                    }
+                }
+            }
+        }
+        buf ^= 1;
+        rb ^= 1;
+    }
+    if constexpr (EPI != 0) {
+        __syncthreads();
+        for (int c = tid; c < N; c += 256) fz.partial[(long)c * gridDim.x + blockIdx.x] = wg_stats[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // part[split, n, k] = sum_{p in split} gy[p, n] x[p, k]
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kWgPC = 16;   // points per LDS stage
@@ -1144,6 +1300,33 @@ int dispatch_rows_sw(const SwPlan& q, const float* x, const float* w, float* y, 
     return fail(NEXTOU_EINVAL, "pw_rows_sw: no kernel for plan %d", q.cfg);
 }
 
+// ---- K-split stationary weights (pw_rows_ks_kernel): K = 528, N <= 144, dense rows of x, one group
+struct KsPlan { bool ok; int tiles16, grid; size_t lds; };
+KsPlan plan_rows_ks(int64_t P, int N, int K, int groups, int64_t ldx, bool pro, int epi) {
+    KsPlan q{};
+    const char* env = getenv("NEXTOU_PW_KS");           // read per call (tests / A-B): 0 switches the kernel off
+    if ((env && env[0] == '0') || groups != 1 || K != kKsK || N % 4 != 0 || N > 16 * kKsTn || ldx != K || epi == 2 ||
+        P < 64 * 4 * (int64_t)cu_count())
+        return q;
+    q.tiles16 = (int)((P + kKsPts - 1) / kKsPts);
+    q.grid = q.tiles16 < cu_count() ? q.tiles16 : cu_count();
+    q.lds = ((size_t)2 * kKsPts * kKsLdk + (size_t)2 * 4 * kKsPts * kKsN4 * 4 + (pro ? (size_t)2 * kKsK : 0)) * sizeof(float) +
+            (epi ? (size_t)kKsTn * 16 * sizeof(double2) : 0);
+    q.ok = true;
+    return q;
+}
+
+template <int PRO, int EPI>
+int launch_rows_ks(const KsPlan& q, const float* x, const float* w, float* y, int P, int N, long ldx, long ldy, const PwFuse& fz, hipStream_t s) {
+    static size_t allowed = 0;
+    if (q.lds > allowed) {
+        if (int e = allow_lds(pw_rows_ks_kernel<PRO, EPI>, q.lds)) return e;
+        allowed = q.lds;
+    }
+    hipLaunchKernelGGL((pw_rows_ks_kernel<PRO, EPI>), dim3(q.grid), dim3(256), q.lds, s, x, w, y, P, N, ldx, ldy, q.tiles16, fz);
+    return check_launch("pw_rows_ks_kernel");
+}
+
 template <int PRO, int EPI>
 int dispatch_rows(const RowsPlan& q, const float* x, const float* w, const float* bias, float* y, int P, int N, int K, int groups, long ldx,
                   long ldy, int vec_store, const PwFuse& fz, hipStream_t s) {
@@ -1383,6 +1566,13 @@ extern "C" int nextou_pw_rows(const float* x, const float* w, const float* bias,
             return dispatch_rows_grp<0>(gp, x, w, y, (int)P, N, K, groups, (long)ldx, (long)ldy, nullptr, s);
         }
     }
+    if (bias == nullptr && vec_store) {
+        const KsPlan ks = plan_rows_ks(P, N, K, groups, ldx, false, 0);
+        if (ks.ok) {
+            ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K, "pw_rows_ks_kernel<plain>[P%lld N%d K%d]", (long long)P, N, K);
+            return launch_rows_ks<0, 0>(ks, x, w, y, (int)P, N, (long)ldx, (long)ldy, PwFuse{}, s);
+        }
+    }
     if (bias == nullptr && vec_store && ldx == K) {
         const SwPlan sw = plan_rows_sw(P, N, K, groups, false);
         if (sw.cfg >= 0) {
@@ -1398,7 +1588,7 @@ extern "C" int nextou_pw_rows(const float* x, const float* w, const float* bias,
 // Which kernel a fused launch takes and how many statistics partials per channel it writes — ONE function for the launch and for the
 // size query (the query assumed dense rows and no prologue while the launch re-planned with the caller's strides, so a strided
 // caller of the C-ABI was told the stationary kernel's count and got pw_rows_kernel's many more partials written past its buffer).
-struct FusedChoice { int kind, tiles; GrpPlan gp; SwPlan sw; RowsPlan q; };     // kind: 0 grouped rows, 1 stationary weights, 2 LDS-tiled
+struct FusedChoice { int kind, tiles; GrpPlan gp; SwPlan sw; RowsPlan q; KsPlan ks; };     // kind: 0 grouped rows, 1 stationary weights, 2 LDS-tiled, 3 K-split
 static FusedChoice choose_rows_fused(int64_t P, int N, int K, int groups, int64_t ldx, int64_t ldy, bool pro, int epi) {
     FusedChoice c{};
     c.q = plan_rows((int)P, N, groups);
@@ -1406,6 +1596,8 @@ static FusedChoice choose_rows_fused(int64_t P, int N, int K, int groups, int64_
         c.gp = plan_rows_grp(P, N, K, groups, ldx, ldy);
         if (c.gp.ok) { c.kind = 0; c.tiles = c.gp.grid; return c; }
     }
+    c.ks = plan_rows_ks(P, N, K, groups, ldx, pro, epi);
+    if (c.ks.ok) { c.kind = 3; c.tiles = c.ks.grid; return c; }
     c.sw = ldx == (int64_t)groups * K ? plan_rows_sw(P, N, K, groups, pro) : SwPlan{-1, 0, 0, 0, 0, 0, 0};
     if (c.sw.cfg >= 0) { c.kind = 1; c.tiles = c.sw.grid; return c; }
     c.kind = 2;
@@ -1454,6 +1646,14 @@ extern "C" int nextou_pw_rows_fused(const float* x, const float* w, float* y, in
                        epi == 1 ? "stats" : "plain", (long long)P, N, K, groups);
         if (epi == 1) return dispatch_rows_grp<1>(gp, x, w, y, Pi, N, K, groups, (long)ldx, (long)ldy, fz.partial, s);
         return dispatch_rows_grp<0>(gp, x, w, y, Pi, N, K, groups, (long)ldx, (long)ldy, nullptr, s);
+    }
+    if (ch.kind == 3) {
+        ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K, "pw_rows_ks_kernel<%s%s>[P%lld N%d K%d]", pro ? "norm-act," : "", epi == 1 ? "stats" : "plain",
+                       (long long)P, N, K);
+        if (!pro && epi == 1) return launch_rows_ks<0, 1>(ch.ks, x, w, y, Pi, N, (long)ldx, (long)ldy, fz, s);
+        if (pro && epi == 1) return launch_rows_ks<1, 1>(ch.ks, x, w, y, Pi, N, (long)ldx, (long)ldy, fz, s);
+        if (pro && epi == 0) return launch_rows_ks<1, 0>(ch.ks, x, w, y, Pi, N, (long)ldx, (long)ldy, fz, s);
+        return launch_rows_ks<0, 0>(ch.ks, x, w, y, Pi, N, (long)ldx, (long)ldy, fz, s);
     }
     if (ch.kind == 1) {
         const SwPlan& sw = ch.sw;

@@ -390,6 +390,7 @@ def test_stationary_weights_rows_kernel(ops, monkeypatch, ci, co):
 
     def run(mode):
         monkeypatch.setenv("NEXTOU_PW_SW", mode)
+        monkeypatch.setenv("NEXTOU_PW_KS", "0")         # (round 5's K-split kernel has its own test below)
         L_.nextou_profile_enable(64)
         out = {"plain": hip.pw_rows(x, w, None, 1), "stats": hip.pw_rows_fused(x, w, 1, want_stats=True),
                "pro": hip.pw_rows_fused(x, w, 1, pro=(scale, shift, 0.01)),
@@ -428,6 +429,69 @@ def test_stationary_weights_rows_kernel(ops, monkeypatch, ci, co):
     s = new["stats"][1].sum(1)
     assert torch.allclose(s[:, 0], y64.sum(0), rtol=1e-6, atol=1e-6 * float(y64.abs().sum(0).max()))
     assert torch.allclose(s[:, 1], y64.square().sum(0), rtol=1e-6)
+
+
+@pytest.mark.parametrize("co,sp", [(132, (33, 45, 45)), (132, (16, 64, 66)), (96, (33, 45, 45)), (144, (5, 120, 121))])
+def test_k_split_stationary_weights_rows_kernel(ops, monkeypatch, co, sp):
+    """pw_rows_ks_kernel (K = 528 split over the four waves of a workgroup, weights in registers, x streamed once, partial products summed
+    through LDS; >= 65 536 points) against pw_rows_kernel and the float64 product: fp32 round-off (the k range is cut at multiples of 132);
+    plain, with the statistics epilogue, with the normalise + activate prologue, with both — the four variants agree bit for bit where
+    their arithmetic is the same, the statistics partials describe the float64 sums of the product; ragged and exact point counts,
+    fewer than nine channel tiles; repeated launches bit-identical."""
+    import ctypes
+    import json
+    from nextou_amd import _lib
+    hip = ops._HIP
+    ci = 528
+    gen = torch.Generator().manual_seed(co + sp[0])
+    x = _cl(torch.randn((1, ci) + sp, generator=gen))
+    w = (torch.randn((co, ci), generator=gen) * 0.1).to(DEV)
+    scale = (torch.rand((ci,), generator=gen) + 0.5).to(DEV)
+    shift = (torch.randn((ci,), generator=gen) * 0.2).to(DEV)
+    L_ = _lib.lib()
+
+    def run(ks):
+        monkeypatch.setenv("NEXTOU_PW_KS", ks)
+        monkeypatch.setenv("NEXTOU_PW_SW", "0")
+        L_.nextou_profile_enable(64)
+        out = {"plain": hip.pw_rows(x, w, None, 1), "stats": hip.pw_rows_fused(x, w, 1, want_stats=True),
+               "pro": hip.pw_rows_fused(x, w, 1, pro=(scale, shift, 0.01)),
+               "pro_stats": hip.pw_rows_fused(x, w, 1, pro=(scale, shift, 0.01), want_stats=True)}
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = L_.nextou_profile_report(buf, len(buf))
+        L_.nextou_profile_enable(0)
+        return out, [r["kernel"] for r in json.loads(buf.value[:n].decode())]
+
+    new, names_new = run("1")
+    again, _ = run("1")
+    old, names_old = run("0")
+    assert all(k.startswith("pw_rows_ks_kernel") for k in names_new), names_new
+    assert all(k.startswith("pw_rows_kernel") for k in names_old), names_old
+    assert torch.equal(new["plain"], new["stats"][0]) and torch.equal(new["pro"][0], new["pro_stats"][0])
+    for key in ("plain",):
+        assert torch.equal(new[key], again[key])
+    for key in ("stats", "pro", "pro_stats"):
+        assert torch.equal(new[key][0], again[key][0])
+        if new[key][1] is not None:
+            assert torch.equal(new[key][1], again[key][1])
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, ci)
+    x64, w64 = rows[::97].double(), w.double()
+    mag = x64.abs() @ w64.abs().t()
+    got = new["plain"].permute(0, 2, 3, 4, 1).reshape(-1, co)[::97].double()
+    assert bool(((got - x64 @ w64.t()).abs() <= 6e-7 * mag + 1e-30).all())
+    assert float((new["plain"] - old["plain"]).abs().max()) <= 1e-5 * float(old["plain"].abs().max())
+    a64 = torch.nn.functional.leaky_relu(torch.addcmul(shift.double(), rows[::97].double(), scale.double()), 0.01)
+    gotp = new["pro"][0].permute(0, 2, 3, 4, 1).reshape(-1, co)[::97].double()
+    assert bool(((gotp - a64 @ w64.t()).abs() <= 2e-6 * (a64.abs() @ w64.abs().t()) + 1e-30).all())
+    assert float((new["pro"][0] - old["pro"][0]).abs().max()) <= 1e-5 * float(old["pro"][0].abs().max())
+    for key in ("stats", "pro_stats"):
+        y64 = new[key][0].permute(0, 2, 3, 4, 1).reshape(-1, co).double()
+        sums = new[key][1].sum(1)
+        assert torch.allclose(sums[:, 0], y64.sum(0), rtol=1e-6, atol=1e-6 * float(y64.abs().sum(0).max()))
+        assert torch.allclose(sums[:, 1], y64.square().sum(0), rtol=1e-6)
+        b = old[key][1].sum(1)
+        assert torch.allclose(sums, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
 
 
 @pytest.mark.parametrize("n,k", [(528, 132), (132, 528), (132, 132), (132, 264)])
