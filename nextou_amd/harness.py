@@ -191,7 +191,13 @@ class GraphedTrainStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # With a process group up, RCCL's watchdog THREAD polls the events of in-flight collectives (hipEventQuery) whenever it likes;
+            # under the default "global" capture mode such a call from another thread while this one captures is an error — and it is
+            # raised inside the watchdog, which terminates the process (seen once in three runs of the world-size-1 averaged step:
+            # "operation not permitted when stream is capturing").  "thread_local" restricts the check to the capturing thread.
+            import torch.distributed as dist
+            mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.loss = step_fn()
         except BaseException:
             # a caller that falls back to the eager step (bench.py --graph auto) gets the reference's eager IndexError back: nobody
