@@ -673,12 +673,14 @@ __global__ __launch_bounds__(64 * NW) void pw_rows_sw_kernel(const float* __rest
 // multiples of 132.  PRO / EPI as above (EPI = 2 is not instantiated: the K = 528 direction never carries it).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kKsPts = 16, kKsK = 4 * kSwSk, kKsLdk = kKsK + 4, kKsTn = 9, kKsN4 = kKsTn * 4;
+constexpr int kKsTnw = 3, kKsWaves = 4 * (kKsTn / kKsTnw), kKsThreads = 64 * kKsWaves;      // 12 waves: (k slab 0..3) x (three channel tiles each)
 
 template <int PRO, int EPI>
-__global__ __launch_bounds__(256) void pw_rows_ks_kernel(const float* __restrict__ X, const float* __restrict__ Wt, float* __restrict__ Y, int P,
+__global__ __launch_bounds__(kKsThreads) void pw_rows_ks_kernel(const float* __restrict__ X, const float* __restrict__ Wt, float* __restrict__ Y, int P,
                                                         int N, long ldx, long ldy, int tiles16, PwFuse fz) {
     constexpr int K = kKsK, LDK = kKsLdk, TN = kKsTn, NCH = kSwNch, SK = kSwSk, ROW4 = K / 4;
-    constexpr int NV = (kKsPts * ROW4 + 255) / 256;                        // float4 per thread per tile (9)
+    constexpr int NT = kKsThreads, TNW = kKsTnw;
+    constexpr int NV = (kKsPts * ROW4 + NT - 1) / NT;                      // float4 per thread per tile (3)
     extern __shared__ float4 pw_smem4[];
     float* xs = reinterpret_cast<float*>(pw_smem4);                        // [2][16][LDK]
     f32x4* red = reinterpret_cast<f32x4*>(xs + 2 * kKsPts * LDK);          // [2][4 waves][16 points][36 quads]
@@ -687,14 +689,17 @@ __global__ __launch_bounds__(256) void pw_rows_ks_kernel(const float* __restrict
     double2* wg_stats = reinterpret_cast<double2*>(psh + (PRO ? K : 0));   // EPI: [144] per-channel (sum, sum of squares) of this workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
+    const int ks = wave & 3, j0 = (wave >> 2) * TNW;                       // this wave's k slab and first channel tile
 
-    // ---- the wave's weights: wreg[j][c] = W[16 j + r16][132 wave + 16 c + 4 kg + {0..3}], wtail[j] = W[..][132 wave + 128 + kg]
-    f32x4 wreg[TN][NCH];
-    float wtail[TN];
+    // ---- the wave's weights: wreg[j][c] = W[16 (j0 + j) + r16][132 ks + 16 c + 4 kg + {0..3}], wtail[j] = W[..][132 ks + 128 + kg]
+    // (99 registers: the first version — four waves, nine tiles each, 297 — went over the 256 architectural VGPRs, the compiler parked
+    // weights in AGPRs and paid a v_accvgpr_read in front of 233 of the 297 MFMAs of every tile: 300-400 us)
+    f32x4 wreg[TNW][NCH];
+    float wtail[TNW];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = j * 16 + r16;
-        const float* wp = Wt + (long)min(n, N - 1) * K + wave * SK;
+    for (int j = 0; j < TNW; ++j) {
+        const int n = (j0 + j) * 16 + r16;
+        const float* wp = Wt + (long)min(n, N - 1) * K + ks * SK;
         const bool ok = n < N;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -704,10 +709,10 @@ __global__ __launch_bounds__(256) void pw_rows_ks_kernel(const float* __restrict
         wtail[j] = ok ? wp[16 * NCH + kg] : 0.f;
     }
     if constexpr (PRO == 1) {
-        for (int k = tid; k < K; k += 256) { psc[k] = fz.pro_scale[k]; psh[k] = fz.pro_shift[k]; }
+        for (int k = tid; k < K; k += NT) { psc[k] = fz.pro_scale[k]; psh[k] = fz.pro_shift[k]; }
     }
     if constexpr (EPI != 0) {
-        for (int c = tid; c < TN * 16; c += 256) wg_stats[c] = make_double2(0.0, 0.0);
+        for (int c = tid; c < TN * 16; c += NT) wg_stats[c] = make_double2(0.0, 0.0);
     }
 
     float4 xr[NV];
@@ -715,7 +720,7 @@ __global__ __launch_bounds__(256) void pw_rows_ks_kernel(const float* __restrict
         const long p0 = (long)tile * kKsPts;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int f = min(tid + i * 256, kKsPts * ROW4 - 1), row = f / ROW4, c4 = f - row * ROW4;
+            const int f = min(tid + i * NT, kKsPts * ROW4 - 1), row = f / ROW4, c4 = f - row * ROW4;
             const long p = min(p0 + row, (long)P - 1);
             xr[i] = ld4(X + p * ldx + c4 * 4);
         }
@@ -725,7 +730,7 @@ __global__ __launch_bounds__(256) void pw_rows_ks_kernel(const float* __restrict
         const long p0 = (long)tile * kKsPts;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int f = tid + i * 256;
+            const int f = tid + i * NT;
             if (f < kKsPts * ROW4) {
                 const int row = f / ROW4, c4 = f - row * ROW4;
                 float4 v = xr[i];
@@ -751,40 +756,39 @@ __global__ __launch_bounds__(256) void pw_rows_ks_kernel(const float* __restrict
         load_tile(next);
         __builtin_amdgcn_sched_barrier(0);
         // ---- this wave's k slice of the tile
-        f32x4 acc[TN];
+        f32x4 acc[TNW];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* base = xs + buf * kKsPts * LDK + r16 * LDK + wave * SK + 4 * kg;
+        for (int j = 0; j < TNW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* base = xs + buf * kKsPts * LDK + r16 * LDK + ks * SK + 4 * kg;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const float4 b = ld4(base + 16 * c);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][c][0], b.x, acc[j], 0, 0, 0);
+            for (int j = 0; j < TNW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][c][0], b.x, acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][c][1], b.y, acc[j], 0, 0, 0);
+            for (int j = 0; j < TNW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][c][1], b.y, acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][c][2], b.z, acc[j], 0, 0, 0);
+            for (int j = 0; j < TNW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][c][2], b.z, acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][c][3], b.w, acc[j], 0, 0, 0);
+            for (int j = 0; j < TNW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][c][3], b.w, acc[j], 0, 0, 0);
         }
         {
             const float bt = base[16 * NCH - 3 * kg];                       // column 128 + kg of the slice
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wtail[j], bt, acc[j], 0, 0, 0);
+            for (int j = 0; j < TNW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wtail[j], bt, acc[j], 0, 0, 0);
         }
         // ---- partial products of (point r16, channels 16 j + 4 kg ..) -> LDS; the next tile -> the other x buffer
-        f32x4* mine = red + ((rb * 4 + wave) * kKsPts + r16) * kKsN4 + kg;
+        f32x4* mine = red + ((rb * 4 + ks) * kKsPts + r16) * kKsN4 + 4 * j0 + kg;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) mine[4 * j] = acc[j];
+        for (int j = 0; j < TNW; ++j) mine[4 * j] = acc[j];
         __builtin_amdgcn_sched_barrier(0);
         store_tile(buf ^ 1, next);
         __syncthreads();
-        // ---- (w0 + w1) + (w2 + w3), rows out, statistics: thread = (point tid & 15, quad 16 round + (tid >> 4))
+        // ---- (s0 + s1) + (s2 + s3) over the four k slabs, rows out, statistics: thread = (point tid & 15, quad tid >> 4)
         const long p = (long)tile * kKsPts + (tid & 15);
         const f32x4* rbase = red + (rb * 4 * kKsPts + (tid & 15)) * kKsN4;
-#pragma unroll
-        for (int round = 0; round < 3; ++round) {
-            const int n4 = 16 * round + (tid >> 4);
+        {
+            const int n4 = tid >> 4;
             if (n4 < n4s) {                                                 // (uniform over a DPP row)
                 const f32x4 a0 = rbase[n4], a1 = rbase[kKsPts * kKsN4 + n4], a2 = rbase[2 * kKsPts * kKsN4 + n4],
                             a3 = rbase[3 * kKsPts * kKsN4 + n4];
@@ -812,7 +816,7 @@ __global__ __launch_bounds__(256) void pw_rows_ks_kernel(const float* __restrict
     }
     if constexpr (EPI != 0) {
         __syncthreads();
-        for (int c = tid; c < N; c += 256) fz.partial[(long)c * gridDim.x + blockIdx.x] = wg_stats[c];
+        for (int c = tid; c < N; c += kKsThreads) fz.partial[(long)c * gridDim.x + blockIdx.x] = wg_stats[c];
     }
 }
 
@@ -1323,7 +1327,7 @@ int launch_rows_ks(const KsPlan& q, const float* x, const float* w, float* y, in
         if (int e = allow_lds(pw_rows_ks_kernel<PRO, EPI>, q.lds)) return e;
         allowed = q.lds;
     }
-    hipLaunchKernelGGL((pw_rows_ks_kernel<PRO, EPI>), dim3(q.grid), dim3(256), q.lds, s, x, w, y, P, N, ldx, ldy, q.tiles16, fz);
+    hipLaunchKernelGGL((pw_rows_ks_kernel<PRO, EPI>), dim3(q.grid), dim3(kKsThreads), q.lds, s, x, w, y, P, N, ldx, ldy, q.tiles16, fz);
     return check_launch("pw_rows_ks_kernel");
 }
 
