@@ -1308,8 +1308,12 @@ int dispatch_rows_sw(const SwPlan& q, const float* x, const float* w, float* y, 
 struct KsPlan { bool ok; int tiles16, grid; size_t lds; };
 KsPlan plan_rows_ks(int64_t P, int N, int K, int groups, int64_t ldx, bool pro, int epi) {
     KsPlan q{};
-    const char* env = getenv("NEXTOU_PW_KS");           // read per call (tests / A-B): 0 switches the kernel off
-    if ((env && env[0] == '0') || groups != 1 || K != kKsK || N % 4 != 0 || N > 16 * kKsTn || ldx != K || epi == 2 ||
+    // Measured at the stage-2 FFN of cfg 2 (P = 172 032, profiles/r05_k7_k_split.md): plain (the data gradient of fc1) 249 us against
+    // pw_rows_kernel's 266; with the normalise + activate prologue and the statistics epilogue (fc2 forward) 289 against 285 — level.  So
+    // the kernel is taken WITHOUT a prologue only; NEXTOU_PW_KS=2 takes it for every instantiated variant (tests, A/B), 0 never.
+    const char* env = getenv("NEXTOU_PW_KS");           // read per call
+    const int mode = env ? atoi(env) : 1;
+    if (mode == 0 || (pro && mode < 2) || groups != 1 || K != kKsK || N % 4 != 0 || N > 16 * kKsTn || ldx != K || epi == 2 ||
         P < 64 * 4 * (int64_t)cu_count())
         return q;
     q.tiles16 = (int)((P + kKsPts - 1) / kKsPts);

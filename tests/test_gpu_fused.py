@@ -463,8 +463,8 @@ def test_k_split_stationary_weights_rows_kernel(ops, monkeypatch, co, sp):
         L_.nextou_profile_enable(0)
         return out, [r["kernel"] for r in json.loads(buf.value[:n].decode())]
 
-    new, names_new = run("1")
-    again, _ = run("1")
+    new, names_new = run("2")           # 2: every instantiated variant (the default, 1, takes the kernel without a prologue only)
+    again, _ = run("2")
     old, names_old = run("0")
     assert all(k.startswith("pw_rows_ks_kernel") for k in names_new), names_new
     assert all(k.startswith("pw_rows_kernel") for k in names_old), names_old
