@@ -130,7 +130,7 @@ def bench_bti(args, dev, L):
         t = torch.nn.functional.interpolate(target, size=shape, mode="nearest")
         g = torch.Generator(device=dev).manual_seed(7)
         logits = torch.randn((2, 14, *shape), generator=g, device=dev) * 1.5
-        logits.scatter_add_(1, t.long(), torch.full_like(t, 3.0))
+        logits.scatter_add_(1, t.long(), torch.full_like(t, args.bti_margin))
         logits.requires_grad_(True)
         for it in range(2 + args.iters):
             if it == 2:
@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--norm", action="store_true", help="bench K6 (norm + LeakyReLU) instead of K1/K2")
     ap.add_argument("--cl", action="store_true", help="with --norm: channels-last tensors")
     ap.add_argument("--mrg", action="store_true", help="bench the K2 + K7 kernel (aggregate + grouped conv) at the cfg-2 stage-2 Swin shape")
+    ap.add_argument("--bti-margin", type=float, default=3.0, help="--bti: logit bonus of the labelled class over N(0, 1.5) noise; 3.0 -> the "
+                    "arg-max disagrees with the labels at many voxels (~80 %% critical), 12.0 -> arg-max == labels (critical voxels only at "
+                    "real label interfaces)")
     ap.add_argument("--bti", action="store_true", help="bench K5 (arg-max labels, critical map, critical-voxel CE) at the cfg-4 scales")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
