@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NEXTOU_ABI_VERSION 11
+#define NEXTOU_ABI_VERSION 12
 
 #define NEXTOU_EINVAL   (-1)  /* bad argument (null pointer, non-positive size, k > M ...) */
 #define NEXTOU_ENOSPACE (-2)  /* workspace too small */
@@ -363,6 +363,15 @@ int nextou_depth_unroll(const float* x_cl, float* out_cl, int B, int C, int D, i
  *     NexToU_Encoder_Decoder.py:311-337) with the up-convolution's bias folded in — the convolution runs bias-free and ATen's separate bias-add pass
  *     over its output never runs.  One read of a and b, one write. */
 int nextou_cat_bias_rows(const float* a, const float* bias, const float* b, float* out, int64_t P, int C1, int C2, nextou_stream_t stream);
+
+/* nextou_filter_flip_t (ABI v12)  out = the filter of the FORWARD convolution that computes the data gradient of a stride-1 convolution with
+ *     filter w (Co, Ci, Kd, Kh, Kw): out (Ci, Co, Kd, Kh, Kw) stored channels-last — out[ci][kd][kh][kw][co] = w[co][ci][Kd-1-kd][Kh-1-kh][Kw-1-kw].
+ *     w is read through its element strides (s_co, s_ci, s_kd, s_kh, s_kw): contiguous and channels-last filters alike; 2-D filters pass
+ *     Kd = 1.  Replaces ATen's transpose -> flip -> contiguous(channels_last) (two copy kernels per convolution and step) in the backward
+ *     of the plain stages' convolutions (reference NexToU_Encoder_Decoder.py:125-136, :281-298 ConvDropoutNormReLU; PyTorch-ROCm keeps
+ *     the convolution itself). */
+int nextou_filter_flip_t(const float* w, float* out, int Co, int Ci, int Kd, int Kh, int Kw, int64_t s_co, int64_t s_ci, int64_t s_kd,
+                         int64_t s_kh, int64_t s_kw, nextou_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K7  point-wise (kernel 1, stride 1) convolutions on channels-last rows — the 1x1 convolutions of the Grapher / FFN

@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("NEXTOU_HIP_LIB") or os.path.join(_PKG_DIR, "libnextou
 
 KNN_AUTO, KNN_FUSED, KNN_NAIVE = 0, 1, 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # name -> (restype, argtypes); mirrors include/nextou_hip.h one to one
 _SIGNATURES = {
@@ -87,6 +87,8 @@ _SIGNATURES = {
     "nextou_cell_gather": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "nextou_cell_scatter": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "nextou_cat_bias_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "nextou_filter_flip_t": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                     c_void_p]),
     "nextou_depth_unroll": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "nextou_pw_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "nextou_pw_wgrad_workspace": (c_int, [c_int64, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),

@@ -454,7 +454,45 @@ __global__ __launch_bounds__(256) void cat_bias_rows_kernel(const float4* __rest
         out[row * cq + q] = v;
     }
 }
+
+// out[ci][kd][kh][kw][co] (channels-last memory of the (Ci, Co, Kd, Kh, Kw) filter) = w[co][ci][Kd-1-kd][Kh-1-kh][Kw-1-kw]: the filter of the
+// forward convolution that computes a stride-1 convolution's data gradient, from the forward filter in either memory layout (element
+// strides).  One 32 x 32 (co, ci) tile per tap through LDS: reads run along ci (contiguous in a channels-last filter), writes along co.
+__global__ __launch_bounds__(256) void filter_flip_t_kernel(const float* __restrict__ w, float* __restrict__ out, int Co, int Ci, int Kh,
+                                                            int Kw, int Kd, long long s_co, long long s_ci, long long s_kd, long long s_kh,
+                                                            long long s_kw) {
+    __shared__ float tile[32][33];
+    const int T = Kd * Kh * Kw, t = blockIdx.z;
+    const int kd = t / (Kh * Kw), kh = (t / Kw) % Kh, kw = t % Kw;
+    const long long off = (long long)(Kd - 1 - kd) * s_kd + (long long)(Kh - 1 - kh) * s_kh + (long long)(Kw - 1 - kw) * s_kw;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = co0 + ty + 8 * j, ci = ci0 + tx;
+        if (co < Co && ci < Ci) tile[ty + 8 * j][tx] = w[(long long)co * s_co + (long long)ci * s_ci + off];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ci = ci0 + ty + 8 * j, co = co0 + tx;
+        if (co < Co && ci < Ci) out[((size_t)ci * T + t) * Co + co] = tile[tx][ty + 8 * j];
+    }
+}
 }  // namespace nextou
+
+extern "C" int nextou_filter_flip_t(const float* w, float* out, int Co, int Ci, int Kd, int Kh, int Kw, int64_t s_co, int64_t s_ci,
+                                    int64_t s_kd, int64_t s_kh, int64_t s_kw, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(w && out, "filter_flip_t: null pointer");
+    NEXTOU_REQUIRE(Co > 0 && Ci > 0 && Kd > 0 && Kh > 0 && Kw > 0 && (long long)Kd * Kh * Kw <= 65535 && Co <= (1 << 20) && Ci <= (1 << 20),
+                   "filter_flip_t: bad size Co=%d Ci=%d kernel (%d,%d,%d)", Co, Ci, Kd, Kh, Kw);
+    NEXTOU_REQUIRE(s_co >= 0 && s_ci >= 0 && s_kd >= 0 && s_kh >= 0 && s_kw >= 0, "filter_flip_t: negative stride");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = Kd * Kh * Kw;
+    ProfScope prof(s, kBoundHbm, 8.0 * (double)Co * Ci * T, "filter_flip_t_kernel[%dx%d k%dx%dx%d]", Co, Ci, Kd, Kh, Kw);
+    hipLaunchKernelGGL(nextou::filter_flip_t_kernel, dim3((unsigned)((Ci + 31) / 32), (unsigned)((Co + 31) / 32), (unsigned)T), dim3(256), 0, s,
+                       w, out, Co, Ci, Kh, Kw, Kd, (long long)s_co, (long long)s_ci, (long long)s_kd, (long long)s_kh, (long long)s_kw);
+    return check_launch("filter_flip_t_kernel");
+}
 
 extern "C" int nextou_cat_bias_rows(const float* a, const float* bias, const float* b, float* out, int64_t P, int C1, int C2,
                                     nextou_stream_t stream) {

@@ -240,6 +240,21 @@ class BucketedGradientAverager:
         return sum(b.flat.numel() * b.flat.element_size() for b in self.buckets)
 
 
+def _capture_safe_process_group_env(backend: str) -> None:
+    """Settings of PyTorch's NCCL (= RCCL) process group for steps that are captured into a hipGraph, applied before the group exists
+    and only where the user has not set the variable.
+
+    ``TORCH_NCCL_CUDA_EVENT_CACHE=0``: by default the group recycles the events of finished collectives.  A collective captured into
+    a graph records its end event in the CAPTURING stream; once that work object dies the event goes back to the pool and a later
+    eager collective may receive it.  Seen on ROCm 7.2 / PyTorch 2.10, about once in ten runs of ``bench.py --force-averager --graph
+    on``: the group's watchdog thread polling a work item's event got ``hipErrorCapturedEvent`` ("operation not permitted on an event
+    last recorded in a capturing stream") and terminated the process.  With fresh events per collective no event ever crosses from a
+    captured work item to an eager one (an event per collective costs microseconds; a step launches a handful)."""
+    import os
+    if backend == "nccl":
+        os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
+
+
 def init_single_process_group(backend: Optional[str] = None) -> None:
     """A world-size-1 default group (``bench.py --force-averager``): the hooks, the bucket copies and the collective
     launches of the N > 1 path run on one GPU so that their overhead can be timed without an 8-GPU node."""
@@ -253,6 +268,7 @@ def init_single_process_group(backend: Optional[str] = None) -> None:
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    _capture_safe_process_group_env(backend)
     dist.init_process_group(backend=backend, rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % port)
 
 
@@ -270,5 +286,6 @@ def init_process_group_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl" and torch.cuda.device_count() > local_rank:
             torch.cuda.set_device(local_rank)
+        _capture_safe_process_group_env(backend)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world

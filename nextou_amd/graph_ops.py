@@ -22,6 +22,7 @@ infrastructure has installed a checker with :func:`install_cpu_checker` (tests/ 
 from __future__ import annotations
 
 import contextlib
+import math
 from typing import Callable, List, Optional
 
 import torch
@@ -554,6 +555,22 @@ class _HipBackend:
         _lib.check(rc, "cell_scatter")
         return out
 
+
+    @staticmethod
+    def filter_flip_t(weight):
+        """(Co, Ci, *k) float32 filter, any dense layout -> (Ci, Co, *k) channels-last: ``weight.transpose(0, 1).flip(spatial axes)``."""
+        L_ = _lib.lib()
+        co, ci = weight.shape[:2]
+        k = [int(v) for v in weight.shape[2:]]
+        st = [int(v) for v in weight.stride()]
+        kd, kh, kw = ([1] * (3 - len(k))) + k
+        s_sp = ([0] * (3 - len(k))) + st[2:]
+        out = _empty_channels_last((ci, co) + tuple(k), weight.device)
+        with torch.cuda.device(weight.device):
+            rc = L_.nextou_filter_flip_t(weight.data_ptr(), out.data_ptr(), co, ci, kd, kh, kw, st[0], st[1], s_sp[0], s_sp[1], s_sp[2],
+                                         _stream_ptr(weight.device))
+        _lib.check(rc, "filter_flip_t")
+        return out
 
     @staticmethod
     def depth_unroll(x_cl):
@@ -1134,6 +1151,81 @@ def _pad_stage(holder, C: int, c_real: int, device) -> torch.Tensor:
     return stage
 
 
+class _ZeroGradRider(torch.autograd.Function):
+    """Identity on ``out``; its backward hands every ``param`` a slice of ONE zero-filled buffer as gradient (see ZeroGradScope)."""
+
+    @staticmethod
+    def forward(ctx, out, *params):
+        ctx.meta = [(tuple(p.shape), p.dtype, p.device) for p in params]
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        pools, grads = {}, []
+        for shape, dtype, device in ctx.meta:
+            key = (dtype, device)
+            pools[key] = pools.get(key, 0) + int(math.prod(shape))
+        bufs = {key: torch.zeros((n,), dtype=key[0], device=key[1]) for key, n in pools.items()}
+        offs = {key: 0 for key in pools}
+        for shape, dtype, device in ctx.meta:
+            key, n = (dtype, device), int(math.prod(shape))
+            grads.append(bufs[key].narrow(0, offs[key], n).view(shape))
+            offs[key] += n
+        return (g,) + tuple(grads)
+
+
+class ZeroGradScope:
+    """The bias of a convolution folded into a batch- / instance-statistics norm has gradient exactly zero (the statistics absorb a
+    per-channel constant); the optimizer must still SEE a zero gradient — weight decay and momentum act on the parameter as they do
+    in the reference, where the gradient is round-off around zero.  Producing that zero per norm is one fill kernel each: 85 launches,
+    0.38 ms of the cfg-2 step (profiles/r05_aten_glue.md).  Inside ``with scope:`` (the network's training forward) the norms hand
+    the bias to their kernels detached and register the parameter here; :meth:`attach` then ties all registered parameters to the
+    network's output through one identity node whose backward zero-fills ONE buffer and returns its slices.  Outside a scope the
+    norms keep the per-norm ``zeros_like``."""
+
+    def __init__(self):
+        self.active = False
+        self._params = {}
+
+    def __enter__(self):
+        self.active = True
+        self._params = {}
+        return self
+
+    def __exit__(self, *exc):
+        self.active = False
+        self._params = {}
+        return False
+
+    def take(self, param, statistics_from_input: bool):
+        """what the norm passes to its autograd function as ``pre_bias``"""
+        if (self.active and param is not None and statistics_from_input and torch.is_grad_enabled() and param.requires_grad
+                and param.is_leaf):
+            self._params[id(param)] = param
+            return param.detach()
+        return param
+
+    def attach(self, outputs):
+        """``outputs`` (tensor, or list / tuple of tensors) with the first gradient-carrying one routed through the rider node"""
+        params = list(self._params.values())
+        self._params = {}
+        if not params or not torch.is_grad_enabled():
+            return outputs
+        seq = list(outputs) if isinstance(outputs, (list, tuple)) else [outputs]
+        for i, t in enumerate(seq):
+            if isinstance(t, torch.Tensor) and t.requires_grad:
+                seq[i] = _ZeroGradRider.apply(t, *params)
+                break
+        else:
+            return outputs
+        if isinstance(outputs, (list, tuple)):
+            return type(outputs)(seq)
+        return seq[0]
+
+
+ZERO_GRADS = ZeroGradScope()
+
+
 def norm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
              running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], training: bool,
              momentum: float, eps: float, negative_slope: float = 1.0, instance: bool = False,
@@ -1167,6 +1259,7 @@ def norm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[tor
         raise ValueError("norm_act: channel padding is only defined for batch statistics")
     if stats_partial is not None and not (instance and x.is_cuda and x.dtype == torch.float32 and pad_holder is None):
         raise ValueError("norm_act: ready-made statistics are for fp32 instance norm on the device")
+    pre_bias = ZERO_GRADS.take(pre_bias, bool(training))       # (instance norm: training is always True)
     return _NormAct.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum),
                           float(eps), float(negative_slope), bool(instance), pre_bias, pad_holder, stats_partial)
 
@@ -1218,6 +1311,12 @@ class _ConvOwnBiasGrad(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None, None
 
 
+def _filter_flip_own() -> bool:
+    """NEXTOU_FILTER_FLIP=0: ATen's transpose -> flip -> contiguous instead of nextou_filter_flip_t (A/B)."""
+    import os
+    return os.environ.get("NEXTOU_FILTER_FLIP", "1") != "0"
+
+
 class _ConvDgradAsForward(torch.autograd.Function):
     """Stride-1 'same' convolution whose data gradient is computed as a FORWARD convolution of the output gradient with
     the flipped, transposed filter — the same numbers in another summation order.  MIOpen's CK forward kernels are
@@ -1243,8 +1342,15 @@ class _ConvDgradAsForward(torch.autograd.Function):
         gy = gy.contiguous(memory_format=cl) if cl is not None else gy.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            wt = weight.transpose(0, 1).flip(*range(2, 2 + n))
-            wt = wt.contiguous(memory_format=cl) if cl is not None else wt.contiguous()
+            if cl is not None and weight.is_cuda and weight.dtype == torch.float32 and gy.dtype == torch.float32 and n in (2, 3) and \
+                    _filter_flip_own():
+                wt = _HIP.filter_flip_t(weight.detach())                        # one launch: transpose + flip + channels-last
+            else:
+                taps = [d for d in range(2, 2 + n) if weight.shape[d] > 1]      # (a flip over size-1 axes is only a copy)
+                wt = weight.transpose(0, 1)
+                if taps:
+                    wt = wt.flip(*taps)
+                wt = wt.contiguous(memory_format=cl) if cl is not None else wt.contiguous()
             gx = torch.ops.aten.convolution(gy, wt, None, ones, ctx.padding, ones, False, zeros, 1)
         if ctx.needs_input_grad[1] and wgrad_depth_unroll_eligible(x, weight, ctx.padding):
             # [3,3,3] kernel: the depth taps become input channels and the weight gradient a 2-D problem (MIOpen's 2-D kernels:
@@ -1504,8 +1610,8 @@ def pointwise_chain(x, residual, conv1, norm1, conv2=None, norm2=None):
         return None
     n1 = _norm_state(norm1)
     n2 = _norm_state(norm2) if norm2 is not None else None
-    cb1 = conv1.bias
-    cb2 = conv2.bias if conv2 is not None else None
+    cb1 = ZERO_GRADS.take(conv1.bias, n1.batch_stats)
+    cb2 = ZERO_GRADS.take(conv2.bias, n2.batch_stats) if conv2 is not None else None
     res = None if residual is None else as_channels_last_rows(residual)
     return _PointwiseChain.apply(x, res, conv1.weight, norm1.weight, norm1.bias, cb1,
                                  None if conv2 is None else conv2.weight, None if norm2 is None else norm2.weight,
@@ -1699,8 +1805,8 @@ def mr_grouped_chain(windows, nn_idx, residual, conv1, norm1, conv2, norm2, spat
         _, _, h, part = _HIP.mr_grouped_rows(_f32c(windows), nn_idx.contiguous(), K, 1, w1m, groups, batch, shape[2:], window, shift,
                                              want_a=False, want_arg=False, want_stats=n1.batch_stats)
         a = h           # (x is only the chain's shape carrier here)
-    return _PointwiseChain.apply(a, res, w1, norm1.weight, norm1.bias, conv1.bias, conv2.weight, norm2.weight, norm2.bias, conv2.bias,
-                                 groups, n1, n2, mode != "fwd", h, part)
+    return _PointwiseChain.apply(a, res, w1, norm1.weight, norm1.bias, ZERO_GRADS.take(conv1.bias, n1.batch_stats), conv2.weight,
+                                 norm2.weight, norm2.bias, ZERO_GRADS.take(conv2.bias, n2.batch_stats), groups, n1, n2, mode != "fwd", h, part)
 
 
 def _norm_state(norm) -> _NormState:

@@ -5,6 +5,7 @@ results and ``state_dict`` keys follow the reference's ``network_architecture/Ne
 """
 from __future__ import annotations
 
+import os
 from typing import List, Tuple, Type, Union
 
 import torch
@@ -15,8 +16,9 @@ from torch.nn.modules.dropout import _DropoutNd
 from .NexToU_Encoder_Decoder import NexToU_Decoder, NexToU_Encoder
 from .channel_pad import pad_multiple, pad_plain_stage_channels
 from .conv_blocks import convert_conv_op_to_dim
-from .layout import channels_last_stages
-from .norm_act import fuse_norm_act, fusion_enabled
+from .. import graph_ops
+from .layout import channels_last_stages, filters_to_channels_last
+from .norm_act import attach_deferred_counters, fuse_norm_act, fusion_enabled
 
 
 class NexToU(nn.Module):
@@ -61,10 +63,13 @@ class NexToU(nn.Module):
                                       deep_supervision, nonlin_first=nonlin_first)
         if fusion_enabled():  # (norm -> LeakyReLU) pairs become one K6 launch; state_dict unchanged
             fuse_norm_act(self)
+            self.__dict__["_batch_counters"] = attach_deferred_counters(self)      # plain attribute: no module, no state
             # the plain conv stages run channels-last on the GPU (layout.py); needs K6's NDHWC kernels, hence here
             self.encoder.channels_last_stages = channels_last_stages(conv_op, self.encoder.n_conv_stages, n_stages)
             # 33 -> 40 / 66 -> 72 channels inside the plain conv stages (channel_pad.py): parameters keep their shapes
             self.padded_modules = pad_plain_stage_channels(self, pad_multiple())
+            if self.encoder.channels_last_stages:      # the filters of channels-last convolutions are stored channels-last as well
+                filters_to_channels_last(self)
             # reduced-precision autocast keeps NDHWC only when the plain stages really run multiple-of-8 channel counts
             plain = list(self.encoder.output_channels)[:self.encoder.n_conv_stages]
             # (the hardware requirement is fixed — 16-byte bf16 / fp16 rows = multiples of 8 channels — whatever NEXTOU_PAD_CHANNELS says:
@@ -73,7 +78,13 @@ class NexToU(nn.Module):
             self.encoder.reduced_precision_layout_ok = runs_padded_to_8 or all(f % 8 == 0 for f in plain)
 
     def forward(self, x):
-        return self.decoder(self.encoder(x))
+        counters = self.__dict__.get("_batch_counters")
+        if counters is None or not self.training or os.environ.get("NEXTOU_STEP_GLUE", "1") == "0":     # ("0": per-norm launches, A/B)
+            return self.decoder(self.encoder(x))
+        # every batch norm's num_batches_tracked advances in one multi-tensor launch on the way out; the (exactly zero) gradients of the
+        # convolution biases folded into statistics norms come from one zero-filled buffer (graph_ops.ZeroGradScope)
+        with counters, graph_ops.ZERO_GRADS as riders:
+            return riders.attach(self.decoder(self.encoder(x)))
 
     def compute_conv_feature_map_size(self, input_size):
         assert len(input_size) == convert_conv_op_to_dim(self.encoder.conv_op), \

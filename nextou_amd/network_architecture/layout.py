@@ -14,6 +14,13 @@ where the data has to move anyway: the window shift / partition / reverse and th
 (csrc/layout_ops.hip) that read or write the channels-last volume directly, and K6 has column-blocked kernels for rows
 wider than 256 channels.  So with ``auto`` every stage of a 3-D model is channels-last from the network input to the logits.
 
+Round 5: the FILTERS of those convolutions are stored channels-last too (:func:`filters_to_channels_last`): the library's
+NDHWC kernels take (K, Z, Y, X, C) filters, and with the parameters stored (K, C, Z, Y, X)-contiguous every step paid one
+conversion of each filter in the forward, one in the backward and one more for the weight gradient on its way into ``.grad``
+(AccumulateGrad copies a gradient whose strides differ from the parameter's) — ~100 small copy kernels, 0.3 ms of the cfg-2
+step (profiles/r05_aten_glue.md).  Shapes, values and the state_dict are unchanged (``load_state_dict`` copies by value, ``.to()``
+keeps the strides); ``NEXTOU_CHANNELS_LAST_FILTERS=0`` keeps them contiguous (A/B).
+
 ``NEXTOU_CHANNELS_LAST_STAGES``: ``auto`` (default: all stages), ``plain`` (round 1: only the stages without graph blocks),
 ``none``, or a comma list of stage indices.  Under reduced-precision autocast the policy applies only together with the
 internal channel padding (:func:`layout_policy_applies`).
@@ -103,3 +110,23 @@ def set_stage_layout(x: torch.Tensor, channels_last: bool, reduced_precision_ok=
     if not x.is_cuda:
         return x
     return to_channels_last(x) if (channels_last and layout_policy_applies(x, reduced_precision_ok)) else x.contiguous()
+
+
+def filters_to_channels_last(root: nn.Module) -> int:
+    """Re-stride, in place, the weight of every 3-D (4-D: 2-D) convolution / transposed convolution under ``root`` whose kernel is
+    larger than 1 to channels_last_3d (channels_last) memory; returns the number of parameters converted.  Kernel-1 filters are
+    the same bytes in both layouts and stay as they are."""
+    if os.environ.get("NEXTOU_CHANNELS_LAST_FILTERS", "1") == "0":
+        return 0
+    n = 0
+    for m in root.modules():
+        if not isinstance(m, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d, nn.ConvTranspose3d)):
+            continue
+        w = m.weight
+        if w is None or not w.is_floating_point() or all(int(k) == 1 for k in w.shape[2:]):
+            continue
+        mf = torch.channels_last if w.dim() == 4 else torch.channels_last_3d
+        if not w.is_contiguous(memory_format=mf):
+            w.data = w.data.contiguous(memory_format=mf)
+            n += 1
+    return n

@@ -27,7 +27,8 @@ from .channel_pad import norm_input_is_padded, pad_image_channels, padded_conv_p
 
 __all__ = ["BatchNormAct1d", "BatchNormAct2d", "BatchNormAct3d", "InstanceNormAct1d", "InstanceNormAct2d",
            "InstanceNormAct3d", "ConvBiasFolded1d", "ConvBiasFolded2d", "ConvBiasFolded3d", "ConvOwnBias2d",
-           "ConvOwnBias3d", "ConvTransposeOwnBias2d", "ConvTransposeOwnBias3d", "fuse_norm_act", "fusion_enabled", "up_conv_cat"]
+           "ConvOwnBias3d", "ConvTransposeOwnBias2d", "ConvTransposeOwnBias3d", "fuse_norm_act", "fusion_enabled", "up_conv_cat", "DeferredCounters",
+           "attach_deferred_counters"]
 
 
 def _pre_bias(norm: nn.Module):
@@ -163,6 +164,52 @@ def _verify_spatial_size(x: torch.Tensor) -> None:
         raise ValueError("Expected more than 1 spatial element when training, got input size %s" % (x.size(),))
 
 
+class DeferredCounters:
+    """``num_batches_tracked += 1`` of every batch norm of a network as ONE multi-tensor launch per forward instead of one
+    single-element kernel per norm (78 launches, 0.34 ms of the cfg-2 step — profiles/r05_aten_glue.md).  The network's forward
+    runs inside ``with counters:``; norms whose momentum is a number (the counter is pure bookkeeping then, as in
+    torch.nn.modules.batchnorm._BatchNorm.forward) hand their counter over instead of advancing it themselves, and leaving the
+    block advances them all — also when the forward raises, so the counters never disagree with the norms that ran.  Norms called
+    outside such a block, or with ``momentum=None`` (cumulative average: the factor needs the counter's value), keep the eager
+    increment."""
+
+    def __init__(self):
+        self.active = False
+        self._pending = []
+
+    def defer(self, counter: torch.Tensor) -> None:
+        self._pending.append(counter)
+
+    def __enter__(self):
+        self.active = True
+        self._pending = []
+        return self
+
+    def __exit__(self, *exc):
+        self.active = False
+        pending, self._pending = self._pending, []
+        times = {}
+        for t in pending:            # a module called twice in one forward counts twice
+            times[id(t)] = (t, times.get(id(t), (t, 0))[1] + 1)
+        for n in sorted({v[1] for v in times.values()}):
+            group = [t for t, k in times.values() if k == n]
+            by_device = {}
+            for t in group:
+                by_device.setdefault(t.device, []).append(t)
+            for tensors in by_device.values():
+                torch._foreach_add_(tensors, n)
+        return False
+
+
+def attach_deferred_counters(root: nn.Module) -> "DeferredCounters":
+    """Give every fused batch norm under ``root`` the same :class:`DeferredCounters` (held in a tuple: not a sub-module)."""
+    counters = DeferredCounters()
+    for m in root.modules():
+        if isinstance(m, _BatchNormAct):
+            m._counter_group = (counters,)
+    return counters
+
+
 class _BatchNormAct:
     negative_slope: float = 1.0
 
@@ -172,8 +219,12 @@ class _BatchNormAct:
         pipeline (graph_ops.pointwise_chain), which runs this norm inside its GEMMs."""
         factor = 0.0 if self.momentum is None else self.momentum
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
-            factor = 1.0 / float(self.num_batches_tracked) if self.momentum is None else self.momentum
+            group = getattr(self, "_counter_group", None)
+            if group is not None and group[0].active and self.momentum is not None:
+                group[0].defer(self.num_batches_tracked)        # one multi-tensor add for the whole network (DeferredCounters)
+            else:
+                self.num_batches_tracked.add_(1)
+                factor = 1.0 / float(self.num_batches_tracked) if self.momentum is None else self.momentum
         use_batch_stats = self.training or (self.running_mean is None and self.running_var is None)
         keep_running = (not self.training) or self.track_running_stats
         return use_batch_stats, factor, keep_running

@@ -308,3 +308,16 @@ def test_cat_bias(hip):
     bias = torch.randn(40, generator=g).to(DEV)
     _guarded(lambda y, b, s: graph_ops._CatBias.apply(y, b, s), [y, bias, skip])
     _guarded(lambda y, s: graph_ops._CatBias.apply(y, None, s), [y, skip])
+
+
+# ---------------------------------------------------------------- filter of the data gradient's forward convolution
+@pytest.mark.parametrize("co,ci,k,layout", [(66, 72, (3, 3, 3), "cl"), (33, 40, (1, 3, 3), "nchw"), (40, 40, (3, 3), "cl"),
+                                             (264, 132, (1, 1, 1), "nchw"), (5, 3, (2, 2, 2), "cl")])
+def test_filter_flip_t(hip, co, ci, k, layout):
+    g = _gen(co + ci)
+    w = torch.randn((co, ci) + k, generator=g).to(DEV)
+    w = _cl(w) if layout == "cl" else w
+    want = _cl(w.transpose(0, 1).flip(*range(2, 2 + len(k))))
+    got = hip.filter_flip_t(w)
+    assert got.shape == want.shape and got.stride() == want.stride() and torch.equal(got, want)
+    _guarded(lambda w: hip.filter_flip_t(w), [w])

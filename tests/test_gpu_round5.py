@@ -81,3 +81,36 @@ print("RESULT", worst, json.loads(buf.value.decode())[0]["kernel"])
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1].split()
     assert line[2].startswith("mr_bwd_arg_kernel"), line          # the float-atomic kernel really ran
     assert float(line[1]) <= 1e-5
+
+
+@pytest.mark.parametrize("shape,kernel", [((2, 40, 6, 20, 24), (3, 3, 3)), ((2, 40, 5, 16, 12), (1, 3, 3)), ((1, 72, 4, 10, 12), (3, 3, 3))])
+def test_dgrad_as_forward_with_own_filter_flip_matches_aten(shape, kernel, monkeypatch):
+    """The data gradient of the plain stages' stride-1 convolutions is a forward convolution with the transposed, flipped filter; that
+    filter comes from nextou_filter_flip_t (one launch) instead of ATen's transpose -> flip -> contiguous.  Same data-gradient bits as the ATen
+    construction (the library convolution that consumes it is the same call), and the gradients agree with the library's own
+    convolution_backward to summation-order round-off — with the filter parameter stored contiguous AND channels-last."""
+    from nextou_amd import graph_ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    B, C = shape[:2]
+    x = torch.randn(shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    pad = tuple(k // 2 for k in kernel)
+    for weight_cl in (False, True):
+        w = (torch.randn((C, C) + kernel, generator=g) * 0.1).to(dev)
+        if weight_cl:
+            w = w.contiguous(memory_format=torch.channels_last_3d)
+        gy = torch.randn(shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("NEXTOU_FILTER_FLIP", mode)
+            xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            y = graph_ops.conv_dgrad_as_forward(xr, wr, pad)
+            res[mode] = (y.detach(),) + torch.autograd.grad(y, (xr, wr), gy)
+        assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])     # same filter bits -> same data gradient
+        # (the weight gradient does not involve the flipped filter; the library's kernel for it may sum with atomics)
+        assert float((res["1"][2] - res["0"][2]).abs().max()) <= 1e-5 * float(res["0"][2].abs().max())
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = torch.nn.functional.conv3d(xr, wr, None, 1, pad)
+        gx, gw = torch.autograd.grad(y, (xr, wr), gy)
+        assert float((res["1"][1] - gx).abs().max()) <= 2e-5 * float(gx.abs().max())
+        assert float((res["1"][2] - gw).abs().max()) <= 2e-4 * float(gw.abs().max())

@@ -402,3 +402,102 @@ def test_reduced_precision_layout_flag_follows_the_hardware_rule(monkeypatch):
         assert mc.build_model(cfg).encoder.reduced_precision_layout_ok is want, spec
     monkeypatch.setenv("NEXTOU_PAD_CHANNELS", "0")
     assert mc.build_model(dict(mc.TINY_3D, features=[32, 64, 24, 48, 48, 48])).encoder.reduced_precision_layout_ok is True
+
+
+def test_batch_counters_advance_once_per_forward_in_one_launch(cpu_checker, monkeypatch):
+    """num_batches_tracked of every fused batch norm advances by one per training forward of the network — through ONE
+    torch._foreach_add_ per forward (norm_act.DeferredCounters), not one single-element add per norm; eval forwards leave the
+    counters alone; a norm called on its own (outside the network's forward), or one with momentum=None, advances eagerly; the
+    state_dict after k forwards equals the un-fused model's."""
+    import os
+    import model_cases as mc
+    from nextou_amd.network_architecture import norm_act
+
+    def build():
+        torch.manual_seed(0)
+        return mc.build_model(mc.TINY_2D)
+
+    monkeypatch.setenv("NEXTOU_FUSE_NORM_ACT", "0")
+    plain = build()
+    monkeypatch.delenv("NEXTOU_FUSE_NORM_ACT")
+    net = build()
+    net.load_state_dict(plain.state_dict())
+    norms = [m for m in net.modules() if isinstance(m, norm_act._BatchNormAct)]
+    assert norms and all(m._counter_group[0] is net._batch_counters for m in norms)
+    calls = []
+    real = torch._foreach_add_
+
+    def spy(tensors, *a, **k):
+        calls.append(len(tensors))
+        return real(tensors, *a, **k)
+    monkeypatch.setattr(torch, "_foreach_add_", spy)
+    x = torch.randn(2, 1, 64, 64)
+    net.train()
+    plain.train()
+    for _ in range(3):
+        net(x)
+        plain(x)
+    assert calls == [len(norms)] * 3                         # one launch per forward, every counter in it
+    assert all(int(m.num_batches_tracked) == 3 for m in norms)
+    for (ka, va), (kb, vb) in zip(net.state_dict().items(), plain.state_dict().items()):
+        assert ka == kb
+        if ka.endswith("num_batches_tracked"):
+            assert int(va) == int(vb) == 3
+    net.eval()
+    net(x)
+    assert all(int(m.num_batches_tracked) == 3 for m in norms) and len(calls) == 3
+    net.train()
+    one = norms[0]
+    one(torch.randn(2, one.num_features, 8, 8))             # outside the network's forward: eager
+    assert int(one.num_batches_tracked) == 4 and len(calls) == 3
+    one.momentum = None                                      # cumulative average: the factor needs the counter now
+    net(x)
+    assert int(one.num_batches_tracked) == 5 and calls[-1] == len(norms) - 1
+    assert all(int(m.num_batches_tracked) == 4 for m in norms[1:])
+    # a forward that raises still advances the counters of the norms that ran (none are left pending)
+    with pytest.raises(Exception):
+        net(torch.randn(2, 3, 64, 64))
+    assert net._batch_counters._pending == [] and not net._batch_counters.active
+
+
+def test_folded_conv_biases_get_their_zero_gradients_from_one_buffer(cpu_checker):
+    """A convolution bias folded into a statistics norm has gradient exactly zero, and the optimizer must see it (weight decay,
+    momentum).  Through the network's forward all of them are slices of ONE zero-filled buffer (graph_ops.ZeroGradScope: one fill
+    per backward pass instead of one per norm); modules called on their own keep the per-norm zeros; no_grad / eval forwards
+    register nothing."""
+    import model_cases as mc
+    from nextou_amd import graph_ops
+    torch.manual_seed(0)
+    net = mc.build_model(mc.TINY_2D).train()
+    folded = [m.bias for m in net.modules() if type(m).__name__.startswith("ConvBiasFolded") and m.bias is not None]
+    assert len(folded) > 4
+    x = torch.randn(2, 1, 64, 64)
+    outs = net(x)
+    assert not graph_ops.ZERO_GRADS.active and graph_ops.ZERO_GRADS._params == {}
+    sum(o.square().mean() for o in outs).backward()
+    stores = set()
+    for p in folded:
+        assert p.grad is not None and p.grad.shape == p.shape and not bool(p.grad.any())
+        stores.add(p.grad.untyped_storage().data_ptr())
+    assert len(stores) == 1                                   # one buffer for all of them
+    others = [p for p in net.parameters() if all(p is not q for q in folded)]
+    assert all(p.grad is not None for p in others if p.requires_grad)
+    # an optimizer step with weight decay moves the folded biases exactly as a zero gradient says
+    before = [p.detach().clone() for p in folded]
+    torch.optim.SGD(net.parameters(), lr=0.1, weight_decay=0.5).step()
+    for b, p in zip(before, folded):
+        assert torch.allclose(p.detach(), b * (1 - 0.1 * 0.5), rtol=1e-6, atol=0)
+    # pieces called on their own (no scope): per-norm zeros, still a gradient
+    net.zero_grad(set_to_none=True)
+    skips = net.encoder(x)
+    sum(s.square().mean() for s in skips).backward()
+    enc = [m.bias for m in net.encoder.modules() if type(m).__name__.startswith("ConvBiasFolded") and m.bias is not None]
+    assert all(p.grad is not None and not bool(p.grad.any()) for p in enc)
+    assert len({p.grad.untyped_storage().data_ptr() for p in enc}) == len(enc)
+    # nothing is registered without autograd
+    net.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        net(x)
+    net.eval()
+    net(x)
+    assert all(p.grad is None for p in folded) and graph_ops.ZERO_GRADS._params == {}

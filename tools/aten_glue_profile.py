@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--stacks", action="store_true", help="group by Python call stack instead of input shapes")
+    ap.add_argument("--parents", action="store_true", help="with --ops: group the matching ops by input shapes AND the chain of enclosing "
+                    "ops (aten::contiguous <- _NormActBackward ...), which names the caller even on the autograd thread")
     ap.add_argument("--ops", default=None, help="comma-separated substrings: list only the ops whose name contains one of them")
     args = ap.parse_args()
     device = torch.device("cuda", 0)
@@ -36,10 +38,30 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=not args.stacks,
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=not args.stacks or args.parents,
                  with_stack=args.stacks) as prof:
         step()
         torch.cuda.synchronize()
+    if args.parents:
+        want = (args.ops or "copy_,fill_,add_").split(",")
+        groups = {}
+        for e in prof.events():
+            dev = getattr(e, "self_device_time_total", 0) or 0
+            if dev <= 0 or not any(o in e.name for o in want):
+                continue
+            chain, p = [], e.cpu_parent
+            while p is not None and len(chain) < 4:
+                chain.append(p.name[:48])
+                p = p.cpu_parent
+            key = (e.name, str(e.input_shapes)[:110], " <- ".join(chain))
+            g = groups.setdefault(key, [0.0, 0])
+            g[0] += dev
+            g[1] += 1
+        print("| self device us | calls | op | input shapes | enclosing ops |\n|---:|---:|---|---|---|")
+        for (name, shapes, chain), (dev, n) in sorted(groups.items(), key=lambda kv: -kv[1][0])[:args.top]:
+            print("| %.0f | %d | `%s` | %s | %s |" % (dev, n, name, shapes, chain))
+        print("total: %.0f us over %d calls" % (sum(v[0] for v in groups.values()), sum(v[1] for v in groups.values())))
+        return
     if args.stacks:
         avg = prof.key_averages(group_by_stack_n=6)
     else:
