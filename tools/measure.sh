@@ -14,6 +14,10 @@
 #   convtable  per-layer table of the library convolutions at the model's own routing (tools/conv_layer_table.py)
 #   heads      K8 against the library route at the cfg-2 head shapes
 #   repro      the guard-page reproducer of MIOpen's backward-data over-read (+ K8 on the same operands)
+#   guard      tests/test_gpu_guard.py + tests/test_gpu_head.py verbose (every own kernel on guard-page operands, outputs and workspaces)
+#   glue       the step's small ATen launches by op, shape and enclosing op (tools/aten_glue_profile.py --parents) + bench A/B of the round-5
+#              glue changes, hipGraph replay and eager (profiles/r05_aten_glue.md)
+#   pwmodes    stage 3-5 blocks with the point-wise convolutions on the library route / on K7 / K7 weight gradient only, replayed graphs
 #   cpusurvey  bench.py --cpu-protocol survey (batch 2, 1 + 3 steps, all physical cores; ~10 min of host time)
 #   closing    tests margins bench configs stages kernels trace pmc5 pmcmrg in that order
 TASK=${1:-closing}
@@ -119,6 +123,26 @@ t_heads() {
 }
 t_repro() {
   python tools/conv_bwd_fault_repro.py --own --repeat 3 --log-dir $OUT/repro_logs 2>&1 | cut -c1-420 > $OUT/conv_bwd_fault_repro.txt; tail -20 $OUT/conv_bwd_fault_repro.txt | cut -c1-160
+}
+t_guard() {
+  python -m pytest tests/test_gpu_guard.py tests/test_gpu_head.py -q -m gpu -p no:cacheprovider 2>&1 | grep -v "MIOpen\|GridwiseOp\|amdgpu.ids" > $OUT/guard_pages_pytest.txt; tail -3 $OUT/guard_pages_pytest.txt
+}
+t_glue() {
+  python tools/aten_glue_profile.py --parents --ops copy_,fill_,add_,flip --top 150 2>&1 | grep -v "amdgpu.ids\|Warning\|warn_once" > $OUT/aten_glue_parents.txt; tail -1 $OUT/aten_glue_parents.txt
+  OLD="NEXTOU_STEP_GLUE=0 NEXTOU_CHANNELS_LAST_FILTERS=0 NEXTOU_FILTER_FLIP=0"
+  for i in 1 2; do
+    python bench.py --no-cpu-baseline --steps 40 > $OUT/glue_graph_new_$i.json 2>/dev/null; field $OUT/glue_graph_new_$i.json
+    env $OLD python bench.py --no-cpu-baseline --steps 40 > $OUT/glue_graph_old_$i.json 2>/dev/null; field $OUT/glue_graph_old_$i.json
+    python bench.py --no-cpu-baseline --steps 20 --graph off > $OUT/glue_eager_new_$i.json 2>/dev/null; field $OUT/glue_eager_new_$i.json
+    env $OLD python bench.py --no-cpu-baseline --steps 20 --graph off > $OUT/glue_eager_old_$i.json 2>/dev/null; field $OUT/glue_eager_old_$i.json
+  done
+}
+t_pwmodes() {
+  rm -f $OUT/pw_modes_stages345.txt
+  for m in 0 1 wgrad; do
+    NEXTOU_PW_GEMM=$m python tools/gnn_stage_profile.py --cl --graph --iters 20 --stages 3,4,5 2>/dev/null | sed "s/^/pw=$m /" >> $OUT/pw_modes_stages345.txt
+  done
+  grep "as replayed" $OUT/pw_modes_stages345.txt
 }
 t_cpusurvey() {
   python bench.py --steps 5 --warmup 3 --cpu-protocol survey > $OUT/bench_cfg2_cpu_survey.json 2> $OUT/bench_cfg2_cpu_survey.log
