@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import threading
 from typing import Callable, List, Optional
 
 import torch
@@ -1174,8 +1175,9 @@ class _ZeroGradRider(torch.autograd.Function):
         return (g,) + tuple(grads)
 
 
-class ZeroGradScope:
-    """The bias of a convolution folded into a batch- / instance-statistics norm has gradient exactly zero (the statistics absorb a
+class ZeroGradScope(threading.local):
+    """(State per thread: replicas driven by threads — nn.DataParallel — each see their own scope.)
+    The bias of a convolution folded into a batch- / instance-statistics norm has gradient exactly zero (the statistics absorb a
     per-channel constant); the optimizer must still SEE a zero gradient — weight decay and momentum act on the parameter as they do
     in the reference, where the gradient is round-off around zero.  Producing that zero per norm is one fill kernel each: 85 launches,
     0.38 ms of the cfg-2 step (profiles/r05_aten_glue.md).  Inside ``with scope:`` (the network's training forward) the norms hand

@@ -18,6 +18,7 @@ runs without its bias, which the norm folds in (:class:`_ConvBiasFolded`).  ``Ne
 from __future__ import annotations
 
 import os
+import threading
 
 import torch
 from torch import nn
@@ -164,8 +165,8 @@ def _verify_spatial_size(x: torch.Tensor) -> None:
         raise ValueError("Expected more than 1 spatial element when training, got input size %s" % (x.size(),))
 
 
-class DeferredCounters:
-    """``num_batches_tracked += 1`` of every batch norm of a network as ONE multi-tensor launch per forward instead of one
+class DeferredCounters(threading.local):
+    """(State per thread, like graph_ops.ZeroGradScope.)  ``num_batches_tracked += 1`` of every batch norm of a network as ONE multi-tensor launch per forward instead of one
     single-element kernel per norm (78 launches, 0.34 ms of the cfg-2 step — profiles/r05_aten_glue.md).  The network's forward
     runs inside ``with counters:``; norms whose momentum is a number (the counter is pure bookkeeping then, as in
     torch.nn.modules.batchnorm._BatchNorm.forward) hand their counter over instead of advancing it themselves, and leaving the
@@ -176,6 +177,9 @@ class DeferredCounters:
     def __init__(self):
         self.active = False
         self._pending = []
+
+    def __reduce__(self):            # deepcopy / pickle of a model: a fresh, idle instance (shared by the copy's norms through the memo)
+        return (DeferredCounters, ())
 
     def defer(self, counter: torch.Tensor) -> None:
         self._pending.append(counter)
