@@ -91,8 +91,16 @@ def move_to(trainer, device, fused_sgd=False):
     # first blamed on this combination is MIOpen's backward-data kernel of the 1x1 head convolution reading past its operand —
     # tools/conv_bwd_fault_repro.py, profiles/r05_n_gt_1.md; the heads run on K8 since.)
     fused = fused_sgd and device.type == "cuda" and os.environ.get("NEXTOU_SGD_FUSED", "1") != "0"
-    trainer.optimizer = torch.optim.SGD(trainer.network.parameters(), trainer.initial_lr, weight_decay=trainer.weight_decay,
-                                        momentum=trainer.momentum, nesterov=True, **({"fused": True} if fused else {}))
+    if device.type == "cuda" and os.environ.get("NEXTOU_CLIP_SGD", "1") != "0":
+        # round 5: the clip and the update on the library's step-glue kernels (nextou_amd/optim.py: a torch.optim.SGD whose step names
+        # its tensors through a table in device memory — 3 launches instead of ~70).  Under the gradient averager the gradients are plain
+        # views of the flat buckets, whose layout differs from channels-last filters: ClipSGD then hands the step to torch's foreach SGD
+        from nextou_amd.optim import ClipSGD
+        trainer.optimizer = ClipSGD(trainer.network.parameters(), trainer.initial_lr, weight_decay=trainer.weight_decay,
+                                    momentum=trainer.momentum, nesterov=True)
+    else:
+        trainer.optimizer = torch.optim.SGD(trainer.network.parameters(), trainer.initial_lr, weight_decay=trainer.weight_decay,
+                                            momentum=trainer.momentum, nesterov=True, **({"fused": True} if fused else {}))
     if hasattr(trainer.loss, "loss") and hasattr(trainer.loss.loss, "ti"):
         trainer.loss = trainer._build_loss()      # interaction tensors follow the device
 
@@ -113,8 +121,11 @@ def make_step(trainer, data, targets, averager, bf16=False):
         loss.backward()
         if averager is not None:
             averager.finalize()
-        torch.nn.utils.clip_grad_norm_(params, 12)
-        trainer.optimizer.step()
+        if hasattr(trainer.optimizer, "clip_and_step"):
+            trainer.optimizer.clip_and_step(12)      # clip_grad_norm_(params, 12) + SGD step on the step-glue kernels
+        else:
+            torch.nn.utils.clip_grad_norm_(params, 12)
+            trainer.optimizer.step()
         return loss
     return step
 
@@ -478,7 +489,9 @@ def main():
                        "gradient_averager": averager is not None,
                        "optimizer": "SGD(nesterov, momentum %g, weight_decay %g, %s)" % (
                            trainer.momentum, trainer.weight_decay,
-                           "fused" if trainer.optimizer.defaults.get("fused") else "foreach"),
+                           {"own": "own clip + update kernels (nextou_amd.optim.ClipSGD)", "torch": "ClipSGD -> torch foreach"}.get(
+                               trainer.optimizer.last_path, "not stepped") if hasattr(trainer.optimizer, "last_path")
+                           else ("fused" if trainer.optimizer.defaults.get("fused") else "foreach")),
                        "step_replayed_as_hipgraph": graphed is not None, "graph_capture_error": capture_error,
                        "parallelism": "dp%d" % world, "final_loss": float(loss.detach())},
             "dist": dist_info,

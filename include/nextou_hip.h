@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NEXTOU_ABI_VERSION 12
+#define NEXTOU_ABI_VERSION 13
 
 #define NEXTOU_EINVAL   (-1)  /* bad argument (null pointer, non-positive size, k > M ...) */
 #define NEXTOU_ENOSPACE (-2)  /* workspace too small */
@@ -372,6 +372,41 @@ int nextou_cat_bias_rows(const float* a, const float* bias, const float* b, floa
  *     the convolution itself). */
 int nextou_filter_flip_t(const float* w, float* out, int Co, int Ci, int Kd, int Kh, int Kw, int64_t s_co, int64_t s_ci, int64_t s_kd,
                          int64_t s_kh, int64_t s_kw, nextou_stream_t stream);
+
+/* nextou_narrow_copy_sum (ABI v13)  dst (P, C) dense = src[:, c_off : c_off + C] of channels-last rows with row stride ld floats, and
+ *     sum_out[c] = sum_p dst[p, c] (float64 partial sums in nextou_channel_sum's order: bit-identical to nextou_channel_sum of the copy) —
+ *     one read of the channel range instead of two.  The backward of the decoder's torch.cat((up-convolution output, skip), 1) (reference
+ *     NexToU_Encoder_Decoder.py:311-337): the transposed convolution's backward needs the first C channels of the gradient as a dense
+ *     tensor, its folded bias their sums.  float32; C, ld and c_off multiples of 4, C <= 128, 16-byte aligned pointers — NEXTOU_ENOTSUP
+ *     otherwise (the caller keeps ATen's narrow().contiguous() + nextou_channel_sum).  ws: nextou_norm_act_workspace_bytes(1, C, P, f32). */
+int nextou_narrow_copy_sum(const float* src, float* dst, float* sum_out, void* ws, size_t ws_bytes, int64_t P, int C, int64_t ld,
+                           int c_off, nextou_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Step glue (ABI v13): gradient clip + SGD update of a whole parameter list.  The step nnU-Net's trainer prescribes for the NexToU
+ * plug-ins (nnUNetTrainer_NexToU inherits nnUNetTrainer.train_step: backward -> clip_grad_norm_(network.parameters(), 12) ->
+ * SGD(momentum 0.99, nesterov, weight_decay 3e-5).step(); reference nnUNetTrainer_NexToU.py:14-22 sets nothing else) runs both as
+ * multi-tensor-apply launches of at most 36-110 tensors each — ~70 launches for the 1 100 parameter tensors of cfg 2.  Here the
+ * tensors are named by a table in DEVICE memory, so each stage is one launch whatever the tensor count:
+ *   table   int64 [n_tensors][4]: parameter pointer, gradient pointer, momentum-buffer pointer (0: none), element count; the three
+ *           tensors of a row are walked as flat float32 arrays and must share one dense layout
+ *   chunks  int32 [n_chunks][2]: (row, chunk index within the row's tensor), chunk_elems elements per chunk (multiple of 4, >= 1024);
+ *           every element of every tensor belongs to exactly one chunk
+ * nextou_grad_norm_clip_coef   norm_coef[0] = || all gradients ||_2 (float64 partial sums per chunk into `partial` (n_chunks doubles),
+ *           summed in a fixed order, rounded to float32), norm_coef[1] = min(1, max_norm / (norm + 1e-6)): clip_grad_norm_'s factor.
+ * nextou_clip_sgd_update       per element: g <- g * norm_coef[1] and stored (norm_coef NULL: no clip, g is only read); d = g + wd * p;
+ *           buf = momentum * buf + d; d = nesterov ? d + momentum * buf : buf; p = p - lr * d.  lr_dev (may be NULL) overrides lr with a
+ *           float in device memory (schedulers under hipGraph replay).  A zero-filled buffer on the first step reproduces torch's
+ *           "buf = clone(grad)".  The products with wd, momentum (Nesterov) and lr are fused multiply-adds, as in ATen's alpha-adds.
+ * ---------------------------------------------------------------------------------------- */
+/* nextou_device_write_i64   dst[0 .. n) <- host_values, carried as kernel arguments (448 values per launch): the way a table reaches
+ *           device memory inside a hipGraph capture — the values live in the graph's nodes, no host buffer is read at replay. */
+int nextou_device_write_i64(int64_t* dst, const int64_t* host_values, int64_t n, nextou_stream_t stream);
+int nextou_grad_norm_clip_coef(const int64_t* table, int n_tensors, const int32_t* chunks, int n_chunks, int chunk_elems,
+                               int64_t total_elems, double* partial, float max_norm, float* norm_coef, nextou_stream_t stream);
+int nextou_clip_sgd_update(const int64_t* table, int n_tensors, const int32_t* chunks, int n_chunks, int chunk_elems, int64_t total_elems,
+                           const float* norm_coef, float lr, const float* lr_dev, float momentum, float weight_decay, int nesterov,
+                           nextou_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K7  point-wise (kernel 1, stride 1) convolutions on channels-last rows — the 1x1 convolutions of the Grapher / FFN

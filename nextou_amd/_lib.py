@@ -22,7 +22,8 @@ LIB_PATH = os.environ.get("NEXTOU_HIP_LIB") or os.path.join(_PKG_DIR, "libnextou
 
 KNN_AUTO, KNN_FUSED, KNN_NAIVE = 0, 1, 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
+EINVAL, ENOSPACE, ENOTSUP = -1, -2, -3       # include/nextou_hip.h
 
 # name -> (restype, argtypes); mirrors include/nextou_hip.h one to one
 _SIGNATURES = {
@@ -87,6 +88,11 @@ _SIGNATURES = {
     "nextou_cell_gather": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "nextou_cell_scatter": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "nextou_cat_bias_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "nextou_narrow_copy_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int64, c_int, c_void_p]),
+    "nextou_device_write_i64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "nextou_grad_norm_clip_coef": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_void_p, c_float, c_void_p, c_void_p]),
+    "nextou_clip_sgd_update": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_void_p, c_float, c_void_p, c_float, c_float,
+                                       c_int, c_void_p]),
     "nextou_filter_flip_t": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int64,
                                      c_void_p]),
     "nextou_depth_unroll": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),

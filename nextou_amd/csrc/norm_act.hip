@@ -595,6 +595,49 @@ __global__ __launch_bounds__(kThreads) void bn_cl_stats_kernel(const T* __restri
     cl_block_sums<VEC>(s, q, C, tact, partial, gridDim.x);
 }
 
+// bn_cl_stats_kernel's sums over a channel RANGE of wider channels-last rows, the range written out densely on the way: the
+// backward of the decoder's cat((up-convolution output + bias, skip), 1) hands the first C of the gradient's C + C2 channels to the
+// transposed convolution — which needs a dense tensor — and their per-channel sums to the bias.  ATen's narrow().contiguous()
+// followed by nextou_channel_sum read the range twice; this reads it once.  Work split, accumulation order and partial layout are
+// bn_cl_stats_kernel's on the dense (P, C) tensor, so the sums are bit-identical to nextou_channel_sum of the copy.
+// C % 4 == 0, ld % 4 == 0, c_off % 4 == 0; span (and hence every workgroup's base) is a multiple of tact * 4, tact a multiple of C:
+// a lane's column never changes and its row advances by (tact * 4) / C per iteration.
+__global__ __launch_bounds__(kThreads) void narrow_copy_stats_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                     double2* __restrict__ partial, long long total, int C, int tact,
+                                                                     long long span, long long ld, int c_off) {
+    double s[4], q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = q[j] = 0.0;
+    if ((int)threadIdx.x < tact) {
+        const long long base = (long long)blockIdx.x * span;
+        const long long end = min(total, base + span);
+        const long long stride = (long long)tact * 4;
+        const long long rows_per_iter = stride / C;
+        long long e = base + (long long)threadIdx.x * 4;
+        const float* sp = src + (e / C) * ld + c_off + (int)(e % C);
+        const long long sstep = rows_per_iter * ld;
+        for (; e + 3 * stride < end; e += 4 * stride, sp += 4 * sstep) {
+            Pack<float, 4> p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u].load_stream(sp + u * sstep);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                p[u].store(dst + e + u * stride);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const double v = (double)p[u].v[j]; s[j] += v; q[j] = fma(v, v, q[j]); }
+            }
+        }
+        for (; e < end; e += stride, sp += sstep) {
+            Pack<float, 4> p;
+            p.load_stream(sp);
+            p.store(dst + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const double v = (double)p.v[j]; s[j] += v; q[j] = fma(v, v, q[j]); }
+        }
+    }
+    cl_block_sums<4>(s, q, C, tact, partial, gridDim.x);
+}
+
 // One workgroup per channel: statistics -> save_mean / save_invstd (+ running statistics), shared by both layouts' callers.
 __global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(const double2* __restrict__ partial, int tiles, double count,
                                                          const float* __restrict__ pre_bias, float* running_mean,
@@ -1537,4 +1580,27 @@ extern "C" int nextou_channel_sum(const void* x, float* out, void* ws, size_t ws
     }
     hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C), dim3(kFinThreads), 0, s, partial, tiles, out);
     return check_launch("channel_sum");
+}
+
+extern "C" int nextou_narrow_copy_sum(const float* src, float* dst, float* sum_out, void* ws, size_t ws_bytes, int64_t P, int C,
+                                      int64_t ld, int c_off, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(src && dst && sum_out && ws, "narrow_copy_sum: null pointer");
+    NEXTOU_REQUIRE(P > 0 && P <= (1ll << 40) && C > 0 && ld >= C && c_off >= 0 && c_off + (int64_t)C <= ld,
+                   "narrow_copy_sum: bad size P=%lld C=%d ld=%lld c_off=%d", (long long)P, C, (long long)ld, c_off);
+    if (C % 4 != 0 || ld % 4 != 0 || c_off % 4 != 0 || use_clw(C) || !aligned16(src) || !aligned16(dst))
+        return fail(NEXTOU_ENOTSUP, "narrow_copy_sum: takes 16-byte aligned rows of at most %d channels, counts and offsets multiples of 4 "
+                    "(C=%d ld=%lld c_off=%d)", kThreads / 2, C, (long long)ld, c_off);
+    const size_t need = nextou_norm_act_workspace_bytes(1, C, P, NEXTOU_DTYPE_F32);
+    if (ws_bytes < need) return fail(NEXTOU_ENOSPACE, "narrow_copy_sum: workspace %zu < %zu bytes", ws_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)P * C;
+    const ClPlan p = plan_cl(total, C, 4, true);        // total % 4 == 0 since C % 4 == 0
+    double2* partial = (double2*)ws;
+    {
+        ProfScope prof(s, kBoundHbm, 8.0 * (double)total, "narrow_copy_stats_kernel[P%lld C%d of %lld]", (long long)P, C, (long long)ld);
+        hipLaunchKernelGGL(narrow_copy_stats_kernel, dim3(p.blocks), dim3(kThreads), (size_t)p.tact * 4 * sizeof(double2), s, src, dst,
+                           partial, total, C, p.tact, p.span, (long long)ld, c_off);
+    }
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C), dim3(kFinThreads), 0, s, partial, p.blocks, sum_out);
+    return check_launch("narrow_copy_sum");
 }

@@ -287,5 +287,11 @@ def init_process_group_from_env(backend: Optional[str] = None):
         if backend == "nccl" and torch.cuda.device_count() > local_rank:
             torch.cuda.set_device(local_rank)
         _capture_safe_process_group_env(backend)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # the first step of every rank runs the convolution library's find pass (tens of seconds alone, longer with N ranks sharing the
+        # host and the library's user database); ranks drift apart by that much before their first collective meets.  The default
+        # watchdog limit (10 min for nccl) is enough on an idle node — a generous one costs nothing and keeps a slow box from being
+        # reported as a hang
+        import datetime
+        minutes = float(os.environ.get("NEXTOU_DIST_TIMEOUT_MIN", "30"))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=minutes))
     return rank, local_rank, world

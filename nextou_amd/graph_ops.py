@@ -478,6 +478,29 @@ class _HipBackend:
         _lib.check(rc, "channel_sum")
         return out
 
+    @staticmethod
+    def narrow_copy_sum(g, c_off, C):
+        """``(g.narrow(1, c_off, C).contiguous(channels_last), its per-channel sums)`` of a dense channels-last float32 ``g`` in ONE
+        pass over the channel range (nextou_narrow_copy_sum), or None for a shape the kernel does not take."""
+        import os
+        if os.environ.get("NEXTOU_NARROW_COPY_SUM", "1") == "0" or g.dtype != torch.float32 or _dense_channels_last(g) is None:
+            return None
+        ld = g.shape[1]
+        if C % 4 or ld % 4 or c_off % 4 or C > 128 or g.data_ptr() % 16:
+            return None
+        L_ = _lib.lib()
+        P = g.numel() // ld
+        dst = _empty_channels_last((g.shape[0], C) + tuple(g.shape[2:]), g.device)
+        out = torch.empty((C,), dtype=torch.float32, device=g.device)
+        ws = torch.empty((int(L_.nextou_norm_act_workspace_bytes(1, C, P, _lib.DTYPE_F32)),), dtype=torch.uint8, device=g.device)
+        with torch.cuda.device(g.device):
+            rc = L_.nextou_narrow_copy_sum(g.data_ptr(), dst.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), P, C, ld, c_off,
+                                           _stream_ptr(g.device))
+        if rc == _lib.ENOTSUP:
+            return None
+        _lib.check(rc, "narrow_copy_sum")
+        return dst, out
+
 
     # ---- K3 / K4: window / pool data movement between channels-last volumes and channel-major rows ----
     @staticmethod
@@ -2073,8 +2096,13 @@ class _CatBias(torch.autograd.Function):
     def backward(ctx, g):
         c1 = ctx.c1
         mf = {4: torch.channels_last, 5: torch.channels_last_3d}[g.dim()]
-        gy = g.narrow(1, 0, c1).contiguous(memory_format=mf)         # the copy the convolution's backward would make anyway
-        gb = _HIP.channel_sum(gy, channels_last=True) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        want_gb = ctx.has_bias and ctx.needs_input_grad[1]
+        both = _HIP.narrow_copy_sum(g, 0, c1) if (want_gb and g.is_cuda) else None       # copy + bias sums in one pass (ABI v13)
+        if both is not None:
+            gy, gb = both
+        else:
+            gy = g.narrow(1, 0, c1).contiguous(memory_format=mf)         # the copy the convolution's backward would make anyway
+            gb = _HIP.channel_sum(gy, channels_last=True) if want_gb else None
         return gy, gb, g.narrow(1, c1, g.shape[1] - c1)
 
 

@@ -131,8 +131,12 @@ class StandaloneTrainerBase:
                                                        self.configuration_manager, self.num_input_channels,
                                                        self.enable_deep_supervision).to(self.device)
         self.loss = self._build_loss()
-        self.optimizer = torch.optim.SGD(self.network.parameters(), self.initial_lr, weight_decay=self.weight_decay,
-                                         momentum=self.momentum, nesterov=True)
+        # nnU-Net's configure_optimizers: SGD(initial_lr, weight_decay, momentum 0.99, nesterov).  ClipSGD is that torch.optim.SGD with
+        # the step (and train_step's gradient clip) on the library's step-glue kernels for float32 GPU parameters; anything else —
+        # a CPU network in the tests — runs torch's own implementation inside it
+        from .optim import ClipSGD
+        self.optimizer = ClipSGD(self.network.parameters(), self.initial_lr, weight_decay=self.weight_decay,
+                                 momentum=self.momentum, nesterov=True)
         return self
 
     def configure_rotation_dummyDA_mirroring_and_inital_patch_size(self):
@@ -154,8 +158,11 @@ class StandaloneTrainerBase:
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.loss(self.network(data), target)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
-        self.optimizer.step()
+        if hasattr(self.optimizer, "clip_and_step"):
+            self.optimizer.clip_and_step(12)
+        else:
+            torch.nn.utils.clip_grad_norm_(self.network.parameters(), 12)
+            self.optimizer.step()
         return loss.detach()
 
 

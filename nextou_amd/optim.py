@@ -1,0 +1,183 @@
+"""``ClipSGD``: nnU-Net's optimizer step — ``clip_grad_norm_(parameters, 12)`` then ``torch.optim.SGD(momentum, nesterov,
+weight_decay).step()`` — on this library's step-glue kernels (csrc/step_glue.hip, ABI v13).
+
+The reference sets no optimizer of its own (nnUNetTrainer_NexToU.py:14-22 inherits nnUNetTrainer's ``configure_optimizers`` and
+``train_step``); the plug-ins' step therefore ends with torch's multi-tensor clip and SGD, ~70 launches of a few dozen workgroups
+for the 1 100 parameter tensors of a cfg-2 network.  ``ClipSGD`` IS a ``torch.optim.SGD`` (same constructor, ``param_groups``,
+``state`` with ``momentum_buffer`` tensors, ``state_dict`` / ``load_state_dict``, LR schedulers) whose ``step()`` names its
+tensors to the kernels through a table in device memory: one launch for the update, two more for the clip
+(:meth:`clip_and_step`), whatever the tensor count.
+
+Same update rule and operation order as ``torch.optim.SGD(foreach=True)``; results agree to the last bit or two (a fused
+multiply-add here, a separately rounded product there — the same spread as between torch's own foreach / fused / single-tensor
+variants).  Anything the kernels do not take (CPU or non-float32 parameters, sparse gradients, dampening, maximize, a gradient
+whose memory layout differs from its parameter's) goes through torch's implementation, unchanged.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+
+__all__ = ["ClipSGD"]
+
+_CHUNK = 16384          # elements per workgroup (64 KB of each tensor)
+
+
+def _same_dense_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return a.shape == b.shape and a.stride() == b.stride()
+
+
+class _Table:
+    """Device table + chunk list + workspace of one set of (parameter, gradient, buffer) tensors.  Immutable once built: the values
+    travel as kernel arguments (nextou_device_write_i64), so a captured hipGraph keeps rewriting — and its kernels keep reading — the
+    table it was captured with; nothing on the host is read at replay and no pinned allocation happens inside a capture."""
+
+    def __init__(self, rows: List[tuple], device: torch.device):
+        import ctypes
+        flat, chunks, total = [], [], 0
+        for i, (p, g, m, n) in enumerate(rows):
+            flat.extend((p, g, m, n))
+            for c in range((n + _CHUNK - 1) // _CHUNK):
+                chunks.append(i | (c << 32))              # int32 pair (row, chunk) as one little-endian int64
+            total += n
+        self.n_tensors, self.n_chunks, self.total = len(rows), len(chunks), total
+        self.table = torch.empty((len(flat),), dtype=torch.int64, device=device)
+        self.chunks = torch.empty((len(chunks),), dtype=torch.int64, device=device)
+        L = _lib.lib()
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            for dst, vals in ((self.table, flat), (self.chunks, chunks)):
+                host = (ctypes.c_int64 * len(vals))(*vals)
+                _lib.check(L.nextou_device_write_i64(dst.data_ptr(), ctypes.cast(host, ctypes.c_void_p), len(vals), stream),
+                           "device_write_i64")
+        self.partial = torch.empty((self.n_chunks,), dtype=torch.float64, device=device)
+        self.norm_coef = torch.empty((2,), dtype=torch.float32, device=device)
+
+
+class ClipSGD(torch.optim.SGD):
+    """``torch.optim.SGD`` with the step (and, through :meth:`clip_and_step`, the gradient clip) on own kernels."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, *, maximize=False,
+                 differentiable=False):
+        # foreach (torch's default on the GPU) is what the fallback path runs
+        super().__init__(params, lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov,
+                         maximize=maximize, differentiable=differentiable)
+        self._tables = {}
+        self._retired = []
+        self.last_path = None            # "own" | "torch": which implementation the last step took (tests, bench line)
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def _plan(self, group):
+        """(rows, device) of one param group for the kernels, or None when torch's implementation has to run it."""
+        if os.environ.get("NEXTOU_CLIP_SGD", "1") == "0":
+            return None
+        if group["dampening"] != 0 or group["maximize"] or group.get("differentiable", False):
+            return None
+        if group["nesterov"] and group["momentum"] <= 0:
+            return None
+        lr = group["lr"]
+        if isinstance(lr, torch.Tensor) and not (lr.is_cuda and lr.dtype == torch.float32 and lr.numel() == 1):
+            return None
+        rows, device = [], None
+        for p in group["params"]:
+            g = p.grad
+            if g is None:
+                continue
+            if not (p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and not g.is_sparse and g.device == p.device):
+                return None
+            if device is None:
+                device = p.device
+            if p.device != device or not p.is_non_overlapping_and_dense() or not _same_dense_layout(p, g):
+                return None
+            m = 0
+            if group["momentum"] != 0:
+                state = self.state[p]
+                buf = state.get("momentum_buffer")
+                if buf is None:
+                    # zeros: momentum * 0 + d = d is torch's "buf = clone(d)" of the first step
+                    buf = state["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if not (buf.is_cuda and buf.dtype == torch.float32 and buf.device == device and _same_dense_layout(p, buf)):
+                    return None
+                m = buf.data_ptr()
+            if p.numel():
+                rows.append((p.data_ptr(), g.data_ptr(), m, p.numel()))
+        if not rows:
+            return None
+        return rows, device
+
+    def _table(self, gi: int, rows, device) -> _Table:
+        key = tuple(rows)
+        cached = self._tables.get(gi)
+        if cached is not None and cached[0] == key:
+            t = cached[1]
+        else:
+            t = _Table(rows, device)
+            self._tables[gi] = (key, t)
+        if torch.cuda.is_current_stream_capturing() and not any(r is t for r in self._retired):
+            self._retired.append(t)               # the captured graph's kernels keep reading this table after a later step replaced it
+        return t
+
+    # ---------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _own_step(self, max_norm: Optional[float]):
+        """The whole step on the kernels; returns the total-norm tensor (None without a clip), or NotImplemented when any group
+        needs torch's implementation (nothing but zero-filled momentum buffers has been created then — torch's update of a
+        zero buffer is its first-step ``buf = clone(d)``)."""
+        plans = [self._plan(g) for g in self.param_groups]
+        live = [(gi, pl) for gi, pl in enumerate(plans) if pl is not None]
+        groups_with_grads = [gi for gi, g in enumerate(self.param_groups) if any(p.grad is not None for p in g["params"])]
+        if not groups_with_grads:
+            return None if max_norm is None else torch.zeros(())
+        if [gi for gi, _ in live] != groups_with_grads:
+            return NotImplemented
+        if max_norm is not None and len(live) != 1:
+            return NotImplemented            # the clip's norm spans all groups: one table
+        L = _lib.lib()
+        norm = None
+        for gi, (rows, device) in live:
+            group = self.param_groups[gi]
+            t = self._table(gi, rows, device)
+            lr = group["lr"]
+            lr_dev = lr.data_ptr() if isinstance(lr, torch.Tensor) else None
+            with torch.cuda.device(device):
+                stream = torch.cuda.current_stream(device).cuda_stream
+                if max_norm is not None:
+                    _lib.check(L.nextou_grad_norm_clip_coef(t.table.data_ptr(), t.n_tensors, t.chunks.data_ptr(), t.n_chunks, _CHUNK,
+                                                            t.total, t.partial.data_ptr(), float(max_norm), t.norm_coef.data_ptr(),
+                                                            stream), "grad_norm_clip_coef")
+                    norm = t.norm_coef[0]
+                _lib.check(L.nextou_clip_sgd_update(t.table.data_ptr(), t.n_tensors, t.chunks.data_ptr(), t.n_chunks, _CHUNK, t.total,
+                                                    t.norm_coef.data_ptr() if max_norm is not None else None,
+                                                    0.0 if lr_dev else float(lr), lr_dev, float(group["momentum"]),
+                                                    float(group["weight_decay"]), int(bool(group["nesterov"])), stream),
+                           "clip_sgd_update")
+        return norm
+
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._own_step(None) is NotImplemented:
+            self.last_path = "torch"
+            super().step()
+        else:
+            self.last_path = "own"
+        return loss
+
+    def clip_and_step(self, max_norm: float) -> torch.Tensor:
+        """``torch.nn.utils.clip_grad_norm_(all parameters of this optimizer, max_norm)`` followed by :meth:`step`; returns the
+        total norm (a 0-dim tensor, no host synchronisation).  The gradients are left scaled, as the clip leaves them."""
+        norm = self._own_step(max_norm)
+        if norm is NotImplemented:
+            self.last_path = "torch"
+            params = [p for g in self.param_groups for p in g["params"]]
+            norm = torch.nn.utils.clip_grad_norm_(params, max_norm)
+            super().step()
+        else:
+            self.last_path = "own"
+        return norm

@@ -321,3 +321,36 @@ def test_filter_flip_t(hip, co, ci, k, layout):
     got = hip.filter_flip_t(w)
     assert got.shape == want.shape and got.stride() == want.stride() and torch.equal(got, want)
     _guarded(lambda w: hip.filter_flip_t(w), [w])
+
+
+# ---------------------------------------------------------------- step glue (ABI v13)
+@pytest.mark.parametrize("C,ld,c_off", [(40, 80, 0), (36, 76, 40), (128, 132, 0)])
+def test_narrow_copy_sum(hip, C, ld, c_off):
+    g = _gen(C + ld)
+    x = _cl(torch.randn((2, ld, 3, 7, 9), generator=g).to(DEV))
+    _guarded(lambda x: hip.narrow_copy_sum(x, c_off, C), [x])
+
+
+@pytest.mark.parametrize("clip", [True, False])
+def test_clip_sgd(hip, clip):
+    """Parameters, gradients and momentum buffers of every size class (one element, odd counts, chunk boundaries, a channels-last
+    filter) on guard pages; the device table, the chunk list and the norm workspace are torch.empty allocations and land there too."""
+    from nextou_amd.optim import ClipSGD
+    g = _gen(17)
+    shapes = [(1,), (37,), (16384,), (16385,), (66, 8, 3, 3, 3), (40001,)]
+    ps = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    ps[4] = _cl(ps[4])
+    gs = [torch.empty_like(p).copy_(torch.randn(p.shape, generator=g).to(DEV) * 4) for p in ps]
+    ms = [torch.empty_like(p).copy_(torch.randn(p.shape, generator=g).to(DEV)) for p in ps]
+    n = len(ps)
+
+    def launch(*tensors):
+        params = [torch.nn.Parameter(t) for t in tensors[:n]]
+        opt = ClipSGD(params, 0.01, momentum=0.99, weight_decay=3e-5, nesterov=True)
+        for p, gr, m in zip(params, tensors[n:2 * n], tensors[2 * n:]):
+            p.grad = gr
+            opt.state[p]["momentum_buffer"] = m
+        out = opt.clip_and_step(12.0) if clip else opt.step()
+        assert opt.last_path == "own"
+        return out.reshape(1).clone() if clip else None
+    _guarded(launch, ps + gs + ms, exact=True, inplace=tuple(range(3 * n)))

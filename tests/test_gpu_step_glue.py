@@ -1,0 +1,202 @@
+"""Step glue (ABI v13): ClipSGD (gradient clip + SGD update on own kernels) against torch.nn.utils.clip_grad_norm_ +
+torch.optim.SGD, eager and inside a captured hipGraph; nextou_narrow_copy_sum against narrow().contiguous() + nextou_channel_sum.
+
+Tolerances: the update rule and its operation order are torch's (foreach SGD); a product that one side rounds separately and the
+other fuses into a multiply-add moves a result by at most one float32 ulp per operation, so parameters / buffers are compared at
+2e-6 relative (to the tensor's largest magnitude), the total norm (float64 partial sums here, float32 there) at 1e-6.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from nextou_amd import _lib, graph_ops
+    _lib.lib()
+    assert "libnextou_hip.so" in open("/proc/self/maps").read(), "HIP extension not loaded into this process"
+    return graph_ops._HIP
+
+
+def _param_set(seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(1,), (37,), (14, 33, 1, 1, 1), (66, 72, 3, 3, 3), (40000,), (16384,), (16385,), (33,), (324, 44, 1, 1, 1)]
+    tensors = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    tensors[3] = tensors[3].contiguous(memory_format=torch.channels_last_3d)      # a filter stored channels-last (layout.py)
+    base = torch.randn((4 + 1001,), generator=g).to(DEV)
+    tensors.append(base[1:1 + 1001])                                                # 4-byte aligned only: the scalar path
+    return tensors
+
+
+def _twin_params(seed):
+    a = [torch.nn.Parameter(t.clone(memory_format=torch.preserve_format)) for t in _param_set(seed)]
+    a[-1] = torch.nn.Parameter(_param_set(seed)[-1])                               # keep the unaligned view (clone would realign it)
+    b = [torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in a]
+    return a, b
+
+
+def _set_grads(ps, qs, step, skip=()):
+    g = torch.Generator().manual_seed(1000 + step)
+    for i, (p, q) in enumerate(zip(ps, qs)):
+        if i in skip:
+            p.grad = q.grad = None
+            continue
+        gr = (torch.randn(p.shape, generator=g) * (3.0 if step % 2 else 0.01)).to(DEV)
+        # gradients arrive in the parameter's layout (AccumulateGrad's contract)
+        p.grad = torch.empty_like(p).copy_(gr)
+        q.grad = torch.empty_like(q).copy_(gr)
+
+
+def _close(a, b, rel=2e-6):
+    scale = float(b.detach().abs().max()) + 1e-30
+    return float((a.detach().double() - b.detach().double()).abs().max()) <= rel * scale
+
+
+@pytest.mark.parametrize("momentum,nesterov,wd", [(0.99, True, 3e-5), (0.9, False, 0.0), (0.0, False, 1e-4)])
+def test_clip_and_step_matches_torch(hip, momentum, nesterov, wd):
+    from nextou_amd.optim import ClipSGD
+    ps, qs = _twin_params(7)
+    own = ClipSGD(ps, 0.01, momentum=momentum, weight_decay=wd, nesterov=nesterov)
+    ref = torch.optim.SGD(qs, 0.01, momentum=momentum, weight_decay=wd, nesterov=nesterov, foreach=True)
+    for step in range(4):
+        _set_grads(ps, qs, step, skip=(4,) if step < 2 else ())        # a parameter without a gradient (the zero-weighted head)
+        n_own = own.clip_and_step(12.0)
+        n_ref = torch.nn.utils.clip_grad_norm_(qs, 12.0)
+        ref.step()
+        assert own.last_path == "own"
+        assert abs(float(n_own) - float(n_ref)) <= 1e-6 * float(n_ref)
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            assert p.stride() == q.stride()
+            assert _close(p, q), "parameter %d after step %d" % (i, step)
+            if q.grad is not None:
+                assert _close(p.grad, q.grad), "clipped gradient %d after step %d" % (i, step)      # the clip leaves g * factor in .grad
+            if momentum:
+                mo, mr = own.state[p].get("momentum_buffer"), ref.state[q].get("momentum_buffer")
+                assert (mo is None) == (mr is None)
+                if mr is not None:
+                    assert mo.stride() == p.stride() and _close(mo, mr), "momentum buffer %d after step %d" % (i, step)
+    # the state is torch.optim.SGD's: a plain SGD loads it and carries on identically
+    plain = torch.optim.SGD([torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in ps], 0.01,
+                            momentum=momentum, weight_decay=wd, nesterov=nesterov)
+    plain.load_state_dict(own.state_dict())
+    assert len(plain.state_dict()["state"]) == len(own.state_dict()["state"])
+
+
+def test_plain_step_and_fallbacks(hip, monkeypatch):
+    from nextou_amd.optim import ClipSGD
+    ps, qs = _twin_params(11)
+    own = ClipSGD(ps, 0.05, momentum=0.99, weight_decay=3e-5, nesterov=True)
+    ref = torch.optim.SGD(qs, 0.05, momentum=0.99, weight_decay=3e-5, nesterov=True, foreach=True)
+    for step in range(3):
+        _set_grads(ps, qs, step)
+        before = [p.grad.clone() for p in ps]
+        own.step()
+        ref.step()
+        assert own.last_path == "own"
+        assert all(torch.equal(p.grad, b) for p, b in zip(ps, before))       # no clip: the gradients are only read
+        assert all(_close(p, q) for p, q in zip(ps, qs))
+    # a gradient in another layout than its parameter: torch's implementation takes the step, same numbers
+    _set_grads(ps, qs, 5)
+    ps[3].grad = ps[3].grad.contiguous()
+    assert ps[3].grad.stride() != ps[3].stride()
+    own.clip_and_step(12.0)
+    torch.nn.utils.clip_grad_norm_(qs, 12.0)
+    ref.step()
+    assert own.last_path == "torch"
+    assert all(_close(p, q) for p, q in zip(ps, qs))
+    # switched off
+    monkeypatch.setenv("NEXTOU_CLIP_SGD", "0")
+    _set_grads(ps, qs, 6)
+    own.step()
+    ref.step()
+    assert own.last_path == "torch" and all(_close(p, q) for p, q in zip(ps, qs))
+
+
+def test_clip_and_step_inside_a_captured_graph(hip):
+    """The table is rebuilt DURING the capture (the gradients of a captured step live in the graph's pool): its values travel as
+    kernel arguments, and later eager steps — which rebuild it again — must not disturb the replays."""
+    from nextou_amd.optim import ClipSGD
+
+    def build():
+        ps = [torch.nn.Parameter(t.clone(memory_format=torch.preserve_format)) for t in _param_set(3)[:8]]
+        opt = ClipSGD(ps, 0.02, momentum=0.99, weight_decay=3e-5, nesterov=True)
+        x = torch.linspace(0.5, 1.5, 8, device=DEV)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = sum(((p * x[i]) ** 2).sum() + p.sum() for i, p in enumerate(ps))
+            loss.backward()
+            opt.clip_and_step(5.0)
+            return loss
+        return ps, opt, step
+
+    ps_e, opt_e, step_e = build()
+    for _ in range(7):
+        step_e()
+    ps_g, opt_g, step_g = build()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step_g()                                   # 1 eager
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step_g()                                   # 2 (the capture does not execute; replays do)
+    graph.replay()
+    graph.replay()
+    step_g()                                       # an eager step in between: new table
+    graph.replay()
+    graph.replay()
+    step_g()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert opt_g.last_path == "own"
+    # 1 eager + 5 replays + 2 eager = 8 steps?  the captured call itself did not run: 1 + 2 + 1 + 2 + 1 + 1 = 8 -> one more on the eager twin
+    step_e()
+    torch.cuda.synchronize()
+    for p, q in zip(ps_g, ps_e):
+        assert _close(p, q, rel=1e-6)
+
+
+@pytest.mark.parametrize("C,ld,c_off,sp", [(40, 80, 0, (3, 8, 9)), (72, 144, 0, (2, 5, 7)), (36, 76, 40, (3, 8, 8)), (4, 8, 4, (1, 3, 5)),
+                                            (128, 132, 0, (2, 4, 4)), (40, 80, 0, (16, 40, 41))])
+def test_narrow_copy_sum_is_the_copy_and_its_channel_sums(hip, C, ld, c_off, sp):
+    g = torch.Generator().manual_seed(C + ld)
+    x = torch.randn((2, ld) + sp, generator=g).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    got = hip.narrow_copy_sum(x, c_off, C)
+    assert got is not None
+    want = x.narrow(1, c_off, C).contiguous(memory_format=torch.channels_last_3d)
+    assert got[0].shape == want.shape and got[0].stride() == want.stride() and torch.equal(got[0], want)
+    assert torch.equal(got[1], hip.channel_sum(want, channels_last=True))          # same partial sums, same order: bit-identical
+    ref = want.double().sum(dim=(0, 2, 3, 4))
+    assert float((got[1].double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max() + 1.0)
+
+
+def test_narrow_copy_sum_declines_what_it_does_not_take(hip):
+    x = torch.randn((2, 270, 2, 4, 4), device=DEV).contiguous(memory_format=torch.channels_last_3d)
+    assert hip.narrow_copy_sum(x, 0, 6) is None            # not a multiple of 4
+    assert hip.narrow_copy_sum(x, 0, 132) is None          # wider than the row-packing kernels take
+    assert hip.narrow_copy_sum(x.contiguous(), 0, 8) is None          # not channels-last
+    assert hip.narrow_copy_sum(x.half(), 0, 8) is None
+
+
+def test_cat_bias_backward_through_the_one_pass_kernel(hip, monkeypatch):
+    from nextou_amd import graph_ops
+    g = torch.Generator().manual_seed(5)
+    y = torch.randn((2, 40, 3, 8, 8), generator=g).to(DEV).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    skip = torch.randn((2, 36, 3, 8, 8), generator=g).to(DEV).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    bias = torch.randn(40, generator=g).to(DEV).requires_grad_(True)
+    go = torch.randn((2, 76, 3, 8, 8), generator=g).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NEXTOU_NARROW_COPY_SUM", mode)
+        out = graph_ops.cat_bias(y, bias, skip)
+        res[mode] = torch.autograd.grad(out, [y, bias, skip], go)
+    for a, b in zip(res["1"], res["0"]):
+        assert torch.equal(a, b)
+    want = torch.autograd.grad(torch.cat((y + bias.view(1, -1, 1, 1, 1), skip), 1), [y, bias, skip], go)
+    assert torch.equal(res["1"][0], want[0]) and torch.equal(res["1"][2], want[2])
+    assert float((res["1"][1] - want[1]).abs().max()) <= 1e-5 * float(want[1].abs().max())

@@ -18,6 +18,8 @@
 #   glue       the step's small ATen launches by op, shape and enclosing op (tools/aten_glue_profile.py --parents) + bench A/B of the round-5
 #              glue changes, hipGraph replay and eager (profiles/r05_aten_glue.md)
 #   pwmodes    stage 3-5 blocks with the point-wise convolutions on the library route / on K7 / K7 weight gradient only, replayed graphs
+#   stepglue   tests of the step-glue kernels (ClipSGD, narrow_copy_sum) + tools/step_ab.py: the bench step against variants without
+#              clip / optimizer and with the own clip + SGD kernels, captured side by side and replayed in alternation
 #   cpusurvey  bench.py --cpu-protocol survey (batch 2, 1 + 3 steps, all physical cores; ~10 min of host time)
 #   closing    tests margins bench configs stages kernels trace pmc5 pmcmrg in that order
 TASK=${1:-closing}
@@ -61,6 +63,10 @@ t_kernels() {
   python tools/kernel_bench.py --norm --cl --iters 10 > $OUT/kernel_bench_norm_cl.txt 2>&1
   python tools/kernel_bench.py --mrg --iters 10 > $OUT/kernel_bench_mrg.txt 2>&1
   grep -E "knn_fused|mr_" $OUT/kernel_bench_cfg2.txt | head -24
+}
+t_stepglue() {
+  python -m pytest tests/test_gpu_step_glue.py tests/test_gpu_guard.py tests/test_gpu_ddp.py -q -m gpu -k "step_glue or narrow or clip_sgd or cat_bias or ddp" -x 2>&1 | grep -v "MIOpen\|amdgpu.ids" | tail -15 > $OUT/stepglue_pytest.txt; tail -3 $OUT/stepglue_pytest.txt
+  python tools/step_ab.py --variants full,no_opt,own,own-ncs --rounds 3 --steps 10 --eager > $OUT/step_ab.txt 2> $OUT/step_ab.log; tail -8 $OUT/step_ab.txt; tail -3 $OUT/step_ab.log
 }
 t_trace() {
   cd /tmp && export TMPDIR=/tmp
