@@ -382,6 +382,23 @@ int nextou_filter_flip_t(const float* w, float* out, int Co, int Ci, int Kd, int
 int nextou_narrow_copy_sum(const float* src, float* dst, float* sum_out, void* ws, size_t ws_bytes, int64_t P, int C, int64_t ld,
                            int c_off, nextou_stream_t stream);
 
+/* nextou_upconv_cat_rows / nextou_upconv_cat_rows_bwd (ABI v13)  the decoder's torch.cat((transpconv(x) + bias, skip), 1) (reference
+ *     NexToU_Encoder_Decoder.py:311-337; transpconvs are built with kernel == stride, :272-276) with the transposed convolution as a K7 GEMM: every
+ *     input point p_in of the (B, D, H, W) volume produces the T = sd*sh*sw taps of its output block independently, so
+ *     y2 (P_in, T*C1) = x (P_in, Cin) . w2^T with w2[(t*C1 + co), ci] = weight[ci, co, t] is one nextou_pw_rows call, and
+ *     nextou_upconv_cat_rows      out[p, :] = [y2[p_in(p), t(p)*C1 : (t(p)+1)*C1] + bias, skip[p, :]] over the rows p of the
+ *         (B, D*sd, H*sh, W*sw) output volume, channels-last, t = ((d2 % sd) sh + h2 % sh) sw + w2 % sw — the "pixel shuffle" rides
+ *         on the concatenation pass (same traffic as nextou_cat_bias_rows);
+ *     nextou_upconv_cat_rows_bwd  gy2 (P_in, T*C1) = the first C1 channels of the gradient rows g (P, C1 + C2), un-shuffled the same
+ *         way, and gbias[c] = sum_p g[p, c] (nextou_narrow_copy_sum's pass and summation order); the data gradient is then
+ *         nextou_pw_rows(gy2, weight viewed (Cin, T*C1)), the filter gradient nextou_pw_wgrad(gy2, x).
+ *     float32, 2-D volumes pass D = sd = 1; C1, C2 multiples of 4, C1 + C2 <= 1024 (bwd: C1 <= 128, else NEXTOU_ENOTSUP); strides 1..4;
+ *     ws of the backward: nextou_norm_act_workspace_bytes(1, C1, P, f32). */
+int nextou_upconv_cat_rows(const float* y2, const float* bias, const float* skip, float* out, int B, int D, int H, int W, int sd, int sh,
+                           int sw, int C1, int C2, nextou_stream_t stream);
+int nextou_upconv_cat_rows_bwd(const float* g, float* gy2, float* gbias, void* ws, size_t ws_bytes, int B, int D, int H, int W, int sd,
+                               int sh, int sw, int C1, int C2, nextou_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Step glue (ABI v13): gradient clip + SGD update of a whole parameter list.  The step nnU-Net's trainer prescribes for the NexToU
  * plug-ins (nnUNetTrainer_NexToU inherits nnUNetTrainer.train_step: backward -> clip_grad_norm_(network.parameters(), 12) ->

@@ -89,6 +89,8 @@ _SIGNATURES = {
     "nextou_cell_scatter": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "nextou_cat_bias_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "nextou_narrow_copy_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int64, c_int, c_void_p]),
+    "nextou_upconv_cat_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "nextou_upconv_cat_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t] + [c_int] * 9 + [c_void_p]),
     "nextou_device_write_i64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "nextou_grad_norm_clip_coef": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_void_p, c_float, c_void_p, c_void_p]),
     "nextou_clip_sgd_update": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_void_p, c_float, c_void_p, c_float, c_float,

@@ -54,6 +54,22 @@ __device__ __forceinline__ long long window_point_row(int win, int p, const Vol&
     return ((long long)d * v.H + h) * v.W + x;
 }
 
+// Transposed convolution with kernel == stride (the decoder's up-convolutions): output volume (B, D2, H2, W2) = input volume times the stride
+struct UpShuffle {
+    int D2, H2, W2, sd, sh, sw;
+};
+__device__ __forceinline__ long long upconv_row(long long row, const UpShuffle& u) {       // output row -> p_in * T + t
+    const unsigned w2 = (unsigned)(row % u.W2);
+    const long long r1 = row / u.W2;
+    const unsigned h2 = (unsigned)(r1 % u.H2);
+    const long long r2 = r1 / u.H2;
+    const unsigned d2 = (unsigned)(r2 % u.D2);
+    const long long b = r2 / u.D2;
+    const unsigned t = ((d2 % u.sd) * u.sh + h2 % u.sh) * u.sw + w2 % u.sw;
+    const long long p_in = ((b * (u.D2 / u.sd) + d2 / u.sd) * (u.H2 / u.sh) + h2 / u.sh) * (u.W2 / u.sw) + w2 / u.sw;
+    return p_in * (u.sd * u.sh * u.sw) + t;
+}
+
 // LDS budget one workgroup of the gather kernels may claim (keeps >= 2 workgroups per CU).
 constexpr int kGatherLdsBytes = 64 * 1024;
 

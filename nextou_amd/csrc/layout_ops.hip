@@ -455,6 +455,30 @@ __global__ __launch_bounds__(256) void cat_bias_rows_kernel(const float4* __rest
     }
 }
 
+// cat_bias_rows_kernel whose first operand is the (P_in, T * C1) product of the up-convolution's input with its filter (K7, nextou_pw_rows):
+// output row p takes the C1 channels of tap t of input point p_in (upconv_row) — the transposed convolution's "pixel shuffle" happens in the
+// pass that concatenates anyway.
+__global__ __launch_bounds__(256) void upconv_cat_rows_kernel(const float4* __restrict__ a, const float4* __restrict__ bias,
+                                                              const float4* __restrict__ b, float4* __restrict__ out, long long P,
+                                                              int c1q, int c2q, int rows_per_pass, UpShuffle u) {
+    const int cq = c1q + c2q;
+    const int r_local = threadIdx.x / cq, q = threadIdx.x - r_local * cq;
+    if (r_local >= rows_per_pass) return;
+    const bool first = q < c1q;
+    const float4 bv = (first && bias) ? bias[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long step = (long long)gridDim.x * rows_per_pass;
+    for (long long row = (long long)blockIdx.x * rows_per_pass + r_local; row < P; row += step) {
+        float4 v;
+        if (first) {
+            v = a[upconv_row(row, u) * c1q + q];
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        } else {
+            v = b[row * c2q + (q - c1q)];
+        }
+        out[row * cq + q] = v;
+    }
+}
+
 // out[ci][kd][kh][kw][co] (channels-last memory of the (Ci, Co, Kd, Kh, Kw) filter) = w[co][ci][Kd-1-kd][Kh-1-kh][Kw-1-kw]: the filter of the
 // forward convolution that computes a stride-1 convolution's data gradient, from the forward filter in either memory layout (element
 // strides).  One 32 x 32 (co, ci) tile per tap through LDS: reads run along ci (contiguous in a channels-last filter), writes along co.
@@ -510,6 +534,28 @@ extern "C" int nextou_cat_bias_rows(const float* a, const float* bias, const flo
                        reinterpret_cast<const float4*>(bias), reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out),
                        (long long)P, C1 / 4, C2 / 4, rpp);
     return check_launch("cat_bias_rows_kernel");
+}
+
+extern "C" int nextou_upconv_cat_rows(const float* y2, const float* bias, const float* skip, float* out, int B, int D, int H, int W, int sd,
+                                      int sh, int sw, int C1, int C2, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(y2 && skip && out, "upconv_cat_rows: null pointer");
+    NEXTOU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && sd >= 1 && sh >= 1 && sw >= 1 && sd <= 4 && sh <= 4 && sw <= 4 && C1 > 0 && C2 > 0 &&
+                   C1 % 4 == 0 && C2 % 4 == 0 && (C1 + C2) / 4 <= 256,
+                   "upconv_cat_rows: bad size B=%d (%d,%d,%d) stride (%d,%d,%d) C %d+%d (multiples of 4, C1 + C2 <= 1024)", B, D, H, W, sd, sh,
+                   sw, C1, C2);
+    NEXTOU_REQUIRE(((reinterpret_cast<uintptr_t>(y2) | reinterpret_cast<uintptr_t>(skip) | reinterpret_cast<uintptr_t>(out) |
+                     reinterpret_cast<uintptr_t>(bias)) & 15u) == 0, "upconv_cat_rows: tensors must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const nextou::UpShuffle u{D * sd, H * sh, W * sw, sd, sh, sw};
+    const long long P = (long long)B * u.D2 * u.H2 * u.W2;
+    const int cq = (C1 + C2) / 4, rpp = 256 / cq;
+    long long blocks = (P + rpp - 1) / rpp;
+    if (blocks > 16384) blocks = 16384;
+    ProfScope prof(s, kBoundHbm, 8.0 * (double)P * (C1 + C2), "upconv_cat_rows_kernel[P%lld C%d+%d s%dx%dx%d]", P, C1, C2, sd, sh, sw);
+    hipLaunchKernelGGL(nextou::upconv_cat_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(y2),
+                       reinterpret_cast<const float4*>(bias), reinterpret_cast<const float4*>(skip), reinterpret_cast<float4*>(out), P,
+                       C1 / 4, C2 / 4, rpp, u);
+    return check_launch("upconv_cat_rows_kernel");
 }
 
 extern "C" int nextou_depth_unroll(const float* x_cl, float* out_cl, int B, int C, int D, int H, int W, nextou_stream_t stream) {

@@ -602,9 +602,14 @@ __global__ __launch_bounds__(kThreads) void bn_cl_stats_kernel(const T* __restri
 // bn_cl_stats_kernel's on the dense (P, C) tensor, so the sums are bit-identical to nextou_channel_sum of the copy.
 // C % 4 == 0, ld % 4 == 0, c_off % 4 == 0; span (and hence every workgroup's base) is a multiple of tact * 4, tact a multiple of C:
 // a lane's column never changes and its row advances by (tact * 4) / C per iteration.
+// SHUF: the dense copy is written "un-shuffled" instead — row p of the (B, D2, H2, W2) output volume of a transposed convolution whose
+// kernel equals its stride (sd, sh, sw) belongs to input point p_in = (b, d2 / sd, h2 / sh, w2 / sw) and tap t = ((d2 % sd) sh + h2 % sh) sw +
+// w2 % sw, and goes to dst[(p_in * T + t) * C + c]: the (P_in, T * C) matrix whose product with the filter is the data gradient.  Reads and
+// sums are unchanged (same order), only the store address differs.
+template <bool SHUF>
 __global__ __launch_bounds__(kThreads) void narrow_copy_stats_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                                      double2* __restrict__ partial, long long total, int C, int tact,
-                                                                     long long span, long long ld, int c_off) {
+                                                                     long long span, long long ld, int c_off, UpShuffle u) {
     double s[4], q[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = q[j] = 0.0;
@@ -614,23 +619,27 @@ __global__ __launch_bounds__(kThreads) void narrow_copy_stats_kernel(const float
         const long long stride = (long long)tact * 4;
         const long long rows_per_iter = stride / C;
         long long e = base + (long long)threadIdx.x * 4;
-        const float* sp = src + (e / C) * ld + c_off + (int)(e % C);
+        long long row = e / C;
+        const int col = (int)(e % C);
+        const float* sp = src + row * ld + c_off + col;
         const long long sstep = rows_per_iter * ld;
-        for (; e + 3 * stride < end; e += 4 * stride, sp += 4 * sstep) {
+        for (; e + 3 * stride < end; e += 4 * stride, sp += 4 * sstep, row += 4 * rows_per_iter) {
             Pack<float, 4> p[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) p[u].load_stream(sp + u * sstep);
+            for (int u4 = 0; u4 < 4; ++u4) p[u4].load_stream(sp + u4 * sstep);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                p[u].store(dst + e + u * stride);
+            for (int u4 = 0; u4 < 4; ++u4) {
+                if (SHUF) p[u4].store(dst + upconv_row(row + u4 * rows_per_iter, u) * C + col);
+                else p[u4].store(dst + e + u4 * stride);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const double v = (double)p[u].v[j]; s[j] += v; q[j] = fma(v, v, q[j]); }
+                for (int j = 0; j < 4; ++j) { const double v = (double)p[u4].v[j]; s[j] += v; q[j] = fma(v, v, q[j]); }
             }
         }
-        for (; e < end; e += stride, sp += sstep) {
+        for (; e < end; e += stride, sp += sstep, row += rows_per_iter) {
             Pack<float, 4> p;
             p.load_stream(sp);
-            p.store(dst + e);
+            if (SHUF) p.store(dst + upconv_row(row, u) * C + col);
+            else p.store(dst + e);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const double v = (double)p.v[j]; s[j] += v; q[j] = fma(v, v, q[j]); }
         }
@@ -1582,25 +1591,44 @@ extern "C" int nextou_channel_sum(const void* x, float* out, void* ws, size_t ws
     return check_launch("channel_sum");
 }
 
-extern "C" int nextou_narrow_copy_sum(const float* src, float* dst, float* sum_out, void* ws, size_t ws_bytes, int64_t P, int C,
-                                      int64_t ld, int c_off, nextou_stream_t stream) {
-    NEXTOU_REQUIRE(src && dst && sum_out && ws, "narrow_copy_sum: null pointer");
+static int narrow_copy_sum_impl(const char* who, const float* src, float* dst, float* sum_out, void* ws, size_t ws_bytes, int64_t P, int C,
+                                int64_t ld, int c_off, const UpShuffle* shuffle, hipStream_t s) {
+    NEXTOU_REQUIRE(src && dst && sum_out && ws, "%s: null pointer", who);
     NEXTOU_REQUIRE(P > 0 && P <= (1ll << 40) && C > 0 && ld >= C && c_off >= 0 && c_off + (int64_t)C <= ld,
-                   "narrow_copy_sum: bad size P=%lld C=%d ld=%lld c_off=%d", (long long)P, C, (long long)ld, c_off);
+                   "%s: bad size P=%lld C=%d ld=%lld c_off=%d", who, (long long)P, C, (long long)ld, c_off);
     if (C % 4 != 0 || ld % 4 != 0 || c_off % 4 != 0 || use_clw(C) || !aligned16(src) || !aligned16(dst))
-        return fail(NEXTOU_ENOTSUP, "narrow_copy_sum: takes 16-byte aligned rows of at most %d channels, counts and offsets multiples of 4 "
-                    "(C=%d ld=%lld c_off=%d)", kThreads / 2, C, (long long)ld, c_off);
+        return fail(NEXTOU_ENOTSUP, "%s: takes 16-byte aligned rows of at most %d channels, counts and offsets multiples of 4 "
+                    "(C=%d ld=%lld c_off=%d)", who, kThreads / 2, C, (long long)ld, c_off);
     const size_t need = nextou_norm_act_workspace_bytes(1, C, P, NEXTOU_DTYPE_F32);
-    if (ws_bytes < need) return fail(NEXTOU_ENOSPACE, "narrow_copy_sum: workspace %zu < %zu bytes", ws_bytes, need);
-    hipStream_t s = (hipStream_t)stream;
+    if (ws_bytes < need) return fail(NEXTOU_ENOSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
     const long long total = (long long)P * C;
     const ClPlan p = plan_cl(total, C, 4, true);        // total % 4 == 0 since C % 4 == 0
     double2* partial = (double2*)ws;
     {
-        ProfScope prof(s, kBoundHbm, 8.0 * (double)total, "narrow_copy_stats_kernel[P%lld C%d of %lld]", (long long)P, C, (long long)ld);
-        hipLaunchKernelGGL(narrow_copy_stats_kernel, dim3(p.blocks), dim3(kThreads), (size_t)p.tact * 4 * sizeof(double2), s, src, dst,
-                           partial, total, C, p.tact, p.span, (long long)ld, c_off);
+        ProfScope prof(s, kBoundHbm, 8.0 * (double)total, "narrow_copy_stats_kernel<%s>[P%lld C%d of %lld]", shuffle ? "unshuffle" : "copy",
+                       (long long)P, C, (long long)ld);
+        const size_t lds = (size_t)p.tact * 4 * sizeof(double2);
+        if (shuffle)
+            hipLaunchKernelGGL(narrow_copy_stats_kernel<true>, dim3(p.blocks), dim3(kThreads), lds, s, src, dst, partial, total, C, p.tact,
+                               p.span, (long long)ld, c_off, *shuffle);
+        else
+            hipLaunchKernelGGL(narrow_copy_stats_kernel<false>, dim3(p.blocks), dim3(kThreads), lds, s, src, dst, partial, total, C, p.tact,
+                               p.span, (long long)ld, c_off, UpShuffle{});
     }
     hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C), dim3(kFinThreads), 0, s, partial, p.blocks, sum_out);
-    return check_launch("narrow_copy_sum");
+    return check_launch(who);
+}
+
+extern "C" int nextou_narrow_copy_sum(const float* src, float* dst, float* sum_out, void* ws, size_t ws_bytes, int64_t P, int C,
+                                      int64_t ld, int c_off, nextou_stream_t stream) {
+    return narrow_copy_sum_impl("narrow_copy_sum", src, dst, sum_out, ws, ws_bytes, P, C, ld, c_off, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int nextou_upconv_cat_rows_bwd(const float* g, float* gy2, float* gbias, void* ws, size_t ws_bytes, int B, int D, int H, int W,
+                                          int sd, int sh, int sw, int C1, int C2, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && sd >= 1 && sh >= 1 && sw >= 1 && sd <= 4 && sh <= 4 && sw <= 4 && C1 > 0 && C2 >= 0,
+                   "upconv_cat_rows_bwd: bad size B=%d (%d,%d,%d) stride (%d,%d,%d) C %d+%d", B, D, H, W, sd, sh, sw, C1, C2);
+    const UpShuffle u{D * sd, H * sh, W * sw, sd, sh, sw};
+    const int64_t P = (int64_t)B * u.D2 * u.H2 * u.W2;
+    return narrow_copy_sum_impl("upconv_cat_rows_bwd", g, gy2, gbias, ws, ws_bytes, P, C1, (int64_t)C1 + C2, 0, &u, (hipStream_t)stream);
 }

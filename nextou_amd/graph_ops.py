@@ -501,6 +501,48 @@ class _HipBackend:
         _lib.check(rc, "narrow_copy_sum")
         return dst, out
 
+    @staticmethod
+    def upconv_cat_rows(y2, bias, skip, stride):
+        """y2: channels-last (B, T*C1, *sp_in) = the K7 product of the up-convolution's input with its filter; skip: dense channels-last
+        (B, C2, *sp_out) -> channels-last (B, C1 + C2, *sp_out) = [pixel-shuffled y2 + bias, skip] (nextou_upconv_cat_rows)."""
+        L_ = _lib.lib()
+        T = 1
+        for s_ in stride:
+            T *= int(s_)
+        B, c1, c2 = y2.shape[0], y2.shape[1] // T, skip.shape[1]
+        sp = tuple(y2.shape[2:])
+        d, h, w = ((1,) + sp)[-3:]
+        sd, sh, sw = ((1,) + tuple(int(v) for v in stride))[-3:]
+        out = _empty_channels_last((B, c1 + c2) + tuple(skip.shape[2:]), y2.device)
+        with torch.cuda.device(y2.device):
+            rc = L_.nextou_upconv_cat_rows(y2.data_ptr(), _ptr(bias), skip.data_ptr(), out.data_ptr(), B, d, h, w, sd, sh, sw, c1, c2,
+                                           _stream_ptr(y2.device))
+        _lib.check(rc, "upconv_cat_rows")
+        return out
+
+    @staticmethod
+    def upconv_cat_rows_bwd(g, c1, sp_in, stride):
+        """g: dense channels-last (B, C1 + C2, *sp_out) -> (gy2 channels-last (B, T*C1, *sp_in), per-channel sums of g[:, :C1]) in one pass,
+        or None for a channel count the kernel does not take."""
+        L_ = _lib.lib()
+        T = 1
+        for s_ in stride:
+            T *= int(s_)
+        B, ctot = g.shape[0], g.shape[1]
+        d, h, w = ((1,) + tuple(sp_in))[-3:]
+        sd, sh, sw = ((1,) + tuple(int(v) for v in stride))[-3:]
+        P = g.numel() // ctot
+        gy2 = _empty_channels_last((B, T * c1) + tuple(sp_in), g.device)
+        gb = torch.empty((c1,), dtype=torch.float32, device=g.device)
+        ws = torch.empty((int(L_.nextou_norm_act_workspace_bytes(1, c1, P, _lib.DTYPE_F32)),), dtype=torch.uint8, device=g.device)
+        with torch.cuda.device(g.device):
+            rc = L_.nextou_upconv_cat_rows_bwd(g.data_ptr(), gy2.data_ptr(), gb.data_ptr(), ws.data_ptr(), ws.numel(), B, d, h, w, sd, sh, sw,
+                                               c1, ctot - c1, _stream_ptr(g.device))
+        if rc == _lib.ENOTSUP:
+            return None
+        _lib.check(rc, "upconv_cat_rows_bwd")
+        return gy2, gb
+
 
     # ---- K3 / K4: window / pool data movement between channels-last volumes and channel-major rows ----
     @staticmethod
@@ -2104,6 +2146,96 @@ class _CatBias(torch.autograd.Function):
             gy = g.narrow(1, 0, c1).contiguous(memory_format=mf)         # the copy the convolution's backward would make anyway
             gb = _HIP.channel_sum(gy, channels_last=True) if want_gb else None
         return gy, gb, g.narrow(1, c1, g.shape[1] - c1)
+
+
+class _UpConvCat(torch.autograd.Function):
+    """``torch.cat((conv_transpose(x, weight) + bias, skip), 1)`` for a transposed convolution whose kernel equals its stride (padding 0,
+    dilation 1, one group — every transpconv of the decoder, reference NexToU_Encoder_Decoder.py:272-276) on dense channels-last fp32
+    volumes.  Such a convolution has no overlapping taps: each input point produces its T = prod(stride) output points independently, so it
+    is the GEMM x (P_in, Cin) . (Cin, T*Cout) followed by a pixel shuffle.  Forward: K7 (nextou_pw_rows) + ONE pass that shuffles, adds the
+    bias and concatenates (nextou_upconv_cat_rows — the traffic of the concatenation that ran anyway).  Backward: one pass un-shuffles the
+    first Cout channels of the gradient and forms the bias sums (nextou_upconv_cat_rows_bwd), then K7's data-gradient GEMM and weight
+    gradient.  The library ran these as a backward-data kernel used forwards at 20 % of the fp32 MFMA peak (profiles/r05_conv_layer_table.md:
+    1 029 + 1 033 us at the full-resolution stage of cfg 2, behind a 685-us concatenation)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, skip, stride):
+        cin, cout = weight.shape[0], weight.shape[1]
+        T = weight.numel() // (cin * cout)
+        # (Cin, Cout, *k) -> rows (t, co) x columns ci: the GEMM's (N, K) operand
+        n = weight.dim() - 2
+        w2 = weight.permute(*range(2, 2 + n), 1, 0).reshape(T * cout, cin).contiguous()
+        y2 = _HIP.pw_rows(x, w2, None, 1)
+        out = _HIP.upconv_cat_rows(y2, None if bias is None else bias.contiguous(), skip, stride)
+        ctx.save_for_backward(x, weight)
+        ctx.stride, ctx.has_bias, ctx.cout = tuple(int(v) for v in stride), bias is not None, cout
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        cin, cout = weight.shape[0], weight.shape[1]
+        n = weight.dim() - 2
+        T = weight.numel() // (cin * cout)
+        mf = {4: torch.channels_last, 5: torch.channels_last_3d}[g.dim()]
+        if _dense_channels_last(g) is None:
+            g = g.contiguous(memory_format=mf)
+        both = _HIP.upconv_cat_rows_bwd(g, cout, tuple(x.shape[2:]), ctx.stride)
+        if both is None:        # wide rows (C1 > 128): ATen's strided copy, then the shuffle as a view + copy
+            gy = g.narrow(1, 0, cout)
+            B = g.shape[0]
+            sp_in = tuple(x.shape[2:])
+            shp = [B, cout]
+            for d_, s_ in zip(sp_in, ctx.stride):
+                shp += [d_, s_]
+            gy = gy.reshape(shp)                                              # (B, co, d, sd, h, sh, w, sw)
+            taps = [3 + 2 * i for i in range(n)]
+            dims = [2 + 2 * i for i in range(n)]
+            gy2 = gy.permute(0, *taps, 1, *dims).reshape((B, T * cout) + sp_in).contiguous(memory_format=mf)
+            gb = gy2.reshape((B, T, cout) + sp_in).sum(dim=[0, 1] + list(range(3, 3 + n))) if ctx.has_bias else None
+        else:
+            gy2, gb = both
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            # gx[p, ci] = sum_{t, co} gy2[p, t*Cout + co] * weight[ci, co, t]: the (N = Cin, K = T*Cout) operand is the filter as stored channels-last
+            w3 = weight.permute(0, *range(2, 2 + n), 1).reshape(cin, T * cout).contiguous()
+            gx = _HIP.pw_rows(gy2, w3, None, 1)
+        if ctx.needs_input_grad[1]:
+            dw2 = _HIP.pw_wgrad(gy2, x, 1)                                   # (T*Cout, Cin)
+            gw = dw2.reshape(tuple(weight.shape[2:]) + (cout, cin)).permute(n + 1, n, *range(n))
+            if weight.dim() in (4, 5) and weight.is_contiguous(memory_format=mf) and not weight.is_contiguous():
+                gw = gw.contiguous(memory_format=mf)                          # the layout the parameter is stored in (layout.filters_to_channels_last)
+            else:
+                gw = gw.contiguous()
+        if not (ctx.has_bias and ctx.needs_input_grad[2]):
+            gb = None
+        return gx, gw, gb, g.narrow(1, cout, g.shape[1] - cout), None
+
+
+def upconv_cat_eligible(x: torch.Tensor, weight: torch.Tensor, bias, skip: torch.Tensor, stride, padding, dilation, output_padding,
+                        groups, kernel_size) -> bool:
+    import os
+    if os.environ.get("NEXTOU_UPCONV_GEMM", "1") == "0":
+        return False
+    if not (x.is_cuda and skip.is_cuda) or x.dtype != torch.float32 or skip.dtype != torch.float32 or weight.dtype != torch.float32:
+        return False
+    if torch.is_autocast_enabled("cuda") or groups != 1 or x.dim() not in (4, 5):
+        return False
+    if tuple(kernel_size) != tuple(stride) or any(int(p) for p in padding) or any(int(d) != 1 for d in dilation) or \
+            any(int(o) for o in output_padding) or any(int(s_) < 1 or int(s_) > 4 for s_ in stride):
+        return False
+    cin, cout, c2 = weight.shape[0], weight.shape[1], skip.shape[1]
+    if x.shape[1] != cin or cin % 4 or cout % 4 or c2 % 4 or cout + c2 > 1024 or x.shape[0] != skip.shape[0]:
+        return False
+    if tuple(skip.shape[2:]) != tuple(int(d_) * int(s_) for d_, s_ in zip(x.shape[2:], stride)):
+        return False
+    if _dense_channels_last(x) is None or _dense_channels_last(skip) is None:
+        return False
+    return bias is None or (bias.dtype == torch.float32 and bias.shape[0] == cout)
+
+
+def upconv_cat(x, weight, bias, skip, stride):
+    return _UpConvCat.apply(x, weight, bias, skip, tuple(stride))
 
 
 def cat_bias_eligible(y: torch.Tensor, bias, skip: torch.Tensor) -> bool:

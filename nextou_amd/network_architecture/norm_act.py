@@ -121,6 +121,10 @@ def up_conv_cat(up: nn.Module, x: torch.Tensor, skip: torch.Tensor) -> torch.Ten
         n = len(up.stride)
         out_pad = up._output_padding(x, None, up.stride, up.padding, up.kernel_size, n, up.dilation) if up.transposed else (0,) * n
         weight, bias = padded_conv_params(up, x, with_bias=True)
+        if up.transposed and graph_ops.upconv_cat_eligible(x, weight, bias, skip, up.stride, up.padding, up.dilation, out_pad, up.groups,
+                                                           up.kernel_size):
+            # kernel == stride: the transposed convolution is a K7 GEMM + a pixel shuffle that rides on the concatenation pass (round 5)
+            return graph_ops.upconv_cat(x, weight, bias, skip, up.stride)
         y = graph_ops.conv_own_bias_grad(x, weight, None, up.stride, up.padding, up.dilation, up.transposed, out_pad, up.groups)
         if graph_ops.cat_bias_eligible(y, bias, skip):
             return graph_ops.cat_bias(y, bias, skip)

@@ -31,6 +31,40 @@ def _same_dense_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
     return a.shape == b.shape and a.stride() == b.stride()
 
 
+def _dense(p: torch.Tensor) -> bool:
+    """True when ``p``'s elements occupy exactly ``numel`` consecutive slots in some dimension order (contiguous, channels-last ...):
+    the tensor can be walked as a flat array."""
+    dims = sorted((d for d in range(p.dim()) if p.shape[d] > 1), key=lambda d: p.stride(d))
+    expect = 1
+    for d in dims:
+        if p.stride(d) != expect:
+            return False
+        expect *= p.shape[d]
+    return True
+
+
+def _stream_of(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+
+
+def _capturing(device: torch.device) -> bool:
+    return device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+
+
+class _on_device:
+    def __init__(self, device):
+        self._ctx = torch.cuda.device(device) if device.type == "cuda" else None
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+
 class _Table:
     """Device table + chunk list + workspace of one set of (parameter, gradient, buffer) tensors.  Immutable once built: the values
     travel as kernel arguments (nextou_device_write_i64), so a captured hipGraph keeps rewriting — and its kernels keep reading — the
@@ -48,8 +82,8 @@ class _Table:
         self.table = torch.empty((len(flat),), dtype=torch.int64, device=device)
         self.chunks = torch.empty((len(chunks),), dtype=torch.int64, device=device)
         L = _lib.lib()
-        with torch.cuda.device(device):
-            stream = torch.cuda.current_stream(device).cuda_stream
+        with _on_device(device):
+            stream = _stream_of(device)
             for dst, vals in ((self.table, flat), (self.chunks, chunks)):
                 host = (ctypes.c_int64 * len(vals))(*vals)
                 _lib.check(L.nextou_device_write_i64(dst.data_ptr(), ctypes.cast(host, ctypes.c_void_p), len(vals), stream),
@@ -68,6 +102,7 @@ class ClipSGD(torch.optim.SGD):
                          maximize=maximize, differentiable=differentiable)
         self._tables = {}
         self._retired = []
+        self._device_type = "cuda"       # (the CPU tests of the table plumbing run the same code on host tensors against a stand-in library)
         self.last_path = None            # "own" | "torch": which implementation the last step took (tests, bench line)
 
     # ---------------------------------------------------------------------------------------------------------------
@@ -80,18 +115,19 @@ class ClipSGD(torch.optim.SGD):
         if group["nesterov"] and group["momentum"] <= 0:
             return None
         lr = group["lr"]
-        if isinstance(lr, torch.Tensor) and not (lr.is_cuda and lr.dtype == torch.float32 and lr.numel() == 1):
+        if isinstance(lr, torch.Tensor) and not (lr.device.type == self._device_type and lr.dtype == torch.float32 and lr.numel() == 1):
             return None
         rows, device = [], None
         for p in group["params"]:
             g = p.grad
             if g is None:
                 continue
-            if not (p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and not g.is_sparse and g.device == p.device):
+            if not (p.device.type == self._device_type and p.dtype == torch.float32 and g.dtype == torch.float32 and not g.is_sparse
+                    and g.device == p.device):
                 return None
             if device is None:
                 device = p.device
-            if p.device != device or not p.is_non_overlapping_and_dense() or not _same_dense_layout(p, g):
+            if p.device != device or not _dense(p) or not _same_dense_layout(p, g):
                 return None
             m = 0
             if group["momentum"] != 0:
@@ -100,7 +136,7 @@ class ClipSGD(torch.optim.SGD):
                 if buf is None:
                     # zeros: momentum * 0 + d = d is torch's "buf = clone(d)" of the first step
                     buf = state["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if not (buf.is_cuda and buf.dtype == torch.float32 and buf.device == device and _same_dense_layout(p, buf)):
+                if not (buf.dtype == torch.float32 and buf.device == device and _same_dense_layout(p, buf)):
                     return None
                 m = buf.data_ptr()
             if p.numel():
@@ -117,7 +153,7 @@ class ClipSGD(torch.optim.SGD):
         else:
             t = _Table(rows, device)
             self._tables[gi] = (key, t)
-        if torch.cuda.is_current_stream_capturing() and not any(r is t for r in self._retired):
+        if _capturing(device) and not any(r is t for r in self._retired):
             self._retired.append(t)               # the captured graph's kernels keep reading this table after a later step replaced it
         return t
 
@@ -143,8 +179,8 @@ class ClipSGD(torch.optim.SGD):
             t = self._table(gi, rows, device)
             lr = group["lr"]
             lr_dev = lr.data_ptr() if isinstance(lr, torch.Tensor) else None
-            with torch.cuda.device(device):
-                stream = torch.cuda.current_stream(device).cuda_stream
+            with _on_device(device):
+                stream = _stream_of(device)
                 if max_norm is not None:
                     _lib.check(L.nextou_grad_norm_clip_coef(t.table.data_ptr(), t.n_tensors, t.chunks.data_ptr(), t.n_chunks, _CHUNK,
                                                             t.total, t.partial.data_ptr(), float(max_norm), t.norm_coef.data_ptr(),

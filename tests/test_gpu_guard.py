@@ -354,3 +354,18 @@ def test_clip_sgd(hip, clip):
         assert opt.last_path == "own"
         return out.reshape(1).clone() if clip else None
     _guarded(launch, ps + gs + ms, exact=True, inplace=tuple(range(3 * n)))
+
+
+@pytest.mark.parametrize("cin,cout,c2,sp,stride", [(72, 40, 40, (3, 6, 5), (1, 2, 2)), (20, 12, 8, (2, 3, 3), (2, 2, 2)), (24, 12, 8, (5, 7), (2, 2))])
+def test_upconv_cat_rows(hip, cin, cout, c2, sp, stride):
+    g = _gen(cin + cout)
+    T = 1
+    for s_ in stride:
+        T *= s_
+    sp_out = tuple(d * s_ for d, s_ in zip(sp, stride))
+    y2 = _cl(torch.randn((2, T * cout) + sp, generator=g).to(DEV))
+    skip = _cl(torch.randn((2, c2) + sp_out, generator=g).to(DEV))
+    bias = torch.randn(cout, generator=g).to(DEV)
+    go = _cl(torch.randn((2, cout + c2) + sp_out, generator=g).to(DEV))
+    _guarded(lambda y2, b, s: hip.upconv_cat_rows(y2, b, s, stride), [y2, bias, skip])
+    _guarded(lambda go: hip.upconv_cat_rows_bwd(go, cout, sp, stride), [go])

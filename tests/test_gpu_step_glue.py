@@ -200,3 +200,63 @@ def test_cat_bias_backward_through_the_one_pass_kernel(hip, monkeypatch):
     want = torch.autograd.grad(torch.cat((y + bias.view(1, -1, 1, 1, 1), skip), 1), [y, bias, skip], go)
     assert torch.equal(res["1"][0], want[0]) and torch.equal(res["1"][2], want[2])
     assert float((res["1"][1] - want[1]).abs().max()) <= 1e-5 * float(want[1].abs().max())
+
+
+# ---------------------------------------------------------------- the decoder's up-convolution as a K7 GEMM + shuffle-concatenation
+def _cl(t):
+    return t.contiguous(memory_format={4: torch.channels_last, 5: torch.channels_last_3d}[t.dim()])
+
+
+@pytest.mark.parametrize("cin,cout,c2,sp,stride", [
+    (72, 40, 40, (3, 6, 5), (1, 2, 2)),          # cfg 2 full-resolution stage (padded channel counts)
+    (132, 72, 72, (2, 3, 4), (2, 2, 2)),
+    (264, 132, 132, (2, 3, 2), (2, 2, 2)),       # rows wider than the one-pass backward takes: ATen's shuffle
+    (24, 12, 8, (5, 7), (2, 2)),                 # 2-D
+    (16, 8, 8, (2, 2, 3), (2, 1, 2)),
+])
+def test_upconv_cat_matches_the_transposed_convolution(hip, cin, cout, c2, sp, stride):
+    from nextou_amd import graph_ops
+    g = torch.Generator().manual_seed(cin + cout)
+    n = len(sp)
+    x = _cl(torch.randn((2, cin) + sp, generator=g).to(DEV)).requires_grad_(True)
+    w = torch.randn((cin, cout) + stride, generator=g).to(DEV)
+    w = (_cl(w) if n == 3 or True else w).requires_grad_(True)          # filters are stored channels-last (layout.py)
+    b = torch.randn(cout, generator=g).to(DEV).requires_grad_(True)
+    sp_out = tuple(d * s for d, s in zip(sp, stride))
+    skip = _cl(torch.randn((2, c2) + sp_out, generator=g).to(DEV)).requires_grad_(True)
+    go = _cl(torch.randn((2, cout + c2) + sp_out, generator=g).to(DEV))
+    assert graph_ops.upconv_cat_eligible(x, w, b, skip, stride, (0,) * n, (1,) * n, (0,) * n, 1, stride)
+    out = graph_ops.upconv_cat(x, w, b, skip, stride)
+    conv = torch.nn.functional.conv_transpose3d if n == 3 else torch.nn.functional.conv_transpose2d
+    ref = torch.cat((conv(x.double(), w.double(), b.double(), stride), skip.double()), 1)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format={2: torch.channels_last, 3: torch.channels_last_3d}[n])
+    scale = float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) <= 2e-6 * scale
+    assert torch.equal(out[:, cout:], skip)
+    got = torch.autograd.grad(out, [x, w, b, skip], go)
+    want = torch.autograd.grad(ref, [x, w, b, skip], go.double())
+    for a, e, name in zip(got, want, ("x", "weight", "bias", "skip")):
+        assert a.shape == e.shape, name
+        assert float((a.double() - e.double()).abs().max()) <= 5e-6 * (float(e.abs().max()) + 1e-30), name
+    assert torch.equal(got[3], go[:, cout:])
+    # without a bias, and through the module-level entry the decoder calls
+    out2 = graph_ops.upconv_cat(x, w, None, skip, stride)
+    ref2 = torch.cat((conv(x.double(), w.double(), None, stride), skip.double()), 1)
+    assert float((out2.double() - ref2).abs().max()) <= 2e-6 * scale
+
+
+def test_up_conv_cat_takes_the_gemm_route_and_its_switch(hip, monkeypatch):
+    from torch import nn
+    from nextou_amd.network_architecture import norm_act
+    up = norm_act.ConvTransposeOwnBias3d(72, 40, (1, 2, 2), (1, 2, 2), bias=True).to(DEV)
+    x = _cl(torch.randn((2, 72, 3, 5, 4), device=DEV)).requires_grad_(True)
+    skip = _cl(torch.randn((2, 40, 3, 10, 8), device=DEV))
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NEXTOU_UPCONV_GEMM", mode)
+        out = norm_act.up_conv_cat(up, x, skip)
+        res[mode] = (out, out.grad_fn.name() if out.grad_fn is not None else "")
+    assert "UpConvCat" in res["1"][1] and "UpConvCat" not in res["0"][1]
+    ref = torch.cat((nn.functional.conv_transpose3d(x, up.weight, up.bias, (1, 2, 2)), skip), 1)
+    for mode in ("1", "0"):
+        assert float((res[mode][0] - ref).abs().max()) <= 1e-5 * float(ref.abs().max())

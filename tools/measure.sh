@@ -65,8 +65,11 @@ t_kernels() {
   grep -E "knn_fused|mr_" $OUT/kernel_bench_cfg2.txt | head -24
 }
 t_stepglue() {
-  python -m pytest tests/test_gpu_step_glue.py tests/test_gpu_guard.py tests/test_gpu_ddp.py -q -m gpu -k "step_glue or narrow or clip_sgd or cat_bias or ddp" -x 2>&1 | grep -v "MIOpen\|amdgpu.ids" | tail -15 > $OUT/stepglue_pytest.txt; tail -3 $OUT/stepglue_pytest.txt
-  python tools/step_ab.py --variants full,no_opt,own,own-ncs --rounds 3 --steps 10 --eager > $OUT/step_ab.txt 2> $OUT/step_ab.log; tail -8 $OUT/step_ab.txt; tail -3 $OUT/step_ab.log
+  python -m pytest tests/test_gpu_step_glue.py tests/test_gpu_guard.py tests/test_gpu_ddp.py tests/test_gpu_parity.py tests/test_gpu_parity2.py -q -m gpu -rf \
+      -k "step_glue or narrow or clip_sgd or cat_bias or upconv or ddp or tiny_models or train_step or graphed or channels_last_policy or own_bias" 2>&1 \
+      | grep -v "MIOpen\|amdgpu.ids" > $OUT/stepglue_pytest_log.txt
+  (grep -E "^(FAILED|ERROR)|^E  " $OUT/stepglue_pytest_log.txt | cut -c1-300 | head -40; tail -4 $OUT/stepglue_pytest_log.txt) > $OUT/stepglue_pytest.txt; cat $OUT/stepglue_pytest.txt
+  python tools/step_ab.py --rounds 3 --steps 10 --eager > $OUT/step_ab.txt 2> $OUT/step_ab.log; tail -8 $OUT/step_ab.txt; tail -3 $OUT/step_ab.log
 }
 t_trace() {
   cd /tmp && export TMPDIR=/tmp

@@ -1,16 +1,15 @@
 #!/usr/bin/env python
-"""What do the gradient clip and the optimizer cost inside the replayed cfg-2 step?  One process, one box: the bench's step and
-variants of it are captured as hipGraphs side by side and replayed in alternation, so box-to-box spread (+-1.5 ms) and clock drift
-cancel.
+"""What do the round-5 step-glue changes buy inside the replayed cfg-2 step?  One process, one box: the bench's step and variants of it
+are captured as hipGraphs side by side and replayed in alternation, so box-to-box spread (+-1.5 ms) and clock drift cancel.
 
-    python tools/step_ab.py [--workload cfg2] [--rounds 3] [--steps 10] [--variants full,no_clip,no_opt,own]
+    python tools/step_ab.py [--workload cfg2] [--rounds 3] [--steps 10] [--variants base,sgd,sgd+ncs,all,no_opt] [--eager]
 
-variants:  full    = bench.py's step (zero_grad, forward, loss, backward, clip_grad_norm_(12), torch.optim.SGD(fused))
-           no_clip = the same without the clip               (probe, not a valid bench step)
-           no_opt  = neither clip nor SGD                    (probe: the floor any optimizer work sits on)
-           own     = clip + SGD through nextou_amd.optim.ClipSGD.clip_and_step (one own launch each for the norm and the update)
-           own-ncs = own, with NEXTOU_NARROW_COPY_SUM=0 while the step is warmed up and captured (the decoder concatenation's backward
-                     as narrow().contiguous() + channel_sum instead of the one-pass kernel)
+variants:  base     = the step as of round 4: clip_grad_norm_(12) + torch.optim.SGD(fused), the decoder concatenation's backward as
+                      narrow().contiguous() + channel_sum, the up-convolutions on the library
+           sgd      = base with clip + SGD on nextou_amd.optim.ClipSGD (own norm / update kernels)
+           sgd+ncs  = sgd with the concatenation's backward as one pass (nextou_narrow_copy_sum)
+           all      = sgd+ncs with the up-convolutions as K7 GEMMs + shuffle-concatenation (graph_ops._UpConvCat): bench.py's default step
+           no_opt   = all without clip and optimizer   (probe, not a valid bench step: the floor any optimizer work sits on)
 """
 import argparse
 import os
@@ -24,7 +23,21 @@ import bench  # noqa: E402
 from nextou_amd.harness import GraphedTrainStep, downsample_targets, synthetic_batch  # noqa: E402
 
 
-def make_variant(kind, workload, device):
+VARIANTS = {     # name -> (optimizer, environment while the step is built, warmed up, captured and run eagerly)
+    "base": ("torch", {"NEXTOU_NARROW_COPY_SUM": "0", "NEXTOU_UPCONV_GEMM": "0"}),
+    "sgd": ("own", {"NEXTOU_NARROW_COPY_SUM": "0", "NEXTOU_UPCONV_GEMM": "0"}),
+    "sgd+ncs": ("own", {"NEXTOU_NARROW_COPY_SUM": "1", "NEXTOU_UPCONV_GEMM": "0"}),
+    "all": ("own", {"NEXTOU_NARROW_COPY_SUM": "1", "NEXTOU_UPCONV_GEMM": "1"}),
+    "no_opt": ("none", {"NEXTOU_NARROW_COPY_SUM": "1", "NEXTOU_UPCONV_GEMM": "1"}),
+}
+
+
+def set_env(name):
+    os.environ.update(VARIANTS[name][1])
+
+
+def make_variant(name, workload, device):
+    kind = VARIANTS[name][0]
     trainer, cfg, batch, classes = bench.build_trainer(workload, device, False)
     bench.move_to(trainer, device, fused_sgd=True)
     if kind == "own":
@@ -44,10 +57,8 @@ def make_variant(kind, workload, device):
         loss.backward()
         if kind == "own":
             trainer.optimizer.clip_and_step(12)
-            return loss
-        if kind in ("full",):
+        elif kind == "torch":
             torch.nn.utils.clip_grad_norm_(params, 12)
-        if kind in ("full", "no_clip"):
             trainer.optimizer.step()
         return loss
     return step, trainer
@@ -58,7 +69,7 @@ def main():
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--variants", default="full,no_clip,no_opt")
+    ap.add_argument("--variants", default="base,sgd,sgd+ncs,all,no_opt")
     ap.add_argument("--eager", action="store_true", help="time the eager steps as well")
     args = ap.parse_args()
     device = torch.device("cuda", 0)
@@ -67,8 +78,8 @@ def main():
     kinds = args.variants.split(",")
     graphs, eager = {}, {}
     for k in kinds:
-        os.environ["NEXTOU_NARROW_COPY_SUM"] = "0" if k.endswith("-ncs") else "1"
-        step, trainer = make_variant(k.replace("-ncs", ""), args.workload, device)
+        set_env(k)
+        step, trainer = make_variant(k, args.workload, device)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -95,7 +106,7 @@ def main():
             rows[k].append(timed(graphs[k][0]))
         if args.eager:
             for k in kinds:
-                os.environ["NEXTOU_NARROW_COPY_SUM"] = "0" if k.endswith("-ncs") else "1"
+                set_env(k)
                 erows[k].append(timed(eager[k]))
     print("| variant | replayed hipGraph, ms / step (%d rounds x %d steps, alternating) | mean |%s" % (
         args.rounds, args.steps, " eager ms / step | mean |" if args.eager else ""))
