@@ -197,12 +197,23 @@ class GraphedTrainStep:
                     step_fn()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                # Let the process group's watchdog thread retire the collectives of the eager warm-up before RCCL's stream joins the
+                # capture.  The watchdog polls its list of in-flight work every 100 ms (hipEventQuery on each work's end event) and
+                # drops what has finished; a work that is still ON the list when the first captured collective pulls RCCL's internal
+                # stream into the capture gets its query answered with hipErrorCapturedEvent ("event last recorded in a capturing
+                # stream": the event's stream is capturing NOW, although the record predates it) and the watchdog terminates the
+                # process.  The window is the watchdog's polling interval after the last eager collective — certain to be hit now and
+                # then with millisecond steps (the tiny test workload: once in ~25 runs, again in this round's GPU suite with the
+                # event cache off), and about one capture in ten per rank for a 170-ms step.  Half a second covers five polls.
+                import time
+                time.sleep(0.5)
             self.graph = torch.cuda.CUDAGraph()
             # With a process group up, RCCL's watchdog THREAD polls the events of in-flight collectives (hipEventQuery) whenever it likes;
             # under the default "global" capture mode such a call from another thread while this one captures is an error — and it is
             # raised inside the watchdog, which terminates the process (seen once in three runs of the world-size-1 averaged step:
             # "operation not permitted when stream is capturing").  "thread_local" restricts the check to the capturing thread.
-            import torch.distributed as dist
             mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
             with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.loss = step_fn()

@@ -102,6 +102,7 @@ class ClipSGD(torch.optim.SGD):
                          maximize=maximize, differentiable=differentiable)
         self._tables = {}
         self._retired = []
+        self._static = {}
         self._device_type = "cuda"       # (the CPU tests of the table plumbing run the same code on host tensors against a stand-in library)
         self.last_path = None            # "own" | "torch": which implementation the last step took (tests, bench line)
 
@@ -118,29 +119,34 @@ class ClipSGD(torch.optim.SGD):
         if isinstance(lr, torch.Tensor) and not (lr.device.type == self._device_type and lr.dtype == torch.float32 and lr.numel() == 1):
             return None
         rows, device = [], None
+        f32, want_m, state, static = torch.float32, group["momentum"] != 0, self.state, self._static
         for p in group["params"]:
             g = p.grad
             if g is None:
                 continue
-            if not (p.device.type == self._device_type and p.dtype == torch.float32 and g.dtype == torch.float32 and not g.is_sparse
-                    and g.device == p.device):
-                return None
+            ptr = p.data_ptr()
+            rec = static.get(id(p))
+            if rec is None or rec[0] != ptr:
+                # what does not change from step to step (checked again when the parameter's storage moves): (pointer, strides, count, device)
+                if not (p.device.type == self._device_type and p.dtype == f32 and _dense(p)):
+                    return None
+                rec = static[id(p)] = (ptr, p.stride(), p.numel(), p.device, p.shape)
             if device is None:
-                device = p.device
-            if p.device != device or not _dense(p) or not _same_dense_layout(p, g):
+                device = rec[3]
+            if g.dtype != f32 or g.is_sparse or g.stride() != rec[1] or g.shape != rec[4] or g.device != device:
                 return None
             m = 0
-            if group["momentum"] != 0:
-                state = self.state[p]
-                buf = state.get("momentum_buffer")
+            if want_m:
+                st = state[p]
+                buf = st.get("momentum_buffer")
                 if buf is None:
                     # zeros: momentum * 0 + d = d is torch's "buf = clone(d)" of the first step
-                    buf = state["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if not (buf.dtype == torch.float32 and buf.device == device and _same_dense_layout(p, buf)):
+                    buf = st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if buf.dtype != f32 or buf.stride() != rec[1] or buf.shape != rec[4] or buf.device != device:
                     return None
                 m = buf.data_ptr()
-            if p.numel():
-                rows.append((p.data_ptr(), g.data_ptr(), m, p.numel()))
+            if rec[2]:
+                rows.append((ptr, g.data_ptr(), m, rec[2]))
         if not rows:
             return None
         return rows, device

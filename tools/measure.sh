@@ -20,6 +20,8 @@
 #   pwmodes    stage 3-5 blocks with the point-wise convolutions on the library route / on K7 / K7 weight gradient only, replayed graphs
 #   stepglue   tests of the step-glue kernels (ClipSGD, narrow_copy_sum) + tools/step_ab.py: the bench step against variants without
 #              clip / optimizer and with the own clip + SGD kernels, captured side by side and replayed in alternation
+#   optim      tools/optim_bench.py (clip + SGD alone: torch's multi-tensor kernels against ClipSGD) + the RCCL capture / watchdog
+#              reproducer (tools/rccl_capture_watchdog_repro.py) + the averaged-step test
 #   cpusurvey  bench.py --cpu-protocol survey (batch 2, 1 + 3 steps, all physical cores; ~10 min of host time)
 #   closing    tests margins bench configs stages kernels trace pmc5 pmcmrg in that order
 TASK=${1:-closing}
@@ -70,6 +72,11 @@ t_stepglue() {
       | grep -v "MIOpen\|amdgpu.ids" > $OUT/stepglue_pytest_log.txt
   (grep -E "^(FAILED|ERROR)|^E  " $OUT/stepglue_pytest_log.txt | cut -c1-300 | head -40; tail -4 $OUT/stepglue_pytest_log.txt) > $OUT/stepglue_pytest.txt; cat $OUT/stepglue_pytest.txt
   python tools/step_ab.py --rounds 3 --steps 10 --eager > $OUT/step_ab.txt 2> $OUT/step_ab.log; tail -8 $OUT/step_ab.txt; tail -3 $OUT/step_ab.log
+}
+t_optim() {
+  python tools/rccl_capture_watchdog_repro.py 3 > $OUT/rccl_capture_watchdog_repro.txt 2>&1; cat $OUT/rccl_capture_watchdog_repro.txt
+  python tools/optim_bench.py 2>&1 | grep -v "amdgpu.ids" > $OUT/optim_bench.txt; cat $OUT/optim_bench.txt
+  python -m pytest tests/test_gpu_ddp.py -q -m gpu -rf -k "averaged_step" 2>&1 | grep -v "MIOpen\|amdgpu.ids" | tail -5 > $OUT/ddp_pytest.txt; tail -3 $OUT/ddp_pytest.txt
 }
 t_trace() {
   cd /tmp && export TMPDIR=/tmp
