@@ -199,14 +199,14 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
-                # Let the process group's watchdog thread retire the collectives of the eager warm-up before RCCL's stream joins the
-                # capture.  The watchdog polls its list of in-flight work every 100 ms (hipEventQuery on each work's end event) and
-                # drops what has finished; a work that is still ON the list when the first captured collective pulls RCCL's internal
-                # stream into the capture gets its query answered with hipErrorCapturedEvent ("event last recorded in a capturing
-                # stream": the event's stream is capturing NOW, although the record predates it) and the watchdog terminates the
-                # process.  The window is the watchdog's polling interval after the last eager collective — certain to be hit now and
-                # then with millisecond steps (the tiny test workload: once in ~25 runs, again in this round's GPU suite with the
-                # event cache off), and about one capture in ten per rank for a 170-ms step.  Half a second covers five polls.
+                # A precaution against the rare hipErrorCapturedEvent of RCCL's watchdog thread ("operation not permitted on an event last
+                # recorded in a capturing stream", raised from WorkNCCL::isCompleted() in Watchdog::runLoop(), which terminates the
+                # process: once in ~25 runs of the tiny averaged step in round 5's first half, once more in its GPU suite with the event
+                # cache already off — ddp._capture_safe_process_group_env).  The watchdog polls the end events of the eager collectives on
+                # its list every 100 ms and drops finished work at the next poll; half a second here means no work of the eager warm-up is
+                # on that list when the capture pulls RCCL's stream in.  Whether a lingering eager work is the trigger is NOT established:
+                # tools/rccl_capture_watchdog_repro.py builds exactly that situation with plain torch and stayed clean 3 / 3 with and
+                # without the pause (profiles/r05_rccl_capture_watchdog_repro.txt).
                 import time
                 time.sleep(0.5)
             self.graph = torch.cuda.CUDAGraph()

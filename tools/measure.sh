@@ -22,6 +22,8 @@
 #              clip / optimizer and with the own clip + SGD kernels, captured side by side and replayed in alternation
 #   optim      tools/optim_bench.py (clip + SGD alone: torch's multi-tensor kernels against ClipSGD) + the RCCL capture / watchdog
 #              reproducer (tools/rccl_capture_watchdog_repro.py) + the averaged-step test
+#   sgdab      bench.py in separate processes, alternating: default (ClipSGD) against NEXTOU_CLIP_SGD=0 (torch's fused SGD + clip) — the
+#              process-level A/B of the optimizer inside the replayed step — and the averaged-step test four times over
 #   cpusurvey  bench.py --cpu-protocol survey (batch 2, 1 + 3 steps, all physical cores; ~10 min of host time)
 #   closing    tests margins bench configs stages kernels trace pmc5 pmcmrg in that order
 TASK=${1:-closing}
@@ -77,6 +79,15 @@ t_optim() {
   python tools/rccl_capture_watchdog_repro.py 3 > $OUT/rccl_capture_watchdog_repro.txt 2>&1; cat $OUT/rccl_capture_watchdog_repro.txt
   python tools/optim_bench.py 2>&1 | grep -v "amdgpu.ids" > $OUT/optim_bench.txt; cat $OUT/optim_bench.txt
   python -m pytest tests/test_gpu_ddp.py -q -m gpu -rf -k "averaged_step" 2>&1 | grep -v "MIOpen\|amdgpu.ids" | tail -5 > $OUT/ddp_pytest.txt; tail -3 $OUT/ddp_pytest.txt
+}
+t_sgdab() {
+  for i in 1 2; do
+    python bench.py --no-cpu-baseline --steps 20 > $OUT/sgdab_own_$i.json 2>/dev/null; field $OUT/sgdab_own_$i.json
+    NEXTOU_CLIP_SGD=0 python bench.py --no-cpu-baseline --steps 20 > $OUT/sgdab_torch_$i.json 2>/dev/null; field $OUT/sgdab_torch_$i.json
+  done
+  for i in 1 2 3 4; do
+    python -m pytest tests/test_gpu_ddp.py -q -m gpu -k "averaged_step_over_rccl" 2>&1 | tail -1
+  done > $OUT/ddp_repeat.txt; cat $OUT/ddp_repeat.txt
 }
 t_trace() {
   cd /tmp && export TMPDIR=/tmp

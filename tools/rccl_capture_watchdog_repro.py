@@ -1,18 +1,21 @@
 #!/usr/bin/env python
-"""Why a step with RCCL collectives must not be captured right after an eager one: a stand-alone reproducer (plain torch, nothing of
-this repository in the child processes).
+"""Does an eager RCCL collective that is still on the process group's watchdog list break a hipGraph capture that follows it?  A
+stand-alone probe (plain torch, nothing of this repository in the child processes) of one hypothesis for the rare
+hipErrorCapturedEvent that terminates the averaged step.
 
 PyTorch's NCCL (= RCCL) process group keeps every eager collective on a list that its watchdog thread polls every 100 ms with
 hipEventQuery on the work's end event; finished work leaves the list at the next poll.  A collective issued inside a hipGraph capture
-pulls the group's internal stream into the capture.  If an eager work is still on the list at that moment, the watchdog's next query of
-its end event — recorded BEFORE the capture, on a stream that is capturing NOW — fails with hipErrorCapturedEvent and the watchdog
-terminates the process ("operation not permitted on an event last recorded in a capturing stream").
+pulls the group's internal stream into the capture.  Hypothesis: if an eager work is still on the list at that moment, the watchdog's
+next query of its end event — recorded BEFORE the capture, on a stream that is capturing NOW — fails with hipErrorCapturedEvent
+("operation not permitted on an event last recorded in a capturing stream") and the watchdog terminates the process.
 
-    python tools/rccl_capture_watchdog_repro.py            # parent: runs the child in both modes, several times each
-    child modes:  immediate   eager all-reduce -> synchronize -> capture { all-reduce; host sleeps 0.3 s }       (expected: dies)
-                  drained     eager all-reduce -> synchronize -> sleep 0.5 s -> the same capture                (expected: clean)
+    python tools/rccl_capture_watchdog_repro.py [runs]     # parent: runs the child in both modes
+    child modes:  immediate   eager all-reduce -> synchronize -> capture { all-reduce; host sleeps 0.3 s }
+                  drained     eager all-reduce -> synchronize -> sleep 0.5 s -> the same capture
 
-nextou_amd.harness.GraphedTrainStep sleeps 0.5 s between its eager warm-up and the capture when a process group is up.
+Result on MI355X / ROCm 7.2 / PyTorch 2.10 (profiles/r05_rccl_capture_watchdog_repro.txt): 3 / 3 clean in BOTH modes — this sequence
+alone does not trigger the error; the hypothesis is not confirmed.  nextou_amd.harness.GraphedTrainStep keeps its 0.5-s pause between
+the eager warm-up and the capture as a precaution that costs nothing.
 """
 import os
 import subprocess
