@@ -170,6 +170,11 @@ def roofline_graph_from(report):
             "K8_head_forward": pick(("head_fwd_kernel", "head_fwd_lds_kernel")),
             "K8_head_backward": pick(("head_bwd_lds_kernel", "head_dgrad_kernel", "head_wgrad_kernel")),
             "K2K7_pool_grouped_forward": pick(("mr_grp_cm_kernel",)),
+            # round 5's step glue (ABI v13): the gradient norm + clip / SGD update over the whole parameter list, the decoder concatenation with the
+            # up-convolution's pixel shuffle (forward) and its one-pass backward (channel range copied / un-shuffled + bias sums)
+            "glue_grad_norm": pick(("multi_sumsq_kernel",)), "glue_clip_sgd": pick(("clip_sgd_kernel",)),
+            "glue_upconv_cat_forward": pick(("upconv_cat_rows_kernel", "cat_bias_rows_kernel")),
+            "glue_cat_backward": pick(("narrow_copy_stats_kernel",)),
             "graph_kernels_ms_per_step": None}
 
 
@@ -489,7 +494,8 @@ def main():
                        "gradient_averager": averager is not None,
                        "optimizer": "SGD(nesterov, momentum %g, weight_decay %g, %s)" % (
                            trainer.momentum, trainer.weight_decay,
-                           {"own": "own clip + update kernels (nextou_amd.optim.ClipSGD)", "torch": "ClipSGD -> torch foreach"}.get(
+                           {"own": "own clip + update kernels (nextou_amd.optim.ClipSGD)",
+                            "torch": "ClipSGD -> torch foreach: %s" % getattr(trainer.optimizer, "last_reason", None)}.get(
                                trainer.optimizer.last_path, "not stepped") if hasattr(trainer.optimizer, "last_path")
                            else ("fused" if trainer.optimizer.defaults.get("fused") else "foreach")),
                        "step_replayed_as_hipgraph": graphed is not None, "graph_capture_error": capture_error,

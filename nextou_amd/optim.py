@@ -10,8 +10,9 @@ tensors to the kernels through a table in device memory: one launch for the upda
 
 Same update rule and operation order as ``torch.optim.SGD(foreach=True)``; results agree to the last bit or two (a fused
 multiply-add here, a separately rounded product there — the same spread as between torch's own foreach / fused / single-tensor
-variants).  Anything the kernels do not take (CPU or non-float32 parameters, sparse gradients, dampening, maximize, a gradient
-whose memory layout differs from its parameter's) goes through torch's implementation, unchanged.
+variants).  Anything the kernels do not take (CPU or non-float32 parameters, sparse gradients, dampening, maximize) goes through
+torch's implementation, unchanged — ``last_path`` / ``last_reason`` say which ran and why; a gradient stored in another element order
+than its parameter is copied into the parameter's order first.
 """
 from __future__ import annotations
 
@@ -28,7 +29,13 @@ _CHUNK = 16384          # elements per workgroup (64 KB of each tensor)
 
 
 def _same_dense_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
-    return a.shape == b.shape and a.stride() == b.stride()
+    """Same element order in memory: equal shapes and equal strides in every dimension LONGER THAN ONE.  (The stride of a size-1
+    dimension is arbitrary — autograd's layout contract for ``.grad`` ignores it too — and the gradients of (N, K, 1, 1, 1) filters
+    routinely arrive with other values there than the parameter has.)"""
+    if a.shape != b.shape:
+        return False
+    sa, sb = a.stride(), b.stride()
+    return sa == sb or all(x == y for x, y, n in zip(sa, sb, a.shape) if n > 1)
 
 
 def _dense(p: torch.Tensor) -> bool:
@@ -105,19 +112,20 @@ class ClipSGD(torch.optim.SGD):
         self._static = {}
         self._device_type = "cuda"       # (the CPU tests of the table plumbing run the same code on host tensors against a stand-in library)
         self.last_path = None            # "own" | "torch": which implementation the last step took (tests, bench line)
+        self.last_reason = None          # why torch's implementation took it
 
     # ---------------------------------------------------------------------------------------------------------------
     def _plan(self, group):
-        """(rows, device) of one param group for the kernels, or None when torch's implementation has to run it."""
+        """(rows, device) of one param group for the kernels, or a string — why torch's implementation has to run it."""
         if os.environ.get("NEXTOU_CLIP_SGD", "1") == "0":
-            return None
+            return "NEXTOU_CLIP_SGD=0"
         if group["dampening"] != 0 or group["maximize"] or group.get("differentiable", False):
-            return None
+            return "dampening / maximize / differentiable"
         if group["nesterov"] and group["momentum"] <= 0:
-            return None
+            return "nesterov without momentum"
         lr = group["lr"]
         if isinstance(lr, torch.Tensor) and not (lr.device.type == self._device_type and lr.dtype == torch.float32 and lr.numel() == 1):
-            return None
+            return "learning-rate tensor not a float32 scalar on the device"
         rows, device = [], None
         f32, want_m, state, static = torch.float32, group["momentum"] != 0, self.state, self._static
         for p in group["params"]:
@@ -129,12 +137,18 @@ class ClipSGD(torch.optim.SGD):
             if rec is None or rec[0] != ptr:
                 # what does not change from step to step (checked again when the parameter's storage moves): (pointer, strides, count, device)
                 if not (p.device.type == self._device_type and p.dtype == f32 and _dense(p)):
-                    return None
+                    return "parameter %s %s on %s, strides %s: not a dense float32 %s tensor" % (
+                        tuple(p.shape), p.dtype, p.device, p.stride(), self._device_type)
                 rec = static[id(p)] = (ptr, p.stride(), p.numel(), p.device, p.shape)
             if device is None:
                 device = rec[3]
-            if g.dtype != f32 or g.is_sparse or g.stride() != rec[1] or g.shape != rec[4] or g.device != device:
-                return None
+            if g.dtype != f32 or g.is_sparse or g.device != device or g.shape != rec[4]:
+                return "gradient %s %s on %s of parameter %s" % (tuple(g.shape), g.dtype, g.device, tuple(p.shape))
+            if g.stride() != rec[1] and not _same_dense_layout(p, g):
+                # a gradient in another element order than its parameter (autograd's layout contract makes this rare: a .grad assigned
+                # by hand, bucket views of another layout): one copy into the parameter's order, then it is walked flat like the rest
+                g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
+                p.grad = g
             m = 0
             if want_m:
                 st = state[p]
@@ -142,13 +156,15 @@ class ClipSGD(torch.optim.SGD):
                 if buf is None:
                     # zeros: momentum * 0 + d = d is torch's "buf = clone(d)" of the first step
                     buf = st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if buf.dtype != f32 or buf.stride() != rec[1] or buf.shape != rec[4] or buf.device != device:
-                    return None
+                if buf.dtype != f32 or buf.device != device or buf.shape != rec[4]:
+                    return "momentum buffer %s %s on %s of parameter %s" % (tuple(buf.shape), buf.dtype, buf.device, tuple(p.shape))
+                if buf.stride() != rec[1] and not _same_dense_layout(p, buf):
+                    buf = st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(buf)
                 m = buf.data_ptr()
             if rec[2]:
                 rows.append((ptr, g.data_ptr(), m, rec[2]))
         if not rows:
-            return None
+            return "no gradients"
         return rows, device
 
     def _table(self, gi: int, rows, device) -> _Table:
@@ -169,15 +185,18 @@ class ClipSGD(torch.optim.SGD):
         """The whole step on the kernels; returns the total-norm tensor (None without a clip), or NotImplemented when any group
         needs torch's implementation (nothing but zero-filled momentum buffers has been created then — torch's update of a
         zero buffer is its first-step ``buf = clone(d)``)."""
-        plans = [self._plan(g) for g in self.param_groups]
-        live = [(gi, pl) for gi, pl in enumerate(plans) if pl is not None]
         groups_with_grads = [gi for gi, g in enumerate(self.param_groups) if any(p.grad is not None for p in g["params"])]
         if not groups_with_grads:
+            self.last_reason = None
             return None if max_norm is None else torch.zeros(())
-        if [gi for gi, _ in live] != groups_with_grads:
+        plans = {gi: self._plan(self.param_groups[gi]) for gi in groups_with_grads}
+        why = [pl for pl in plans.values() if isinstance(pl, str)]
+        if not why and max_norm is not None and len(plans) != 1:
+            why = ["the clip's norm spans %d parameter groups (the kernels take one table)" % len(plans)]
+        self.last_reason = why[0] if why else None
+        if why:
             return NotImplemented
-        if max_norm is not None and len(live) != 1:
-            return NotImplemented            # the clip's norm spans all groups: one table
+        live = sorted(plans.items())
         L = _lib.lib()
         norm = None
         for gi, (rows, device) in live:

@@ -97,15 +97,23 @@ def test_plain_step_and_fallbacks(hip, monkeypatch):
         assert own.last_path == "own"
         assert all(torch.equal(p.grad, b) for p, b in zip(ps, before))       # no clip: the gradients are only read
         assert all(_close(p, q) for p, q in zip(ps, qs))
-    # a gradient in another layout than its parameter: torch's implementation takes the step, same numbers
+    # a gradient in another element order than its parameter is copied into the parameter's order; other strides in size-1 dimensions
+    # (what the gradients of (N, K, 1, 1, 1) filters arrive with) are the same element order: the kernels take both
     _set_grads(ps, qs, 5)
     ps[3].grad = ps[3].grad.contiguous()
     assert ps[3].grad.stride() != ps[3].stride()
+    ps[2].grad = torch.as_strided(ps[2].grad.clone(), ps[2].shape, (33, 1, 462, 462, 462))
     own.clip_and_step(12.0)
     torch.nn.utils.clip_grad_norm_(qs, 12.0)
     ref.step()
-    assert own.last_path == "torch"
+    assert own.last_path == "own" and own.last_reason is None and ps[3].grad.stride() == ps[3].stride()
     assert all(_close(p, q) for p, q in zip(ps, qs))
+    # what the kernels do not take goes to torch, with the reason
+    dbl = [torch.nn.Parameter(torch.randn(9, device=DEV, dtype=torch.float64))]
+    o2 = ClipSGD(dbl, 0.01, momentum=0.9)
+    dbl[0].grad = torch.randn_like(dbl[0])
+    o2.step()
+    assert o2.last_path == "torch" and "float32" in o2.last_reason
     # switched off
     monkeypatch.setenv("NEXTOU_CLIP_SGD", "0")
     _set_grads(ps, qs, 6)

@@ -156,19 +156,32 @@ def test_clip_sgd_hands_over_what_the_kernels_do_not_take(stand_in):
     own._device_type = "cpu"
     for p in ps:
         p.grad = torch.empty_like(p).normal_()
-    ps[3].grad = ps[3].grad.contiguous()                 # another layout than the channels-last parameter
+    # another element order than the channels-last parameter: copied into the parameter's order, then the kernels take the step
+    qs = [torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in ps]
+    for p, q in zip(ps, qs):
+        q.grad = p.grad.clone(memory_format=torch.preserve_format)
+    ps[3].grad = ps[3].grad.contiguous()
+    assert ps[3].grad.stride() != ps[3].stride()
+    # the stride of a size-1 dimension is arbitrary (autograd's layout contract ignores it): still the same element order
+    ps[2].grad = torch.as_strided(ps[2].grad.clone(), ps[2].shape, (33, 1, 462, 462, 462))
     own.clip_and_step(5.0)
-    assert own.last_path == "torch" and stand_in.calls == []
+    assert own.last_path == "own" and own.last_reason is None and ps[3].grad.stride() == ps[3].stride()
+    ref = torch.optim.SGD(qs, 0.01, momentum=0.9, nesterov=True)
+    torch.nn.utils.clip_grad_norm_(qs, 5.0)
+    ref.step()
+    for p, q in zip(ps, qs):
+        assert float((p.detach() - q.detach()).abs().max()) <= 2e-6 * float(q.detach().abs().max())
+    stand_in.calls.clear()
     own2 = ClipSGD([torch.nn.Parameter(torch.randn(5).double())], 0.01)
     own2._device_type = "cpu"
     own2.param_groups[0]["params"][0].grad = torch.randn(5).double()
     own2.step()
-    assert own2.last_path == "torch"
+    assert own2.last_path == "torch" and "float32" in own2.last_reason
     own3 = ClipSGD([torch.nn.Parameter(torch.randn(5))], 0.01, momentum=0.9, dampening=0.1)
     own3._device_type = "cpu"
     own3.param_groups[0]["params"][0].grad = torch.randn(5)
     own3.step()
-    assert own3.last_path == "torch"
+    assert own3.last_path == "torch" and "dampening" in own3.last_reason and stand_in.calls == []
 
 
 # ------------------------------------------------------------------------------------------------ _UpConvCat on emulated passes

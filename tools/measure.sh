@@ -24,6 +24,8 @@
 #              reproducer (tools/rccl_capture_watchdog_repro.py) + the averaged-step test
 #   sgdab      bench.py in separate processes, alternating: default (ClipSGD) against NEXTOU_CLIP_SGD=0 (torch's fused SGD + clip) — the
 #              process-level A/B of the optimizer inside the replayed step — and the averaged-step test four times over
+#   benchfinal the headline line (default: ClipSGD, one-pass concatenation backward, up-convolutions as GEMMs; with cpu_baseline) and the same
+#              step with NEXTOU_CLIP_SGD=0 (torch's clip + fused SGD)
 #   cpusurvey  bench.py --cpu-protocol survey (batch 2, 1 + 3 steps, all physical cores; ~10 min of host time)
 #   closing    tests margins bench configs stages kernels trace pmc5 pmcmrg in that order
 TASK=${1:-closing}
@@ -88,6 +90,11 @@ t_sgdab() {
   for i in 1 2 3 4; do
     python -m pytest tests/test_gpu_ddp.py -q -m gpu -k "averaged_step_over_rccl" 2>&1 | tail -1
   done > $OUT/ddp_repeat.txt; cat $OUT/ddp_repeat.txt
+}
+t_benchfinal() {
+  python bench.py > $OUT/bench_cfg2_default.json 2> $OUT/bench_cfg2_default.log; field $OUT/bench_cfg2_default.json
+  python -c "import json;d=json.load(open('$OUT/bench_cfg2_default.json'));print(d['config']['optimizer']);print({k:(v['avg_us'],v['frac']) for k,v in d['roofline_graph'].items() if v and k.startswith('glue')})"
+  NEXTOU_CLIP_SGD=0 python bench.py --no-cpu-baseline > $OUT/bench_cfg2_torch_sgd.json 2>/dev/null; field $OUT/bench_cfg2_torch_sgd.json
 }
 t_trace() {
   cd /tmp && export TMPDIR=/tmp
