@@ -137,7 +137,7 @@ def padded_conv_params(module: nn.Module, x: torch.Tensor, with_bias: bool):
     spec: Optional[ConvPad] = getattr(module, "_pad_spec", None)
     bias = module.bias if with_bias else None
     if spec is None:
-        return module.weight, bias
+        return filter_layout_for(x, module.weight), bias
     pad_in, pad_out = conv_pad_plan(module, x)
     w = module.weight
     in_axis, out_axis = (0, 1) if module.transposed else (1, 0)
@@ -147,7 +147,20 @@ def padded_conv_params(module: nn.Module, x: torch.Tensor, with_bias: bool):
         w = _pad_axis(w, out_axis, padded(w.shape[out_axis], spec.multiple))
         if bias is not None:
             bias = _pad_axis(bias, 0, w.shape[out_axis])
-    return w, bias
+    return filter_layout_for(x, w), bias
+
+
+def filter_layout_for(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """The filter in the layout this call's input asks for.  Filters with a kernel larger than 1 are STORED channels-last
+    (layout.filters_to_channels_last), and the library takes the output's layout from the filter as well as from the input: a
+    channels-last filter turns an NCDHW stage channels-last behind the layout policy's back.  Where the policy keeps a stage NCDHW —
+    reduced precision without the channel padding, ``NEXTOU_REDUCED_PRECISION_LAYOUT=ncdhw`` (layout.layout_policy_applies: NDHWC at
+    33 / 66 bf16 channels was round 1's 309-vs-185-ms regression) — the call gets the contiguous form: the per-call conversion that the
+    stored layout saves on the default, all-channels-last path.  A channels-last input — dense NDHWC, or the single-channel image
+    re-strided by layout.to_channels_last — has stride 1 on its channel axis."""
+    if w.dim() < 4 or not x.is_cuda or w.is_contiguous() or x.dim() != w.dim() or x.stride(1) == 1:
+        return w
+    return w.contiguous()
 
 
 def pad_image_channels(module: nn.Module, x: torch.Tensor, weight: torch.Tensor):
