@@ -26,6 +26,8 @@
 #              process-level A/B of the optimizer inside the replayed step — and the averaged-step test four times over
 #   benchfinal the headline line (default: ClipSGD, one-pass concatenation backward, up-convolutions as GEMMs; with cpu_baseline) and the same
 #              step with NEXTOU_CLIP_SGD=0 (torch's clip + fused SGD)
+#   averaged   bench.py --force-averager --graph on at cfg 2: the N > 1 step (hooks, buckets, RCCL collectives on a world-size-1 group) at the
+#              closing tree, next to the plain step's line
 #   cpusurvey  bench.py --cpu-protocol survey (batch 2, 1 + 3 steps, all physical cores; ~10 min of host time)
 #   closing    tests margins bench configs stages kernels trace pmc5 pmcmrg in that order
 TASK=${1:-closing}
@@ -95,6 +97,10 @@ t_benchfinal() {
   python bench.py > $OUT/bench_cfg2_default.json 2> $OUT/bench_cfg2_default.log; field $OUT/bench_cfg2_default.json
   python -c "import json;d=json.load(open('$OUT/bench_cfg2_default.json'));print(d['config']['optimizer']);print({k:(v['avg_us'],v['frac']) for k,v in d['roofline_graph'].items() if v and k.startswith('glue')})"
   NEXTOU_CLIP_SGD=0 python bench.py --no-cpu-baseline > $OUT/bench_cfg2_torch_sgd.json 2>/dev/null; field $OUT/bench_cfg2_torch_sgd.json
+}
+t_averaged() {
+  python bench.py --no-cpu-baseline --steps 10 --warmup 3 --force-averager --graph on > $OUT/bench_cfg2_averaged.json 2> $OUT/bench_cfg2_averaged.log; field $OUT/bench_cfg2_averaged.json
+  python -c "import json;d=json.load(open('$OUT/bench_cfg2_averaged.json'));print(d['config']['optimizer'], d['dist']['backend'], d['config']['gradient_averager'])"
 }
 t_trace() {
   cd /tmp && export TMPDIR=/tmp
