@@ -402,8 +402,8 @@ int nextou_upconv_cat_rows_bwd(const float* g, float* gy2, float* gbias, void* w
 /* ------------------------------------------------------------------------------------------
  * Step glue (ABI v13): gradient clip + SGD update of a whole parameter list.  The step nnU-Net's trainer prescribes for the NexToU
  * plug-ins (nnUNetTrainer_NexToU inherits nnUNetTrainer.train_step: backward -> clip_grad_norm_(network.parameters(), 12) ->
- * SGD(momentum 0.99, nesterov, weight_decay 3e-5).step(); reference nnUNetTrainer_NexToU.py:14-22 sets nothing else) runs both as
- * multi-tensor-apply launches of at most 36-110 tensors each — ~70 launches for the 1 100 parameter tensors of cfg 2.  Here the
+ * SGD(momentum 0.99, nesterov, weight_decay 3e-5).step(); reference nnUNetTrainer_NexToU.py:17-91 overrides only build_network_architecture) runs both as
+ * multi-tensor-apply launches of at most 36-110 tensors each — a few dozen launches (575 us replayed) for the 358 trainable tensors of cfg 2.  Here the
  * tensors are named by a table in DEVICE memory, so each stage is one launch whatever the tensor count:
  *   table   int64 [n_tensors][4]: parameter pointer, gradient pointer, momentum-buffer pointer (0: none), element count; the three
  *           tensors of a row are walked as flat float32 arrays and must share one dense layout

@@ -2,8 +2,8 @@
 //
 // The training step the plug-in surface prescribes (nnU-Net's train_step, mirrored by nextou_amd/harness.py) ends with
 // clip_grad_norm_(parameters, 12) and torch.optim.SGD(momentum 0.99, nesterov, weight decay).step().  PyTorch runs both as
-// multi-tensor-apply kernels whose launch arguments hold at most 36-110 tensors and 320 chunks: for the 1 100 parameter tensors
-// of a cfg-2 network that is ~70 launches, most of them a few dozen small workgroups on 256 CUs.  Here the tensors are named by a
+// multi-tensor-apply kernels whose launch arguments hold at most 36-110 tensors and 320 chunks: for the 358 trainable tensors
+// of a cfg-2 network that is a few dozen launches, most of them a few dozen small workgroups on 256 CUs (575 us replayed).  Here the tensors are named by a
 // TABLE IN DEVICE MEMORY (one row per tensor: parameter, gradient, momentum buffer, element count) and a list of (tensor, chunk)
 // pairs, so one launch covers every tensor with one workgroup per 64-KB chunk:
 //     multi_sumsq_kernel     per-chunk sum of squares of the gradients (float64, fixed order)

@@ -37,7 +37,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .layout import layout_policy_applies
+from .layout import layout_policy_applies, runs_in_fp32
 
 
 _force_entry: Optional[bool] = None     # test hook: True / False overrides the entry modules' per-call decision
@@ -157,8 +157,15 @@ def filter_layout_for(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     reduced precision without the channel padding, ``NEXTOU_REDUCED_PRECISION_LAYOUT=ncdhw`` (layout.layout_policy_applies: NDHWC at
     33 / 66 bf16 channels was round 1's 309-vs-185-ms regression) — the call gets the contiguous form: the per-call conversion that the
     stored layout saves on the default, all-channels-last path.  A channels-last input — dense NDHWC, or the single-channel image
-    re-strided by layout.to_channels_last — has stride 1 on its channel axis."""
-    if w.dim() < 4 or not x.is_cuda or w.is_contiguous() or x.dim() != w.dim() or x.stride(1) == 1:
+    re-strided by layout.to_channels_last — has stride 1 on its channel axis.
+
+    Reduced precision (bf16 / fp16 autocast) always gets the contiguous form: autocast's cast keeps a filter's strides, and the library's
+    reduced-precision solvers for channels-last FILTERS were never part of a clean measured run — the one `bench.py --autocast-bf16` run of
+    the tree that stored filters channels-last ended in a GPU memory fault (known issue), while contiguous filters are
+    what every earlier bf16 / fp16 run and test used."""
+    if w.dim() < 4 or not x.is_cuda or w.is_contiguous() or x.dim() != w.dim():
+        return w
+    if x.stride(1) == 1 and runs_in_fp32(x):
         return w
     return w.contiguous()
 

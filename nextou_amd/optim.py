@@ -1,9 +1,9 @@
 """``ClipSGD``: nnU-Net's optimizer step — ``clip_grad_norm_(parameters, 12)`` then ``torch.optim.SGD(momentum, nesterov,
 weight_decay).step()`` — on this library's step-glue kernels (csrc/step_glue.hip, ABI v13).
 
-The reference sets no optimizer of its own (nnUNetTrainer_NexToU.py:14-22 inherits nnUNetTrainer's ``configure_optimizers`` and
-``train_step``); the plug-ins' step therefore ends with torch's multi-tensor clip and SGD, ~70 launches of a few dozen workgroups
-for the 1 100 parameter tensors of a cfg-2 network.  ``ClipSGD`` IS a ``torch.optim.SGD`` (same constructor, ``param_groups``,
+The reference sets no optimizer of its own (nnUNetTrainer_NexToU.py:17-91 overrides only build_network_architecture and inherits nnUNetTrainer's ``configure_optimizers`` and
+``train_step``); the plug-ins' step therefore ends with torch's multi-tensor clip and SGD — a few dozen launches of a few dozen workgroups
+each for the 358 trainable tensors of a cfg-2 network (575 us replayed, profiles/r05_step_glue2.md).  ``ClipSGD`` IS a ``torch.optim.SGD`` (same constructor, ``param_groups``,
 ``state`` with ``momentum_buffer`` tensors, ``state_dict`` / ``load_state_dict``, LR schedulers) whose ``step()`` names its
 tensors to the kernels through a table in device memory: one launch for the update, two more for the clip
 (:meth:`clip_and_step`), whatever the tensor count.
