@@ -14,6 +14,8 @@
 #   convtable  per-layer table of the library convolutions at the model's own routing (tools/conv_layer_table.py)
 #   heads      K8 against the library route at the cfg-2 head shapes
 #   repro      the guard-page reproducer of MIOpen's backward-data over-read (+ K8 on the same operands)
+#   reprobf16  the guard-page reproducer with bf16 operands (tiny and cfg-2 head shapes) + two bf16 bench lines: the reduced-precision fault
+#              of round 5's closing tree
 #   guard      tests/test_gpu_guard.py + tests/test_gpu_head.py verbose (every own kernel on guard-page operands, outputs and workspaces)
 #   glue       the step's small ATen launches by op, shape and enclosing op (tools/aten_glue_profile.py --parents) + bench A/B of the round-5
 #              glue changes, hipGraph replay and eager (profiles/r05_aten_glue.md)
@@ -163,6 +165,11 @@ t_heads() {
 }
 t_repro() {
   python tools/conv_bwd_fault_repro.py --own --repeat 3 --log-dir $OUT/repro_logs 2>&1 | cut -c1-420 > $OUT/conv_bwd_fault_repro.txt; tail -20 $OUT/conv_bwd_fault_repro.txt | cut -c1-160
+}
+t_reprobf16() {      # next round's first call: the bf16 head convolution on guard pages + the reduced-precision bench lines (known issue)
+  python tools/conv_bwd_fault_repro.py --dtype bf16 --repeat 3 --log-dir $OUT/repro_bf16_logs 2>&1 | cut -c1-420 > $OUT/conv_bwd_fault_repro_bf16.txt; tail -20 $OUT/conv_bwd_fault_repro_bf16.txt | cut -c1-160
+  python tools/conv_bwd_fault_repro.py --dtype bf16 --size cfg2 --repeat 2 --log-dir $OUT/repro_bf16_logs 2>&1 | cut -c1-420 > $OUT/conv_bwd_fault_repro_bf16_cfg2.txt; tail -20 $OUT/conv_bwd_fault_repro_bf16_cfg2.txt | cut -c1-160
+  for i in 1 2; do python bench.py --no-cpu-baseline --steps 10 --warmup 3 --autocast-bf16 > $OUT/bench_cfg2_bf16_$i.json 2> $OUT/bench_cfg2_bf16_$i.log; field $OUT/bench_cfg2_bf16_$i.json || tail -2 $OUT/bench_cfg2_bf16_$i.log; done
 }
 t_guard() {
   python -m pytest tests/test_gpu_guard.py tests/test_gpu_head.py -q -m gpu -p no:cacheprovider 2>&1 | grep -v "MIOpen\|GridwiseOp\|amdgpu.ids" > $OUT/guard_pages_pytest.txt; tail -3 $OUT/guard_pages_pytest.txt
