@@ -114,6 +114,14 @@ class ClipSGD(torch.optim.SGD):
         self.last_path = None            # "own" | "torch": which implementation the last step took (tests, bench line)
         self.last_reason = None          # why torch's implementation took it
 
+    def __setstate__(self, state):
+        # torch.optim.Optimizer pickles defaults / state / param_groups only: the tables (device pointers of another process) start empty
+        super().__setstate__(state)
+        self._tables, self._retired, self._static = {}, [], {}
+        self.__dict__.setdefault("_device_type", "cuda")
+        self.__dict__.setdefault("last_path", None)
+        self.__dict__.setdefault("last_reason", None)
+
     # ---------------------------------------------------------------------------------------------------------------
     def _plan(self, group):
         """(rows, device) of one param group for the kernels, or a string — why torch's implementation has to run it."""

@@ -184,6 +184,27 @@ def test_clip_sgd_hands_over_what_the_kernels_do_not_take(stand_in):
     assert own3.last_path == "torch" and "dampening" in own3.last_reason and stand_in.calls == []
 
 
+def test_clip_sgd_survives_pickle_and_deepcopy(stand_in):
+    import copy
+    import pickle
+    from nextou_amd.optim import ClipSGD
+    ps = [torch.nn.Parameter(t.clone()) for t in _params()[:3]]
+    own = ClipSGD(ps, 0.01, momentum=0.9, nesterov=True)
+    own._device_type = "cpu"
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    own.step()
+    assert own.last_path == "own"
+    for other in (pickle.loads(pickle.dumps(own)), copy.deepcopy(own)):
+        other._device_type = "cpu"
+        assert isinstance(other, torch.optim.SGD) and other._tables == {} or other is not own
+        for p in other.param_groups[0]["params"]:
+            p.grad = torch.randn_like(p)
+        other.step()                                   # builds its own table for its own tensors
+        assert other.last_path == "own"
+        assert all("momentum_buffer" in other.state[p] for p in other.param_groups[0]["params"])
+
+
 # ------------------------------------------------------------------------------------------------ _UpConvCat on emulated passes
 def _upconv_row(row, D2, H2, W2, sd, sh, sw):
     """include/nextou_hip.h, nextou_upconv_cat_rows: output row -> p_in * T + t."""
