@@ -295,3 +295,49 @@ def test_upconv_cat_is_the_transposed_convolution(monkeypatch, cin, cout, c2, sp
     assert float((out - torch.cat((conv(x, wc, b, stride), skip), 1)).abs().max()) <= 1e-12
     gw = torch.autograd.grad(out, [wc], go)[0]
     assert float((gw - torch.autograd.grad(torch.cat((conv(x, wc, b, stride), skip), 1), [wc], go)[0]).abs().max()) <= 1e-10
+
+
+def test_clip_sgd_on_the_gradient_averager_s_bucket_views(stand_in):
+    """Under the gradient averager ``p.grad`` is a plain slice of a flat bucket: for a parameter stored channels-last that is another
+    element order.  ClipSGD copies such a gradient into the parameter's order and takes the step itself (world-size-1 gloo group, real
+    BucketedGradientAverager, the kernels' stand-in)."""
+    import socket
+
+    import torch.distributed as dist
+    from nextou_amd.ddp import BucketedGradientAverager
+    from nextou_amd.optim import ClipSGD
+    if dist.is_initialized():
+        pytest.skip("another test left a process group up")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("gloo", rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % port)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Conv3d(4, 6, 3, padding=1), torch.nn.Conv3d(6, 2, 1))
+        net[0].weight.data = net[0].weight.data.contiguous(memory_format=torch.channels_last_3d)       # layout.filters_to_channels_last
+        ref = torch.nn.Sequential(torch.nn.Conv3d(4, 6, 3, padding=1), torch.nn.Conv3d(6, 2, 1))
+        ref.load_state_dict(net.state_dict())
+        averager = BucketedGradientAverager(net, bucket_bytes=1 << 10)
+        own = ClipSGD(net.parameters(), 0.05, momentum=0.9, nesterov=True, weight_decay=1e-4)
+        own._device_type = "cpu"
+        plain = torch.optim.SGD(ref.parameters(), 0.05, momentum=0.9, nesterov=True, weight_decay=1e-4)
+        x = torch.randn(2, 4, 3, 5, 5)
+        for _ in range(3):
+            averager.zero_grad()
+            net(x).square().mean().backward()
+            averager.finalize()
+            assert net[0].weight.grad.stride() != net[0].weight.stride()          # the bucket view is a plain slice
+            own.clip_and_step(0.05)
+            assert own.last_path == "own", own.last_reason
+            assert net[0].weight.grad.stride() == net[0].weight.stride()
+            plain.zero_grad(set_to_none=True)
+            ref(x).square().mean().backward()
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.05)
+            plain.step()
+            for p, q in zip(net.parameters(), ref.parameters()):
+                assert float((p.detach() - q.detach()).abs().max()) <= 2e-6 * float(q.detach().abs().max())
+        averager.remove_hooks()
+    finally:
+        dist.destroy_process_group()
