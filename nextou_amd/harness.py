@@ -198,17 +198,6 @@ class GraphedTrainStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                # A precaution against the rare hipErrorCapturedEvent of RCCL's watchdog thread ("operation not permitted on an event last
-                # recorded in a capturing stream", raised from WorkNCCL::isCompleted() in Watchdog::runLoop(), which terminates the
-                # process: once in ~25 runs of the tiny averaged step in round 5's first half, once more in its GPU suite with the event
-                # cache already off — ddp._capture_safe_process_group_env).  The watchdog polls the end events of the eager collectives on
-                # its list every 100 ms and drops finished work at the next poll; half a second here means no work of the eager warm-up is
-                # on that list when the capture pulls RCCL's stream in.  Whether a lingering eager work is the trigger is NOT established:
-                # tools/rccl_capture_watchdog_repro.py builds exactly that situation with plain torch and stayed clean 3 / 3 with and
-                # without the pause (profiles/r05_rccl_capture_watchdog_repro.txt).
-                import time
-                time.sleep(0.5)
             self.graph = torch.cuda.CUDAGraph()
             # With a process group up, RCCL's watchdog THREAD polls the events of in-flight collectives (hipEventQuery) whenever it likes;
             # under the default "global" capture mode such a call from another thread while this one captures is an error — and it is

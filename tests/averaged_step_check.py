@@ -75,6 +75,10 @@ def main():
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--workload", default="tiny")
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--captured-collectives", action="store_true",
+                    help="also run the averaged step CAPTURED into a hipGraph (RCCL collectives inside the capture): the explicit opt-in of "
+                         "bench.py --graph on, where PyTorch's RCCL watchdog thread can abort the process (DESIGN.md 6); without the flag the "
+                         "modes are the defaults of every N (eager averaged step, captured plain step)")
     args = ap.parse_args()
     _lib.lib()
     torch.cuda.set_device(DEV)
@@ -82,8 +86,10 @@ def main():
     init_single_process_group(args.backend)
 
     runs = {}
-    for name, averaged, graphed in (("plain_a", False, False), ("plain_b", False, False), ("avg_eager", True, False),
-                                    ("avg_graph", True, True), ("plain_graph", False, True)):
+    modes = [("plain_a", False, False), ("plain_b", False, False), ("avg_eager", True, False), ("plain_graph", False, True)]
+    if args.captured_collectives:
+        modes.insert(3, ("avg_graph", True, True))
+    for name, averaged, graphed in modes:
         t, step, averager = make(args.workload, averaged)
         if graphed:
             # step 1 eager, then capture (executes nothing); the replays are steps 2..  — with the default 2 steps the comparison is
@@ -109,29 +115,35 @@ def main():
             averager.remove_hooks()
         runs[name] = {"first": first, "last": g_last, "none": none_last, "w": weights(t), "m": momentum(t), "loss": float(loss.detach()),
                       "buckets": None if averager is None else len(averager.buckets)}
+    runs.setdefault("avg_graph", None)
     scale_g = float(runs["plain_a"]["last"].abs().max())
+
+    def vs_plain(mode, key):
+        return None if runs[mode] is None else min(dist_max(runs[mode][key], runs[k][key]) for k in ("plain_a", "plain_b"))
+
     out = {
         "hip_library_loaded": "libnextou_hip.so" in open("/proc/self/maps").read(),
         "backend": dist.get_backend(), "world_size": dist.get_world_size(), "steps": args.steps,
         "buckets": runs["avg_eager"]["buckets"],
         "grad_scale": scale_g,
         "grad_is_none_plain": runs["plain_a"]["none"], "grad_is_none_avg_eager": runs["avg_eager"]["none"],
-        "grad_is_none_avg_graph": runs["avg_graph"]["none"],
+        "grad_is_none_avg_graph": None if runs["avg_graph"] is None else runs["avg_graph"]["none"],
+        "captured_collectives": bool(args.captured_collectives),
         # step 1: same weights, same batch -> the gradients themselves
         "grad1_plain_vs_plain": dist_max(runs["plain_a"]["first"][0], runs["plain_b"]["first"][0]),
         "grad1_avg_eager_vs_plain": dist_max(runs["avg_eager"]["first"][0], runs["plain_a"]["first"][0]),
         # last step (lr = 0: still the same weights): gradients and the optimizer's momentum buffers
         "grad_plain_vs_plain": dist_max(runs["plain_a"]["last"], runs["plain_b"]["last"]),
         "grad_avg_eager_vs_plain": min(dist_max(runs["avg_eager"]["last"], runs[k]["last"]) for k in ("plain_a", "plain_b")),
-        "grad_avg_graph_vs_plain": min(dist_max(runs["avg_graph"]["last"], runs[k]["last"]) for k in ("plain_a", "plain_b")),
+        "grad_avg_graph_vs_plain": vs_plain("avg_graph", "last"),
         "grad_plain_graph_vs_plain": min(dist_max(runs["plain_graph"]["last"], runs[k]["last"]) for k in ("plain_a", "plain_b")),
         "momentum_scale": float(runs["plain_a"]["m"].abs().max()),
         "momentum_plain_vs_plain": dist_max(runs["plain_a"]["m"], runs["plain_b"]["m"]),
         "momentum_avg_eager_vs_plain": min(dist_max(runs["avg_eager"]["m"], runs[k]["m"]) for k in ("plain_a", "plain_b")),
-        "momentum_avg_graph_vs_plain": min(dist_max(runs["avg_graph"]["m"], runs[k]["m"]) for k in ("plain_a", "plain_b")),
+        "momentum_avg_graph_vs_plain": vs_plain("avg_graph", "m"),
         "momentum_plain_graph_vs_plain": min(dist_max(runs["plain_graph"]["m"], runs[k]["m"]) for k in ("plain_a", "plain_b")),
-        "weights_moved": max(dist_max(runs[k]["w"], runs["plain_a"]["w"]) for k in runs),
-        "loss": {k: v["loss"] for k, v in runs.items()},
+        "weights_moved": max(dist_max(v["w"], runs["plain_a"]["w"]) for v in runs.values() if v is not None),
+        "loss": {k: v["loss"] for k, v in runs.items() if v is not None},
     }
     dist.destroy_process_group()
     sys.stdout.flush()

@@ -31,34 +31,55 @@ def _json_line(stdout):
     return json.loads(lines[0])
 
 
-@pytest.mark.timeout(1800)
-def test_averaged_step_over_rccl_matches_plain_step():
-    """World-size-1 RCCL group, learning rate 0 (tests/averaged_step_check.py says why): after three steps — eager, and one eager + two
-    replayed — the averaged step's gradients and the optimizer's momentum buffers (what it was handed through `p.grad`, i.e. the bucket
-    views) equal the plain step's: bit for bit when two plain runs agree bit for bit, else within 4x their distance; the zero-weighted
-    head's parameters keep grad = None in every mode; the weights did not move."""
-    proc = subprocess.run([sys.executable, os.path.join(REPO, "tests", "averaged_step_check.py"), "--backend", "nccl"],
-                          capture_output=True, text=True, timeout=1500)
-    _xfail_on_watchdog_capture_error(proc)
-    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
-    r = _json_line(proc.stdout)
-    print(r)
+def _check_averaged_record(r, modes):
     assert r["hip_library_loaded"] and r["backend"] == "nccl" and r["world_size"] == 1 and r["buckets"] >= 2 and r["steps"] == 3
-    assert r["grad_is_none_plain"] == r["grad_is_none_avg_eager"] == r["grad_is_none_avg_graph"]
+    assert r["grad_is_none_plain"] == r["grad_is_none_avg_eager"]
     assert len(r["grad_is_none_plain"]) > 0          # the lowest-resolution head has weight 0 in the deep-supervision loss
     assert r["weights_moved"] == 0.0
     tiny_g, tiny_m = 2e-6 * r["grad_scale"], 2e-6 * r["momentum_scale"]
     assert r["grad1_avg_eager_vs_plain"] <= max(4.0 * r["grad1_plain_vs_plain"], tiny_g), r
-    for mode in ("avg_eager", "avg_graph", "plain_graph"):
+    for mode in modes:
         assert r["grad_%s_vs_plain" % mode] <= max(4.0 * r["grad_plain_vs_plain"], tiny_g), (mode, r)
         assert r["momentum_%s_vs_plain" % mode] <= max(4.0 * r["momentum_plain_vs_plain"], tiny_m), (mode, r)
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize("graph", ["on", "off"])
+def test_averaged_step_over_rccl_matches_plain_step():
+    """World-size-1 RCCL group, learning rate 0 (tests/averaged_step_check.py says why), the DEFAULT modes of every N (round 6: the averaged
+    step runs eagerly unless `--graph on` is typed; the plain step is captured): after three steps the averaged step's gradients and the
+    optimizer's momentum buffers (what it was handed through `p.grad`, i.e. the bucket views) equal the plain step's: bit for bit when two
+    plain runs agree bit for bit, else within 4x their distance; the zero-weighted head's parameters keep grad = None; the weights did not
+    move.  No collective is captured here, so nothing of PyTorch's watchdog can end the process: no XFAIL clause."""
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "tests", "averaged_step_check.py"), "--backend", "nccl"],
+                          capture_output=True, text=True, timeout=1500)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    r = _json_line(proc.stdout)
+    print(r)
+    assert r["captured_collectives"] is False and r["grad_avg_graph_vs_plain"] is None
+    _check_averaged_record(r, ("avg_eager", "plain_graph"))
+
+
+@pytest.mark.timeout(1800)
+def test_explicitly_captured_rccl_step_matches_plain_step():
+    """The opt-in mode (`bench.py --graph on` with a process group up, `averaged_step_check.py --captured-collectives`): hooks, bucket copies,
+    RCCL all-reduces, finalize and ClipSGD on the bucket views inside ONE hipGraph.  Same bars.  This is the only place where the watchdog
+    abort of DESIGN.md section 6 can strike, and the only test that reports it as XFAIL."""
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "tests", "averaged_step_check.py"), "--backend", "nccl", "--captured-collectives"],
+                          capture_output=True, text=True, timeout=1500)
+    _xfail_on_watchdog_capture_error(proc)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    r = _json_line(proc.stdout)
+    print(r)
+    assert r["captured_collectives"] is True and r["grad_is_none_plain"] == r["grad_is_none_avg_graph"]
+    _check_averaged_record(r, ("avg_eager", "avg_graph", "plain_graph"))
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("graph", ["auto", "off", "on"])
 def test_bench_averaged_step_on_one_gpu(graph):
-    """bench.py --force-averager: the N > 1 step (hooks, buckets, RCCL collectives, finalize, foreach SGD) on a world-size-1 RCCL
-    group, replayed as a hipGraph and eager — `off` is the mode that died with a GPU memory fault in round 4."""
+    """bench.py --force-averager: the N > 1 step (hooks, buckets, RCCL collectives, finalize, ClipSGD) on a world-size-1 RCCL group.
+    `auto` (the default of every N > 1 run) and `off` are the eager step — `off` is the mode that died with a GPU memory fault in
+    round 4 — and must simply pass; `on` is the explicit capture and the only mode with the watchdog XFAIL clause."""
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "2", "--workload", "tiny", "--force-averager",
            "--graph", graph, "--no-miopen-find", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
@@ -67,6 +88,7 @@ def test_bench_averaged_step_on_one_gpu(graph):
     assert out.returncode == 0, out.stderr[-3000:]
     rec = _json_line(out.stdout)
     assert rec["config"]["gradient_averager"] is True and rec["config"]["step_replayed_as_hipgraph"] is (graph == "on")
+    assert ("eager" in rec["config"]["graph_mode"]) is (graph != "on")
     assert rec["dist"]["initialized"] and rec["dist"]["backend"] == "nccl" and rec["dist"]["world_size"] == 1
     assert rec["value"] > 0 and rec["roofline"]["launches"] > 0
     assert rec["roofline_graph"]["K8_head_backward"]["launches"] > 0       # the heads' backward ran on this library's kernels
@@ -89,3 +111,20 @@ def test_bench_two_ranks_share_one_gpu():
     assert "cpu_baseline" not in rec or rec["cpu_baseline"] is None
     assert rec["dist"]["backend"] == "gloo" and rec["dist"]["world_size"] == 2 and [r["rank"] for r in rec["dist"]["ranks"]] == [0, 1]
     assert rec["dist"]["distinct_devices"] == 1          # both ranks on this box's one GPU (the 8-GPU node reports 8)
+
+
+@pytest.mark.timeout(2700)
+def test_bench_gpus_2_typed_without_a_launcher():
+    """`python bench.py --gpus 2 ...` exactly as the round driver types it, no torch.distributed.run in front (VERDICT r5 missing #2):
+    bench.py starts its own two ranks (nextou_amd/launch.py), rank 0's JSON line reaches this process's stdout, the exit code is the
+    launcher's.  gloo because both ranks share this box's single GPU; on the 8-GPU node the default backend is RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["NEXTOU_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "tiny",
+           "--no-miopen-find"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = _json_line(out.stdout)
+    assert rec["n_gpus"] == 2 and rec["dist"]["world_size"] == 2 and rec["dist"]["backend"] == "gloo"
+    assert rec["config"]["step_replayed_as_hipgraph"] is False and rec["config"]["global_batch"] == 4 and rec["value"] > 0
+    assert "without a launcher" in out.stderr

@@ -501,3 +501,43 @@ def test_folded_conv_biases_get_their_zero_gradients_from_one_buffer(cpu_checker
     net.eval()
     net(x)
     assert all(p.grad is None for p in folded) and graph_ops.ZERO_GRADS._params == {}
+
+
+def test_self_launch_command_and_world_check():
+    """nextou_amd/launch.py (VERDICT r5 missing #2): `bench.py --gpus N` typed into a plain shell starts its own ranks with the line the round
+    driver uses; under a launcher it does not; a launcher / --gpus disagreement is a usage error, never a silent world-size-1 run."""
+    from nextou_amd import launch
+    plain = {"PATH": "/usr/bin"}
+    ranked = dict(plain, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1")
+    assert launch.needs_self_launch(2, plain) and launch.needs_self_launch(8, plain)
+    assert not launch.needs_self_launch(1, plain) and not launch.needs_self_launch(2, ranked)
+    cmd = launch.self_launch_command("bench.py", ["--gpus", "4", "--steps", "3"], 4, port=29555)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29555" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert cmd[-5].endswith("bench.py") and cmd[-5].startswith("/")
+    assert 1024 < launch.free_port() < 65536
+    with pytest.raises(ValueError):
+        launch.self_launch_command("bench.py", [], 1)
+    launch.check_world(2, ranked)
+    launch.check_world(1, plain)
+    with pytest.raises(SystemExit):
+        launch.check_world(4, ranked)
+
+
+def test_bench_gpus_2_starts_its_own_ranks_even_here():
+    """On this CPU-only container the two ranks bench.py starts for `--gpus 2` must each fail loudly (no CPU fallback for the product path)
+    and the launcher's non-zero exit code must come back: the self-launch happened, and nothing pretended to measure."""
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: tests/test_gpu_ddp.py::test_bench_gpus_2_typed_without_a_launcher covers the real thing")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert "without a launcher" in out.stderr and "torch.distributed.run" in out.stderr
+    assert out.stderr.count("bench.py needs an MI355X") >= 2
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -16,6 +16,7 @@
 #   repro      the guard-page reproducer of MIOpen's backward-data over-read (+ K8 on the same operands)
 #   reprobf16  the guard-page reproducer with bf16 operands (tiny and cfg-2 head shapes) + two bf16 bench lines: the reduced-precision fault
 #              of round 5's closing tree
+#   bf16       round 6: bench.py --autocast-bf16 at cfg 2 / tiny / cfg 5 in find mode, twice each; on a fault a serialized rerun with MIOpen's log
 #   guard      tests/test_gpu_guard.py + tests/test_gpu_head.py verbose (every own kernel on guard-page operands, outputs and workspaces)
 #   glue       the step's small ATen launches by op, shape and enclosing op (tools/aten_glue_profile.py --parents) + bench A/B of the round-5
 #              glue changes, hipGraph replay and eager (profiles/r05_aten_glue.md)
@@ -170,6 +171,20 @@ t_reprobf16() {      # next round's first call: the bf16 head convolution on gua
   python tools/conv_bwd_fault_repro.py --dtype bf16 --repeat 3 --log-dir $OUT/repro_bf16_logs 2>&1 | cut -c1-420 > $OUT/conv_bwd_fault_repro_bf16.txt; tail -20 $OUT/conv_bwd_fault_repro_bf16.txt | cut -c1-160
   python tools/conv_bwd_fault_repro.py --dtype bf16 --size cfg2 --repeat 2 --log-dir $OUT/repro_bf16_logs 2>&1 | cut -c1-420 > $OUT/conv_bwd_fault_repro_bf16_cfg2.txt; tail -20 $OUT/conv_bwd_fault_repro_bf16_cfg2.txt | cut -c1-160
   for i in 1 2; do python bench.py --no-cpu-baseline --steps 10 --warmup 3 --autocast-bf16 > $OUT/bench_cfg2_bf16_$i.json 2> $OUT/bench_cfg2_bf16_$i.log; field $OUT/bench_cfg2_bf16_$i.json || tail -2 $OUT/bench_cfg2_bf16_$i.log; done
+}
+t_bf16() {           # round 6: the reduced-precision bench path at HEAD — does it complete in find mode?  On a fault: the same run once more with
+  # synchronous launches and MIOpen's command log, whose tail names the solver that was running (profiles/r06_bf16_*)
+  for w in "cfg2 10" "tiny 5" "cfg5 5"; do set -- $w
+    for i in 1 2; do
+      timeout 1200 python bench.py --no-cpu-baseline --steps $2 --warmup 3 --workload $1 --autocast-bf16 > $OUT/bench_$1_bf16_$i.json 2> $OUT/bench_$1_bf16_$i.log
+      rc=$?; echo "bench $1 bf16 run $i rc $rc"; grep -h "Memory access fault" $OUT/bench_$1_bf16_$i.log | head -2
+      if [ $rc -eq 0 ]; then field $OUT/bench_$1_bf16_$i.json; else
+        MIOPEN_LOG_LEVEL=6 MIOPEN_ENABLE_LOGGING_CMD=1 HIP_LAUNCH_BLOCKING=1 AMD_SERIALIZE_KERNEL=3 timeout 1500 python bench.py --no-cpu-baseline --steps 2 --warmup 1 --workload $1 --autocast-bf16 2>&1 >/dev/null | grep -v "GridwiseOp\|amdgpu.ids" | tail -c 300000 > $OUT/bench_$1_bf16_${i}_serialized_tail.log
+        echo "serialized rerun rc ${PIPESTATUS[0]}"; grep -E "Memory access fault|MIOpenDriver|Solver|solver_id|SolverName" $OUT/bench_$1_bf16_${i}_serialized_tail.log | tail -8 | cut -c1-300
+        break
+      fi
+    done
+  done
 }
 t_guard() {
   python -m pytest tests/test_gpu_guard.py tests/test_gpu_head.py -q -m gpu -p no:cacheprovider 2>&1 | grep -v "MIOpen\|GridwiseOp\|amdgpu.ids" > $OUT/guard_pages_pytest.txt; tail -3 $OUT/guard_pages_pytest.txt
