@@ -186,6 +186,9 @@ def roofline_graph_from(report):
             "K8_head_forward": pick(("head_fwd_kernel", "head_fwd_lds_kernel")),
             "K8_head_backward": pick(("head_bwd_lds_kernel", "head_dgrad_kernel", "head_wgrad_kernel")),
             "K2K7_pool_grouped_forward": pick(("mr_grp_cm_kernel",)),
+            # round 6 (ABI v14): the stem block — first conv -> norm -> act of the network without the convolution's output in memory
+            "K9_stem_forward": pick(("stem_apply_kernel",)), "K9_stem_backward": pick(("stem_bwd_kernel",)),
+            "K9_stem_moments": pick(("stem_moments_kernel",)),
             # round 5's step glue (ABI v13): the gradient norm + clip / SGD update over the whole parameter list, the decoder concatenation with the
             # up-convolution's pixel shuffle (forward) and its one-pass backward (channel range copied / un-shuffled + bias sums)
             "glue_grad_norm": pick(("multi_sumsq_kernel",)), "glue_clip_sgd": pick(("clip_sgd_kernel",)),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NEXTOU_ABI_VERSION 13
+#define NEXTOU_ABI_VERSION 14
 
 #define NEXTOU_EINVAL   (-1)  /* bad argument (null pointer, non-positive size, k > M ...) */
 #define NEXTOU_ENOSPACE (-2)  /* workspace too small */
@@ -538,6 +538,33 @@ int nextou_mr_grouped_cm(const float* x, const float* y, const int32_t* nn_idx, 
 int nextou_norm_act_fwd_partials(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
                                  float* y, float* save_mean, float* save_invstd, const double* partial, int n_partial, int B, int C,
                                  int64_t S, int param_period, float momentum, float eps, float slope, nextou_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K9  the stem block (ABI v14): the network's first ConvDropoutNormReLU — conv_op(1, features[0], [1,]3x3, stride 1, padding 1, bias)
+ * -> BatchNorm -> LeakyReLU on the ONE-channel image (reference NexToU_Encoder_Decoder.py:125-141, encoder.stages[0], first block)
+ * and the autograd of the three, without ever storing the convolution's output.  Replaces, per step at cfg 2: the library convolution
+ * (forward + weight gradient), K6's statistics / apply / backward-reduce / backward-apply passes over its 881-MB output.
+ *   x        (B, D, H, W) fp32 image (D = 1 for a 2-D network), dense
+ *   weight   (C, 9) = the filter (C, 1, [1,] 3, 3) as stored; pre_bias (C,) or NULL = the convolution's bias (folded into the
+ *            statistics, as in nextou_norm_act_fwd); gamma / beta (C,) or NULL = the norm's affine
+ *   y        (B, D, H, W, Cpad) channels-last rows, Cpad >= C a multiple of 4, <= 48; channels C .. Cpad-1 are written as zeros (the
+ *            padding channels of channel_pad.py)
+ *   save_mean / save_invstd (C,) out; moments (54 doubles) out: the tap sums X1[9] and the packed upper triangle of the 9 x 9 tap
+ *            autocorrelation — what the backward needs besides (S1, S2); running_mean / running_var updated as F.batch_norm does
+ *   training = 0: running statistics, no moments pass (forward only: the backward below is the batch-statistics one)
+ * nextou_stem_bwd: gweight (C, 9), ggamma (C,), gbeta (C,) — any may be NULL — from gy (B, D, H, W, Cpad) in one pass.  The image gets no
+ * gradient (the caller routes an image that requires one through the library convolution); d/d pre_bias is exactly zero.
+ * workspace: nextou_stem_workspace_bytes() bytes, contents irrelevant.  Float64 sums in a fixed order: bit-reproducible.
+ * HBM-bound: 4 V (1 + Cpad) bytes each way for V = B D H W voxels. */
+size_t nextou_stem_workspace_bytes(int B, int D, int H, int W, int Cpad);
+int nextou_stem_fwd(const float* x, const float* weight, const float* pre_bias, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, double* moments,
+                    void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, int Cpad, int training,
+                    float momentum, float eps, float slope, nextou_stream_t stream);
+int nextou_stem_bwd(const float* x, const float* gy, const float* weight, const float* gamma, const float* beta,
+                    const float* save_mean, const float* save_invstd, const double* moments, float* gweight, float* ggamma,
+                    float* gbeta, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, int Cpad,
+                    float slope, nextou_stream_t stream);
 
 #ifdef __cplusplus
 }

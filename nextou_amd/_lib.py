@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("NEXTOU_HIP_LIB") or os.path.join(_PKG_DIR, "libnextou
 
 KNN_AUTO, KNN_FUSED, KNN_NAIVE = 0, 1, 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 EINVAL, ENOSPACE, ENOTSUP = -1, -2, -3       # include/nextou_hip.h
 
 # name -> (restype, argtypes); mirrors include/nextou_hip.h one to one
@@ -124,6 +124,9 @@ _SIGNATURES = {
     "nextou_head_rows_bwd_workspace": (c_int, [c_int64, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "nextou_head_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int,
                                      c_int64, c_int64, c_void_p]),
+    "nextou_stem_workspace_bytes": (c_size_t, [c_int] * 5),
+    "nextou_stem_fwd": (c_int, [c_void_p] * 12 + [c_size_t] + [c_int] * 7 + [c_float, c_float, c_float, c_void_p]),
+    "nextou_stem_bwd": (c_int, [c_void_p] * 12 + [c_size_t] + [c_int] * 6 + [c_float, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libnextou_hip.so")
 
 HIP_SOURCES = ["capi.hip", "knn_graph.hip", "mr_aggregate.hip", "bti_critical.hip", "norm_act.hip", "layout_ops.hip",
-               "pw_gemm.hip", "head_rows.hip", "step_glue.hip"]
+               "pw_gemm.hip", "head_rows.hip", "step_glue.hip", "stem_conv.hip"]
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off",                         # explicit fmaf only: bit-exact vs the oracle

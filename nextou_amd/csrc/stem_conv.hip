@@ -1,0 +1,375 @@
+// K9 — the network's first block in one pass each way: convolution of the ONE-channel image (kernel 1x3x3 in 3-D, 3x3 in 2-D, stride 1,
+// zero padding 1) -> batch norm -> LeakyReLU.  Reference: NexToU_Encoder_Decoder.py:125-141 (encoder.stages[0]'s first
+// ConvDropoutNormReLU: conv_op(input_channels, features[0], kernel_sizes[0], 1, bias) -> norm_op -> nonlin), the autograd of the three.
+//
+// Why own kernels: the library runs this layer as a GEMM with K = 9 (forward 466 us = 4 % of the MFMA peak, weight
+// gradient 2 342 us at cfg 2) and the block around it moves the 881-MB convolution output z = conv(x) through HBM six times (conv write,
+// statistics read, apply read, backward reduce read, backward apply read + dz write, weight gradient read) although z is a function of
+// nine numbers per voxel.  Here z never exists in memory:
+//   forward   (1) stem_moments_kernel   one pass over the image (22 MB): X1[t] = sum_v x_t(v), A[t][t'] = sum_v x_t(v) x_t'(v) over the
+//                 nine taps, float64.  The batch statistics of every output channel follow from them by linearity —
+//                 sum_v z_c = sum_t w_ct X1[t],  sum_v z_c^2 = sum_tt' w_ct w_ct' A[t][t'] — (2) stem_stats_kernel, then K6's own
+//                 finalize (nextou_norm_finalize: mean / invstd / running statistics / folded conv bias);
+//             (3) stem_apply_kernel     y[v][c] = leaky(fmaf(z_c(v), scale_c, shift_c)), z_c(v) = the fp32 fma chain over the taps in
+//                 ascending tap order; reads the image, writes the channels-last rows once (zero padding channels included).
+//   backward  (4) stem_bwd_kernel       one pass over gy (+ the image): dy' = gy * (pre-activation > 0 ? 1 : slope) with the
+//                 pre-activation recomputed by the same chain (bit-identical to the forward's, so the mask is the forward's),
+//                 S1[c] = sum dy', S2[c][t] = sum dy' x_t;
+//             (5) stem_bwd_finalize_kernel  everything the three ops' autograd returns is linear in (S1, S2) given the moments:
+//                 gbeta = S1, ggamma = sum dy' zhat = invstd (sum_t w_ct S2[c][t] - mean S1),
+//                 gw[c][t] = scale ( S2[c][t] - (S1/n) X1[t] - (ggamma/n) invstd (sum_t' w_ct' A[t'][t] - mean X1[t]) ).
+//                 The image needs no gradient (the caller checks), the folded conv bias gets exactly zero under batch statistics.
+// HBM-bound: forward 4 V (1 + Cpad) bytes, backward 4 V (1 + Cpad) bytes for V voxels.  Sums: fp32 over a thread's own voxels (<= a few
+// hundred terms), float64 across threads and workgroups in a fixed order: bit-reproducible.
+#include "common.h"
+
+namespace nextou {
+namespace {
+
+constexpr int kTaps = 9;
+constexpr int kMom = kTaps + kTaps * (kTaps + 1) / 2;      // X1[9] + upper triangle of A (45)
+constexpr int kVox = 32;                                   // voxels of a row chunk per workgroup iteration
+constexpr int kMomThreads = 256;
+
+__host__ __device__ constexpr int tri(int a, int b) {      // packed index of A[a][b], a <= b
+    return kTaps + a * kTaps - a * (a - 1) / 2 + (b - a);
+}
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// taps of voxel (row r, column w): t[ky * 3 + kx] = x[h + ky - 1][w + kx - 1], zero outside the plane (cross-correlation, as ATen)
+__device__ __forceinline__ void load_taps(const float* __restrict__ p, int w, int W, bool up, bool down, bool active, float (&t)[kTaps]) {
+    const bool l = active && w > 0, r = active && w + 1 < W;
+    t[0] = (up && l) ? p[-W - 1] : 0.f;
+    t[1] = (up && active) ? p[-W] : 0.f;
+    t[2] = (up && r) ? p[-W + 1] : 0.f;
+    t[3] = l ? p[-1] : 0.f;
+    t[4] = active ? p[0] : 0.f;
+    t[5] = r ? p[1] : 0.f;
+    t[6] = (down && l) ? p[W - 1] : 0.f;
+    t[7] = (down && active) ? p[W] : 0.f;
+    t[8] = (down && r) ? p[W + 1] : 0.f;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// (1) moments of the taps.  Flat voxel ranges per workgroup; every thread keeps the 54 sums of its own voxels in float64 (products of two
+// floats are exact in float64).
+__global__ __launch_bounds__(kMomThreads) void stem_moments_kernel(const float* __restrict__ x, double* __restrict__ partial, long long V,
+                                                                   int H, int W, long long span) {
+    double acc[kMom];
+#pragma unroll
+    for (int i = 0; i < kMom; ++i) acc[i] = 0.0;
+    const long long base = (long long)blockIdx.x * span;
+    const long long end = min(V, base + span);
+    for (long long v = base + threadIdx.x; v < end; v += kMomThreads) {
+        const int w = (int)(v % W);
+        const int h = (int)((v / W) % H);
+        float t[kTaps];
+        load_taps(x + v, w, W, h > 0, h + 1 < H, true, t);
+        double d[kTaps];
+#pragma unroll
+        for (int a = 0; a < kTaps; ++a) { d[a] = (double)t[a]; acc[a] += d[a]; }
+#pragma unroll
+        for (int a = 0; a < kTaps; ++a)
+#pragma unroll
+            for (int b = a; b < kTaps; ++b) acc[tri(a, b)] = fma(d[a], d[b], acc[tri(a, b)]);
+    }
+    __shared__ double red[kMomThreads / 64][kMom];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < kMom; ++i) {
+        const double s = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kMom) {
+        double s = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < kMomThreads / 64; ++wv) s += red[wv][threadIdx.x];
+        partial[(size_t)blockIdx.x * kMom + threadIdx.x] = s;
+    }
+}
+
+// (2) moments -> per-channel (sum z, sum z^2): nextou_norm_finalize's `partial` with tiles = 1
+__global__ __launch_bounds__(256) void stem_stats_kernel(const double* __restrict__ partial, int G, const float* __restrict__ weight, int C,
+                                                         double* __restrict__ moments, double2* __restrict__ stats) {
+    __shared__ double part[4][kMom];
+    __shared__ double M[kMom];
+    const int t = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+    if (t < kMom) {
+        double s = 0.0;
+        for (int g = quarter; g < G; g += 4) s += partial[(size_t)g * kMom + t];
+        part[quarter][t] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kMom) {
+        const double s = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        M[threadIdx.x] = s;
+        moments[threadIdx.x] = s;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double w[kTaps];
+#pragma unroll
+        for (int a = 0; a < kTaps; ++a) w[a] = (double)weight[c * kTaps + a];
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int a = 0; a < kTaps; ++a) {
+            s = fma(w[a], M[a], s);
+            q = fma(w[a] * w[a], M[tri(a, a)], q);
+#pragma unroll
+            for (int b = a + 1; b < kTaps; ++b) q = fma(2.0 * w[a] * w[b], M[tri(a, b)], q);
+        }
+        stats[c] = make_double2(s, q);
+    }
+}
+
+struct Affine {          // a thread's four channels: filter taps + K6's affine (scale = gamma * invstd, shift = fmaf(-mean, scale, beta))
+    float w[4][kTaps], scale[4], shift[4];
+};
+
+__device__ __forceinline__ void load_affine(Affine& a, int c0, int C, const float* __restrict__ weight, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + j;
+        const bool real = c < C;
+#pragma unroll
+        for (int t = 0; t < kTaps; ++t) a.w[j][t] = real ? weight[c * kTaps + t] : 0.f;
+        const float sc = real ? (gamma ? gamma[c] : 1.f) * invstd[c] : 0.f;
+        a.scale[j] = sc;
+        a.shift[j] = real ? fmaf(-mean[c], sc, beta ? beta[c] : 0.f) : 0.f;
+    }
+}
+
+// the convolution value itself: one fp32 fma chain over the taps in ascending order (forward and backward share it bit for bit)
+__device__ __forceinline__ float conv_chain(const float (&w)[kTaps], const float (&t)[kTaps]) {
+    float z = w[0] * t[0];
+#pragma unroll
+    for (int k = 1; k < kTaps; ++k) z = fmaf(w[k], t[k], z);
+    return z;
+}
+
+// (3) y rows.  A workgroup = kVox voxels x Q channel quads; rows [r0, r1) of the (B * D * H, W) image per workgroup.
+__global__ void stem_apply_kernel(const float* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                  float* __restrict__ y, int R, int H, int W, int C, int Q, int rows_per_wg, float slope) {
+    const int q = threadIdx.x % Q, vs = threadIdx.x / Q;
+    Affine a;
+    load_affine(a, 4 * q, C, weight, gamma, beta, mean, invstd);
+    const int Cp = 4 * Q;
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+    const int chunks = (W + kVox - 1) / kVox;
+    const int items = (r1 - r0) * chunks;
+#pragma unroll 2
+    for (int it = 0; it < items; ++it) {
+        const int r = r0 + it / chunks, w = (it % chunks) * kVox + vs;
+        const int h = r % H;
+        const bool active = w < W;
+        const long long v = (long long)r * W + w;
+        float t[kTaps];
+        load_taps(x + v, w, W, h > 0, h + 1 < H, active, t);
+        float4 o;
+        o.x = leaky(fmaf(conv_chain(a.w[0], t), a.scale[0], a.shift[0]), slope);
+        o.y = leaky(fmaf(conv_chain(a.w[1], t), a.scale[1], a.shift[1]), slope);
+        o.z = leaky(fmaf(conv_chain(a.w[2], t), a.scale[2], a.shift[2]), slope);
+        o.w = leaky(fmaf(conv_chain(a.w[3], t), a.scale[3], a.shift[3]), slope);
+        if (active) *reinterpret_cast<float4*>(y + v * Cp + 4 * q) = o;
+    }
+}
+
+// (4) S1 / S2 partial sums.  Dynamic LDS: kVox * Q * 40 floats.
+__global__ void stem_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ weight,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, double* __restrict__ partial, int R, int H, int W, int C, int Q,
+                                int rows_per_wg, float slope) {
+    extern __shared__ float red[];
+    const int q = threadIdx.x % Q, vs = threadIdx.x / Q;
+    Affine a;
+    load_affine(a, 4 * q, C, weight, gamma, beta, mean, invstd);
+    const int Cp = 4 * Q;
+    float s1[4], s2[4][kTaps];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s1[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < kTaps; ++t) s2[j][t] = 0.f;
+    }
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+    const int chunks = (W + kVox - 1) / kVox;
+    const int items = (r1 - r0) * chunks;
+#pragma unroll 2
+    for (int it = 0; it < items; ++it) {
+        const int r = r0 + it / chunks, w = (it % chunks) * kVox + vs;
+        const int h = r % H;
+        const bool active = w < W;
+        const long long v = (long long)r * W + w;
+        float t[kTaps];
+        load_taps(x + v, w, W, h > 0, h + 1 < H, active, t);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) g = *reinterpret_cast<const float4*>(gy + v * Cp + 4 * q);
+        const float gj[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float pre = fmaf(conv_chain(a.w[j], t), a.scale[j], a.shift[j]);
+            const float dy = pre > 0.f ? gj[j] : gj[j] * slope;
+            s1[j] += dy;
+#pragma unroll
+            for (int k = 0; k < kTaps; ++k) s2[j][k] = fmaf(dy, t[k], s2[j][k]);
+        }
+    }
+    // red[vs][(4q + j) * 10 + k]: k = 0 -> S1, 1 + t -> S2[t]
+    const int per = Cp * (kTaps + 1);
+    float* mine = red + (size_t)vs * per + (size_t)(4 * q) * (kTaps + 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mine[j * (kTaps + 1)] = s1[j];
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) mine[j * (kTaps + 1) + 1 + k] = s2[j][k];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < per; i += blockDim.x) {
+        double s = 0.0;
+#pragma unroll 8
+        for (int u = 0; u < kVox; ++u) s += (double)red[(size_t)u * per + i];
+        partial[(size_t)blockIdx.x * per + i] = s;
+    }
+}
+
+// (5) one wave per real channel: totals in a fixed order, then the parameter gradients in float64
+__global__ __launch_bounds__(64) void stem_bwd_finalize_kernel(const double* __restrict__ partial, int G, int Cp, const float* __restrict__ weight,
+                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const double* __restrict__ moments, double count,
+                                                               float* __restrict__ gweight, float* __restrict__ ggamma, float* __restrict__ gbeta) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int per = Cp * (kTaps + 1);
+    double tot[kTaps + 1];
+#pragma unroll
+    for (int k = 0; k <= kTaps; ++k) tot[k] = 0.0;
+    for (int g = lane; g < G; g += 64) {
+        const double* p = partial + (size_t)g * per + (size_t)c * (kTaps + 1);
+#pragma unroll
+        for (int k = 0; k <= kTaps; ++k) tot[k] += p[k];
+    }
+#pragma unroll
+    for (int k = 0; k <= kTaps; ++k) tot[k] = wave_sum(tot[k]);
+    const double S1 = tot[0];
+    double w[kTaps];
+#pragma unroll
+    for (int t = 0; t < kTaps; ++t) w[t] = (double)weight[c * kTaps + t];
+    const double m = (double)mean[c], is = (double)invstd[c];
+    const double scale = (gamma ? (double)gamma[c] : 1.0) * is;
+    double wS2 = 0.0;
+#pragma unroll
+    for (int t = 0; t < kTaps; ++t) wS2 = fma(w[t], tot[1 + t], wS2);
+    const double dot = is * (wS2 - m * S1);            // sum dy' * zhat
+    if (lane == 0) {
+        if (ggamma) ggamma[c] = (float)dot;
+        if (gbeta) gbeta[c] = (float)S1;
+    }
+    if (lane < kTaps && gweight) {
+        const int t = lane;
+        double wA = 0.0;
+        for (int u = 0; u < kTaps; ++u) wA = fma(w[u], moments[u <= t ? tri(u, t) : tri(t, u)], wA);
+        const double zx = is * (wA - m * moments[t]);   // sum_v zhat x_t
+        double s2t = 0.0;                               // tot[1 + t] with a runtime t: select without indexing registers dynamically
+#pragma unroll
+        for (int u = 0; u < kTaps; ++u) s2t = (u == t) ? tot[1 + u] : s2t;
+        gweight[c * kTaps + t] = (float)(scale * (s2t - (S1 / count) * moments[t] - (dot / count) * zx));
+    }
+}
+
+int moments_groups(long long V) { return (int)max(1LL, min(512LL, (V + 8LL * kMomThreads - 1) / (8LL * kMomThreads))); }
+int apply_groups(int R) { return min(R, 3072); }
+int bwd_groups(int R) { return min(R, 1536); }
+
+}  // namespace
+}  // namespace nextou
+
+using namespace nextou;
+
+extern "C" size_t nextou_stem_workspace_bytes(int B, int D, int H, int W, int Cpad) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cpad <= 0) return 0;
+    const long long V = (long long)B * D * H * W;
+    const long long R = (long long)B * D * H;
+    const size_t fwd = (size_t)moments_groups(V) * kMom * sizeof(double) + (size_t)Cpad * sizeof(double2);
+    const size_t bwd = (size_t)bwd_groups((int)min(R, (long long)INT32_MAX)) * Cpad * (kTaps + 1) * sizeof(double);
+    return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int nextou_stem_fwd(const float* x, const float* weight, const float* pre_bias, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, double* moments,
+                               void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, int Cpad, int training,
+                               float momentum, float eps, float slope, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(x && weight && y && save_mean && save_invstd, "stem_fwd: null pointer");
+    NEXTOU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && Cpad >= C && Cpad % 4 == 0 && Cpad <= 48, "stem_fwd: 0 < C <= Cpad <= 48, Cpad a multiple of 4");
+    NEXTOU_REQUIRE((long long)B * D * H < INT32_MAX, "stem_fwd: more than 2^31 image rows");
+    NEXTOU_REQUIRE(((uintptr_t)y & 15) == 0, "stem_fwd: y must be 16-byte aligned");
+    NEXTOU_REQUIRE(!training || moments, "stem_fwd: training needs the moments output (the backward reads it)");
+    NEXTOU_REQUIRE(!training || workspace_bytes >= nextou_stem_workspace_bytes(B, D, H, W, Cpad), "stem_fwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const long long V = (long long)B * D * H * W;
+    const int R = B * D * H;
+    if (training) {
+        const int G = moments_groups(V);
+        double* partial = static_cast<double*>(workspace);
+        double2* stats = reinterpret_cast<double2*>(partial + (size_t)G * kMom);
+        const long long span = (V + G - 1) / G;
+        {
+            ProfScope prof(s, kBoundHbm, 4.0 * (double)V, "stem_moments_kernel[B%d S%lld]", B, V / B);
+            hipLaunchKernelGGL(stem_moments_kernel, dim3(G), dim3(kMomThreads), 0, s, x, partial, V, H, W, span);
+        }
+        hipLaunchKernelGGL(stem_stats_kernel, dim3(1), dim3(256), 0, s, partial, G, weight, C, moments, stats);
+        int rc = check_launch("stem_moments_kernel");
+        if (rc) return rc;
+        rc = nextou_norm_finalize(reinterpret_cast<const double*>(stats), 1, (double)V, pre_bias, running_mean, running_var, save_mean,
+                                  save_invstd, nullptr, nullptr, nullptr, nullptr, C, 1, momentum, eps, stream);
+        if (rc) return rc;
+    } else {
+        const int rc = nextou_norm_finalize(nullptr, 0, (double)V, pre_bias, running_mean, running_var, save_mean, save_invstd, nullptr,
+                                            nullptr, nullptr, nullptr, C, 0, momentum, eps, stream);
+        if (rc) return rc;
+    }
+    const int Q = Cpad / 4;
+    const int G = apply_groups(R);
+    const int rows_per_wg = (R + G - 1) / G;
+    ProfScope prof(s, kBoundHbm, 4.0 * (double)V * (1.0 + Cpad), "stem_apply_kernel[B%d C%d S%lld]", B, Cpad, V / B);
+    hipLaunchKernelGGL(stem_apply_kernel, dim3((R + rows_per_wg - 1) / rows_per_wg), dim3(kVox * Q), 0, s, x, weight, gamma, beta, save_mean,
+                       save_invstd, y, R, H, W, C, Q, rows_per_wg, slope);
+    return check_launch("stem_apply_kernel");
+}
+
+extern "C" int nextou_stem_bwd(const float* x, const float* gy, const float* weight, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, const double* moments, float* gweight, float* ggamma,
+                               float* gbeta, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, int Cpad,
+                               float slope, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(x && gy && weight && save_mean && save_invstd && moments && workspace, "stem_bwd: null pointer");
+    NEXTOU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && Cpad >= C && Cpad % 4 == 0 && Cpad <= 48, "stem_bwd: 0 < C <= Cpad <= 48, Cpad a multiple of 4");
+    NEXTOU_REQUIRE((long long)B * D * H < INT32_MAX, "stem_bwd: more than 2^31 image rows");
+    NEXTOU_REQUIRE(((uintptr_t)gy & 15) == 0, "stem_bwd: gy must be 16-byte aligned");
+    NEXTOU_REQUIRE(workspace_bytes >= nextou_stem_workspace_bytes(B, D, H, W, Cpad), "stem_bwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const long long V = (long long)B * D * H * W;
+    const int R = B * D * H;
+    const int Q = Cpad / 4;
+    const int G0 = bwd_groups(R);
+    const int rows_per_wg = (R + G0 - 1) / G0;
+    const int G = (R + rows_per_wg - 1) / rows_per_wg;
+    double* partial = static_cast<double*>(workspace);
+    const size_t lds = (size_t)kVox * Cpad * (kTaps + 1) * sizeof(float);
+    {
+        ProfScope prof(s, kBoundHbm, 4.0 * (double)V * (1.0 + Cpad), "stem_bwd_kernel[B%d C%d S%lld]", B, Cpad, V / B);
+        hipLaunchKernelGGL(stem_bwd_kernel, dim3(G), dim3(kVox * Q), lds, s, x, gy, weight, gamma, beta, save_mean, save_invstd, partial, R, H, W,
+                           C, Q, rows_per_wg, slope);
+    }
+    int rc = check_launch("stem_bwd_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(stem_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, partial, G, Cpad, weight, gamma, save_mean, save_invstd, moments,
+                       (double)V, gweight, ggamma, gbeta);
+    return check_launch("stem_bwd_finalize_kernel");
+}

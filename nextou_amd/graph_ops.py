@@ -719,6 +719,46 @@ class _HipBackend:
         return gx, gw, gb
 
 
+    # ---- K9: the stem block (one-channel image -> conv [1,]3x3 -> batch norm -> LeakyReLU) without the convolution's output in memory ----
+    @staticmethod
+    def stem_fwd(x, w2, pre_bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope, c_pad):
+        """x: dense (B, 1, *sp) float32 image; w2 (C, 9) contiguous -> (y channels-last (B, c_pad, *sp), mean (C,), invstd (C,), moments (54,) f64 | None)"""
+        L_ = _lib.lib()
+        B, sp = x.shape[0], tuple(x.shape[2:])
+        D, H, W = (1,) * (3 - len(sp)) + sp
+        C = w2.shape[0]
+        y = _empty_channels_last((B, c_pad) + sp, x.device)
+        mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+        moments = torch.empty((54,), dtype=torch.float64, device=x.device) if training else None
+        need = int(L_.nextou_stem_workspace_bytes(B, D, H, W, c_pad))
+        ws = torch.empty((max(need, 8) // 8,), dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L_.nextou_stem_fwd(x.data_ptr(), w2.data_ptr(), _ptr(pre_bias), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                    y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(moments), ws.data_ptr(), ws.numel() * 8,
+                                    B, D, H, W, C, c_pad, 1 if training else 0, float(momentum), float(eps), float(slope), _stream_ptr(x.device))
+        _lib.check(rc, "stem_fwd")
+        return y, mean, invstd, moments
+
+    @staticmethod
+    def stem_bwd(x, gy_cl, w2, gamma, beta, mean, invstd, moments, slope, want_gw, want_gg, want_gb):
+        """(gw (C, 9) | None, ggamma (C,) | None, gbeta (C,) | None) of the stem block from gy_cl, dense channels-last (B, c_pad, *sp) float32."""
+        L_ = _lib.lib()
+        B, sp = x.shape[0], tuple(x.shape[2:])
+        D, H, W = (1,) * (3 - len(sp)) + sp
+        C, c_pad = w2.shape[0], gy_cl.shape[1]
+        gw = torch.empty((C, 9), dtype=torch.float32, device=x.device) if want_gw else None
+        gg = torch.empty((C,), dtype=torch.float32, device=x.device) if want_gg else None
+        gb = torch.empty((C,), dtype=torch.float32, device=x.device) if want_gb else None
+        need = int(L_.nextou_stem_workspace_bytes(B, D, H, W, c_pad))
+        ws = torch.empty((max(need, 8) // 8,), dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L_.nextou_stem_bwd(x.data_ptr(), gy_cl.data_ptr(), w2.data_ptr(), _ptr(gamma), _ptr(beta), mean.data_ptr(), invstd.data_ptr(),
+                                    moments.data_ptr(), _ptr(gw), _ptr(gg), _ptr(gb), ws.data_ptr(), ws.numel() * 8, B, D, H, W, C, c_pad,
+                                    float(slope), _stream_ptr(x.device))
+        _lib.check(rc, "stem_bwd")
+        return gw, gg, gb
+
     # ---- K7 + K6 fused: statistics epilogue / operand prologue GEMMs and K6 in pieces ----
     @staticmethod
     def pw_rows_fused(x_cl, w2, groups, pro=None, want_stats=False, bwd=None):
@@ -1484,6 +1524,98 @@ def head_rows_eligible(conv: torch.nn.Module, x: torch.Tensor, weight: torch.Ten
 
 def head_rows(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     return _HeadConv.apply(x, weight, bias)
+
+
+class _StemBlock(torch.autograd.Function):
+    """The network's first ConvDropoutNormReLU — conv(1 -> C, [1,]3x3) -> BatchNorm -> LeakyReLU (reference
+    NexToU_Encoder_Decoder.py:125-141, encoder.stages[0]) — on K9 (csrc/stem_conv.hip): the batch statistics come from the nine-tap
+    moments of the image, the output rows are written once, and the backward is one pass over the incoming gradient; the convolution's
+    881-MB output (cfg 2) is never stored.  Saves the image and 2C + 54 numbers."""
+
+    @staticmethod
+    def forward(ctx, x, weight, conv_bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope, c_pad):
+        w2 = weight.detach().reshape(weight.shape[0], 9).contiguous()
+        y, mean, invstd, moments = _HIP.stem_fwd(x, w2, conv_bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope, c_pad)
+        if training:
+            ctx.save_for_backward(x, w2, gamma, beta, mean, invstd, moments)
+        ctx.cfg = (bool(training), float(slope), tuple(weight.shape), conv_bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        training, slope, wshape, conv_bias = ctx.cfg
+        if not training:
+            raise RuntimeError("stem block (K9): the backward exists for batch statistics only; graph_ops.stem_block_eligible routes an "
+                               "eval-mode block whose parameters need gradients through the op-by-op modules")
+        x, w2, gamma, beta, mean, invstd, moments = ctx.saved_tensors
+        gy = gy.contiguous(memory_format={4: torch.channels_last, 5: torch.channels_last_3d}[gy.dim()])
+        if gy.dtype != torch.float32:
+            gy = gy.float()
+        need = ctx.needs_input_grad
+        gw, gg, gb = _HIP.stem_bwd(x, gy, w2, gamma, beta, mean, invstd, moments, slope, need[1], gamma is not None and need[3],
+                                   beta is not None and need[4])
+        gbias = torch.zeros_like(conv_bias) if (conv_bias is not None and need[2]) else None      # batch statistics absorb a per-channel constant
+        return (None, None if gw is None else gw.reshape(wshape), gbias, gg, gb, None, None, None, None, None, None, None)
+
+
+STEM_BLOCK_DEFAULT = "1"
+
+
+def stem_block_eligible(conv: torch.nn.Module, norm: torch.nn.Module, x: torch.Tensor) -> bool:
+    """The first block of the network on K9: a one-channel fp32 device image in the channels-last stage layout (stride 1 on its channel
+    axis, layout.to_channels_last), outside autocast, that needs no gradient itself; a 1 -> C convolution with kernel [1,]3x3, stride 1,
+    zero padding [0,]1,1 whose bias is folded into a fused BATCH norm directly behind it; C (after the internal channel padding) a
+    multiple of 4 up to 48.  Batch statistics (training), or running statistics when nothing needs a gradient.
+    ``NEXTOU_STEM_BLOCK=0`` hands the block back to the library convolution + K6 (A/B)."""
+    import os
+    from .network_architecture import norm_act as na
+    if os.environ.get("NEXTOU_STEM_BLOCK", STEM_BLOCK_DEFAULT) == "0":
+        return False
+    if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype != torch.float32 or torch.is_autocast_enabled("cuda"):
+        return False
+    if x.dim() not in (4, 5) or x.shape[1] != 1 or x.stride(1) != 1 or (x.requires_grad and torch.is_grad_enabled()):
+        return False
+    if not isinstance(conv, (torch.nn.Conv2d, torch.nn.Conv3d)) or not isinstance(norm, na._BatchNormAct) or conv.transposed:
+        return False
+    nd = x.dim() - 2
+    want_k = (3, 3) if nd == 2 else (1, 3, 3)
+    want_p = (1, 1) if nd == 2 else (0, 1, 1)
+    if conv.in_channels != 1 or conv.groups != 1 or tuple(conv.kernel_size) != want_k or isinstance(conv.padding, str) or \
+            tuple(conv.padding) != want_p or any(v != 1 for v in conv.stride) or any(v != 1 for v in conv.dilation) or \
+            conv.padding_mode != "zeros" or conv.weight.dtype != torch.float32:
+        return False
+    src = getattr(norm, "_pre_bias_src", None)
+    if conv.bias is not None and (src is None or src[0] is not conv):       # a bias that is NOT folded into the norm: not this block
+        return False
+    if norm.num_features != conv.out_channels or x.numel() == 0 or not x[:, 0].is_contiguous():     # (batch and spatial axes dense, row-major)
+        return False
+    use_batch_stats = norm.training or (norm.running_mean is None and norm.running_var is None)
+    if not use_batch_stats and torch.is_grad_enabled() and any(p.requires_grad for p in list(conv.parameters()) + list(norm.parameters())):
+        return False
+    rows = x.numel() // max(int(x.shape[-1]), 1)
+    return 0 < rows < 2 ** 31
+
+
+def stem_block(x: torch.Tensor, conv: torch.nn.Module, norm: torch.nn.Module) -> torch.Tensor:
+    """``norm(conv(x))`` of the stem block through K9 (see :func:`stem_block_eligible`); ``None`` when the channel padding decided for
+    this call gives a channel count the kernels do not take (the caller then runs the modules)."""
+    from .network_architecture import channel_pad as cp
+    from .network_architecture import norm_act as na
+    C = conv.out_channels
+    c_pad = C
+    if getattr(conv, "_pad_spec", None) is not None:
+        _, pad_out = cp.conv_pad_plan(conv, x)          # the entry module's decision (and the shared regime) exactly as the op-by-op path makes it
+        if pad_out:
+            c_pad = cp.padded(C, conv._pad_spec.multiple)
+    if c_pad % 4 or c_pad > 48:
+        return None
+    if norm.training:
+        na._verify_batch_size(x)            # (one input channel: the same count of values per channel as the convolution's output)
+    use_batch_stats, factor, keep_running = norm._step()
+    pre_bias = ZERO_GRADS.take(conv.bias, bool(use_batch_stats))
+    return _StemBlock.apply(x, conv.weight, pre_bias, norm.weight, norm.bias, norm.running_mean if keep_running else None,
+                            norm.running_var if keep_running else None, bool(use_batch_stats), float(factor), float(norm.eps),
+                            float(norm.negative_slope), int(c_pad))
 
 
 PW_GEMM_DEFAULT = "0"

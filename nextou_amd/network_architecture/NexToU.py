@@ -18,7 +18,7 @@ from .channel_pad import pad_multiple, pad_plain_stage_channels
 from .conv_blocks import convert_conv_op_to_dim
 from .. import graph_ops
 from .layout import channels_last_stages, filters_to_channels_last
-from .norm_act import attach_deferred_counters, fuse_norm_act, fusion_enabled
+from .norm_act import attach_deferred_counters, fuse_norm_act, fuse_stem_block, fusion_enabled
 
 
 class NexToU(nn.Module):
@@ -68,6 +68,7 @@ class NexToU(nn.Module):
             self.encoder.channels_last_stages = channels_last_stages(conv_op, self.encoder.n_conv_stages, n_stages)
             # 33 -> 40 / 66 -> 72 channels inside the plain conv stages (channel_pad.py): parameters keep their shapes
             self.padded_modules = pad_plain_stage_channels(self, pad_multiple())
+            self.stem_block_fused = fuse_stem_block(self)       # K9 (round 6): first conv -> norm -> act block without the conv output in HBM
             if self.encoder.channels_last_stages:      # the filters of channels-last convolutions are stored channels-last as well
                 filters_to_channels_last(self)
             # reduced-precision autocast keeps NDHWC only when the plain stages really run multiple-of-8 channel counts

@@ -165,7 +165,9 @@ def filter_layout_for(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     what every earlier bf16 / fp16 run and test used."""
     if w.dim() < 4 or not x.is_cuda or w.is_contiguous() or x.dim() != w.dim():
         return w
-    if x.stride(1) == 1 and runs_in_fp32(x):
+    if x.stride(1) == 1 and (runs_in_fp32(x) or os.environ.get("NEXTOU_REDUCED_PRECISION_FILTERS", "contiguous") == "stored"):
+        # ("stored": the channels-last filter under autocast too — the configuration of round 5's faulting run, kept reachable for the
+        # A/B that convicts or clears it, profiles/r06_bf16/)
         return w
     return w.contiguous()
 

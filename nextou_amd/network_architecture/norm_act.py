@@ -28,7 +28,7 @@ from .channel_pad import norm_input_is_padded, pad_image_channels, padded_conv_p
 
 __all__ = ["BatchNormAct1d", "BatchNormAct2d", "BatchNormAct3d", "InstanceNormAct1d", "InstanceNormAct2d",
            "InstanceNormAct3d", "ConvBiasFolded1d", "ConvBiasFolded2d", "ConvBiasFolded3d", "ConvOwnBias2d",
-           "ConvOwnBias3d", "ConvTransposeOwnBias2d", "ConvTransposeOwnBias3d", "fuse_norm_act", "fusion_enabled", "up_conv_cat", "DeferredCounters",
+           "ConvOwnBias3d", "ConvTransposeOwnBias2d", "ConvTransposeOwnBias3d", "fuse_norm_act", "fusion_enabled", "up_conv_cat", "DeferredCounters", "StemSequential", "fuse_stem_block",
            "attach_deferred_counters"]
 
 
@@ -296,6 +296,35 @@ _FUSED = {
     nn.BatchNorm1d: BatchNormAct1d, nn.BatchNorm2d: BatchNormAct2d, nn.BatchNorm3d: BatchNormAct3d,
     nn.InstanceNorm1d: InstanceNormAct1d, nn.InstanceNorm2d: InstanceNormAct2d, nn.InstanceNorm3d: InstanceNormAct3d,
 }
+
+
+class StemSequential(nn.Sequential):
+    """``all_modules`` of the network's first ConvDropoutNormReLU (conv -> fused norm [-> Identity]): the same modules, the same
+    state_dict keys; when the call qualifies (graph_ops.stem_block_eligible) the pair runs on K9 — csrc/stem_conv.hip, the
+    convolution's output never stored — otherwise module by module as any nn.Sequential."""
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        if len(mods) >= 2 and all(type(m) is nn.Identity for m in mods[2:]) and graph_ops.stem_block_eligible(mods[0], mods[1], x):
+            y = graph_ops.stem_block(x, mods[0], mods[1])
+            if y is not None:
+                return y
+        return super().forward(x)
+
+
+def fuse_stem_block(model: nn.Module) -> bool:
+    """Class swap of the first block's ``all_modules`` (3-D and 2-D alike; what qualifies is decided per call).  Returns whether the
+    swap was made."""
+    try:
+        block = model.encoder.stages[0][0].convs[0]
+    except (AttributeError, IndexError, TypeError, KeyError):
+        return False
+    seq = getattr(block, "all_modules", None)
+    if type(seq) is not nn.Sequential or len(seq) < 2 or not isinstance(seq[0], (nn.Conv2d, nn.Conv3d)) or \
+            not isinstance(seq[1], _BatchNormAct) or seq[0].in_channels != 1:
+        return False
+    seq.__class__ = StemSequential
+    return True
 
 
 def fusion_enabled() -> bool:

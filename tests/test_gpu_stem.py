@@ -1,0 +1,201 @@
+"""K9, the stem block (csrc/stem_conv.hip): conv(1 -> C, [1,]3x3) -> BatchNorm -> LeakyReLU of the network's first ConvDropoutNormReLU
+(reference NexToU_Encoder_Decoder.py:125-141) with the convolution's output never stored.
+
+Bars (floating point, stated here): against the same three ops in float64 on the GPU — forward 2e-5 of the output scale, parameter
+gradients 1e-4 of each gradient's scale, running statistics 1e-5 relative; bit-identical run to run; identical to the module-by-module
+path of the same model (library convolution + K6) to the fp32 round-off of that path; every operand on guard pages."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nextou_amd import _lib, graph_ops
+    _lib.lib()
+    assert "libnextou_hip.so" in open("/proc/self/maps").read(), "HIP extension not loaded into this process"
+    return graph_ops
+
+
+def _image(shape, seed, offset=0.0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(shape, generator=g) + offset).to(DEV)
+    strides = list(x.stride())
+    strides[1] = 1                      # layout.to_channels_last of a one-channel tensor
+    return x.as_strided(x.shape, strides)
+
+
+def _reference(x, w, cb, gamma, beta, rm, rv, momentum, eps, slope, gy, training=True):
+    """float64 conv -> batch_norm -> leaky_relu and its autograd"""
+    xd = x.double().contiguous()
+    wd, cbd, gd, bd = (t.double().clone().requires_grad_(True) for t in (w, cb, gamma, beta))
+    rmd, rvd = rm.double().clone(), rv.double().clone()
+    pad = (1, 1) if x.dim() == 4 else (0, 1, 1)
+    z = (F.conv2d if x.dim() == 4 else F.conv3d)(xd, wd, cbd, 1, pad)
+    y = F.leaky_relu(F.batch_norm(z, rmd, rvd, gd, bd, training, momentum, eps), slope)
+    if gy is not None:
+        y.backward(gy.double())
+    return y.detach(), wd.grad, cbd.grad, gd.grad, bd.grad, rmd, rvd
+
+
+@pytest.mark.parametrize("shape,C,c_pad,offset", [
+    ((2, 1, 5, 37, 45), 33, 40, 0.0),        # ragged row length (45 = 32 + 13), padded channels
+    ((1, 1, 3, 7, 192), 6, 8, 2.5),          # image with a large mean: the statistics' cancellation
+    ((2, 1, 1, 1, 9), 8, 8, 0.0),            # a single image row per sample: every vertical tap is padding
+    ((3, 1, 4, 2, 1), 4, 4, 0.0),            # a single column
+    ((2, 1, 64, 96), 12, 12, -1.0),          # 2-D network (kernel 3x3)
+    ((1, 1, 6, 50, 33), 40, 48, 0.3),        # widest row the kernels take
+])
+def test_stem_block_against_float64(ops, shape, C, c_pad, offset):
+    x = _image(shape, 1, offset)
+    g = torch.Generator().manual_seed(2)
+    kshape = (C, 1, 3, 3) if len(shape) == 4 else (C, 1, 1, 3, 3)
+    w = (torch.randn(kshape, generator=g) * 0.4).to(DEV).requires_grad_(True)
+    cb = torch.randn(C, generator=g).to(DEV).requires_grad_(True)
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).to(DEV).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g)).to(DEV).requires_grad_(True)
+    rm0, rv0 = torch.randn(C, generator=g).to(DEV), (0.5 + torch.rand(C, generator=g)).to(DEV)
+    slope, eps, mom = 0.01, 1e-5, 0.1
+    out_shape = (shape[0], c_pad) + tuple(shape[2:])
+    gy = torch.randn(out_shape, generator=g).to(DEV).contiguous(memory_format=torch.channels_last if len(shape) == 4 else torch.channels_last_3d)
+
+    def run():
+        for p in (w, cb, gamma, beta):
+            p.grad = None
+        rm, rv = rm0.clone(), rv0.clone()
+        y = ops._StemBlock.apply(x, w, cb, gamma, beta, rm, rv, True, mom, eps, slope, c_pad)
+        y.backward(gy)
+        return y.detach(), w.grad.clone(), cb.grad.clone(), gamma.grad.clone(), beta.grad.clone(), rm, rv
+
+    y, gw, gcb, gg, gb, rm, rv = run()
+    assert y.shape == out_shape and y.is_contiguous(memory_format=torch.channels_last if len(shape) == 4 else torch.channels_last_3d)
+    assert float(y[:, C:].abs().max()) == 0.0 if c_pad > C else True          # padding channels: exact zeros
+    ry, rgw, rgcb, rgg, rgb, rrm, rrv = _reference(x, w.detach(), cb.detach(), gamma.detach(), beta.detach(), rm0, rv0, mom, eps, slope, gy[:, :C])
+    scale = float(ry.abs().max())
+    assert float((y[:, :C].double() - ry).abs().max()) <= 2e-5 * scale
+    for name, a, e in (("weight", gw, rgw), ("gamma", gg, rgg), ("beta", gb, rgb)):
+        assert float((a.double() - e).abs().max()) <= 1e-4 * (float(e.abs().max()) + 1e-30), name
+    assert float(gcb.abs().max()) == 0.0 and float(rgcb.abs().max()) <= 1e-6 * float(rgb.abs().max() + 1)   # the folded bias: exactly 0 here, round-off there
+    assert torch.allclose(rm.double(), rrm, rtol=1e-5, atol=1e-6) and torch.allclose(rv.double(), rrv, rtol=1e-5, atol=1e-7)
+    again = run()
+    for a, b in zip((y, gw, gcb, gg, gb, rm, rv), again):
+        assert torch.equal(a, b), "K9 is not bit-reproducible"
+
+
+def test_stem_block_eval_uses_running_statistics(ops):
+    x = _image((2, 1, 3, 20, 40), 3)
+    g = torch.Generator().manual_seed(4)
+    C = 8
+    w, cb = (torch.randn((C, 1, 1, 3, 3), generator=g) * 0.4).to(DEV), torch.randn(C, generator=g).to(DEV)
+    gamma, beta = (1 + 0.3 * torch.randn(C, generator=g)).to(DEV), torch.randn(C, generator=g).to(DEV)
+    rm, rv = torch.randn(C, generator=g).to(DEV), (0.5 + torch.rand(C, generator=g)).to(DEV)
+    rm_before, rv_before = rm.clone(), rv.clone()
+    with torch.no_grad():
+        y = ops._StemBlock.apply(x, w, cb, gamma, beta, rm, rv, False, 0.1, 1e-5, 0.01, C)
+    ry = _reference(x, w, cb, gamma, beta, rm, rv, 0.1, 1e-5, 0.01, None, training=False)[0]
+    assert float((y.double() - ry).abs().max()) <= 2e-5 * float(ry.abs().max())
+    assert torch.equal(rm, rm_before) and torch.equal(rv, rv_before)
+
+
+def _tiny_model(stem, seed=0):
+    from nextou_amd.harness import config_3d_fullres_nextou
+    from nextou_amd.nnUNetTrainer.nnUNetTrainer_NexToU import nnUNetTrainer_NexToU
+    os.environ["NEXTOU_STEM_BLOCK"] = stem
+    cfg = config_3d_fullres_nextou(patch_size=(32, 128, 128), base=6, max_features=48, batch_size=2)
+    torch.manual_seed(seed)
+    tr = nnUNetTrainer_NexToU(cfg, 5, device=DEV, log=None).initialize()
+    return tr, cfg
+
+
+def test_model_takes_the_stem_block_and_matches_the_module_path(ops, monkeypatch):
+    """The same tiny 3-D network (padded plain stages: 6 -> 8 channels) with its first block on K9 and module by module: every head and
+    every parameter gradient agree to the fp32 round-off of the library path; the K9 kernels really ran (launch profile)."""
+    import ctypes
+    import json
+    from nextou_amd import _lib
+    from nextou_amd.harness import downsample_targets, synthetic_batch
+    monkeypatch.setenv("NEXTOU_STEM_BLOCK", "1")
+    results = {}
+    for stem in ("1", "0"):
+        tr, cfg = _tiny_model(stem)
+        assert tr.network.stem_block_fused
+        data, target = synthetic_batch(cfg, 1, 5, 2, DEV, seed=5)
+        _lib.lib().nextou_profile_enable(4096)
+        outs = tr.network(data)
+        loss = tr.loss(outs, downsample_targets(target, outs))
+        loss.backward()
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 20)
+        n = _lib.lib().nextou_profile_report(buf, len(buf))
+        _lib.lib().nextou_profile_enable(0)
+        labels = [r["kernel"] for r in json.loads(buf.value.decode())] if n else []
+        assert any(l.startswith("stem_apply_kernel") for l in labels) is (stem == "1")
+        assert any(l.startswith("stem_bwd_kernel") for l in labels) is (stem == "1")
+        results[stem] = ([o.detach().clone() for o in outs], {k: p.grad.detach().clone() for k, p in tr.network.named_parameters() if p.grad is not None},
+                         tr.network.encoder.stages[0][0].convs[0].norm.running_var.clone())
+    monkeypatch.setenv("NEXTOU_STEM_BLOCK", "1")
+    (o1, g1, rv1), (o0, g0, rv0) = results["1"], results["0"]
+    for a, b in zip(o1, o0):
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max())
+    assert g1.keys() == g0.keys()
+    worst = max(float((g1[k] - g0[k]).abs().max()) / (float(g0[k].abs().max()) + 1e-12) for k in g0 if float(g0[k].abs().max()) > 1e-6)
+    assert worst <= 5e-3, worst         # the tiny random-label network amplifies 1e-7 differences of the first block (cf. tests/averaged_step_check.py)
+    stem_keys = [k for k in g0 if k.startswith("encoder.stages.0.0.convs.0.") and "all_modules" not in k]
+    assert stem_keys
+    assert torch.allclose(rv1, rv0, rtol=1e-5)
+
+
+def test_stem_block_declines_what_it_does_not_take(ops):
+    tr, cfg = _tiny_model("1")
+    blk = tr.network.encoder.stages[0][0].convs[0]
+    conv, norm = blk.all_modules[0], blk.all_modules[1]
+    x = _image((2, 1, 32, 128, 128), 7)
+    assert ops.stem_block_eligible(conv, norm, x)
+    assert not ops.stem_block_eligible(conv, norm, x.contiguous())                     # NCDHW stage layout: the module path
+    assert not ops.stem_block_eligible(conv, norm, x.clone().requires_grad_(True))     # an image that needs its gradient
+    assert not ops.stem_block_eligible(conv, norm, x.cpu())
+    assert not ops.stem_block_eligible(conv, norm, x.half())
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert not ops.stem_block_eligible(conv, norm, x)
+    tr.network.eval()
+    assert not ops.stem_block_eligible(conv, norm, x)                                  # running statistics + parameters that need gradients
+    with torch.no_grad():
+        assert ops.stem_block_eligible(conv, norm, x)
+        y = blk(x)
+    assert y.shape[1] == 8 and float(y[:, 6:].abs().max()) == 0.0
+
+
+def test_stem_block_on_guard_pages(ops):
+    from tools.guard_alloc import GuardScope
+    C, c_pad = 33, 40
+    shape = (2, 1, 3, 21, 45)
+    g = torch.Generator().manual_seed(9)
+    base = [torch.randn(shape, generator=g), torch.randn((C, 9), generator=g) * 0.4, torch.randn(C, generator=g), 1 + 0.1 * torch.randn(C, generator=g),
+            torch.randn(C, generator=g), torch.zeros(C), torch.ones(C), torch.randn((shape[0], c_pad) + shape[2:], generator=g)]
+    base = [t.to(DEV) for t in base]
+    base[-1] = base[-1].contiguous(memory_format=torch.channels_last_3d)
+
+    def launch(x, w2, cb, gamma, beta, rm, rv, gy):
+        y, mean, invstd, moments = ops._HIP.stem_fwd(x, w2, cb, gamma, beta, rm, rv, True, 0.1, 1e-5, 0.01, c_pad)
+        gw, gg, gb = ops._HIP.stem_bwd(x, gy, w2, gamma, beta, mean, invstd, moments, 0.01, True, True, True)
+        return y, mean, invstd, moments, gw, gg, gb, rm, rv
+
+    want = launch(*[t.clone(memory_format=torch.preserve_format) for t in base])
+    torch.cuda.synchronize()
+    for flush in ("end", "start"):
+        scope = GuardScope(flush=flush, align=16)
+        try:
+            gin = [scope.like(t.clone(memory_format=torch.preserve_format)) for t in base]
+            with scope.patched_outputs():
+                got = launch(*gin)
+            torch.cuda.synchronize()
+            for a, e in zip(got, want):
+                assert torch.equal(a, e), "guarded launch (%s-flush) differs from the plain one" % flush
+        finally:
+            torch.cuda.synchronize()
+            scope.close()

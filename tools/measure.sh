@@ -186,6 +186,35 @@ t_bf16() {           # round 6: the reduced-precision bench path at HEAD — doe
     done
   done
 }
+t_bf16ab() {         # round 6: the configuration of round 5's faulting bf16 run (channels-last stored filters reach the library under autocast), 3 runs,
+  # then the same with synchronous launches + MIOpen's log if one of them faults: convicts or clears the filter layout
+  for i in 1 2 3; do
+    NEXTOU_REDUCED_PRECISION_FILTERS=stored timeout 900 python bench.py --no-cpu-baseline --steps 5 --warmup 3 --autocast-bf16 > $OUT/bench_cfg2_bf16_stored_$i.json 2> $OUT/bench_cfg2_bf16_stored_$i.log
+    rc=$?; echo "bf16 stored-filter run $i rc $rc"; grep -h "Memory access fault" $OUT/bench_cfg2_bf16_stored_$i.log | head -2
+    if [ $rc -ne 0 ]; then
+      NEXTOU_REDUCED_PRECISION_FILTERS=stored MIOPEN_LOG_LEVEL=6 MIOPEN_ENABLE_LOGGING_CMD=1 HIP_LAUNCH_BLOCKING=1 AMD_SERIALIZE_KERNEL=3 timeout 1500 python bench.py --no-cpu-baseline --steps 2 --warmup 1 --autocast-bf16 2>&1 >/dev/null | grep -v "GridwiseOp\|amdgpu.ids" | tail -c 300000 > $OUT/bench_cfg2_bf16_stored_serialized_tail.log
+      echo "serialized rerun rc ${PIPESTATUS[0]}"; grep -E "Memory access fault|MIOpenDriver|Solver|solver_id|SolverName" $OUT/bench_cfg2_bf16_stored_serialized_tail.log | tail -8 | cut -c1-300
+      break
+    else field $OUT/bench_cfg2_bf16_stored_$i.json; fi
+  done
+}
+t_stem() {           # round 6: K9 tests + the headline line with and without the stem block on the same box
+  python -m pytest tests/test_gpu_stem.py tests/test_gpu_ddp.py -q -m gpu -rf -x 2>&1 | grep -v "MIOpen\|GridwiseOp\|amdgpu.ids" | tail -30 > $OUT/stem_pytest.txt; tail -12 $OUT/stem_pytest.txt
+  for i in 1 2; do
+    python bench.py --no-cpu-baseline --steps 20 > $OUT/bench_stem_on_$i.json 2> $OUT/bench_stem_on_$i.log; field $OUT/bench_stem_on_$i.json || tail -5 $OUT/bench_stem_on_$i.log
+    NEXTOU_STEM_BLOCK=0 python bench.py --no-cpu-baseline --steps 20 > $OUT/bench_stem_off_$i.json 2> $OUT/bench_stem_off_$i.log; field $OUT/bench_stem_off_$i.json
+  done
+  python -c "
+import json
+d=json.load(open('$OUT/bench_stem_on_1.json'))
+import sys
+sys.path.insert(0,'.')
+" ; python - <<PYEOF
+import json
+d=json.load(open('$OUT/bench_stem_on_1.json'))
+print('own ms', d['roofline']['own_kernels_ms_per_step'])
+PYEOF
+}
 t_guard() {
   python -m pytest tests/test_gpu_guard.py tests/test_gpu_head.py -q -m gpu -p no:cacheprovider 2>&1 | grep -v "MIOpen\|GridwiseOp\|amdgpu.ids" > $OUT/guard_pages_pytest.txt; tail -3 $OUT/guard_pages_pytest.txt
 }
