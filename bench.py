@@ -173,8 +173,8 @@ def roofline_graph_from(report):
         """the launch shape of these kernels that sits furthest below its roofline (the small stage-4 / 5 calls)"""
         rows = [_roofline_entry(r) for r in report if r["kernel"].startswith(prefixes)]
         return min(rows, key=lambda e: e["frac"]) if rows else None
-    return {"K1_knn": pick(("knn_fused_kernel", "knn_window_kernel")), "K2_mr_forward": pick(("mr_fwd",)), "K2_mr_backward": pick(("mr_bwd",)),
-            "K1_knn_worst_shape": worst(("knn_fused_kernel", "knn_window_kernel")), "K2_mr_forward_worst_shape": worst(("mr_fwd",)),
+    return {"K1_knn": pick(("knn_fused_kernel", "knn_window_kernel", "knn_small_kernel")), "K2_mr_forward": pick(("mr_fwd",)), "K2_mr_backward": pick(("mr_bwd",)),
+            "K1_knn_worst_shape": worst(("knn_fused_kernel", "knn_window_kernel", "knn_small_kernel")), "K2_mr_forward_worst_shape": worst(("mr_fwd",)),
             "K2K7_mr_grouped_forward": pick(("mr_grp_rows_kernel",)), "K2K7_mr_grouped_backward": pick(("mr_grp_rows_bwd_kernel",)),
             "K5_argmax_labels": pick(("argmax_labels_kernel",)), "K5_bti_critical": pick(("bti_critical_kernel",)),
             "K5_bti_ce_forward": pick(("bti_ce_fwd_kernel",)), "K5_bti_ce_backward": pick(("bti_ce_bwd_kernel",)),

@@ -57,27 +57,29 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// (1) moments of the taps.  Flat voxel ranges per workgroup; every thread keeps the 54 sums of its own voxels in float64 (products of two
-// floats are exact in float64).
-__global__ __launch_bounds__(kMomThreads) void stem_moments_kernel(const float* __restrict__ x, double* __restrict__ partial, long long V,
-                                                                   int H, int W, long long span) {
+// (1) moments of the taps.  Image rows [r0, r1) per workgroup, a thread per column (no index division anywhere); every thread keeps the 54
+// sums of its own voxels in float64 (products of two floats are exact in float64).
+__global__ __launch_bounds__(kMomThreads) void stem_moments_kernel(const float* __restrict__ x, double* __restrict__ partial, int R, int H, int W,
+                                                                   int rows_per_wg) {
     double acc[kMom];
 #pragma unroll
     for (int i = 0; i < kMom; ++i) acc[i] = 0.0;
-    const long long base = (long long)blockIdx.x * span;
-    const long long end = min(V, base + span);
-    for (long long v = base + threadIdx.x; v < end; v += kMomThreads) {
-        const int w = (int)(v % W);
-        const int h = (int)((v / W) % H);
-        float t[kTaps];
-        load_taps(x + v, w, W, h > 0, h + 1 < H, true, t);
-        double d[kTaps];
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+    int h = r0 % H;
+    for (int r = r0; r < r1; ++r) {
+        const bool up = h > 0, down = h + 1 < H;
+        for (int w = threadIdx.x; w < W; w += kMomThreads) {
+            float t[kTaps];
+            load_taps(x + (long long)r * W + w, w, W, up, down, true, t);
+            double d[kTaps];
 #pragma unroll
-        for (int a = 0; a < kTaps; ++a) { d[a] = (double)t[a]; acc[a] += d[a]; }
+            for (int a = 0; a < kTaps; ++a) { d[a] = (double)t[a]; acc[a] += d[a]; }
 #pragma unroll
-        for (int a = 0; a < kTaps; ++a)
+            for (int a = 0; a < kTaps; ++a)
 #pragma unroll
-            for (int b = a; b < kTaps; ++b) acc[tri(a, b)] = fma(d[a], d[b], acc[tri(a, b)]);
+                for (int b = a; b < kTaps; ++b) acc[tri(a, b)] = fma(d[a], d[b], acc[tri(a, b)]);
+        }
+        h = h + 1 == H ? 0 : h + 1;
     }
     __shared__ double red[kMomThreads / 64][kMom];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -156,7 +158,7 @@ __device__ __forceinline__ float conv_chain(const float (&w)[kTaps], const float
 }
 
 // (3) y rows.  A workgroup = kVox voxels x Q channel quads; rows [r0, r1) of the (B * D * H, W) image per workgroup.
-__global__ void stem_apply_kernel(const float* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ gamma,
+__global__ __launch_bounds__(kVox * 12) void stem_apply_kernel(const float* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
                                   float* __restrict__ y, int R, int H, int W, int C, int Q, int rows_per_wg, float slope) {
     const int q = threadIdx.x % Q, vs = threadIdx.x / Q;
@@ -164,27 +166,28 @@ __global__ void stem_apply_kernel(const float* __restrict__ x, const float* __re
     load_affine(a, 4 * q, C, weight, gamma, beta, mean, invstd);
     const int Cp = 4 * Q;
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
-    const int chunks = (W + kVox - 1) / kVox;
-    const int items = (r1 - r0) * chunks;
+    int h = r0 % H;
+    for (int r = r0; r < r1; ++r) {
+      const bool up = h > 0, down = h + 1 < H;
+      h = h + 1 == H ? 0 : h + 1;
 #pragma unroll 2
-    for (int it = 0; it < items; ++it) {
-        const int r = r0 + it / chunks, w = (it % chunks) * kVox + vs;
-        const int h = r % H;
+      for (int w = vs; w < W + vs; w += kVox) {          // (every thread runs the same number of chunks; `active` masks the ragged one)
         const bool active = w < W;
         const long long v = (long long)r * W + w;
         float t[kTaps];
-        load_taps(x + v, w, W, h > 0, h + 1 < H, active, t);
+        load_taps(x + v, w, W, up, down, active, t);
         float4 o;
         o.x = leaky(fmaf(conv_chain(a.w[0], t), a.scale[0], a.shift[0]), slope);
         o.y = leaky(fmaf(conv_chain(a.w[1], t), a.scale[1], a.shift[1]), slope);
         o.z = leaky(fmaf(conv_chain(a.w[2], t), a.scale[2], a.shift[2]), slope);
         o.w = leaky(fmaf(conv_chain(a.w[3], t), a.scale[3], a.shift[3]), slope);
         if (active) *reinterpret_cast<float4*>(y + v * Cp + 4 * q) = o;
+      }
     }
 }
 
 // (4) S1 / S2 partial sums.  Dynamic LDS: kVox * Q * 40 floats.
-__global__ void stem_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ weight,
+__global__ __launch_bounds__(kVox * 12) void stem_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ weight,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, double* __restrict__ partial, int R, int H, int W, int C, int Q,
                                 int rows_per_wg, float slope) {
@@ -201,16 +204,16 @@ __global__ void stem_bwd_kernel(const float* __restrict__ x, const float* __rest
         for (int t = 0; t < kTaps; ++t) s2[j][t] = 0.f;
     }
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
-    const int chunks = (W + kVox - 1) / kVox;
-    const int items = (r1 - r0) * chunks;
+    int h = r0 % H;
+    for (int r = r0; r < r1; ++r) {
+      const bool up = h > 0, down = h + 1 < H;
+      h = h + 1 == H ? 0 : h + 1;
 #pragma unroll 2
-    for (int it = 0; it < items; ++it) {
-        const int r = r0 + it / chunks, w = (it % chunks) * kVox + vs;
-        const int h = r % H;
+      for (int w = vs; w < W + vs; w += kVox) {
         const bool active = w < W;
         const long long v = (long long)r * W + w;
         float t[kTaps];
-        load_taps(x + v, w, W, h > 0, h + 1 < H, active, t);
+        load_taps(x + v, w, W, up, down, active, t);
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (active) g = *reinterpret_cast<const float4*>(gy + v * Cp + 4 * q);
         const float gj[4] = {g.x, g.y, g.z, g.w};
@@ -222,6 +225,7 @@ __global__ void stem_bwd_kernel(const float* __restrict__ x, const float* __rest
 #pragma unroll
             for (int k = 0; k < kTaps; ++k) s2[j][k] = fmaf(dy, t[k], s2[j][k]);
         }
+      }
     }
     // red[vs][(4q + j) * 10 + k]: k = 0 -> S1, 1 + t -> S2[t]
     const int per = Cp * (kTaps + 1);
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(64) void stem_bwd_finalize_kernel(const double* __r
     }
 }
 
-int moments_groups(long long V) { return (int)max(1LL, min(512LL, (V + 8LL * kMomThreads - 1) / (8LL * kMomThreads))); }
+int moments_groups(int R) { return min(R, 2048); }
 int apply_groups(int R) { return min(R, 3072); }
 int bwd_groups(int R) { return min(R, 1536); }
 
@@ -295,9 +299,8 @@ using namespace nextou;
 
 extern "C" size_t nextou_stem_workspace_bytes(int B, int D, int H, int W, int Cpad) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cpad <= 0) return 0;
-    const long long V = (long long)B * D * H * W;
     const long long R = (long long)B * D * H;
-    const size_t fwd = (size_t)moments_groups(V) * kMom * sizeof(double) + (size_t)Cpad * sizeof(double2);
+    const size_t fwd = (size_t)moments_groups((int)min(R, (long long)INT32_MAX)) * kMom * sizeof(double) + (size_t)Cpad * sizeof(double2);
     const size_t bwd = (size_t)bwd_groups((int)min(R, (long long)INT32_MAX)) * Cpad * (kTaps + 1) * sizeof(double);
     return fwd > bwd ? fwd : bwd;
 }
@@ -316,13 +319,14 @@ extern "C" int nextou_stem_fwd(const float* x, const float* weight, const float*
     const long long V = (long long)B * D * H * W;
     const int R = B * D * H;
     if (training) {
-        const int G = moments_groups(V);
+        const int G0 = moments_groups(R);
+        const int rows_m = (R + G0 - 1) / G0;
+        const int G = (R + rows_m - 1) / rows_m;
         double* partial = static_cast<double*>(workspace);
-        double2* stats = reinterpret_cast<double2*>(partial + (size_t)G * kMom);
-        const long long span = (V + G - 1) / G;
+        double2* stats = reinterpret_cast<double2*>(partial + (size_t)G0 * kMom);
         {
             ProfScope prof(s, kBoundHbm, 4.0 * (double)V, "stem_moments_kernel[B%d S%lld]", B, V / B);
-            hipLaunchKernelGGL(stem_moments_kernel, dim3(G), dim3(kMomThreads), 0, s, x, partial, V, H, W, span);
+            hipLaunchKernelGGL(stem_moments_kernel, dim3(G), dim3(kMomThreads), 0, s, x, partial, R, H, W, rows_m);
         }
         hipLaunchKernelGGL(stem_stats_kernel, dim3(1), dim3(256), 0, s, partial, G, weight, C, moments, stats);
         int rc = check_launch("stem_moments_kernel");

@@ -215,6 +215,12 @@ d=json.load(open('$OUT/bench_stem_on_1.json'))
 print('own ms', d['roofline']['own_kernels_ms_per_step'])
 PYEOF
 }
+t_k1small() {        # round 6: the one-launch kernel for a handful of small self graphs — tests, then the K1 rows of the kernel bench with and without it
+  python -m pytest tests/test_gpu_knn_small.py tests/test_gpu_stem.py tests/test_gpu_parity.py -q -m gpu -rf -k "knn or stem or small" 2>&1 | grep -v "MIOpen\|GridwiseOp\|amdgpu.ids" | tail -30 > $OUT/k1small_pytest.txt; tail -8 $OUT/k1small_pytest.txt
+  python tools/stem_bench.py > $OUT/stem_bench.txt 2>&1; cat $OUT/stem_bench.txt
+  python tools/kernel_bench.py --cfg 2 --iters 10 2>&1 | grep -E "knn_" > $OUT/kernel_bench_k1_small.txt; grep -E "^s[45]" $OUT/kernel_bench_k1_small.txt
+  NEXTOU_KNN_SMALL=0 python tools/kernel_bench.py --cfg 2 --iters 10 2>&1 | grep -E "knn_" > $OUT/kernel_bench_k1_nosmall.txt; grep -E "^s[45]" $OUT/kernel_bench_k1_nosmall.txt
+}
 t_guard() {
   python -m pytest tests/test_gpu_guard.py tests/test_gpu_head.py -q -m gpu -p no:cacheprovider 2>&1 | grep -v "MIOpen\|GridwiseOp\|amdgpu.ids" > $OUT/guard_pages_pytest.txt; tail -3 $OUT/guard_pages_pytest.txt
 }
