@@ -37,28 +37,35 @@ __host__ __device__ constexpr int tri(int a, int b) {      // packed index of A[
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-// taps of voxel (row r, column w): t[ky * 3 + kx] = x[h + ky - 1][w + kx - 1], zero outside the plane (cross-correlation, as ATen).
-// `row` = x + r * W.  Every load is UNCONDITIONAL on a clamped address (the image is dense, a clamped neighbour is always inside it) and the
-// zero padding is a select afterwards: written as `cond ? p[i] : 0` the compiler turned the nine loads into nine branches with a wait each —
-// nine dependent round trips per voxel (the first version of these kernels: 314 / 446 / 129 us where HBM allows 150).
-__device__ __forceinline__ void load_taps(const float* __restrict__ row, int w, int W, bool up, bool down, bool active, float (&t)[kTaps]) {
+// The nine taps of voxel (row r, column w) are t[ky * 3 + kx] = x[h + ky - 1][w + kx - 1], zero outside the plane (cross-correlation, as
+// ATen).  Every streaming kernel below walks DOWN the image rows at a fixed column, so the 3 x 3 window slides: per voxel three new values
+// (row r + 2, one iteration ahead of their use) instead of nine.  All loads are UNCONDITIONAL on clamped coordinates (the image is dense, a
+// clamped neighbour is always inside it) and the zero padding is a select at the use: written as `cond ? p[i] : 0` the compiler turned
+// every load into a branch with a wait — nine dependent round trips per voxel (the first version: 314 / 446 / 129 us where HBM allows 150).
+struct Cols { int l, c, r; };                                       // clamped column indices of (w - 1, w, w + 1)
+__device__ __forceinline__ Cols clamp_cols(int w, int W) {
     const int wc = min(w, W - 1);
-    const int wl = max(wc - 1, 0), wr = min(wc + 1, W - 1);
-    const float* __restrict__ ru = row - (up ? W : 0);
-    const float* __restrict__ rd = row + (down ? W : 0);
-    const float a0 = ru[wl], a1 = ru[wc], a2 = ru[wr];
-    const float a3 = row[wl], a4 = row[wc], a5 = row[wr];
-    const float a6 = rd[wl], a7 = rd[wc], a8 = rd[wr];
+    return Cols{max(wc - 1, 0), wc, min(wc + 1, W - 1)};
+}
+__device__ __forceinline__ void load_row3(const float* __restrict__ x, int r, int R, int W, const Cols& k, float (&o)[3]) {
+    const float* __restrict__ p = x + (long long)min(max(r, 0), R - 1) * W;
+    o[0] = p[k.l];
+    o[1] = p[k.c];
+    o[2] = p[k.r];
+}
+// window rows (r - 1, r, r + 1) -> taps; h = r mod H decides the vertical padding, (w, W) the horizontal one
+__device__ __forceinline__ void window_taps(const float (&u)[3], const float (&m)[3], const float (&d)[3], int w, int W, bool up, bool down,
+                                            bool active, float (&t)[kTaps]) {
     const bool l = active && w > 0, r = active && w + 1 < W;
-    t[0] = (up && l) ? a0 : 0.f;
-    t[1] = (up && active) ? a1 : 0.f;
-    t[2] = (up && r) ? a2 : 0.f;
-    t[3] = l ? a3 : 0.f;
-    t[4] = active ? a4 : 0.f;
-    t[5] = r ? a5 : 0.f;
-    t[6] = (down && l) ? a6 : 0.f;
-    t[7] = (down && active) ? a7 : 0.f;
-    t[8] = (down && r) ? a8 : 0.f;
+    t[0] = (up && l) ? u[0] : 0.f;
+    t[1] = (up && active) ? u[1] : 0.f;
+    t[2] = (up && r) ? u[2] : 0.f;
+    t[3] = l ? m[0] : 0.f;
+    t[4] = active ? m[1] : 0.f;
+    t[5] = r ? m[2] : 0.f;
+    t[6] = (down && l) ? d[0] : 0.f;
+    t[7] = (down && active) ? d[1] : 0.f;
+    t[8] = (down && r) ? d[2] : 0.f;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -67,43 +74,51 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// (1) moments of the taps.  Image rows [r0, r1) per workgroup, a thread per column (no index division anywhere); every thread keeps the 54
-// sums of its own voxels in float64 (products of two floats are exact in float64).
+// (1) moments of the taps.  A workgroup = 256 columns x a segment of image rows; every thread keeps the 54 sums of its own voxels in float64
+// (products of two floats are exact in float64).
 __global__ __launch_bounds__(kMomThreads) void stem_moments_kernel(const float* __restrict__ x, double* __restrict__ partial, int R, int H, int W,
-                                                                   int rows_per_wg) {
+                                                                   int rows_per_seg, int col_blocks) {
     double acc[kMom];
 #pragma unroll
     for (int i = 0; i < kMom; ++i) acc[i] = 0.0;
-    const int r0 = blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+    const int cb = blockIdx.x % col_blocks, seg = blockIdx.x / col_blocks;
+    const int w = cb * kMomThreads + threadIdx.x;
+    const bool active = w < W;
+    const Cols k = clamp_cols(w, W);
+    const int r0 = seg * rows_per_seg, r1 = min(R, r0 + rows_per_seg);
+    constexpr int RB = 2;                                   // image rows per iteration: their RB + 2 window rows are loaded as ONE batch
     int h = r0 % H;
-    for (int r = r0; r < r1; ++r) {
-        const bool up = h > 0, down = h + 1 < H;
-        for (int w = threadIdx.x; w < W; w += kMomThreads) {
-            float t[kTaps];
-            load_taps(x + (long long)r * W, w, W, up, down, true, t);
-            double d[kTaps];
+    for (int r = r0; r < r1; r += RB) {
+        float rows[RB + 2][3];
 #pragma unroll
-            for (int a = 0; a < kTaps; ++a) { d[a] = (double)t[a]; acc[a] += d[a]; }
+        for (int i = 0; i < RB + 2; ++i) load_row3(x, r - 1 + i, R, W, k, rows[i]);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            float t[kTaps];
+            window_taps(rows[i], rows[i + 1], rows[i + 2], w, W, h > 0, h + 1 < H, active && r + i < r1, t);
+            h = h + 1 == H ? 0 : h + 1;
+            double dd[kTaps];
+#pragma unroll
+            for (int a = 0; a < kTaps; ++a) { dd[a] = (double)t[a]; acc[a] += dd[a]; }
 #pragma unroll
             for (int a = 0; a < kTaps; ++a)
 #pragma unroll
-                for (int b = a; b < kTaps; ++b) acc[tri(a, b)] = fma(d[a], d[b], acc[tri(a, b)]);
+                for (int b = a; b < kTaps; ++b) acc[tri(a, b)] = fma(dd[a], dd[b], acc[tri(a, b)]);
         }
-        h = h + 1 == H ? 0 : h + 1;
     }
     __shared__ double red[kMomThreads / 64][kMom];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < kMom; ++i) {
-        const double s = wave_sum(acc[i]);
-        if (lane == 0) red[wave][i] = s;
+        const double sum = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = sum;
     }
     __syncthreads();
     if (threadIdx.x < kMom) {
-        double s = 0.0;
+        double sum = 0.0;
 #pragma unroll
-        for (int wv = 0; wv < kMomThreads / 64; ++wv) s += red[wv][threadIdx.x];
-        partial[(size_t)blockIdx.x * kMom + threadIdx.x] = s;
+        for (int wv = 0; wv < kMomThreads / 64; ++wv) sum += red[wv][threadIdx.x];
+        partial[(size_t)blockIdx.x * kMom + threadIdx.x] = sum;
     }
 }
 
@@ -168,41 +183,49 @@ __device__ __forceinline__ float conv_chain(const float (&w)[kTaps], const float
     return z;
 }
 
-// (3) y rows.  A workgroup = kVox voxels x Q channel quads; rows [r0, r1) of the (B * D * H, W) image per workgroup.
+// (3) y rows.  A workgroup = kVox columns x Q channel quads, walking down a segment of image rows with the sliding window.
 __global__ __launch_bounds__(kVox * 12) void stem_apply_kernel(const float* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                  float* __restrict__ y, int R, int H, int W, int C, int Q, int rows_per_wg, float slope) {
+                                  float* __restrict__ y, int R, int H, int W, int C, int Q, int rows_per_seg, int chunks, float slope) {
     const int q = threadIdx.x % Q, vs = threadIdx.x / Q;
     Affine a;
     load_affine(a, 4 * q, C, weight, gamma, beta, mean, invstd);
     const int Cp = 4 * Q;
-    const int r0 = blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
-    int h = r0 % H;
-    for (int r = r0; r < r1; ++r) {
-      const bool up = h > 0, down = h + 1 < H;
-      h = h + 1 == H ? 0 : h + 1;
-#pragma unroll 2
-      for (int w = vs; w < W + vs; w += kVox) {          // (every thread runs the same number of chunks; `active` masks the ragged one)
-        const bool active = w < W;
-        const long long v = (long long)r * W + w;
-        float t[kTaps];
-        load_taps(x + (long long)r * W, w, W, up, down, active, t);
-        float4 o;
-        o.x = leaky(fmaf(conv_chain(a.w[0], t), a.scale[0], a.shift[0]), slope);
-        o.y = leaky(fmaf(conv_chain(a.w[1], t), a.scale[1], a.shift[1]), slope);
-        o.z = leaky(fmaf(conv_chain(a.w[2], t), a.scale[2], a.shift[2]), slope);
-        o.w = leaky(fmaf(conv_chain(a.w[3], t), a.scale[3], a.shift[3]), slope);
-        if (active) *reinterpret_cast<float4*>(y + v * Cp + 4 * q) = o;
-      }
+    const int chunk = blockIdx.x % chunks, seg = blockIdx.x / chunks;
+    const int w = chunk * kVox + vs;
+    const bool active = w < W;
+    const Cols k = clamp_cols(w, W);
+    const int r0 = seg * rows_per_seg, r1 = min(R, r0 + rows_per_seg);
+    constexpr int RB = 4;                                   // image rows per iteration: RB + 2 window rows loaded as ONE batch of 18 loads,
+    int h = r0 % H;                                         // so the memory latency is paid once per RB voxels (no cross-iteration register copies)
+    float* yp = y + ((long long)r0 * W + k.c) * Cp + 4 * q;
+    const long long ystep = (long long)W * Cp;
+    for (int r = r0; r < r1; r += RB) {
+        float rows[RB + 2][3];
+#pragma unroll
+        for (int i = 0; i < RB + 2; ++i) load_row3(x, r - 1 + i, R, W, k, rows[i]);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            float t[kTaps];
+            window_taps(rows[i], rows[i + 1], rows[i + 2], w, W, h > 0, h + 1 < H, active, t);
+            h = h + 1 == H ? 0 : h + 1;
+            float4 o;
+            o.x = leaky(fmaf(conv_chain(a.w[0], t), a.scale[0], a.shift[0]), slope);
+            o.y = leaky(fmaf(conv_chain(a.w[1], t), a.scale[1], a.shift[1]), slope);
+            o.z = leaky(fmaf(conv_chain(a.w[2], t), a.scale[2], a.shift[2]), slope);
+            o.w = leaky(fmaf(conv_chain(a.w[3], t), a.scale[3], a.shift[3]), slope);
+            if (active && r + i < r1) *reinterpret_cast<float4*>(yp + i * ystep) = o;
+        }
+        yp += RB * ystep;
     }
 }
 
-// (4) S1 / S2 partial sums.  Dynamic LDS: kVox * Q * 40 floats.
+// (4) S1 / S2 partial sums: the same walk, the gradient row one iteration ahead as well.
 __global__ __launch_bounds__(kVox * 12) void stem_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ weight,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, double* __restrict__ partial, int R, int H, int W, int C, int Q,
-                                int rows_per_wg, float slope) {
-    extern __shared__ float red[];
+                                int rows_per_seg, int chunks, float slope) {
+    __shared__ float red[kVox * 12 * (kTaps + 1)];          // one channel of every quad at a time: [vs][q][10]
     const int q = threadIdx.x % Q, vs = threadIdx.x / Q;
     Affine a;
     load_affine(a, 4 * q, C, weight, gamma, beta, mean, invstd);
@@ -214,45 +237,58 @@ __global__ __launch_bounds__(kVox * 12) void stem_bwd_kernel(const float* __rest
 #pragma unroll
         for (int t = 0; t < kTaps; ++t) s2[j][t] = 0.f;
     }
-    const int r0 = blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+    const int chunk = blockIdx.x % chunks, seg = blockIdx.x / chunks;
+    const int w = chunk * kVox + vs;
+    const bool active = w < W;
+    const Cols k = clamp_cols(w, W);
+    const int r0 = seg * rows_per_seg, r1 = min(R, r0 + rows_per_seg);
+    constexpr int RB = 4;                                   // as in stem_apply_kernel: RB + 2 window rows and RB gradient pieces per batch
+    const long long gstep = (long long)W * Cp;
+    const float* gp = gy + ((long long)r0 * W + k.c) * Cp + 4 * q;
     int h = r0 % H;
-    for (int r = r0; r < r1; ++r) {
-      const bool up = h > 0, down = h + 1 < H;
-      h = h + 1 == H ? 0 : h + 1;
-#pragma unroll 2
-      for (int w = vs; w < W + vs; w += kVox) {
-        const bool active = w < W;
-        const long long v = (long long)r * W + w;
-        float t[kTaps];
-        load_taps(x + (long long)r * W, w, W, up, down, active, t);
-        float4 g = *reinterpret_cast<const float4*>(gy + ((long long)r * W + min(w, W - 1)) * Cp + 4 * q);       // unconditional, clamped column
-        if (!active) g = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float gj[4] = {g.x, g.y, g.z, g.w};
+    for (int r = r0; r < r1; r += RB) {
+        float rows[RB + 2][3];
+        float4 g[RB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float pre = fmaf(conv_chain(a.w[j], t), a.scale[j], a.shift[j]);
-            const float dy = pre > 0.f ? gj[j] : gj[j] * slope;
-            s1[j] += dy;
+        for (int i = 0; i < RB + 2; ++i) load_row3(x, r - 1 + i, R, W, k, rows[i]);
 #pragma unroll
-            for (int k = 0; k < kTaps; ++k) s2[j][k] = fmaf(dy, t[k], s2[j][k]);
+        for (int i = 0; i < RB; ++i) g[i] = *reinterpret_cast<const float4*>(gp + (r + i < r1 ? i : 0) * gstep);     // (clamped: a row past the segment re-reads row r)
+        gp += RB * gstep;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            float t[kTaps];
+            const bool on = active && r + i < r1;
+            window_taps(rows[i], rows[i + 1], rows[i + 2], w, W, h > 0, h + 1 < H, on, t);
+            h = h + 1 == H ? 0 : h + 1;
+            const float gj[4] = {g[i].x, g[i].y, g[i].z, g[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pre = fmaf(conv_chain(a.w[j], t), a.scale[j], a.shift[j]);
+                float dy = pre > 0.f ? gj[j] : gj[j] * slope;
+                dy = on ? dy : 0.f;
+                s1[j] += dy;
+#pragma unroll
+                for (int kk = 0; kk < kTaps; ++kk) s2[j][kk] = fmaf(dy, t[kk], s2[j][kk]);
+            }
         }
-      }
     }
-    // red[vs][(4q + j) * 10 + k]: k = 0 -> S1, 1 + t -> S2[t]
-    const int per = Cp * (kTaps + 1);
-    float* mine = red + (size_t)vs * per + (size_t)(4 * q) * (kTaps + 1);
+    // partial[(4q + j) * 10 + kk]: kk = 0 -> S1, 1 + t -> S2[t]; the workgroup's kVox column lanes are summed in float64, in lane order
+    const int per = Cp * (kTaps + 1), qw = Q * (kTaps + 1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        mine[j * (kTaps + 1)] = s1[j];
+        __syncthreads();
+        float* mine = red + vs * qw + q * (kTaps + 1);
+        mine[0] = s1[j];
 #pragma unroll
-        for (int k = 0; k < kTaps; ++k) mine[j * (kTaps + 1) + 1 + k] = s2[j][k];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < per; i += blockDim.x) {
-        double s = 0.0;
+        for (int kk = 0; kk < kTaps; ++kk) mine[1 + kk] = s2[j][kk];
+        __syncthreads();
+        for (int i = threadIdx.x; i < qw; i += blockDim.x) {
+            double sum = 0.0;
 #pragma unroll 8
-        for (int u = 0; u < kVox; ++u) s += (double)red[(size_t)u * per + i];
-        partial[(size_t)blockIdx.x * per + i] = s;
+            for (int v = 0; v < kVox; ++v) sum += (double)red[v * qw + i];
+            const int qq = i / (kTaps + 1), kk = i - qq * (kTaps + 1);
+            partial[(size_t)blockIdx.x * per + (size_t)(4 * qq + j) * (kTaps + 1) + kk] = sum;
+        }
     }
 }
 
@@ -299,9 +335,22 @@ __global__ __launch_bounds__(64) void stem_bwd_finalize_kernel(const double* __r
     }
 }
 
-int moments_groups(int R) { return min(R, 2048); }
-int apply_groups(int R) { return min(R, 3072); }
-int bwd_groups(int R) { return min(R, 1536); }
+struct SegPlan { int blocks_w, segs, rows_per_seg, grid; };
+// a grid of (column blocks) x (row segments) with about `target` workgroups; segments of at least 8 rows (the window's warm-up is 3 loads)
+SegPlan seg_plan(int R, int W, int cols_per_wg, int target) {
+    SegPlan p;
+    p.blocks_w = (W + cols_per_wg - 1) / cols_per_wg;
+    int segs = target / p.blocks_w;
+    if (segs > (R + 7) / 8) segs = (R + 7) / 8;
+    if (segs < 1) segs = 1;
+    p.rows_per_seg = (R + segs - 1) / segs;
+    p.segs = (R + p.rows_per_seg - 1) / p.rows_per_seg;
+    p.grid = p.segs * p.blocks_w;
+    return p;
+}
+SegPlan moments_plan(int R, int W) { return seg_plan(R, W, kMomThreads, 1024); }
+SegPlan apply_plan(int R, int W) { return seg_plan(R, W, kVox, 3072); }
+SegPlan bwd_plan(int R, int W) { return seg_plan(R, W, kVox, 1536); }
 
 }  // namespace
 }  // namespace nextou
@@ -310,9 +359,11 @@ using namespace nextou;
 
 extern "C" size_t nextou_stem_workspace_bytes(int B, int D, int H, int W, int Cpad) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cpad <= 0) return 0;
-    const long long R = (long long)B * D * H;
-    const size_t fwd = (size_t)moments_groups((int)min(R, (long long)INT32_MAX)) * kMom * sizeof(double) + (size_t)Cpad * sizeof(double2);
-    const size_t bwd = (size_t)bwd_groups((int)min(R, (long long)INT32_MAX)) * Cpad * (kTaps + 1) * sizeof(double);
+    const long long R64 = (long long)B * D * H;
+    if (R64 >= INT32_MAX) return 0;
+    const int R = (int)R64;
+    const size_t fwd = (size_t)moments_plan(R, W).grid * kMom * sizeof(double) + (size_t)Cpad * sizeof(double2);
+    const size_t bwd = (size_t)bwd_plan(R, W).grid * Cpad * (kTaps + 1) * sizeof(double);
     return fwd > bwd ? fwd : bwd;
 }
 
@@ -330,14 +381,13 @@ extern "C" int nextou_stem_fwd(const float* x, const float* weight, const float*
     const long long V = (long long)B * D * H * W;
     const int R = B * D * H;
     if (training) {
-        const int G0 = moments_groups(R);
-        const int rows_m = (R + G0 - 1) / G0;
-        const int G = (R + rows_m - 1) / rows_m;
+        const SegPlan mp = moments_plan(R, W);
+        const int G = mp.grid;
         double* partial = static_cast<double*>(workspace);
-        double2* stats = reinterpret_cast<double2*>(partial + (size_t)G0 * kMom);
+        double2* stats = reinterpret_cast<double2*>(partial + (size_t)G * kMom);
         {
             ProfScope prof(s, kBoundHbm, 4.0 * (double)V, "stem_moments_kernel[B%d S%lld]", B, V / B);
-            hipLaunchKernelGGL(stem_moments_kernel, dim3(G), dim3(kMomThreads), 0, s, x, partial, R, H, W, rows_m);
+            hipLaunchKernelGGL(stem_moments_kernel, dim3(G), dim3(kMomThreads), 0, s, x, partial, R, H, W, mp.rows_per_seg, mp.blocks_w);
         }
         hipLaunchKernelGGL(stem_stats_kernel, dim3(1), dim3(256), 0, s, partial, G, weight, C, moments, stats);
         int rc = check_launch("stem_moments_kernel");
@@ -351,11 +401,10 @@ extern "C" int nextou_stem_fwd(const float* x, const float* weight, const float*
         if (rc) return rc;
     }
     const int Q = Cpad / 4;
-    const int G = apply_groups(R);
-    const int rows_per_wg = (R + G - 1) / G;
+    const SegPlan ap = apply_plan(R, W);
     ProfScope prof(s, kBoundHbm, 4.0 * (double)V * (1.0 + Cpad), "stem_apply_kernel[B%d C%d S%lld]", B, Cpad, V / B);
-    hipLaunchKernelGGL(stem_apply_kernel, dim3((R + rows_per_wg - 1) / rows_per_wg), dim3(kVox * Q), 0, s, x, weight, gamma, beta, save_mean,
-                       save_invstd, y, R, H, W, C, Q, rows_per_wg, slope);
+    hipLaunchKernelGGL(stem_apply_kernel, dim3(ap.grid), dim3(kVox * Q), 0, s, x, weight, gamma, beta, save_mean, save_invstd, y, R, H, W, C, Q,
+                       ap.rows_per_seg, ap.blocks_w, slope);
     return check_launch("stem_apply_kernel");
 }
 
@@ -372,15 +421,13 @@ extern "C" int nextou_stem_bwd(const float* x, const float* gy, const float* wei
     const long long V = (long long)B * D * H * W;
     const int R = B * D * H;
     const int Q = Cpad / 4;
-    const int G0 = bwd_groups(R);
-    const int rows_per_wg = (R + G0 - 1) / G0;
-    const int G = (R + rows_per_wg - 1) / rows_per_wg;
+    const SegPlan bp = bwd_plan(R, W);
+    const int G = bp.grid;
     double* partial = static_cast<double*>(workspace);
-    const size_t lds = (size_t)kVox * Cpad * (kTaps + 1) * sizeof(float);
     {
         ProfScope prof(s, kBoundHbm, 4.0 * (double)V * (1.0 + Cpad), "stem_bwd_kernel[B%d C%d S%lld]", B, Cpad, V / B);
-        hipLaunchKernelGGL(stem_bwd_kernel, dim3(G), dim3(kVox * Q), lds, s, x, gy, weight, gamma, beta, save_mean, save_invstd, partial, R, H, W,
-                           C, Q, rows_per_wg, slope);
+        hipLaunchKernelGGL(stem_bwd_kernel, dim3(G), dim3(kVox * Q), 0, s, x, gy, weight, gamma, beta, save_mean, save_invstd, partial, R, H, W,
+                           C, Q, bp.rows_per_seg, bp.blocks_w, slope);
     }
     int rc = check_launch("stem_bwd_kernel");
     if (rc) return rc;
