@@ -125,7 +125,7 @@ _SIGNATURES = {
     "nextou_head_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int,
                                      c_int64, c_int64, c_void_p]),
     "nextou_stem_workspace_bytes": (c_size_t, [c_int] * 5),
-    "nextou_stem_fwd": (c_int, [c_void_p] * 12 + [c_size_t] + [c_int] * 7 + [c_float, c_float, c_float, c_void_p]),
+    "nextou_stem_fwd": (c_int, [c_void_p] * 13 + [c_size_t] + [c_int] * 7 + [c_float, c_float, c_float, c_void_p]),
     "nextou_stem_bwd": (c_int, [c_void_p] * 12 + [c_size_t] + [c_int] * 6 + [c_float, c_void_p]),
 }
 

@@ -12,16 +12,16 @@
 //                 finalize (nextou_norm_finalize: mean / invstd / running statistics / folded conv bias);
 //             (3) stem_apply_kernel     y[v][c] = leaky(fmaf(z_c(v), scale_c, shift_c)), z_c(v) = the fp32 fma chain over the taps in
 //                 ascending tap order; reads the image, writes the channels-last rows once (zero padding channels included).
-//   backward  (4) stem_bwd_kernel       one pass over gy (+ the image): dy' = gy * (pre-activation > 0 ? 1 : slope) with the
-//                 pre-activation recomputed by the same chain (bit-identical to the forward's, so the mask is the forward's),
-//                 S1[c] = sum dy', S2[c][t] = sum dy' x_t;
+//   backward  (4) stem_bwd_kernel       one pass over gy (+ the image): dy' = gy * (pre-activation > 0 ? 1 : slope) — the mask is one byte per
+//                 (voxel, channel quad) written by (3) — S1[c] = sum dy', S2[c][t] = sum dy' x_t;
 //             (5) stem_bwd_finalize_kernel  everything the three ops' autograd returns is linear in (S1, S2) given the moments:
 //                 gbeta = S1, ggamma = sum dy' zhat = invstd (sum_t w_ct S2[c][t] - mean S1),
 //                 gw[c][t] = scale ( S2[c][t] - (S1/n) X1[t] - (ggamma/n) invstd (sum_t' w_ct' A[t'][t] - mean X1[t]) ).
 //                 The image needs no gradient (the caller checks), the folded conv bias gets exactly zero under batch statistics.
-// HBM-bound: forward 4 V (1 + Cpad) bytes, backward 4 V (1 + Cpad) bytes for V voxels.  Sums: fp32 over a thread's own voxels (<= a few
+// HBM-bound: V (4 + 4 Cpad + Cpad / 4) bytes each way for V voxels.  Sums: fp32 over a thread's own voxels (<= a few
 // hundred terms), float64 across threads and workgroups in a fixed order: bit-reproducible.
 #include "common.h"
+#include <cstdlib>
 
 namespace nextou {
 namespace {
@@ -186,7 +186,8 @@ __device__ __forceinline__ float conv_chain(const float (&w)[kTaps], const float
 // (3) y rows.  A workgroup = kVox columns x Q channel quads, walking down a segment of image rows with the sliding window.
 __global__ __launch_bounds__(kVox * 12) void stem_apply_kernel(const float* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                  float* __restrict__ y, int R, int H, int W, int C, int Q, int rows_per_seg, int chunks, float slope) {
+                                  float* __restrict__ y, uint32_t* __restrict__ act, int R, int H, int W, int C, int Q, int rows_per_seg,
+                                  int chunks, float slope) {
     const int q = threadIdx.x % Q, vs = threadIdx.x / Q;
     Affine a;
     load_affine(a, 4 * q, C, weight, gamma, beta, mean, invstd);
@@ -200,8 +201,13 @@ __global__ __launch_bounds__(kVox * 12) void stem_apply_kernel(const float* __re
     int h = r0 % H;                                         // so the memory latency is paid once per RB voxels (no cross-iteration register copies)
     float* yp = y + ((long long)r0 * W + k.c) * Cp + 4 * q;
     const long long ystep = (long long)W * Cp;
+    // the LeakyReLU mask for the backward: one dword per (block of RB = 4 image rows, column, quad), bit 4 i + j = pre-activation of channel 4q + j
+    // at row 4 block + i > 0 — ONE dword store per batch (a byte per voxel cost 70 us, 2-byte words were no better: sub-dword accesses are the slow kind); segments start at
+    // multiples of 4 rows (seg_plan), so blocks never straddle workgroups
+    uint32_t* mp = act ? act + ((long long)(r0 / 4) * W + k.c) * Q + q : nullptr;
     for (int r = r0; r < r1; r += RB) {
         float rows[RB + 2][3];
+        unsigned bits = 0;
 #pragma unroll
         for (int i = 0; i < RB + 2; ++i) load_row3(x, r - 1 + i, R, W, k, rows[i]);
 #pragma unroll
@@ -209,26 +215,26 @@ __global__ __launch_bounds__(kVox * 12) void stem_apply_kernel(const float* __re
             float t[kTaps];
             window_taps(rows[i], rows[i + 1], rows[i + 2], w, W, h > 0, h + 1 < H, active, t);
             h = h + 1 == H ? 0 : h + 1;
-            float4 o;
-            o.x = leaky(fmaf(conv_chain(a.w[0], t), a.scale[0], a.shift[0]), slope);
-            o.y = leaky(fmaf(conv_chain(a.w[1], t), a.scale[1], a.shift[1]), slope);
-            o.z = leaky(fmaf(conv_chain(a.w[2], t), a.scale[2], a.shift[2]), slope);
-            o.w = leaky(fmaf(conv_chain(a.w[3], t), a.scale[3], a.shift[3]), slope);
+            const float p0 = fmaf(conv_chain(a.w[0], t), a.scale[0], a.shift[0]), p1 = fmaf(conv_chain(a.w[1], t), a.scale[1], a.shift[1]);
+            const float p2 = fmaf(conv_chain(a.w[2], t), a.scale[2], a.shift[2]), p3 = fmaf(conv_chain(a.w[3], t), a.scale[3], a.shift[3]);
+            const float4 o = make_float4(leaky(p0, slope), leaky(p1, slope), leaky(p2, slope), leaky(p3, slope));
             if (active && r + i < r1) *reinterpret_cast<float4*>(yp + i * ystep) = o;
+            bits |= ((p0 > 0.f ? 1u : 0u) | (p1 > 0.f ? 2u : 0u) | (p2 > 0.f ? 4u : 0u) | (p3 > 0.f ? 8u : 0u)) << (4 * i);
         }
         yp += RB * ystep;
+        if (mp) {
+            if (active) *mp = bits;
+            mp += (long long)W * Q;
+        }
     }
 }
 
-// (4) S1 / S2 partial sums: the same walk, the gradient row one iteration ahead as well.
-__global__ __launch_bounds__(kVox * 12) void stem_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ weight,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
-                                const float* __restrict__ invstd, double* __restrict__ partial, int R, int H, int W, int C, int Q,
-                                int rows_per_seg, int chunks, float slope) {
+// (4) S1 / S2 partial sums: the same walk over the gradient rows; the activation's mask comes from the forward's byte per (voxel, quad)
+// (recomputing the pre-activation here cost 40 fma + 36 weight registers per thread: the kernel was instruction-bound at 2.5 waves per SIMD).
+__global__ __launch_bounds__(kVox * 12) void stem_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, const uint32_t* __restrict__ act,
+                                double* __restrict__ partial, int R, int H, int W, int Q, int rows_per_seg, int chunks, float slope) {
     __shared__ float red[kVox * 12 * (kTaps + 1)];          // one channel of every quad at a time: [vs][q][10]
     const int q = threadIdx.x % Q, vs = threadIdx.x / Q;
-    Affine a;
-    load_affine(a, 4 * q, C, weight, gamma, beta, mean, invstd);
     const int Cp = 4 * Q;
     float s1[4], s2[4][kTaps];
 #pragma unroll
@@ -242,9 +248,10 @@ __global__ __launch_bounds__(kVox * 12) void stem_bwd_kernel(const float* __rest
     const bool active = w < W;
     const Cols k = clamp_cols(w, W);
     const int r0 = seg * rows_per_seg, r1 = min(R, r0 + rows_per_seg);
-    constexpr int RB = 4;                                   // as in stem_apply_kernel: RB + 2 window rows and RB gradient pieces per batch
+    constexpr int RB = 4;                                   // as in stem_apply_kernel: RB + 2 window rows, RB gradient pieces and RB mask bytes per batch
     const long long gstep = (long long)W * Cp;
     const float* gp = gy + ((long long)r0 * W + k.c) * Cp + 4 * q;
+    const uint32_t* mp = act + ((long long)(r0 / 4) * W + k.c) * Q + q;
     int h = r0 % H;
     for (int r = r0; r < r1; r += RB) {
         float rows[RB + 2][3];
@@ -253,7 +260,9 @@ __global__ __launch_bounds__(kVox * 12) void stem_bwd_kernel(const float* __rest
         for (int i = 0; i < RB + 2; ++i) load_row3(x, r - 1 + i, R, W, k, rows[i]);
 #pragma unroll
         for (int i = 0; i < RB; ++i) g[i] = *reinterpret_cast<const float4*>(gp + (r + i < r1 ? i : 0) * gstep);     // (clamped: a row past the segment re-reads row r)
+        const unsigned mk = *mp;
         gp += RB * gstep;
+        mp += (long long)W * Q;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             float t[kTaps];
@@ -263,8 +272,7 @@ __global__ __launch_bounds__(kVox * 12) void stem_bwd_kernel(const float* __rest
             const float gj[4] = {g[i].x, g[i].y, g[i].z, g[i].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float pre = fmaf(conv_chain(a.w[j], t), a.scale[j], a.shift[j]);
-                float dy = pre > 0.f ? gj[j] : gj[j] * slope;
+                float dy = (mk >> (4 * i + j)) & 1u ? gj[j] : gj[j] * slope;
                 dy = on ? dy : 0.f;
                 s1[j] += dy;
 #pragma unroll
@@ -343,7 +351,7 @@ SegPlan seg_plan(int R, int W, int cols_per_wg, int target) {
     int segs = target / p.blocks_w;
     if (segs > (R + 7) / 8) segs = (R + 7) / 8;
     if (segs < 1) segs = 1;
-    p.rows_per_seg = (R + segs - 1) / segs;
+    p.rows_per_seg = ((R + segs - 1) / segs + 3) & ~3;      // multiples of 4: the kernels' row blocks (and the mask's 4-row words) never straddle segments
     p.segs = (R + p.rows_per_seg - 1) / p.rows_per_seg;
     p.grid = p.segs * p.blocks_w;
     return p;
@@ -368,8 +376,8 @@ extern "C" size_t nextou_stem_workspace_bytes(int B, int D, int H, int W, int Cp
 }
 
 extern "C" int nextou_stem_fwd(const float* x, const float* weight, const float* pre_bias, const float* gamma, const float* beta,
-                               float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, double* moments,
-                               void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, int Cpad, int training,
+                               float* running_mean, float* running_var, float* y, uint32_t* act_mask, float* save_mean, float* save_invstd,
+                               double* moments, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, int Cpad, int training,
                                float momentum, float eps, float slope, nextou_stream_t stream) {
     NEXTOU_REQUIRE(x && weight && y && save_mean && save_invstd, "stem_fwd: null pointer");
     NEXTOU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && Cpad >= C && Cpad % 4 == 0 && Cpad <= 48, "stem_fwd: 0 < C <= Cpad <= 48, Cpad a multiple of 4");
@@ -402,17 +410,17 @@ extern "C" int nextou_stem_fwd(const float* x, const float* weight, const float*
     }
     const int Q = Cpad / 4;
     const SegPlan ap = apply_plan(R, W);
-    ProfScope prof(s, kBoundHbm, 4.0 * (double)V * (1.0 + Cpad), "stem_apply_kernel[B%d C%d S%lld]", B, Cpad, V / B);
-    hipLaunchKernelGGL(stem_apply_kernel, dim3(ap.grid), dim3(kVox * Q), 0, s, x, weight, gamma, beta, save_mean, save_invstd, y, R, H, W, C, Q,
-                       ap.rows_per_seg, ap.blocks_w, slope);
+    ProfScope prof(s, kBoundHbm, (double)V * (4.0 + 4.0 * Cpad + (act_mask ? 1.0 * Q : 0.0)), "stem_apply_kernel[B%d C%d S%lld]", B, Cpad, V / B);
+    hipLaunchKernelGGL(stem_apply_kernel, dim3(ap.grid), dim3(kVox * Q), 0, s, x, weight, gamma, beta, save_mean, save_invstd, y, act_mask, R, H, W,
+                       C, Q, ap.rows_per_seg, ap.blocks_w, slope);
     return check_launch("stem_apply_kernel");
 }
 
-extern "C" int nextou_stem_bwd(const float* x, const float* gy, const float* weight, const float* gamma, const float* beta,
+extern "C" int nextou_stem_bwd(const float* x, const float* gy, const uint32_t* act_mask, const float* weight, const float* gamma,
                                const float* save_mean, const float* save_invstd, const double* moments, float* gweight, float* ggamma,
                                float* gbeta, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, int Cpad,
                                float slope, nextou_stream_t stream) {
-    NEXTOU_REQUIRE(x && gy && weight && save_mean && save_invstd && moments && workspace, "stem_bwd: null pointer");
+    NEXTOU_REQUIRE(x && gy && act_mask && weight && save_mean && save_invstd && moments && workspace, "stem_bwd: null pointer");
     NEXTOU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && Cpad >= C && Cpad % 4 == 0 && Cpad <= 48, "stem_bwd: 0 < C <= Cpad <= 48, Cpad a multiple of 4");
     NEXTOU_REQUIRE((long long)B * D * H < INT32_MAX, "stem_bwd: more than 2^31 image rows");
     NEXTOU_REQUIRE(((uintptr_t)gy & 15) == 0, "stem_bwd: gy must be 16-byte aligned");
@@ -425,9 +433,8 @@ extern "C" int nextou_stem_bwd(const float* x, const float* gy, const float* wei
     const int G = bp.grid;
     double* partial = static_cast<double*>(workspace);
     {
-        ProfScope prof(s, kBoundHbm, 4.0 * (double)V * (1.0 + Cpad), "stem_bwd_kernel[B%d C%d S%lld]", B, Cpad, V / B);
-        hipLaunchKernelGGL(stem_bwd_kernel, dim3(G), dim3(kVox * Q), 0, s, x, gy, weight, gamma, beta, save_mean, save_invstd, partial, R, H, W,
-                           C, Q, bp.rows_per_seg, bp.blocks_w, slope);
+        ProfScope prof(s, kBoundHbm, (double)V * (4.0 + 4.0 * Cpad + 1.0 * Q), "stem_bwd_kernel[B%d C%d S%lld]", B, Cpad, V / B);
+        hipLaunchKernelGGL(stem_bwd_kernel, dim3(G), dim3(kVox * Q), 0, s, x, gy, act_mask, partial, R, H, W, Q, bp.rows_per_seg, bp.blocks_w, slope);
     }
     int rc = check_launch("stem_bwd_kernel");
     if (rc) return rc;

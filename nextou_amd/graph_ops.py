@@ -721,8 +721,9 @@ class _HipBackend:
 
     # ---- K9: the stem block (one-channel image -> conv [1,]3x3 -> batch norm -> LeakyReLU) without the convolution's output in memory ----
     @staticmethod
-    def stem_fwd(x, w2, pre_bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope, c_pad):
-        """x: dense (B, 1, *sp) float32 image; w2 (C, 9) contiguous -> (y channels-last (B, c_pad, *sp), mean (C,), invstd (C,), moments (54,) f64 | None)"""
+    def stem_fwd(x, w2, pre_bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope, c_pad, want_mask=True):
+        """x: dense (B, 1, *sp) float32 image; w2 (C, 9) contiguous -> (y channels-last (B, c_pad, *sp), mean (C,), invstd (C,), moments (54,) f64 | None,
+        act (ceil(B D H / 4), W, c_pad / 4) int32 | None: the LeakyReLU mask bits the backward reads)"""
         L_ = _lib.lib()
         B, sp = x.shape[0], tuple(x.shape[2:])
         D, H, W = (1,) * (3 - len(sp)) + sp
@@ -731,17 +732,18 @@ class _HipBackend:
         mean = torch.empty((C,), dtype=torch.float32, device=x.device)
         invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
         moments = torch.empty((54,), dtype=torch.float64, device=x.device) if training else None
+        act = torch.empty(((B * D * H + 3) // 4, W, c_pad // 4), dtype=torch.int32, device=x.device) if (training and want_mask) else None
         need = int(L_.nextou_stem_workspace_bytes(B, D, H, W, c_pad))
         ws = torch.empty((max(need, 8) // 8,), dtype=torch.float64, device=x.device)
         with torch.cuda.device(x.device):
             rc = L_.nextou_stem_fwd(x.data_ptr(), w2.data_ptr(), _ptr(pre_bias), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                                    y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(moments), ws.data_ptr(), ws.numel() * 8,
+                                    y.data_ptr(), _ptr(act), mean.data_ptr(), invstd.data_ptr(), _ptr(moments), ws.data_ptr(), ws.numel() * 8,
                                     B, D, H, W, C, c_pad, 1 if training else 0, float(momentum), float(eps), float(slope), _stream_ptr(x.device))
         _lib.check(rc, "stem_fwd")
-        return y, mean, invstd, moments
+        return y, mean, invstd, moments, act
 
     @staticmethod
-    def stem_bwd(x, gy_cl, w2, gamma, beta, mean, invstd, moments, slope, want_gw, want_gg, want_gb):
+    def stem_bwd(x, gy_cl, act, w2, gamma, mean, invstd, moments, slope, want_gw, want_gg, want_gb):
         """(gw (C, 9) | None, ggamma (C,) | None, gbeta (C,) | None) of the stem block from gy_cl, dense channels-last (B, c_pad, *sp) float32."""
         L_ = _lib.lib()
         B, sp = x.shape[0], tuple(x.shape[2:])
@@ -753,7 +755,7 @@ class _HipBackend:
         need = int(L_.nextou_stem_workspace_bytes(B, D, H, W, c_pad))
         ws = torch.empty((max(need, 8) // 8,), dtype=torch.float64, device=x.device)
         with torch.cuda.device(x.device):
-            rc = L_.nextou_stem_bwd(x.data_ptr(), gy_cl.data_ptr(), w2.data_ptr(), _ptr(gamma), _ptr(beta), mean.data_ptr(), invstd.data_ptr(),
+            rc = L_.nextou_stem_bwd(x.data_ptr(), gy_cl.data_ptr(), act.data_ptr(), w2.data_ptr(), _ptr(gamma), mean.data_ptr(), invstd.data_ptr(),
                                     moments.data_ptr(), _ptr(gw), _ptr(gg), _ptr(gb), ws.data_ptr(), ws.numel() * 8, B, D, H, W, C, c_pad,
                                     float(slope), _stream_ptr(x.device))
         _lib.check(rc, "stem_bwd")
@@ -1530,14 +1532,16 @@ class _StemBlock(torch.autograd.Function):
     """The network's first ConvDropoutNormReLU — conv(1 -> C, [1,]3x3) -> BatchNorm -> LeakyReLU (reference
     NexToU_Encoder_Decoder.py:125-141, encoder.stages[0]) — on K9 (csrc/stem_conv.hip): the batch statistics come from the nine-tap
     moments of the image, the output rows are written once, and the backward is one pass over the incoming gradient; the convolution's
-    881-MB output (cfg 2) is never stored.  Saves the image and 2C + 54 numbers."""
+    881-MB output (cfg 2) is never stored.  Saves the image, 2C + 54 numbers and one mask byte per voxel and channel quad (55 MB at cfg 2, moved as dwords)."""
 
     @staticmethod
     def forward(ctx, x, weight, conv_bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope, c_pad):
         w2 = weight.detach().reshape(weight.shape[0], 9).contiguous()
-        y, mean, invstd, moments = _HIP.stem_fwd(x, w2, conv_bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope, c_pad)
-        if training:
-            ctx.save_for_backward(x, w2, gamma, beta, mean, invstd, moments)
+        need_bwd = training and any(t is not None and t.requires_grad for t in (weight, conv_bias, gamma, beta))
+        y, mean, invstd, moments, act = _HIP.stem_fwd(x, w2, conv_bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope, c_pad,
+                                                      want_mask=need_bwd)
+        if need_bwd:
+            ctx.save_for_backward(x, w2, gamma, beta, mean, invstd, moments, act)
         ctx.cfg = (bool(training), float(slope), tuple(weight.shape), conv_bias)
         return y
 
@@ -1547,12 +1551,12 @@ class _StemBlock(torch.autograd.Function):
         if not training:
             raise RuntimeError("stem block (K9): the backward exists for batch statistics only; graph_ops.stem_block_eligible routes an "
                                "eval-mode block whose parameters need gradients through the op-by-op modules")
-        x, w2, gamma, beta, mean, invstd, moments = ctx.saved_tensors
+        x, w2, gamma, beta, mean, invstd, moments, act = ctx.saved_tensors
         gy = gy.contiguous(memory_format={4: torch.channels_last, 5: torch.channels_last_3d}[gy.dim()])
         if gy.dtype != torch.float32:
             gy = gy.float()
         need = ctx.needs_input_grad
-        gw, gg, gb = _HIP.stem_bwd(x, gy, w2, gamma, beta, mean, invstd, moments, slope, need[1], gamma is not None and need[3],
+        gw, gg, gb = _HIP.stem_bwd(x, gy, act, w2, gamma, mean, invstd, moments, slope, need[1], gamma is not None and need[3],
                                    beta is not None and need[4])
         gbias = torch.zeros_like(conv_bias) if (conv_bias is not None and need[2]) else None      # batch statistics absorb a per-channel constant
         return (None, None if gw is None else gw.reshape(wshape), gbias, gg, gb, None, None, None, None, None, None, None)

@@ -203,9 +203,9 @@ def test_stem_block_on_guard_pages(ops):
     base[-1] = base[-1].contiguous(memory_format=torch.channels_last_3d)
 
     def launch(x, w2, cb, gamma, beta, rm, rv, gy):
-        y, mean, invstd, moments = ops._HIP.stem_fwd(x, w2, cb, gamma, beta, rm, rv, True, 0.1, 1e-5, 0.01, c_pad)
-        gw, gg, gb = ops._HIP.stem_bwd(x, gy, w2, gamma, beta, mean, invstd, moments, 0.01, True, True, True)
-        return y, mean, invstd, moments, gw, gg, gb, rm, rv
+        y, mean, invstd, moments, act = ops._HIP.stem_fwd(x, w2, cb, gamma, beta, rm, rv, True, 0.1, 1e-5, 0.01, c_pad)
+        gw, gg, gb = ops._HIP.stem_bwd(x, gy, act, w2, gamma, mean, invstd, moments, 0.01, True, True, True)
+        return y, mean, invstd, moments, act, gw, gg, gb, rm, rv
 
     want = launch(*[t.clone(memory_format=torch.preserve_format) for t in base])
     torch.cuda.synchronize()

@@ -31,8 +31,8 @@ def main():
         if it == 2:
             torch.cuda.synchronize()
             _lib.lib().nextou_profile_enable(1024)
-        y, mean, invstd, mom = H.stem_fwd(x, w2, cb, gamma, beta, rm, rv, True, 0.1, 1e-5, 0.01, cp)
-        H.stem_bwd(x, gy, w2, gamma, beta, mean, invstd, mom, 0.01, True, True, True)
+        y, mean, invstd, mom, act = H.stem_fwd(x, w2, cb, gamma, beta, rm, rv, True, 0.1, 1e-5, 0.01, cp)
+        H.stem_bwd(x, gy, act, w2, gamma, mean, invstd, mom, 0.01, True, True, True)
     torch.cuda.synchronize()
     buf = ctypes.create_string_buffer(1 << 16)
     _lib.lib().nextou_profile_report(buf, len(buf))
