@@ -95,8 +95,9 @@ def move_to(trainer, device, fused_sgd=False):
     fused = fused_sgd and device.type == "cuda" and os.environ.get("NEXTOU_SGD_FUSED", "1") != "0"
     if device.type == "cuda" and os.environ.get("NEXTOU_CLIP_SGD", "1") != "0":
         # round 5: the clip and the update on the library's step-glue kernels (nextou_amd/optim.py: a torch.optim.SGD whose step names
-        # its tensors through a table in device memory — 3 launches, 144 us replayed against torch's 575).  Under the gradient averager the gradients are plain
-        # views of the flat buckets, whose layout differs from channels-last filters: ClipSGD then hands the step to torch's foreach SGD
+        # its tensors through a table in device memory — 3 launches, 144 us replayed against torch's 575).  Under the gradient averager the gradients are
+        # views of the flat buckets; a view whose element order differs from its channels-last filter is copied into the filter's order first
+        # (optim.ClipSGD._plan), the step itself stays on the own kernels
         from nextou_amd.optim import ClipSGD
         trainer.optimizer = ClipSGD(trainer.network.parameters(), trainer.initial_lr, weight_decay=trainer.weight_decay,
                                     momentum=trainer.momentum, nesterov=True)

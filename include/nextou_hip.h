@@ -313,6 +313,15 @@ int nextou_norm_act_bwd(const void* x, const void* gy, const float* weight, cons
                         int B, int C, int64_t S, int param_period, int dtype, int channels_last,
                         int training, float slope, nextou_stream_t stream);
 
+/* nextou_norm_act_bwd with TWO incoming gradients summed on load (ABI v14): the output of a plain encoder stage feeds the next stage AND,
+ * as the skip connection, the decoder's concatenation (reference NexToU_Encoder_Decoder.py:143-150, :311-337); autograd would add the
+ * two gradients in a pass of its own.  Channels-last fp32, C <= 128 and a multiple of 4; gy2: rows of C floats at row stride ld2 >= C
+ * (a channel range of the concatenation's gradient where it lies).  Everything else as nextou_norm_act_bwd(channels_last = 1). */
+int nextou_norm_act_bwd_two(const float* x, const float* gy, const float* gy2, int64_t ld2, const float* weight, const float* bias,
+                            const float* save_mean, const float* save_invstd, float* gx, float* gweight, float* gbias,
+                            void* workspace, size_t workspace_bytes, int B, int C, int64_t S, int training, float slope,
+                            nextou_stream_t stream);
+
 /* Per-channel sum over batch and space: out[c] = sum_{b,s} x[b,c,s] (float64 accumulation, fixed order) — the bias
  * gradient of a convolution that is not followed by a norm (segmentation heads, transposed convolutions), which
  * PyTorch-ROCm computes with a generic reduction that collapses on channels-last tensors (5.5 ms for 727 MB).

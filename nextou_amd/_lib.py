@@ -80,6 +80,8 @@ _SIGNATURES = {
     "nextou_norm_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_int, c_int, c_int64, c_int, c_int, c_int, c_int,
                                     c_float, c_void_p]),
+    "nextou_norm_act_bwd_two": (c_int, [c_void_p, c_void_p, c_void_p, c_int64] + [c_void_p] * 8 + [c_size_t, c_int, c_int, c_int64, c_int, c_float,
+                                        c_void_p]),
     "nextou_channel_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int64, c_int, c_int,
                                    c_void_p]),
     "nextou_window_gather": (c_int, [c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),

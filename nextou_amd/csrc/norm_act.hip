@@ -1000,6 +1000,151 @@ void launch_cl_bwd(const NormArgs& a, const ClPlan& p, hipStream_t s, const char
 }
 
 
+// ------------------------------------------------------------------------------------------------------------
+// K6's channels-last backward with TWO incoming gradients, summed on load (round 6): the tensor a plain encoder stage hands both to the
+// next stage and — as the skip connection — to the decoder's concatenation (reference NexToU_Encoder_Decoder.py:143-150 `skips.append`,
+// :311-337 `torch.cat((x, skip), 1)`) receives one gradient from each.  Autograd adds them in a pass of its own (aten::add: 564 us for the
+// 881-MB stage-0 tensor of cfg 2, 2 x 209 us at stage 1) and K6's reduce and apply passes then read the sum; here the two passes read both
+// gradients instead (dz = g1 + g2, the same fp32 add).  gy2 is the concatenation's gradient where it lies: rows of C floats at a row stride
+// ld2 >= C (a channel range of the wider concatenated rows).  fp32, 16-byte aligned pieces (C, ld2, the channel offset multiples of 4).
+// ------------------------------------------------------------------------------------------------------------
+struct TwoGrad {
+    const float* p;          // gy2 + row * ld2 + col of the thread's first element
+    long long step;          // elements per loop stride: (tact * 4 / C) rows * ld2
+};
+__device__ inline TwoGrad two_grad_at(const float* gy2, long long ld2, long long e, int C, long long stride) {
+    const long long row = e / C;
+    const int col = (int)(e - row * C);
+    return TwoGrad{gy2 + row * ld2 + col, (stride / C) * ld2};
+}
+
+__global__ __launch_bounds__(kThreads) void bn_cl_bwd_reduce2_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                     const float* __restrict__ gy2, long long ld2, double2* __restrict__ partial,
+                                                                     const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                     const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                                     long long total, int C, int tact, long long span, float slope) {
+    constexpr int VEC = 4;
+    double s1[VEC], s2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.0;
+    if ((int)threadIdx.x < tact) {
+        int ch[VEC];
+        cl_channels<VEC>(C, ch);
+        float scale[VEC], shift[VEC], mean[VEC], invstd[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float w = weight ? weight[ch[j]] : 1.f, b = bias ? bias[ch[j]] : 0.f;
+            mean[j] = save_mean[ch[j]];
+            invstd[j] = save_invstd[ch[j]];
+            scale[j] = w * invstd[j];
+            shift[j] = fmaf(-mean[j], scale[j], b);
+        }
+        const long long base = (long long)blockIdx.x * span;
+        const long long end = min(total, base + span);
+        const long long stride = (long long)tact * VEC;
+        long long e = base + (long long)threadIdx.x * VEC;
+        TwoGrad t = two_grad_at(gy2, ld2, e, C, stride);
+        for (; e + stride < end; e += 2 * stride) {
+            Pack<float, VEC> p[2], g[2], h[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { p[u].load_stream(x + e + u * stride); g[u].load_stream(gy + e + u * stride); h[u].load_stream(t.p + u * t.step); }
+            t.p += 2 * t.step;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float gsum = g[u].v[j] + h[u].v[j];
+                    const float z = fmaf(p[u].v[j], scale[j], shift[j]);
+                    const float dz = z > 0.f ? gsum : gsum * slope;
+                    const float xh = (p[u].v[j] - mean[j]) * invstd[j];
+                    s1[j] += (double)dz;
+                    s2[j] = fma((double)dz, (double)xh, s2[j]);
+                }
+        }
+        for (; e < end; e += stride) {
+            Pack<float, VEC> p, g, h;
+            p.load_stream(x + e);
+            g.load_stream(gy + e);
+            h.load_stream(t.p);
+            t.p += t.step;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float gsum = g.v[j] + h.v[j];
+                const float z = fmaf(p.v[j], scale[j], shift[j]);
+                const float dz = z > 0.f ? gsum : gsum * slope;
+                const float xh = (p.v[j] - mean[j]) * invstd[j];
+                s1[j] += (double)dz;
+                s2[j] = fma((double)dz, (double)xh, s2[j]);
+            }
+        }
+    }
+    cl_block_sums<VEC>(s1, s2, C, tact, partial, gridDim.x);
+}
+
+__global__ __launch_bounds__(kThreads) void bn_cl_bwd_apply2_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                    const float* __restrict__ gy2, long long ld2, float* __restrict__ gx,
+                                                                    const float2* __restrict__ coeff, const float* __restrict__ weight,
+                                                                    const float* __restrict__ bias, const float* __restrict__ save_mean,
+                                                                    const float* __restrict__ save_invstd, long long total, int C, int tact,
+                                                                    long long span, float slope) {
+    constexpr int VEC = 4;
+    if ((int)threadIdx.x >= tact) return;
+    int ch[VEC];
+    cl_channels<VEC>(C, ch);
+    float scale[VEC], shift[VEC], mean[VEC], invstd[VEC], k1[VEC], k2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const float w = weight ? weight[ch[j]] : 1.f, b = bias ? bias[ch[j]] : 0.f;
+        mean[j] = save_mean[ch[j]];
+        invstd[j] = save_invstd[ch[j]];
+        scale[j] = w * invstd[j];
+        shift[j] = fmaf(-mean[j], scale[j], b);
+        const float2 k = coeff[ch[j]];
+        k1[j] = k.x;
+        k2[j] = k.y;
+    }
+    const long long base = (long long)blockIdx.x * span;
+    const long long end = min(total, base + span);
+    const long long stride = (long long)tact * VEC;
+    long long e = base + (long long)threadIdx.x * VEC;
+    TwoGrad t = two_grad_at(gy2, ld2, e, C, stride);
+    for (; e + stride < end; e += 2 * stride) {
+        Pack<float, VEC> p[2], g[2], h[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { p[u].load(x + e + u * stride); g[u].load(gy + e + u * stride); h[u].load(t.p + u * t.step); }
+        t.p += 2 * t.step;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float gsum = g[u].v[j] + h[u].v[j];
+                const float z = fmaf(p[u].v[j], scale[j], shift[j]);
+                const float dz = z > 0.f ? gsum : gsum * slope;
+                const float xh = (p[u].v[j] - mean[j]) * invstd[j];
+                g[u].v[j] = scale[j] * ((dz - k1[j]) - xh * k2[j]);
+            }
+            g[u].store(gx + e + u * stride);
+        }
+    }
+    for (; e < end; e += stride) {
+        Pack<float, VEC> p, g, h;
+        p.load(x + e);
+        g.load(gy + e);
+        h.load(t.p);
+        t.p += t.step;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float gsum = g.v[j] + h.v[j];
+            const float z = fmaf(p.v[j], scale[j], shift[j]);
+            const float dz = z > 0.f ? gsum : gsum * slope;
+            const float xh = (p.v[j] - mean[j]) * invstd[j];
+            g.v[j] = scale[j] * ((dz - k1[j]) - xh * k2[j]);
+        }
+        g.store(gx + e);
+    }
+}
+
+
 // ======================================================================================================
 // Channels-last, WIDE rows (C > 256: the graph stages' 264 / 324 / 528 / 648 / 1056 / 1296-channel tensors, and any C
 // when NEXTOU_CLW=1).  x is R = B*S rows of C contiguous channels, cut into column blocks of CW = cx * VEC channels and
@@ -1422,6 +1567,38 @@ extern "C" int nextou_norm_act_bwd(const void* x, const void* gy, const float* w
         return fail(NEXTOU_ENOSPACE, "norm_act_bwd: workspace %zu < %zu bytes", ws_bytes, (size_t)C * p.tiles * sizeof(double2));
     norm_dispatch<false>(a, p, dtype, (hipStream_t)stream);
     return check_launch("bn_bwd_apply_kernel");
+}
+
+// K6's backward for a channels-last fp32 tensor (C <= 128: the bn_cl kernels) whose gradient arrives as TWO tensors — see bn_cl_bwd_reduce2_kernel.
+extern "C" int nextou_norm_act_bwd_two(const float* x, const float* gy, const float* gy2, int64_t ld2, const float* weight, const float* bias,
+                                       const float* save_mean, const float* save_invstd, float* gx, float* gweight, float* gbias, void* ws,
+                                       size_t ws_bytes, int B, int C, int64_t S, int training, float slope, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(x && gy && gy2 && gx && save_mean && save_invstd && ws, "norm_act_bwd_two: null pointer");
+    if (int rc = check_common("norm_act_bwd_two", B, C, S, 0, NEXTOU_DTYPE_F32, 1)) return rc;
+    if (use_clw(C) || C % 4 != 0 || ld2 < C || ld2 % 4 != 0 || !(aligned16(x) && aligned16(gy) && aligned16(gy2) && aligned16(gx)))
+        return fail(NEXTOU_ENOTSUP, "norm_act_bwd_two: C = %d (<= 128, a multiple of 4), ld2 = %lld (>= C, a multiple of 4) and 16-byte aligned operands only",
+                    C, (long long)ld2);
+    if (ws_bytes < nextou_norm_act_workspace_bytes(B, C, S, NEXTOU_DTYPE_F32))
+        return fail(NEXTOU_ENOSPACE, "norm_act_bwd_two: workspace %zu < %zu bytes", ws_bytes, nextou_norm_act_workspace_bytes(B, C, S, NEXTOU_DTYPE_F32));
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)B * C * S;
+    const ClPlan p = plan_cl(total, C, 4, true);
+    if (p.vec != 4) return fail(NEXTOU_ENOTSUP, "norm_act_bwd_two: the element count must be a multiple of 4");
+    const double bytes = (double)total * sizeof(float);
+    const double count = (double)B * (double)S;
+    double2* partial = (double2*)ws;
+    float2* coeff = reinterpret_cast<float2*>(reinterpret_cast<char*>(ws) + kCoeffOffset(B, C, S));
+    const size_t lds = (size_t)p.tact * 4 * sizeof(double2);
+    {
+        ProfScope prof(s, kBoundHbm, 3.0 * bytes, "bn_cl_bwd_reduce2_kernel<f32>[B%d C%d S%lld]", B, C, (long long)S);
+        hipLaunchKernelGGL(bn_cl_bwd_reduce2_kernel, dim3(p.blocks), dim3(kThreads), lds, s, x, gy, gy2, (long long)ld2, partial, weight, bias, save_mean,
+                           save_invstd, total, C, p.tact, p.span, slope);
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kFinThreads), 0, s, partial, p.blocks, count, coeff, gweight, gbias, training);
+    ProfScope prof(s, kBoundHbm, 4.0 * bytes, "bn_cl_bwd_apply2_kernel<f32>[B%d C%d S%lld]", B, C, (long long)S);
+    hipLaunchKernelGGL(bn_cl_bwd_apply2_kernel, dim3(p.blocks), dim3(kThreads), 0, s, x, gy, gy2, (long long)ld2, gx, coeff, weight, bias, save_mean,
+                       save_invstd, total, C, p.tact, p.span, slope);
+    return check_launch("bn_cl_bwd_apply2_kernel");
 }
 
 // K6's forward for a channel-major (B, C, S) fp32 tensor whose (sum, sum of squares) partials another kernel already wrote —

@@ -31,7 +31,7 @@ class _Bucket:
     @staticmethod
     def _view_like(flat: torch.Tensor, offset: int, p: torch.Tensor) -> torch.Tensor:
         import os
-        if os.environ.get("NEXTOU_DDP_STRIDED_VIEWS", "0") == "1" and _dense_strides(p) and not p.is_contiguous():
+        if os.environ.get("NEXTOU_DDP_STRIDED_VIEWS", "1") != "0" and _dense_strides(p) and not p.is_contiguous():
             return flat.as_strided(p.shape, p.stride(), flat.storage_offset() + offset)
         return flat[offset:offset + p.numel()].view_as(p)
 
@@ -43,9 +43,10 @@ class _Bucket:
             total += p.numel()
         self.n_grad = total
         self.flat = torch.zeros(total + len(params), dtype=params[0].dtype, device=params[0].device)
-        # plain reshaped slices of the flat buffer (the layout every round's runs used).  NEXTOU_DDP_STRIDED_VIEWS=1: views with the
-        # PARAMETER's strides (a channels-last convolution weight keeps its permuted layout), so that optimizers that walk parameter,
-        # gradient and momentum as flat arrays (torch.optim.SGD(fused=True)) pair the right elements — opt-in, see bench.move_to
+        # views with the PARAMETER's strides where it is dense but not contiguous (a channels-last convolution weight keeps its permuted
+        # element order inside its slice of the flat buffer): optimizers that walk parameter, gradient and momentum as flat arrays
+        # (ClipSGD's kernels, torch.optim.SGD(fused=True)) pair the right elements without first copying ~100 filter gradients out of the
+        # buckets every step.  NEXTOU_DDP_STRIDED_VIEWS=0: plain reshaped slices (rounds 2-5)
         self.views = [self._view_like(self.flat, o, p) for o, p in zip(self.offsets, params)]
         self.flags = self.flat[total:]
         self.pending = len(params)

@@ -464,6 +464,24 @@ class _HipBackend:
         return gx, gw, gb
 
     @staticmethod
+    def norm_act_bwd_two(x, gy, gy2, weight, bias, save_mean, save_invstd, training, slope):
+        """K6's channels-last backward with the gradient arriving as two tensors (summed on load): ``gy`` dense like ``x``, ``gy2`` a
+        channel range of wider channels-last rows (``two_gradients_eligible``).  -> (gx, gweight, gbias)"""
+        L_ = _lib.lib()
+        B, C = x.shape[:2]
+        S = x.numel() // (B * C)
+        gx = torch.empty_like(x)
+        gw = torch.empty((C,), dtype=torch.float32, device=x.device)
+        gb = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((int(L_.nextou_norm_act_workspace_bytes(B, C, S, _lib.DTYPE_F32)),), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L_.nextou_norm_act_bwd_two(x.data_ptr(), gy.data_ptr(), gy2.data_ptr(), int(gy2.stride(-1)), _ptr(weight), _ptr(bias),
+                                            save_mean.data_ptr(), save_invstd.data_ptr(), gx.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), B, C, S, int(training), float(slope), _stream_ptr(x.device))
+        _lib.check(rc, "norm_act_bwd_two")
+        return gx, gw, gb
+
+    @staticmethod
     def channel_sum(x, channels_last=False):
         """(C,) float32 sums over batch and space of x (B,C,*sp) in either memory layout."""
         L_ = _lib.lib()
@@ -1224,9 +1242,16 @@ class _NormAct(torch.autograd.Function):
     def backward(ctx, gy):
         x3, weight, bias, mean, invstd = ctx.saved_tensors
         training, slope, period, shape, B, C, eps, cl, c_real = ctx.cfg
+        box = getattr(ctx, "fork_box", None)            # skip_fork(): the skip connection's gradient, parked by _SkipFork.backward
+        g2 = box.pop() if box else None
         if gy.dtype != x3.dtype:
             gy = gy.to(x3.dtype)
-        if cl is not None:
+        if g2 is not None and not (cl is not None and two_gradients_eligible(x3, gy, g2)):
+            gy = gy + g2                                 # what autograd itself would have done
+            g2 = None
+        if g2 is not None:
+            gx, gw, gb = _HIP.norm_act_bwd_two(x3, gy.contiguous(memory_format=cl), g2, weight, bias, mean, invstd, training, slope)
+        elif cl is not None:
             gx, gw, gb = _backend_for(x3).norm_act_bwd(x3, gy.contiguous(memory_format=cl), weight, bias, mean, invstd,
                                                        training, slope, 0, eps, channels_last=True)
         else:
@@ -1248,6 +1273,63 @@ class _NormAct(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None, None, None, gpre, None, None
 
 
+def two_gradients_eligible(x: torch.Tensor, gy: torch.Tensor, g2: torch.Tensor) -> bool:
+    """K6's two-gradient backward (nextou_norm_act_bwd_two): dense channels-last fp32 ``x`` with C <= 128 a multiple of 4, and ``g2`` the
+    same logical shape as a channel range of wider channels-last rows (stride 1 on the channel axis, row stride a multiple of 4, dense
+    rows in batch / space order, 16-byte aligned) — the ``g.narrow(1, c, C)`` the concatenation's backward hands the skip connection."""
+    import os
+    if os.environ.get("NEXTOU_SKIP_FORK", "1") == "0":
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and g2.dtype == torch.float32 and gy.dtype == torch.float32) or x.dim() not in (4, 5):
+        return False
+    C = x.shape[1]
+    if tuple(g2.shape) != tuple(x.shape) or C % 4 or C > 128 or _dense_channels_last(x) is None:
+        return False
+    ld = g2.stride(-1)
+    if g2.stride(1) != 1 or ld < C or ld % 4 or g2.data_ptr() % 16 or x.data_ptr() % 16:
+        return False
+    expect = ld
+    for d in range(x.dim() - 1, 1, -1):                 # spatial axes innermost first, then the batch: rows in (B, *spatial) order
+        if g2.stride(d) != expect:
+            return False
+        expect *= x.shape[d]
+    return g2.stride(0) == expect
+
+
+class _SkipFork(torch.autograd.Function):
+    """Identity with two outputs for a tensor that has two consumers — an encoder stage's output going to the next stage and, as the skip
+    connection, to the decoder (reference NexToU_Encoder_Decoder.py:143-150).  Its backward does NOT add the two incoming gradients: it
+    parks the second in the box shared with the producing _NormAct node, whose backward kernels read both (nextou_norm_act_bwd_two) or,
+    where they cannot, add them there.  Saves autograd's own aten::add pass over the stage-0 / stage-1 tensors (0.98 ms of the cfg-2 step)."""
+
+    @staticmethod
+    def forward(ctx, y, box):
+        ctx.box = box
+        ctx.set_materialize_grads(False)
+        return y.view_as(y), y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g_main, g_skip):
+        if g_skip is None or g_main is None:
+            return (g_main if g_skip is None else g_skip), None
+        ctx.box.append(g_skip)
+        return g_main, None
+
+
+def skip_fork(y: torch.Tensor):
+    """``(y_next, y_skip)``: the same values twice; when ``y`` comes straight out of a fused norm (_NormAct) and gradients are being
+    recorded, the two are tied to that node so that its backward takes their gradients unsummed (see _SkipFork).  Anything else:
+    ``(y, y)``."""
+    import os
+    node = y.grad_fn
+    if node is None or not torch.is_grad_enabled() or type(node).__name__ != "_NormActBackward" or \
+            os.environ.get("NEXTOU_SKIP_FORK", "1") == "0" or getattr(node, "fork_box", None) is not None:
+        return y, y
+    box = []
+    node.fork_box = box
+    return _SkipFork.apply(y, box)
+
+
 def _pad_stage(holder, C: int, c_real: int, device) -> torch.Tensor:
     """The persistent (5, C) parameter stage of a norm module whose input carries ``C - c_real`` zero channels."""
     stage = getattr(holder, "_pad_stage", None)
@@ -1260,7 +1342,12 @@ def _pad_stage(holder, C: int, c_real: int, device) -> torch.Tensor:
 
 
 class _ZeroGradRider(torch.autograd.Function):
-    """Identity on ``out``; its backward hands every ``param`` a slice of ONE zero-filled buffer as gradient (see ZeroGradScope)."""
+    """Identity on ``out``; its backward hands every ``param`` a slice of ONE zero-filled buffer as gradient (see ZeroGradScope).
+    Two consequences of the form (both stated rather than worked around): the output is a view created inside a custom
+    Function, so an IN-PLACE op on the network's first gradient-carrying output raises autograd's usual error for such views (nnU-Net's
+    losses do not modify logits in place); and the zero gradients reach the folded conv biases only when the loss depends on that output —
+    a loss built from the other heads alone leaves them ``grad = None`` (weight decay / momentum then skip them for that step, where the
+    reference would apply them to a round-off-sized gradient)."""
 
     @staticmethod
     def forward(ctx, out, *params):

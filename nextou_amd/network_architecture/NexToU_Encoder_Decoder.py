@@ -676,9 +676,16 @@ class NexToU_Encoder(nn.Module):
 
     def forward(self, x):
         skips = []
+        last = len(self.stages) - 1
         for s, stage in enumerate(self.stages):
             x = stage(set_stage_layout(x, s in self.channels_last_stages, self.reduced_precision_layout_ok))
-            skips.append(x)
+            if self.return_skips and s < last:
+                # two consumers (the next stage, the decoder's concatenation): where the stage ends in a fused norm its backward takes the
+                # two gradients unsummed (graph_ops.skip_fork); elsewhere this is (x, x)
+                x, skip = graph_ops.skip_fork(x)
+                skips.append(skip)
+            else:
+                skips.append(x)
         return skips if self.return_skips else skips[-1]
 
     def compute_conv_feature_map_size(self, input_size):

@@ -103,10 +103,13 @@ class ClipSGD(torch.optim.SGD):
     """``torch.optim.SGD`` with the step (and, through :meth:`clip_and_step`, the gradient clip) on own kernels."""
 
     def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, *, maximize=False,
-                 differentiable=False):
-        # foreach (torch's default on the GPU) is what the fallback path runs
+                 foreach=None, differentiable=False, fused=None):
+        # torch.optim.SGD's constructor, keyword for keyword (ADVICE r5): `foreach` / `fused` choose what the FALLBACK path runs (torch's
+        # default on the GPU is foreach); the own kernels do not need either
         super().__init__(params, lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov,
-                         maximize=maximize, differentiable=differentiable)
+                         maximize=maximize, foreach=foreach, differentiable=differentiable, fused=fused)
+        self._clip_request = None        # clip_and_step() -> step(): the max norm of this one step
+        self._clip_norm = None
         self._tables = {}
         self._retired = []
         self._static = {}
@@ -121,6 +124,8 @@ class ClipSGD(torch.optim.SGD):
         self.__dict__.setdefault("_device_type", "cuda")
         self.__dict__.setdefault("last_path", None)
         self.__dict__.setdefault("last_reason", None)
+        self.__dict__.setdefault("_clip_request", None)
+        self.__dict__.setdefault("_clip_norm", None)
 
     # ---------------------------------------------------------------------------------------------------------------
     def _plan(self, group):
@@ -231,22 +236,32 @@ class ClipSGD(torch.optim.SGD):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if self._own_step(None) is NotImplemented:
-            self.last_path = "torch"
-            super().step()
-        else:
-            self.last_path = "own"
-        return loss
-
-    def clip_and_step(self, max_norm: float) -> torch.Tensor:
-        """``torch.nn.utils.clip_grad_norm_(all parameters of this optimizer, max_norm)`` followed by :meth:`step`; returns the
-        total norm (a 0-dim tensor, no host synchronisation).  The gradients are left scaled, as the clip leaves them."""
+        max_norm, self._clip_request = self._clip_request, None
         norm = self._own_step(max_norm)
         if norm is NotImplemented:
             self.last_path = "torch"
-            params = [p for g in self.param_groups for p in g["params"]]
-            norm = torch.nn.utils.clip_grad_norm_(params, max_norm)
+            if max_norm is not None:
+                params = [p for g in self.param_groups for p in g["params"]]
+                norm = torch.nn.utils.clip_grad_norm_(params, max_norm)
+            else:
+                norm = None
             super().step()
         else:
             self.last_path = "own"
+        self._clip_norm = norm
+        return loss
+
+    def clip_and_step(self, max_norm: float) -> torch.Tensor:
+        """``torch.nn.utils.clip_grad_norm_(all parameters of this optimizer, max_norm)`` followed by :meth:`step` — through ``self.step``,
+        i.e. with the optimizer's step pre / post hooks, the profiler's record and the LR schedulers' bookkeeping; returns the
+        total norm (a 0-dim tensor, no host synchronisation).  The gradients are left scaled, as the clip leaves them.  The returned
+        tensor is the caller's own copy outside a stream capture; inside one it is the table's buffer, rewritten by every replay."""
+        self._clip_request = float(max_norm)
+        try:
+            self.step()
+        finally:
+            self._clip_request = None
+        norm, self._clip_norm = self._clip_norm, None
+        if isinstance(norm, torch.Tensor) and norm.is_cuda and not _capturing(norm.device):
+            norm = norm.clone()
         return norm

@@ -297,10 +297,14 @@ def test_upconv_cat_is_the_transposed_convolution(monkeypatch, cin, cout, c2, sp
     assert float((gw - torch.autograd.grad(torch.cat((conv(x, wc, b, stride), skip), 1), [wc], go)[0]).abs().max()) <= 1e-10
 
 
-def test_clip_sgd_on_the_gradient_averager_s_bucket_views(stand_in):
-    """Under the gradient averager ``p.grad`` is a plain slice of a flat bucket: for a parameter stored channels-last that is another
-    element order.  ClipSGD copies such a gradient into the parameter's order and takes the step itself (world-size-1 gloo group, real
-    BucketedGradientAverager, the kernels' stand-in)."""
+@pytest.mark.parametrize("strided_views", ["1", "0"])
+def test_clip_sgd_on_the_gradient_averager_s_bucket_views(stand_in, monkeypatch, strided_views):
+    """Under the gradient averager ``p.grad`` is a view of a flat bucket.  Default (round 6): the view carries the PARAMETER's
+    strides, so a channels-last filter's gradient sits in the bucket in the filter's own element order and ClipSGD walks it in place —
+    ``p.grad`` stays inside the bucket.  ``NEXTOU_DDP_STRIDED_VIEWS=0``: a plain slice, another element order; ClipSGD copies such a
+    gradient into the parameter's order first.  Either way the step is the kernels' (world-size-1 gloo group, real
+    BucketedGradientAverager, the kernels' stand-in) and equals torch's."""
+    monkeypatch.setenv("NEXTOU_DDP_STRIDED_VIEWS", strided_views)
     import socket
 
     import torch.distributed as dist
@@ -328,10 +332,14 @@ def test_clip_sgd_on_the_gradient_averager_s_bucket_views(stand_in):
             averager.zero_grad()
             net(x).square().mean().backward()
             averager.finalize()
-            assert net[0].weight.grad.stride() != net[0].weight.stride()          # the bucket view is a plain slice
+            bucket = averager.buckets[averager._slot[net[0].weight][0]].flat
+            inside = lambda t: bucket.data_ptr() <= t.data_ptr() < bucket.data_ptr() + bucket.numel() * 4      # noqa: E731
+            assert inside(net[0].weight.grad)
+            assert (net[0].weight.grad.stride() == net[0].weight.stride()) is (strided_views == "1")
             own.clip_and_step(0.05)
             assert own.last_path == "own", own.last_reason
             assert net[0].weight.grad.stride() == net[0].weight.stride()
+            assert inside(net[0].weight.grad) is (strided_views == "1")          # "0": ClipSGD re-pointed p.grad at its copy
             plain.zero_grad(set_to_none=True)
             ref(x).square().mean().backward()
             torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.05)
