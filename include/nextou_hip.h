@@ -408,6 +408,14 @@ int nextou_upconv_cat_rows(const float* y2, const float* bias, const float* skip
 int nextou_upconv_cat_rows_bwd(const float* g, float* gy2, float* gbias, void* ws, size_t ws_bytes, int B, int D, int H, int W, int sd,
                                int sh, int sw, int C1, int C2, nextou_stream_t stream);
 
+/* nextou_pw_rows_up (ABI v14): the up-convolution's GEMM with the pixel shuffle in its store — the product row of input point p, column
+ * t * cout + co, goes to channel co of the output point that tap t of p lands on, in rows of pitch ld_out (the concatenation buffer
+ * (B, D sd, H sh, W sw, ld_out): its first cout channels), bias[co] added.  Strides 1, 2 or 4; cout, K, ldx, ld_out multiples of 4.
+ * nextou_upconv_cat_rows with y2 == NULL then fills only the skip half: together they are nextou_pw_rows + nextou_upconv_cat_rows
+ * without the (P_in, T cout) intermediate — one 881-MB write and read less at the full-resolution stage of cfg 2. */
+int nextou_pw_rows_up(const float* x, const float* w, const float* bias, float* out, int N, int K, int64_t ldx, int64_t ld_out, int B, int D,
+                      int H, int W, int sd, int sh, int sw, int cout, nextou_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Step glue (ABI v13): gradient clip + SGD update of a whole parameter list.  The step nnU-Net's trainer prescribes for the NexToU
  * plug-ins (nnUNetTrainer_NexToU inherits nnUNetTrainer.train_step: backward -> clip_grad_norm_(network.parameters(), 12) ->

@@ -101,6 +101,7 @@ _SIGNATURES = {
                                      c_void_p]),
     "nextou_depth_unroll": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "nextou_pw_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "nextou_pw_rows_up": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64] + [c_int] * 8 + [c_void_p]),
     "nextou_pw_wgrad_workspace": (c_int, [c_int64, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "nextou_pw_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int64, c_int64,
                                 c_int, c_void_p]),

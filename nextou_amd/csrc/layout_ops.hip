@@ -470,6 +470,7 @@ __global__ __launch_bounds__(256) void upconv_cat_rows_kernel(const float4* __re
     for (long long row = (long long)blockIdx.x * rows_per_pass + r_local; row < P; row += step) {
         float4 v;
         if (first) {
+            if (a == nullptr) continue;            // the up-sampled half is already in place (nextou_pw_rows_up wrote it): only the skip half
             v = a[upconv_row(row, u) * c1q + q];
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         } else {
@@ -538,7 +539,7 @@ extern "C" int nextou_cat_bias_rows(const float* a, const float* bias, const flo
 
 extern "C" int nextou_upconv_cat_rows(const float* y2, const float* bias, const float* skip, float* out, int B, int D, int H, int W, int sd,
                                       int sh, int sw, int C1, int C2, nextou_stream_t stream) {
-    NEXTOU_REQUIRE(y2 && skip && out, "upconv_cat_rows: null pointer");
+    NEXTOU_REQUIRE(skip && out, "upconv_cat_rows: null pointer");          // y2 == NULL: fill the skip half only (the first C1 channels stay as they are)
     NEXTOU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && sd >= 1 && sh >= 1 && sw >= 1 && sd <= 4 && sh <= 4 && sw <= 4 && C1 > 0 && C2 > 0 &&
                    C1 % 4 == 0 && C2 % 4 == 0 && (C1 + C2) / 4 <= 256,
                    "upconv_cat_rows: bad size B=%d (%d,%d,%d) stride (%d,%d,%d) C %d+%d (multiples of 4, C1 + C2 <= 1024)", B, D, H, W, sd, sh,
@@ -551,7 +552,8 @@ extern "C" int nextou_upconv_cat_rows(const float* y2, const float* bias, const 
     const int cq = (C1 + C2) / 4, rpp = 256 / cq;
     long long blocks = (P + rpp - 1) / rpp;
     if (blocks > 16384) blocks = 16384;
-    ProfScope prof(s, kBoundHbm, 8.0 * (double)P * (C1 + C2), "upconv_cat_rows_kernel[P%lld C%d+%d s%dx%dx%d]", P, C1, C2, sd, sh, sw);
+    ProfScope prof(s, kBoundHbm, 8.0 * (double)P * (y2 ? C1 + C2 : C2), "upconv_cat_rows_kernel%s[P%lld C%d+%d s%dx%dx%d]", y2 ? "" : "<skip half>", P, C1,
+                   C2, sd, sh, sw);
     hipLaunchKernelGGL(nextou::upconv_cat_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(y2),
                        reinterpret_cast<const float4*>(bias), reinterpret_cast<const float4*>(skip), reinterpret_cast<float4*>(out), P,
                        C1 / 4, C2 / 4, rpp, u);

@@ -79,6 +79,12 @@ struct PwFuse {
     long ldh;
     const float *epi_w, *epi_b, *epi_mean, *epi_invstd;     // EPI = 2: the norm whose backward statistics are collected
     float epi_slope;
+    // up_cout > 0 (pw_rows_kernel, EPI = 0 only): the product is a transposed convolution with kernel == stride (every power-of-two
+    // stride up to 4) — column n = t * up_cout + co of input point p goes to channel co of the OUTPUT point the tap t of p lands on,
+    // row pitch ldy (the concatenation buffer: the up-sampled half is written where torch.cat would copy it); up_bias[co] added
+    int up_cout;
+    UpShuffle up;
+    const float* up_bias;
 };
 
 // sum over the 16 lanes of a DPP row (lanes that share lane >> 4), result in every lane; fixed tree
@@ -216,6 +222,41 @@ __global__ __launch_bounds__(256, 2) void pw_rows_kernel(const float* __restrict
     };
 
     auto epilogue = [&](int p0, int n0) __attribute__((always_inline)) {
+        if (EPI == 0 && fz.up_cout > 0) {
+            // transposed-convolution store: rows of the output volume (see PwFuse).  The input point's coordinates once per point tile,
+            // the tap's offset per channel tile with shifts (strides are 1, 2 or 4)
+            const UpShuffle& u = fz.up;
+            const int Wi = u.W2 / u.sw, Hi = u.H2 / u.sh, Di = u.D2 / u.sd;
+            const int lw = u.sw >> 1, lh = u.sh >> 1;                        // log2 of 1 / 2 / 4 is 0 / 1 / 2 = s >> 1
+            long long rowbase[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int p = min(p0 + (wave * TM + i) * 16 + r16, P - 1);
+                const int w_ = p % Wi, q1 = p / Wi;
+                const int h_ = q1 % Hi, q2 = q1 / Hi;
+                const int d_ = q2 % Di, b_ = q2 / Di;
+                rowbase[i] = (((long long)b_ * u.D2 + (long long)d_ * u.sd) * u.H2 + (long long)h_ * u.sh) * u.W2 + (long long)w_ * u.sw;
+            }
+            const float inv_cout = 1.0f / (float)fz.up_cout;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + j * 16 + kg * 4;
+                if (n >= N) continue;
+                const int t = (int)(((float)n + 0.5f) * inv_cout);           // exact for n < 2^20 (n, up_cout integers; four channels never straddle a tap)
+                const int co = n - t * fz.up_cout;
+                const int tw = t & (u.sw - 1), th = (t >> lw) & (u.sh - 1), td = t >> (lw + lh);
+                const long long toff = ((long long)td * u.H2 + th) * u.W2 + tw;
+                const float4 bv = fz.up_bias ? ld4(fz.up_bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int p = p0 + (wave * TM + i) * 16 + r16;
+                    if (p >= P) continue;
+                    *reinterpret_cast<float4*>(Y + (rowbase[i] + toff) * ldy + co) =
+                        make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
+                }
+            }
+            return;
+        }
         // D tile: column = lane & 15 = point, row = 4 (lane >> 4) + reg = channel -> one 16-byte store per tile and lane
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -1591,6 +1632,28 @@ extern "C" int nextou_pw_rows(const float* x, const float* w, const float* bias,
     ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K * groups, "pw_rows_kernel<%d,%d>[P%lld N%d K%d g%d]", q.tm, q.tn, (long long)P, N, K,
                    groups);
     return dispatch_rows<0, 0>(q, x, w, bias, y, (int)P, N, K, groups, (long)ldx, (long)ldy, vec_store, PwFuse{}, s);
+}
+
+// nextou_pw_rows for a transposed convolution whose kernel equals its stride, writing straight into the concatenation buffer: see PwFuse::up_cout.
+extern "C" int nextou_pw_rows_up(const float* x, const float* w, const float* bias, float* out, int N, int K, int64_t ldx, int64_t ld_out, int B,
+                                 int D, int H, int W, int sd, int sh, int sw, int cout, nextou_stream_t stream) {
+    NEXTOU_REQUIRE(x && w && out, "pw_rows_up: null pointer");
+    NEXTOU_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && (long long)B * D * H * W < 0x7fffffffLL, "pw_rows_up: bad input volume");
+    const int64_t P = (int64_t)B * D * H * W;
+    auto pow2_le4 = [](int v) { return v == 1 || v == 2 || v == 4; };
+    NEXTOU_REQUIRE(pow2_le4(sd) && pow2_le4(sh) && pow2_le4(sw), "pw_rows_up: strides must be 1, 2 or 4 (got %d, %d, %d)", sd, sh, sw);
+    NEXTOU_REQUIRE(cout > 0 && cout % 4 == 0 && N == cout * sd * sh * sw && N < (1 << 20), "pw_rows_up: N = %d is not cout (%d, a multiple of 4) x taps", N, cout);
+    if (int e = check_pw("pw_rows_up", P, N, K, 1, ldx, N, K, N)) return e;
+    NEXTOU_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && ld_out % 4 == 0 && ld_out >= cout && aligned16(x) && aligned16(w) && aligned16(out) &&
+                   (!bias || aligned16(bias)), "pw_rows_up: K, ldx, ld_out multiples of 4 and 16-byte aligned tensors");
+    const RowsPlan q = plan_rows((int)P, N, 1, false);
+    hipStream_t s = (hipStream_t)stream;
+    PwFuse fz{};
+    fz.up_cout = cout;
+    fz.up = UpShuffle{D * sd, H * sh, W * sw, sd, sh, sw};
+    fz.up_bias = bias;
+    ProfScope prof(s, kBoundMfma, 2.0 * (double)P * N * K, "pw_rows_kernel<%d,%d|up>[P%lld N%d K%d s%dx%dx%d]", q.tm, q.tn, (long long)P, N, K, sd, sh, sw);
+    return dispatch_rows<0, 0>(q, x, w, nullptr, out, (int)P, N, K, 1, (long)ldx, (long)ld_out, 1, fz, s);
 }
 
 // Which kernel a fused launch takes and how many statistics partials per channel it writes — ONE function for the launch and for the

@@ -539,6 +539,26 @@ class _HipBackend:
         return out
 
     @staticmethod
+    def upconv_cat_direct(x, w2, bias, skip, stride, cout):
+        """The same concatenation without the (P_in, T * C1) intermediate (round 6): K7 stores the up-convolution's product rows where the
+        pixel shuffle puts them, inside the concatenation buffer (nextou_pw_rows_up); one pass copies the skip half beside them
+        (nextou_upconv_cat_rows, y2 = NULL).  x: dense channels-last (B, Cin, *sp_in); w2 (T * cout, Cin); strides 1 / 2 / 4."""
+        L_ = _lib.lib()
+        B, cin, c2 = x.shape[0], x.shape[1], skip.shape[1]
+        sp = tuple(x.shape[2:])
+        d, h, w = ((1,) + sp)[-3:]
+        sd, sh, sw = ((1,) + tuple(int(v) for v in stride))[-3:]
+        out = _empty_channels_last((B, cout + c2) + tuple(skip.shape[2:]), x.device)
+        with torch.cuda.device(x.device):
+            rc = L_.nextou_pw_rows_up(x.data_ptr(), w2.data_ptr(), _ptr(bias), out.data_ptr(), w2.shape[0], cin, cin, cout + c2, B, d, h, w,
+                                      sd, sh, sw, cout, _stream_ptr(x.device))
+            _lib.check(rc, "pw_rows_up")
+            rc = L_.nextou_upconv_cat_rows(None, None, skip.data_ptr(), out.data_ptr(), B, d, h, w, sd, sh, sw, cout, c2,
+                                           _stream_ptr(x.device))
+        _lib.check(rc, "upconv_cat_rows(skip half)")
+        return out
+
+    @staticmethod
     def upconv_cat_rows_bwd(g, c1, sp_in, stride):
         """g: dense channels-last (B, C1 + C2, *sp_out) -> (gy2 channels-last (B, T*C1, *sp_in), per-channel sums of g[:, :C1]) in one pass,
         or None for a channel count the kernel does not take."""
@@ -2388,8 +2408,12 @@ class _UpConvCat(torch.autograd.Function):
         # (Cin, Cout, *k) -> rows (t, co) x columns ci: the GEMM's (N, K) operand
         n = weight.dim() - 2
         w2 = weight.permute(*range(2, 2 + n), 1, 0).reshape(T * cout, cin).contiguous()
-        y2 = _HIP.pw_rows(x, w2, None, 1)
-        out = _HIP.upconv_cat_rows(y2, None if bias is None else bias.contiguous(), skip, stride)
+        b_ = None if bias is None else bias.contiguous()
+        import os
+        if all(int(v) in (1, 2, 4) for v in stride) and os.environ.get("NEXTOU_UPCONV_DIRECT", "1") != "0":
+            out = _HIP.upconv_cat_direct(x, w2, b_, skip, stride, cout)       # the shuffle in the GEMM's store: no (P_in, T*Cout) intermediate
+        else:
+            out = _HIP.upconv_cat_rows(_HIP.pw_rows(x, w2, None, 1), b_, skip, stride)
         ctx.save_for_backward(x, weight)
         ctx.stride, ctx.has_bias, ctx.cout = tuple(int(v) for v in stride), bias is not None, cout
         return out

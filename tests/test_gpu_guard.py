@@ -369,3 +369,18 @@ def test_upconv_cat_rows(hip, cin, cout, c2, sp, stride):
     go = _cl(torch.randn((2, cout + c2) + sp_out, generator=g).to(DEV))
     _guarded(lambda y2, b, s: hip.upconv_cat_rows(y2, b, s, stride), [y2, bias, skip])
     _guarded(lambda go: hip.upconv_cat_rows_bwd(go, cout, sp, stride), [go])
+
+
+@pytest.mark.parametrize("cin,cout,c2,sp,stride", [(72, 40, 40, (3, 6, 5), (1, 2, 2)), (20, 12, 8, (2, 3, 3), (2, 2, 2)), (24, 12, 8, (5, 7), (2, 4))])
+def test_upconv_cat_direct(hip, cin, cout, c2, sp, stride):
+    """Round 6: the up-convolution's GEMM storing into the concatenation buffer (nextou_pw_rows_up) + the skip-half pass."""
+    g = _gen(cin + cout + 1)
+    T = 1
+    for s_ in stride:
+        T *= s_
+    sp_out = tuple(d * s_ for d, s_ in zip(sp, stride))
+    x = _cl(torch.randn((2, cin) + sp, generator=g).to(DEV))
+    w2 = torch.randn((T * cout, cin), generator=g).to(DEV)
+    skip = _cl(torch.randn((2, c2) + sp_out, generator=g).to(DEV))
+    bias = torch.randn(cout, generator=g).to(DEV)
+    _guarded(lambda x, w2, b, s: hip.upconv_cat_direct(x, w2, b, s, stride, cout), [x, w2, bias, skip])

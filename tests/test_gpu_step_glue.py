@@ -253,6 +253,41 @@ def test_upconv_cat_matches_the_transposed_convolution(hip, cin, cout, c2, sp, s
     assert float((out2.double() - ref2).abs().max()) <= 2e-6 * scale
 
 
+@pytest.mark.parametrize("cin,cout,c2,sp,stride", [
+    (72, 40, 40, (3, 6, 37), (1, 2, 2)),         # ragged point count (666 input points: partial tiles), cfg 2's full-resolution stage shapes
+    (132, 72, 72, (2, 3, 4), (2, 2, 2)),
+    (8, 4, 12, (3, 2, 5), (4, 1, 2)),            # a stride of 4, one of 1
+    (24, 12, 8, (5, 7), (2, 4)),                 # 2-D
+    (16, 8, 8, (2, 2, 3), (3, 1, 2)),            # a stride of 3: not a power of two -> the two-pass route
+])
+def test_upconv_cat_direct_store_equals_the_two_pass_route(hip, monkeypatch, cin, cout, c2, sp, stride):
+    """Round 6: K7 stores the up-convolution's product where the pixel shuffle puts it, inside the concatenation buffer
+    (nextou_pw_rows_up + the skip-half pass); NEXTOU_UPCONV_DIRECT=0 keeps product -> shuffle-concatenation.  Same MFMA chain, same
+    bias add: bit-identical outputs, and the launch profile says which route ran."""
+    import ctypes
+    import json
+    from nextou_amd import _lib, graph_ops
+    g = torch.Generator().manual_seed(3 * cin + cout)
+    x = _cl(torch.randn((2, cin) + sp, generator=g).to(DEV))
+    w = _cl(torch.randn((cin, cout) + stride, generator=g).to(DEV))
+    b = torch.randn(cout, generator=g).to(DEV)
+    skip = _cl(torch.randn((2, c2) + tuple(d * s_ for d, s_ in zip(sp, stride)), generator=g).to(DEV))
+    outs, labels = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NEXTOU_UPCONV_DIRECT", mode)
+        _lib.lib().nextou_profile_enable(64)
+        outs[mode] = graph_ops.upconv_cat(x, w, b, skip, stride)
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = _lib.lib().nextou_profile_report(buf, len(buf))
+        _lib.lib().nextou_profile_enable(0)
+        labels[mode] = [r["kernel"] for r in json.loads(buf.value.decode())] if n else []
+    assert torch.equal(outs["1"], outs["0"])
+    direct = all(v in (1, 2, 4) for v in stride)
+    assert any("|up>" in l for l in labels["1"]) is direct and any("<skip half>" in l for l in labels["1"]) is direct, labels["1"]
+    assert not any("|up>" in l for l in labels["0"])
+
+
 def test_up_conv_cat_takes_the_gemm_route_and_its_switch(hip, monkeypatch):
     from torch import nn
     from nextou_amd.network_architecture import norm_act

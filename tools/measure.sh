@@ -221,6 +221,15 @@ t_k1small() {        # round 6: the one-launch kernel for a handful of small sel
   python tools/kernel_bench.py --cfg 2 --iters 10 2>&1 | grep -E "knn_" > $OUT/kernel_bench_k1_small.txt; grep -E "^s[45]" $OUT/kernel_bench_k1_small.txt
   NEXTOU_KNN_SMALL=0 python tools/kernel_bench.py --cfg 2 --iters 10 2>&1 | grep -E "knn_" > $OUT/kernel_bench_k1_nosmall.txt; grep -E "^s[45]" $OUT/kernel_bench_k1_nosmall.txt
 }
+t_ab6() {            # round 6: same-box A/B of the round's step changes — default against K9 / small kNN / skip fork switched off, alternating
+  OLD="NEXTOU_STEM_BLOCK=0 NEXTOU_KNN_SMALL=0 NEXTOU_SKIP_FORK=0"
+  for i in 1 2; do
+    python bench.py --no-cpu-baseline --steps 20 > $OUT/ab6_new_$i.json 2>/dev/null; field $OUT/ab6_new_$i.json
+    env $OLD python bench.py --no-cpu-baseline --steps 20 > $OUT/ab6_old_$i.json 2>/dev/null; field $OUT/ab6_old_$i.json
+  done
+  NEXTOU_SKIP_FORK=0 python bench.py --no-cpu-baseline --steps 20 > $OUT/ab6_nofork.json 2>/dev/null; field $OUT/ab6_nofork.json
+  NEXTOU_STEM_BLOCK=0 python bench.py --no-cpu-baseline --steps 20 > $OUT/ab6_nostem.json 2>/dev/null; field $OUT/ab6_nostem.json
+}
 t_guard() {
   python -m pytest tests/test_gpu_guard.py tests/test_gpu_head.py -q -m gpu -p no:cacheprovider 2>&1 | grep -v "MIOpen\|GridwiseOp\|amdgpu.ids" > $OUT/guard_pages_pytest.txt; tail -3 $OUT/guard_pages_pytest.txt
 }
