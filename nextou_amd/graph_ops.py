@@ -1297,9 +1297,6 @@ def two_gradients_eligible(x: torch.Tensor, gy: torch.Tensor, g2: torch.Tensor) 
     """K6's two-gradient backward (nextou_norm_act_bwd_two): dense channels-last fp32 ``x`` with C <= 128 a multiple of 4, and ``g2`` the
     same logical shape as a channel range of wider channels-last rows (stride 1 on the channel axis, row stride a multiple of 4, dense
     rows in batch / space order, 16-byte aligned) — the ``g.narrow(1, c, C)`` the concatenation's backward hands the skip connection."""
-    import os
-    if os.environ.get("NEXTOU_SKIP_FORK", "1") == "0":
-        return False
     if not (x.is_cuda and x.dtype == torch.float32 and g2.dtype == torch.float32 and gy.dtype == torch.float32) or x.dim() not in (4, 5):
         return False
     C = x.shape[1]
@@ -1316,11 +1313,15 @@ def two_gradients_eligible(x: torch.Tensor, gy: torch.Tensor, g2: torch.Tensor) 
     return g2.stride(0) == expect
 
 
+SKIP_FORK_DEFAULT = "0"
+
+
 class _SkipFork(torch.autograd.Function):
     """Identity with two outputs for a tensor that has two consumers — an encoder stage's output going to the next stage and, as the skip
     connection, to the decoder (reference NexToU_Encoder_Decoder.py:143-150).  Its backward does NOT add the two incoming gradients: it
     parks the second in the box shared with the producing _NormAct node, whose backward kernels read both (nextou_norm_act_bwd_two) or,
-    where they cannot, add them there.  Saves autograd's own aten::add pass over the stage-0 / stage-1 tensors (0.98 ms of the cfg-2 step)."""
+    where they cannot, add them there.  Removes autograd's own aten::add pass over the stage-0 / stage-1 tensors (0.98 ms of the cfg-2
+    step) — at the price of reading the strided skip gradient twice; see skip_fork for the measured outcome."""
 
     @staticmethod
     def forward(ctx, y, box):
@@ -1339,11 +1340,15 @@ class _SkipFork(torch.autograd.Function):
 def skip_fork(y: torch.Tensor):
     """``(y_next, y_skip)``: the same values twice; when ``y`` comes straight out of a fused norm (_NormAct) and gradients are being
     recorded, the two are tied to that node so that its backward takes their gradients unsummed (see _SkipFork).  Anything else:
-    ``(y, y)``."""
+    ``(y, y)``.
+
+    OFF by default (``NEXTOU_SKIP_FORK=1`` switches it on): measured on one MI355X box, cfg 2, alternating runs
+    (profiles/r06_step_ab.md) the step takes 166.16 / 166.25 ms with it and 166.19 ms without — the two-gradient kernels read the skip
+    gradient as 160-byte halves of 320-byte rows (half-used cache lines, twice), which costs what autograd's add pass saved."""
     import os
     node = y.grad_fn
     if node is None or not torch.is_grad_enabled() or type(node).__name__ != "_NormActBackward" or \
-            os.environ.get("NEXTOU_SKIP_FORK", "1") == "0" or getattr(node, "fork_box", None) is not None:
+            os.environ.get("NEXTOU_SKIP_FORK", SKIP_FORK_DEFAULT) != "1" or getattr(node, "fork_box", None) is not None:
         return y, y
     box = []
     node.fork_box = box

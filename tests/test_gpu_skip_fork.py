@@ -1,4 +1,5 @@
-"""The skip connection's gradient without autograd's add pass (graph_ops.skip_fork, nextou_norm_act_bwd_two; reference
+"""(An experiment kept reachable: OFF by default, NEXTOU_SKIP_FORK=1 — measured neutral on the cfg-2 step, graph_ops.skip_fork.)
+The skip connection's gradient without autograd's add pass (graph_ops.skip_fork, nextou_norm_act_bwd_two; reference
 NexToU_Encoder_Decoder.py:143-150 `skips.append(x)`, :311-337 `torch.cat((x, skip), 1)`): K6's channels-last backward reads the two incoming
 gradients — the next stage's (dense) and the concatenation's (a channel range of wider rows) — and sums them on load.  Bar: identical
 results to the plain path (autograd's aten::add, then nextou_norm_act_bwd) up to the fp32 rounding of the float64 partial sums' inputs —

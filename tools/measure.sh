@@ -156,6 +156,8 @@ t_pmcjson() {
   probe mrgswin python $R/tools/kernel_bench.py --mrg --iters 3 --only swin
   probe mrgpool2 python $R/tools/kernel_bench.py --mrg --iters 3 --only "pool s2"
   probe head python $R/tools/head_bench.py --iters 3 --own-only --only "full res"
+  probe stem python $R/tools/stem_bench.py --iters 3 --two          # round 6: K9 and K6's two-gradient backward at the stage-0 tensor
+  probe s5pool python $R/tools/kernel_bench.py --cfg 2 --iters 3 --only "s5 Pool"      # knn_small_kernel
   cd $R
 }
 t_convtable() {
