@@ -193,7 +193,8 @@ def roofline_graph_from(report):
             # round 5's step glue (ABI v13): the gradient norm + clip / SGD update over the whole parameter list, the decoder concatenation with the
             # up-convolution's pixel shuffle (forward) and its one-pass backward (channel range copied / un-shuffled + bias sums)
             "glue_grad_norm": pick(("multi_sumsq_kernel",)), "glue_clip_sgd": pick(("clip_sgd_kernel",)),
-            "glue_upconv_cat_forward": pick(("upconv_cat_rows_kernel", "cat_bias_rows_kernel")),
+            "glue_upconv_cat_forward": pick(("upconv_cat_rows_kernel", "cat_bias_rows_kernel", "cat_skip_half_kernel")),
+            "K7_upconv_store_in_place": pick(("pw_rows_kernel<2,11|up>", "pw_rows_kernel<2,9|up>", "pw_rows_kernel<2,7|up>", "pw_rows_kernel<2,6|up>")),
             "glue_cat_backward": pick(("narrow_copy_stats_kernel",)),
             "graph_kernels_ms_per_step": None}
 

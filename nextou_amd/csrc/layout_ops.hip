@@ -480,6 +480,24 @@ __global__ __launch_bounds__(256) void upconv_cat_rows_kernel(const float4* __re
     }
 }
 
+// The skip half alone (nextou_upconv_cat_rows with y2 == NULL: the up-sampled half was stored in place by nextou_pw_rows_up): every thread
+// moves a 16-byte piece of the skip rows into channels C1 .. C1 + C2 of the wide rows — no idle lanes (run through upconv_cat_rows_kernel
+// with half of every wave skipping its rows this copy took as long as the whole two-operand pass).
+__global__ __launch_bounds__(256) void cat_skip_half_kernel(const float4* __restrict__ b, float4* __restrict__ out, long long P, int c1q, int c2q,
+                                                            int rows_per_pass) {
+    const int r_local = threadIdx.x / c2q, q = threadIdx.x - r_local * c2q;
+    if (r_local >= rows_per_pass) return;
+    const int cq = c1q + c2q;
+    const long long step = (long long)gridDim.x * rows_per_pass;
+    long long row = (long long)blockIdx.x * rows_per_pass + r_local;
+    for (; row + step < P; row += 2 * step) {
+        const float4 v0 = b[row * c2q + q], v1 = b[(row + step) * c2q + q];
+        out[row * cq + c1q + q] = v0;
+        out[(row + step) * cq + c1q + q] = v1;
+    }
+    if (row < P) out[row * cq + c1q + q] = b[row * c2q + q];
+}
+
 // out[ci][kd][kh][kw][co] (channels-last memory of the (Ci, Co, Kd, Kh, Kw) filter) = w[co][ci][Kd-1-kd][Kh-1-kh][Kw-1-kw]: the filter of the
 // forward convolution that computes a stride-1 convolution's data gradient, from the forward filter in either memory layout (element
 // strides).  One 32 x 32 (co, ci) tile per tap through LDS: reads run along ci (contiguous in a channels-last filter), writes along co.
@@ -549,6 +567,15 @@ extern "C" int nextou_upconv_cat_rows(const float* y2, const float* bias, const 
     hipStream_t s = (hipStream_t)stream;
     const nextou::UpShuffle u{D * sd, H * sh, W * sw, sd, sh, sw};
     const long long P = (long long)B * u.D2 * u.H2 * u.W2;
+    if (y2 == nullptr && C2 / 4 <= 256) {
+        const int rpp2 = 256 / (C2 / 4);
+        long long blocks2 = (P + rpp2 - 1) / rpp2;
+        if (blocks2 > 16384) blocks2 = 16384;
+        ProfScope prof(s, kBoundHbm, 8.0 * (double)P * C2, "cat_skip_half_kernel[P%lld C%d+%d]", P, C1, C2);
+        hipLaunchKernelGGL(nextou::cat_skip_half_kernel, dim3((unsigned)blocks2), dim3(256), 0, s, reinterpret_cast<const float4*>(skip),
+                           reinterpret_cast<float4*>(out), P, C1 / 4, C2 / 4, rpp2);
+        return check_launch("cat_skip_half_kernel");
+    }
     const int cq = (C1 + C2) / 4, rpp = 256 / cq;
     long long blocks = (P + rpp - 1) / rpp;
     if (blocks > 16384) blocks = 16384;

@@ -2415,8 +2415,12 @@ class _UpConvCat(torch.autograd.Function):
         w2 = weight.permute(*range(2, 2 + n), 1, 0).reshape(T * cout, cin).contiguous()
         b_ = None if bias is None else bias.contiguous()
         import os
-        if all(int(v) in (1, 2, 4) for v in stride) and os.environ.get("NEXTOU_UPCONV_DIRECT", "1") != "0":
-            out = _HIP.upconv_cat_direct(x, w2, b_, skip, stride, cout)       # the shuffle in the GEMM's store: no (P_in, T*Cout) intermediate
+        if all(int(v) in (1, 2, 4) for v in stride) and os.environ.get("NEXTOU_UPCONV_DIRECT", "0") == "1":
+            # the shuffle in the GEMM's store, no (P_in, T*Cout) intermediate — OFF by default: measured level with the two-pass route
+            # (165.79 / 165.71 vs 165.76 / 165.89 ms per cfg-2 step, one box, alternating; profiles/r06_step_ab.md).  Both halves of the
+            # concatenation are then written as 160-byte pieces of 320-byte rows, which the memory system takes at ~2.7 TB/s where the
+            # one pass that writes whole rows runs at 5.2
+            out = _HIP.upconv_cat_direct(x, w2, b_, skip, stride, cout)
         else:
             out = _HIP.upconv_cat_rows(_HIP.pw_rows(x, w2, None, 1), b_, skip, stride)
         ctx.save_for_backward(x, weight)
