@@ -1471,6 +1471,348 @@ static void norm_dispatch_clw(const NormArgs& a, const ClwPlan& p, int dtype, hi
 // which channels-last scheme a call takes: the row-packing kernels need C <= 256 and keep only C of their 256 lanes busy
 // once a row no longer fits twice (C > 128: 52 % at C = 132, where the column-blocked scheme reaches 82 %).
 // NEXTOU_CLW=1 forces the wide scheme for every C, NEXTOU_CLW=2 restricts it to C > 256 (A/B).
+// ======================================================================================================
+// K6 for SMALL tensors in ONE launch each way (round 6, SURVEY.md 8(f)-1 at stages 4 / 5).  A graph-stage block of cfg 2 runs five norms
+// over tensors of 0.4 - 14 MB; as statistics -> finalize -> apply (and reduce -> finalize -> apply backwards) each of them is six launches of
+// 4 - 9 us whose run time is latency, not bytes (profiles/r06_gnn45_kernels.txt).  Statistics are per channel, so a workgroup that owns ALL
+// elements of its channels needs nobody else: statistics, finalisation and apply in one kernel, no workspace, no cross-workgroup step.
+//   bn_one_cl_kernel    channels-last rows (R, C): a workgroup owns a column block of 4 NQ channels (NQ = 1 | 2 float4 per row) and walks all
+//                       rows twice (second pass L2 / L1-hot); C / (4 NQ) workgroups.  The lines of a row are shared by 8 / NQ column blocks, which
+//                       the L2 absorbs at these sizes — plan_one() bounds the tensor.
+//   bn_one_rows_kernel  channel-major (B, C, S): a wave owns a channel (batch statistics over its B rows) or — param_period > 0, the caller's
+//                       (1, B' C, S) view — one row (instance statistics); C / 4 workgroups.
+// Same arithmetic as the multi-launch kernels (float64 sums in a fixed order, K6's finalize and apply expressions term for term), so results
+// differ from them only in the order of the float64 partial sums.  fp32, 16-byte aligned, element counts as plan_one() says; everything else
+// (and NEXTOU_K6_ONE=0) takes the multi-launch path.
+// ======================================================================================================
+constexpr int kOneThreads = 256;
+
+__device__ __forceinline__ double wave_sum_from(double v, int lowest) {     // xor tree over lane offsets 32 .. lowest: lanes equal mod `lowest` meet
+    for (int o = 32; o >= lowest; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct OneAffine { float mean, invstd, scale, shift; };
+
+// what bn_finalize_kernel + the apply kernels' prologue compute, for one channel, from its (sum, sum of squares) or the running statistics
+__device__ inline OneAffine one_finalize(double s, double q, double count, int c, int pc, const float* weight, const float* bias,
+                                         const float* pre_bias, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                                         int training, float momentum, float eps, bool writer) {
+    OneAffine a;
+    double var = 0.0;
+    if (training) {
+        const double m = s / count;
+        var = q / count - m * m;
+        if (var < 0.0) var = 0.0;
+        a.mean = (float)m;
+        a.invstd = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+        a.mean = running_mean[c] - (pre_bias ? pre_bias[pc] : 0.f);
+        a.invstd = 1.0f / sqrtf(running_var[c] + eps);
+    }
+    a.scale = (weight ? weight[pc] : 1.f) * a.invstd;
+    a.shift = fmaf(-a.mean, a.scale, bias ? bias[pc] : 0.f);
+    if (writer) {
+        if (save_mean) save_mean[c] = a.mean;
+        if (save_invstd) save_invstd[c] = a.invstd;
+        if (training && running_mean) {
+            const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            const double batch_mean = (double)a.mean + (pre_bias ? (double)pre_bias[pc] : 0.0);
+            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * batch_mean);
+            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+        }
+    }
+    return a;
+}
+
+template <int NQ, bool BWD>
+__global__ __launch_bounds__(kOneThreads) void bn_one_cl_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ out,
+                                                                 const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                 const float* __restrict__ pre_bias, float* running_mean, float* running_var,
+                                                                 float* save_mean, float* save_invstd, float* __restrict__ gweight,
+                                                                 float* __restrict__ gbias, long long R, int C, int training, float momentum,
+                                                                 float eps, float slope) {
+    constexpr int CW = 4 * NQ, RL = kOneThreads / NQ;
+    __shared__ double2 red[kOneThreads / 64][CW];
+    __shared__ float4 aff[CW];              // forward: (scale, shift, -, -); backward: (k1, k2, -, -)
+    const int rq = threadIdx.x % NQ, rl = threadIdx.x / NQ;
+    const int c0 = blockIdx.x * CW + 4 * rq;
+    const bool live = c0 < C;                // (C % 4 == 0: a float4 is all inside or all outside)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double count = (double)R;
+    const float* xp = x + (live ? c0 : 0);
+    float sc[4], sh[4], mn[4], is[4];
+    if (BWD) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = live ? c0 + j : 0;
+            mn[j] = save_mean[c];
+            is[j] = save_invstd[c];
+            sc[j] = (weight ? weight[c] : 1.f) * is[j];
+            sh[j] = fmaf(-mn[j], sc[j], bias ? bias[c] : 0.f);
+        }
+    }
+    // ---- pass 1: (sum, sum of squares) | (sum dz, sum dz * xhat)
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    if (!BWD ? training != 0 : true) {
+        constexpr int U = 4;
+        long long r = rl;
+        for (; r + (U - 1) * RL < R; r += U * RL) {
+            float4 v[U], g[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                v[u] = *reinterpret_cast<const float4*>(xp + (r + u * RL) * C);
+                if (BWD) g[u] = *reinterpret_cast<const float4*>(gy + (live ? c0 : 0) + (r + u * RL) * C);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                const float gv[4] = {BWD ? g[u].x : 0.f, BWD ? g[u].y : 0.f, BWD ? g[u].z : 0.f, BWD ? g[u].w : 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (BWD) {
+                        const float z = fmaf(xv[j], sc[j], sh[j]);
+                        const float dz = z > 0.f ? gv[j] : gv[j] * slope;
+                        const float xh = (xv[j] - mn[j]) * is[j];
+                        a[j] += (double)dz;
+                        b[j] = fma((double)dz, (double)xh, b[j]);
+                    } else {
+                        const double d = (double)xv[j];
+                        a[j] += d;
+                        b[j] = fma(d, d, b[j]);
+                    }
+                }
+            }
+        }
+        for (; r < R; r += RL) {
+            const float4 v = *reinterpret_cast<const float4*>(xp + r * C);
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (BWD) g = *reinterpret_cast<const float4*>(gy + (live ? c0 : 0) + r * C);
+            const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (BWD) {
+                    const float z = fmaf(xv[j], sc[j], sh[j]);
+                    const float dz = z > 0.f ? gv[j] : gv[j] * slope;
+                    const float xh = (xv[j] - mn[j]) * is[j];
+                    a[j] += (double)dz;
+                    b[j] = fma((double)dz, (double)xh, b[j]);
+                } else {
+                    const double d = (double)xv[j];
+                    a[j] += d;
+                    b[j] = fma(d, d, b[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = wave_sum_from(a[j], NQ);
+            b[j] = wave_sum_from(b[j], NQ);
+            if (lane < NQ) red[wave][4 * lane + j] = make_double2(a[j], b[j]);     // lane == rq for the lowest lanes of a wave (64 % NQ == 0)
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < CW) {
+        const int c = blockIdx.x * CW + threadIdx.x;
+        if (c < C) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int w = 0; w < kOneThreads / 64; ++w) { s += red[w][threadIdx.x].x; q += red[w][threadIdx.x].y; }
+            if (BWD) {
+                aff[threadIdx.x] = training ? make_float4((float)(s / count), (float)(q / count), 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gweight) gweight[c] = (float)q;
+                if (gbias) gbias[c] = (float)s;
+            } else {
+                const OneAffine f = one_finalize(s, q, count, c, c, weight, bias, pre_bias, running_mean, running_var, save_mean, save_invstd,
+                                                 training, momentum, eps, true);
+                aff[threadIdx.x] = make_float4(f.scale, f.shift, 0.f, 0.f);
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    float p0[4], p1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { p0[j] = aff[4 * rq + j].x; p1[j] = aff[4 * rq + j].y; }
+    // ---- pass 2: y | gx
+    float* op = out + c0;
+    const float* gp = BWD ? gy + c0 : nullptr;
+    constexpr int U2 = 4;
+    long long r = rl;
+    for (; r + (U2 - 1) * RL < R; r += U2 * RL) {
+        float4 v[U2], g[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            v[u] = *reinterpret_cast<const float4*>(xp + (r + u * RL) * C);
+            if (BWD) g[u] = *reinterpret_cast<const float4*>(gp + (r + u * RL) * C);
+        }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            const float gv[4] = {BWD ? g[u].x : 0.f, BWD ? g[u].y : 0.f, BWD ? g[u].z : 0.f, BWD ? g[u].w : 0.f};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (BWD) {
+                    const float z = fmaf(xv[j], sc[j], sh[j]);
+                    const float dz = z > 0.f ? gv[j] : gv[j] * slope;
+                    const float xh = (xv[j] - mn[j]) * is[j];
+                    o[j] = sc[j] * ((dz - p0[j]) - xh * p1[j]);
+                } else {
+                    o[j] = leaky(fmaf(xv[j], p0[j], p1[j]), slope);
+                }
+            }
+            *reinterpret_cast<float4*>(op + (r + u * RL) * C) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    for (; r < R; r += RL) {
+        const float4 v = *reinterpret_cast<const float4*>(xp + r * C);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (BWD) g = *reinterpret_cast<const float4*>(gp + r * C);
+        const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (BWD) {
+                const float z = fmaf(xv[j], sc[j], sh[j]);
+                const float dz = z > 0.f ? gv[j] : gv[j] * slope;
+                const float xh = (xv[j] - mn[j]) * is[j];
+                o[j] = sc[j] * ((dz - p0[j]) - xh * p1[j]);
+            } else {
+                o[j] = leaky(fmaf(xv[j], p0[j], p1[j]), slope);
+            }
+        }
+        *reinterpret_cast<float4*>(op + r * C) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(kOneThreads) void bn_one_rows_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ out,
+                                                                   const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                   const float* __restrict__ pre_bias, float* running_mean, float* running_var,
+                                                                   float* save_mean, float* save_invstd, float* __restrict__ gweight,
+                                                                   float* __restrict__ gbias, int B, int C, long long S, int wmod, int training,
+                                                                   float momentum, float eps, float slope) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (kOneThreads / 64) + wave;
+    if (c >= C) return;                      // (whole waves leave: no barrier below)
+    const int pc = wmod > 0 ? c % wmod : c;
+    const double count = (double)B * (double)S;
+    const long long S4 = S >> 2;            // S % 4 == 0 (plan_one)
+    float sc = 0.f, sh = 0.f, mn = 0.f, is = 0.f;
+    if (BWD) {
+        mn = save_mean[c];
+        is = save_invstd[c];
+        sc = (weight ? weight[pc] : 1.f) * is;
+        sh = fmaf(-mn, sc, bias ? bias[pc] : 0.f);
+    }
+    double a = 0.0, b = 0.0;
+    if (BWD || training) {
+        for (int bb = 0; bb < B; ++bb) {
+            const float4* xr = reinterpret_cast<const float4*>(x + ((long long)bb * C + c) * S);
+            const float4* gr = BWD ? reinterpret_cast<const float4*>(gy + ((long long)bb * C + c) * S) : nullptr;
+            long long i = lane;
+            for (; i + 192 < S4; i += 256) {
+                float4 v[4], g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v[u] = xr[i + 64 * u]; if (BWD) g[u] = gr[i + 64 * u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    const float gv[4] = {BWD ? g[u].x : 0.f, BWD ? g[u].y : 0.f, BWD ? g[u].z : 0.f, BWD ? g[u].w : 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (BWD) {
+                            const float z = fmaf(xv[j], sc, sh);
+                            const float dz = z > 0.f ? gv[j] : gv[j] * slope;
+                            a += (double)dz;
+                            b = fma((double)dz, (double)((xv[j] - mn) * is), b);
+                        } else {
+                            const double d = (double)xv[j];
+                            a += d;
+                            b = fma(d, d, b);
+                        }
+                    }
+                }
+            }
+            for (; i < S4; i += 64) {
+                const float4 v = xr[i];
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (BWD) g = gr[i];
+                const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (BWD) {
+                        const float z = fmaf(xv[j], sc, sh);
+                        const float dz = z > 0.f ? gv[j] : gv[j] * slope;
+                        a += (double)dz;
+                        b = fma((double)dz, (double)((xv[j] - mn) * is), b);
+                    } else {
+                        const double d = (double)xv[j];
+                        a += d;
+                        b = fma(d, d, b);
+                    }
+                }
+            }
+        }
+        a = wave_sum_from(a, 1);
+        b = wave_sum_from(b, 1);
+    }
+    float p0, p1;
+    if (BWD) {
+        p0 = training ? (float)(a / count) : 0.f;
+        p1 = training ? (float)(b / count) : 0.f;
+        if (lane == 0) {
+            if (gweight) gweight[c] = (float)b;
+            if (gbias) gbias[c] = (float)a;
+        }
+    } else {
+        const OneAffine f = one_finalize(a, b, count, c, pc, weight, bias, pre_bias, wmod > 0 ? nullptr : running_mean,
+                                         wmod > 0 ? nullptr : running_var, save_mean, save_invstd, training, momentum, eps, lane == 0);
+        p0 = f.scale;
+        p1 = f.shift;
+    }
+    for (int bb = 0; bb < B; ++bb) {
+        const float4* xr = reinterpret_cast<const float4*>(x + ((long long)bb * C + c) * S);
+        const float4* gr = BWD ? reinterpret_cast<const float4*>(gy + ((long long)bb * C + c) * S) : nullptr;
+        float4* orow = reinterpret_cast<float4*>(out + ((long long)bb * C + c) * S);
+        for (long long i = lane; i < S4; i += 64) {
+            const float4 v = xr[i];
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (BWD) g = gr[i];
+            const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (BWD) {
+                    const float z = fmaf(xv[j], sc, sh);
+                    const float dz = z > 0.f ? gv[j] : gv[j] * slope;
+                    o[j] = sc * ((dz - p0) - ((xv[j] - mn) * is) * p1);
+                } else {
+                    o[j] = leaky(fmaf(xv[j], p0, p1), slope);
+                }
+            }
+            orow[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// 0: not taken; 1 | 2: float4 columns per workgroup (channels-last); 3: the channel-major kernel
+static int plan_one(int B, int C, long long S, int channels_last, int dtype, int param_period, bool aligned, int n_partial) {
+    static const bool enabled = [] { const char* e = getenv("NEXTOU_K6_ONE"); return !(e && e[0] == '0'); }();
+    if (!enabled || dtype != NEXTOU_DTYPE_F32 || !aligned || n_partial > 0) return 0;
+    const long long total = (long long)B * C * S;
+    long long max_total = 4LL << 20;                            // 16 MB: every line is re-fetched by the 8 / NQ column blocks that share it
+    if (const char* e = getenv("NEXTOU_K6_ONE_MAX")) max_total = atoll(e);       // experiments
+    if (total > max_total) return 0;
+    if (channels_last) {
+        if (param_period || C % 4 != 0) return 0;
+        return C >= 512 ? 2 : 1;
+    }
+    if (S % 4 != 0 || (long long)B * S > (1LL << 16)) return 0;                  // a wave per channel: at most 64 K elements of statistics each
+    return 3;
+}
+
 static bool use_clw(int C) {
     static const int mode = [] { const char* e = getenv("NEXTOU_CLW"); return e ? atoi(e) : 0; }();
     if (mode == 1) return true;
@@ -1516,6 +1858,27 @@ extern "C" int nextou_norm_act_fwd(const void* x, const float* weight, const flo
     a.x = x; a.y = y; a.weight = weight; a.bias = bias; a.pre_bias = pre_bias; a.running_mean = running_mean; a.running_var = running_var;
     a.save_mean = save_mean; a.save_invstd = save_invstd; a.partial = (double2*)ws; a.B = B; a.C = C; a.S = S;
     a.wmod = param_period; a.training = training; a.momentum = momentum; a.eps = eps; a.slope = slope;
+    if (const int one = plan_one(B, C, S, channels_last, dtype, param_period, aligned16(x) && aligned16(y), 0)) {
+        hipStream_t s = (hipStream_t)stream;
+        const float* xf = (const float*)x;
+        float* yf = (float*)y;
+        const double bytes = 4.0 * B * (double)C * (double)S;
+        if (one == 3) {
+            ProfScope prof(s, kBoundHbm, 2.0 * bytes, "bn_one_rows_kernel<fwd>[B%d C%d S%lld]", B, C, (long long)S);
+            hipLaunchKernelGGL((bn_one_rows_kernel<false>), dim3(cdiv(C, kOneThreads / 64)), dim3(kOneThreads), 0, s, xf, nullptr, yf, weight, bias, pre_bias,
+                               running_mean, running_var, save_mean, save_invstd, nullptr, nullptr, B, C, (long long)S, param_period, training, momentum,
+                               eps, slope);
+        } else {
+            ProfScope prof(s, kBoundHbm, 2.0 * bytes, "bn_one_cl_kernel<fwd,%d>[R%lld C%d]", one, (long long)B * S, C);
+            if (one == 2)
+                hipLaunchKernelGGL((bn_one_cl_kernel<2, false>), dim3(cdiv(C, 8)), dim3(kOneThreads), 0, s, xf, nullptr, yf, weight, bias, pre_bias,
+                                   running_mean, running_var, save_mean, save_invstd, nullptr, nullptr, (long long)B * S, C, training, momentum, eps, slope);
+            else
+                hipLaunchKernelGGL((bn_one_cl_kernel<1, false>), dim3(cdiv(C, 4)), dim3(kOneThreads), 0, s, xf, nullptr, yf, weight, bias, pre_bias,
+                                   running_mean, running_var, save_mean, save_invstd, nullptr, nullptr, (long long)B * S, C, training, momentum, eps, slope);
+        }
+        return check_launch("bn_one_kernel<fwd>");
+    }
     if (channels_last) {
         NEXTOU_REQUIRE(save_mean && save_invstd, "norm_act_fwd: the channels-last path needs save_mean / save_invstd");
         NEXTOU_REQUIRE(!training || (ws && ws_bytes >= nextou_norm_act_workspace_bytes(B, C, S, dtype)),
@@ -1550,6 +1913,29 @@ extern "C" int nextou_norm_act_bwd(const void* x, const void* gy, const float* w
     a.save_mean = const_cast<float*>(save_mean); a.save_invstd = const_cast<float*>(save_invstd);
     a.gweight = gweight; a.gbias = gbias; a.partial = (double2*)ws; a.B = B; a.C = C; a.S = S; a.wmod = param_period;
     a.training = training; a.slope = slope;
+    if (const int one = plan_one(B, C, S, channels_last, dtype, param_period, aligned16(x) && aligned16(gy) && aligned16(gx), 0)) {
+        hipStream_t s = (hipStream_t)stream;
+        const float *xf = (const float*)x, *gf = (const float*)gy;
+        float* of = (float*)gx;
+        const double bytes = 4.0 * B * (double)C * (double)S;
+        if (one == 3) {
+            ProfScope prof(s, kBoundHbm, 3.0 * bytes, "bn_one_rows_kernel<bwd>[B%d C%d S%lld]", B, C, (long long)S);
+            hipLaunchKernelGGL((bn_one_rows_kernel<true>), dim3(cdiv(C, kOneThreads / 64)), dim3(kOneThreads), 0, s, xf, gf, of, weight, bias, nullptr, nullptr,
+                               nullptr, const_cast<float*>(save_mean), const_cast<float*>(save_invstd), gweight, gbias, B, C, (long long)S, param_period,
+                               training, 0.f, 0.f, slope);
+        } else {
+            ProfScope prof(s, kBoundHbm, 3.0 * bytes, "bn_one_cl_kernel<bwd,%d>[R%lld C%d]", one, (long long)B * S, C);
+            if (one == 2)
+                hipLaunchKernelGGL((bn_one_cl_kernel<2, true>), dim3(cdiv(C, 8)), dim3(kOneThreads), 0, s, xf, gf, of, weight, bias, nullptr, nullptr, nullptr,
+                                   const_cast<float*>(save_mean), const_cast<float*>(save_invstd), gweight, gbias, (long long)B * S, C, training, 0.f, 0.f,
+                                   slope);
+            else
+                hipLaunchKernelGGL((bn_one_cl_kernel<1, true>), dim3(cdiv(C, 4)), dim3(kOneThreads), 0, s, xf, gf, of, weight, bias, nullptr, nullptr, nullptr,
+                                   const_cast<float*>(save_mean), const_cast<float*>(save_invstd), gweight, gbias, (long long)B * S, C, training, 0.f, 0.f,
+                                   slope);
+        }
+        return check_launch("bn_one_kernel<bwd>");
+    }
     if (channels_last) {
         if (ws_bytes < nextou_norm_act_workspace_bytes(B, C, S, dtype))
             return fail(NEXTOU_ENOSPACE, "norm_act_bwd: workspace %zu < %zu bytes", ws_bytes, nextou_norm_act_workspace_bytes(B, C, S, dtype));
