@@ -1478,7 +1478,7 @@ static void norm_dispatch_clw(const NormArgs& a, const ClwPlan& p, int dtype, hi
 // elements of its channels needs nobody else: statistics, finalisation and apply in one kernel, no workspace, no cross-workgroup step.
 //   bn_one_cl_kernel    channels-last rows (R, C): a workgroup owns a column block of 4 NQ channels (NQ = 1 | 2 float4 per row) and walks all
 //                       rows twice (second pass L2 / L1-hot); C / (4 NQ) workgroups.  The lines of a row are shared by 8 / NQ column blocks, which
-//                       the L2 absorbs at these sizes — plan_one() bounds the tensor.
+//                       the L2 absorbs at these sizes — plan_one() bounds the tensor (<= 2 MB: stage 5 of cfg 2; measured, see there).
 //   bn_one_rows_kernel  channel-major (B, C, S): a wave owns a channel (batch statistics over its B rows) or — param_period > 0, the caller's
 //                       (1, B' C, S) view — one row (instance statistics); C / 4 workgroups.
 // Same arithmetic as the multi-launch kernels (float64 sums in a fixed order, K6's finalize and apply expressions term for term), so results
@@ -1802,7 +1802,10 @@ static int plan_one(int B, int C, long long S, int channels_last, int dtype, int
     static const bool enabled = [] { const char* e = getenv("NEXTOU_K6_ONE"); return !(e && e[0] == '0'); }();
     if (!enabled || dtype != NEXTOU_DTYPE_F32 || !aligned || n_partial > 0) return 0;
     const long long total = (long long)B * C * S;
-    long long max_total = 4LL << 20;                            // 16 MB: every line is re-fetched by the 8 / NQ column blocks that share it
+    // measured as replayed blocks (profiles/r06_k6_one.md): stage 5 of cfg 2 (336 rows: FFN 131 -> 106 us, graphers 254 -> 218 / 240 -> 203 us
+    // forward + backward) wins, stage 4 (2 688 rows: FFN 282 -> 318 us) loses — a workgroup walking 2 688 rows of 16-byte pieces is slower than
+    // three launches that spread them over the chip — so: tensors up to 2 MB
+    long long max_total = 1LL << 19;
     if (const char* e = getenv("NEXTOU_K6_ONE_MAX")) max_total = atoll(e);       // experiments
     if (total > max_total) return 0;
     if (channels_last) {

@@ -35,12 +35,12 @@ def _labels(fn):
 
 CASES = [
     # shape, channels-last, instance period
-    ((2, 324, 8, 14, 12), True, 0),        # cfg-2 stage 4: fc1 / fc2 / FFN output
-    ((2, 1296, 8, 14, 12), True, 0),       # the FFN's hidden tensor: two float4 columns per workgroup
-    ((2, 324, 4, 7, 6), True, 0),          # stage 5
+    ((2, 324, 4, 7, 6), True, 0),          # cfg-2 stage 5: fc1 / fc2 / FFN output
+    ((2, 1296, 4, 7, 6), True, 0),         # the FFN's hidden tensor: two float4 columns per workgroup
+    ((1, 520, 8, 14, 8), True, 0),         # 896 rows, a ragged last column block (520 = 65 x 8)
     ((1, 8, 3, 5, 7), True, 0),            # ragged rows, fewer rows than row lanes
     ((3, 12, 9, 11), True, 0),             # 2-D
-    ((1, 2 * 648, 1344), False, 648),      # Pool MRConv's InstanceNorm at stage 4: the caller's (1, B C, S) view
+    ((1, 2 * 648, 168), False, 648),       # Pool MRConv's InstanceNorm at stage 5: the caller's (1, B C, S) view
     ((2, 10, 160), False, 0),              # channel-major batch statistics over two rows per channel
     ((1, 6, 4), False, 3),                 # one float4 per row
 ]
@@ -82,7 +82,7 @@ def test_one_launch_norm_equals_the_multi_launch_path(ops, monkeypatch, shape, c
         assert float((a_ - e_).abs().max()) <= 2e-6 * float(e_.abs().max()) + 1e-30, name
 
 
-@pytest.mark.parametrize("shape", [(2, 324, 4, 7, 6), (2, 520, 3, 5, 4)])
+@pytest.mark.parametrize("shape", [(2, 324, 4, 7, 6), (2, 520, 3, 5, 4)])     # (both below the 2-MB bound of plan_one)
 def test_one_launch_norm_against_float64_autograd(ops, shape):
     g = torch.Generator().manual_seed(shape[1])
     mf = torch.channels_last_3d
