@@ -47,7 +47,7 @@ sys.path.insert(0, REPO)
 from nextou_amd import _lib, graph_ops  # noqa: E402
 from nextou_amd.ddp import BucketedGradientAverager, init_process_group_from_env, init_single_process_group  # noqa: E402
 from nextou_amd.launch import check_world, needs_self_launch, self_launch  # noqa: E402
-from nextou_amd.harness import (GraphedTrainStep, config_3d_fullres_nextou, deep_supervision_weights, downsample_targets,  # noqa: E402
+from nextou_amd.harness import (GraphedTrainStep, SplitGraphedTrainStep, config_3d_fullres_nextou, deep_supervision_weights, downsample_targets,  # noqa: E402
                                 synthetic_batch)
 from nextou_amd.loss.nnunet_losses import DeepSupervisionWrapper, RobustCrossEntropyLoss  # noqa: E402
 from nextou_amd.nnUNetTrainer.nnUNetTrainer_NexToU import nnUNetTrainer_NexToU  # noqa: E402
@@ -108,29 +108,56 @@ def move_to(trainer, device, fused_sgd=False):
         trainer.loss = trainer._build_loss()      # interaction tensors follow the device
 
 
-def make_step(trainer, data, targets, averager, bf16=False):
-    params = [p for p in trainer.network.parameters() if p.requires_grad]
+class TrainStep:
+    """One training step in three parts — ``part1`` (zero_grad -> forward -> loss -> backward [+ the buckets' stragglers filled]), ``between``
+    (the bucket all-reduces still to launch, and the join) and ``part2`` (1 / world scale -> clip_grad_norm_(12) -> SGD) — so that it can run
+    eagerly (``step()``), as one hipGraph (harness.GraphedTrainStep(step)) or as two graphs around eager collectives
+    (harness.SplitGraphedTrainStep(step.part1, step.between, step.part2))."""
 
-    def step():
-        if averager is not None:
-            averager.zero_grad()                 # same effect, keeps the flat buckets
-        trainer.optimizer.zero_grad(set_to_none=True)
-        if bf16:
+    def __init__(self, trainer, data, targets, averager, bf16=False):
+        self.trainer, self.data, self.targets, self.averager, self.bf16 = trainer, data, targets, averager, bf16
+        self.params = [p for p in trainer.network.parameters() if p.requires_grad]
+
+    def part1(self):
+        tr = self.trainer
+        if self.averager is not None:
+            self.averager.zero_grad()                 # same effect, keeps the flat buckets
+        tr.optimizer.zero_grad(set_to_none=True)
+        if self.bf16:
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                outs = trainer.network(data)
-            loss = trainer.loss([o.float() for o in outs], targets)
+                outs = tr.network(self.data)
+            loss = tr.loss([o.float() for o in outs], self.targets)
         else:
-            loss = trainer.loss(trainer.network(data), targets)
+            loss = tr.loss(tr.network(self.data), self.targets)
         loss.backward()
-        if averager is not None:
-            averager.finalize()
-        if hasattr(trainer.optimizer, "clip_and_step"):
-            trainer.optimizer.clip_and_step(12)      # clip_grad_norm_(params, 12) + SGD step on the step-glue kernels
-        else:
-            torch.nn.utils.clip_grad_norm_(params, 12)
-            trainer.optimizer.step()
+        if self.averager is not None:
+            self.averager.fill_missing()
         return loss
-    return step
+
+    def between(self):
+        if self.averager is not None:
+            self.averager.reduce_all()
+            self.averager.wait_all()
+
+    def part2(self):
+        tr = self.trainer
+        if self.averager is not None:
+            self.averager.finish_local()
+        if hasattr(tr.optimizer, "clip_and_step"):
+            tr.optimizer.clip_and_step(12)            # clip_grad_norm_(params, 12) + SGD step on the step-glue kernels
+        else:
+            torch.nn.utils.clip_grad_norm_(self.params, 12)
+            tr.optimizer.step()
+
+    def __call__(self):
+        loss = self.part1()
+        self.between()
+        self.part2()
+        return loss
+
+
+def make_step(trainer, data, targets, averager, bf16=False):
+    return TrainStep(trainer, data, targets, averager, bf16)
 
 
 def profile_report():
@@ -375,12 +402,13 @@ def main():
     ap.add_argument("--autocast-bf16", action="store_true",
                     help="informational (cfg-5 regime): conv stages under bf16 autocast, graph ops stay fp32; "
                          "never the headline number")
-    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="replay the training step as one captured hipGraph (harness.GraphedTrainStep).  auto = on for N = 1, every workload "
-                         "(cfg 4: the BTI target validation runs on the device, checked after timing), falling back to the eager step if the "
-                         "capture fails (error reported in the JSON line); auto = OFF whenever a process group is up (N > 1, --force-averager): "
-                         "capturing RCCL collectives can end in an uncatchable abort inside PyTorch's watchdog thread (DESIGN.md 6), so the "
-                         "averaged step is captured only on an explicit `on`, which raises if the capture fails")
+    ap.add_argument("--graph", choices=("auto", "on", "off", "split"), default="auto",
+                    help="how the step is replayed.  auto: N = 1 -> ONE captured hipGraph (harness.GraphedTrainStep; cfg 4: the BTI target "
+                         "validation runs on the device, checked after timing); with a process group up (N > 1, --force-averager) -> `split`: two "
+                         "hipGraphs around EAGER bucket all-reduces (harness.SplitGraphedTrainStep) — no collective is captured, because capturing "
+                         "RCCL collectives can end in an uncatchable abort inside PyTorch's watchdog thread (DESIGN.md 6).  auto falls back to the "
+                         "eager step if a capture fails (error reported in the JSON line).  on: one graph, collectives included (raises if the "
+                         "capture fails); off: the eager step")
     ap.add_argument("--channels-last", action="store_true",
                     help="experiment: run the dense stages in channels_last_3d (NDHWC) memory format")
     args = ap.parse_args()
@@ -431,23 +459,31 @@ def main():
     # auto: the whole step as one hipGraph, N = 1 and N > 1 alike (the averaged step is capturable: RCCL collectives on their
     # own stream, no host synchronisation in the hooks or in finalize() once the warm-up steps have seen the gradient pattern)
     # (gloo — the two-ranks-on-one-GPU test backend — synchronises with the host inside its collectives and cannot be captured)
-    # round 6: with a process group up the default is the EAGER step — same kernels, same overlap of
-    # the bucket all-reduces with backward; the captured averaged step stays available under `--graph on`
-    want_graph = args.graph == "on" or (args.graph == "auto" and averager is None)
-    graph_mode = ("captured (--graph on)" if args.graph == "on" else "eager (--graph off)" if args.graph == "off" else
-                  "captured (auto: no process group)" if averager is None else
-                  "eager (auto: a process group is up; RCCL collectives are captured only on --graph on)")
+    # round 6: with a process group up the default keeps the collectives OUT of any capture — two graphs
+    # around eager all-reduces; the single graph with captured collectives stays available under `--graph on`
+    split = args.graph == "split" or (args.graph == "auto" and averager is not None)
+    want_graph = args.graph in ("on", "split") or args.graph == "auto"
+    graph_mode = ("one graph, collectives captured (--graph on)" if args.graph == "on" else "eager (--graph off)" if args.graph == "off" else
+                  "one graph (auto: no process group)" if not split else
+                  "two graphs around eager collectives (%s)" % ("--graph split" if args.graph == "split" else
+                                                                "auto: a process group is up; RCCL collectives are captured only on --graph on"))
     graphed, capture_error = None, None
     if want_graph:
         try:
-            graphed = GraphedTrainStep(step, warmup=1, network=trainer.network, loss=trainer.loss)
+            if split and averager is not None:
+                averager.defer_collectives = True
+                graphed = SplitGraphedTrainStep(step.part1, step.between, step.part2, warmup=1, network=trainer.network, loss=trainer.loss)
+            else:
+                graphed = GraphedTrainStep(step, warmup=1, network=trainer.network, loss=trainer.loss)
             for _ in range(2):
                 graphed()
         except Exception as exc:
             # never silent: `--graph on` fails; `auto` falls back to the eager step — the same computation —
             # and the JSON line says so (config.step_replayed_as_hipgraph = false, config.graph_capture_error)
-            if args.graph == "on":
+            if args.graph in ("on", "split"):
                 raise
+            if averager is not None:
+                averager.defer_collectives = False        # the eager step overlaps the collectives with backward again
             capture_error = "%s: %s" % (type(exc).__name__, exc)
             print("bench.py: hipGraph capture failed (%s); timing the eager step" % capture_error, file=sys.stderr)
             graphed = None
@@ -542,7 +578,8 @@ def main():
                             "torch": "ClipSGD -> torch foreach: %s" % getattr(trainer.optimizer, "last_reason", None)}.get(
                                trainer.optimizer.last_path, "not stepped") if hasattr(trainer.optimizer, "last_path")
                            else ("fused" if trainer.optimizer.defaults.get("fused") else "foreach")),
-                       "step_replayed_as_hipgraph": graphed is not None, "graph_capture_error": capture_error, "graph_mode": graph_mode,
+                       "step_replayed_as_hipgraph": graphed is not None, "graph_capture_error": capture_error,
+                       "graph_mode": graph_mode if graphed is not None or not want_graph else "eager (the capture failed)",
                        "parallelism": "dp%d" % world, "final_loss": float(loss.detach())},
             "dist": dist_info,
             "parity": parity_record(args.workload),

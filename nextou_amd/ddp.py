@@ -26,7 +26,7 @@ import torch.distributed as dist
 class _Bucket:
     """One flat all-reduce unit: the gradients of ``params`` back to back, then one float per parameter that says
     whether any rank produced a gradient for it this step (summed by the same collective — no extra launch)."""
-    __slots__ = ("flat", "params", "offsets", "views", "flags", "pending", "filled", "work", "n_grad")
+    __slots__ = ("flat", "params", "offsets", "views", "flags", "pending", "filled", "work", "n_grad", "ready")
 
     @staticmethod
     def _view_like(flat: torch.Tensor, offset: int, p: torch.Tensor) -> torch.Tensor:
@@ -52,6 +52,7 @@ class _Bucket:
         self.pending = len(params)
         self.filled = [False] * len(params)
         self.work = None
+        self.ready = False           # filled (copies + flags written) in this step
 
 
 def _dense_strides(p: torch.Tensor) -> bool:
@@ -111,6 +112,10 @@ class BucketedGradientAverager:
         self._produced_cache = {}
         self._missing_cache = {}
         self._mismatch = torch.zeros((), dtype=torch.long, device=params[0].device) if params else None
+        # True: the hooks only FILL the buckets (copies, flags); the collectives are launched by reduce_all() after backward — the form a step
+        # captured as two hipGraphs around eager collectives needs (harness.SplitGraphedTrainStep); False: each bucket is all-reduced the
+        # moment it is full, overlapping the rest of backward
+        self.defer_collectives = False
         for bi, b in enumerate(self.buckets):
             for pi, p in enumerate(b.params):
                 self._slot[p] = (bi, pi)
@@ -156,6 +161,16 @@ class BucketedGradientAverager:
 
     @torch.no_grad()
     def _launch(self, b: _Bucket) -> None:
+        self._fill(b)
+        if not self.defer_collectives:
+            self._reduce(b)
+
+    @torch.no_grad()
+    def _reduce(self, b: _Bucket) -> None:
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    @torch.no_grad()
+    def _fill(self, b: _Bucket) -> None:
         src, dst, empty = [], [], []
         for pi, p in enumerate(b.params):
             if b.filled[pi]:
@@ -173,7 +188,7 @@ class BucketedGradientAverager:
         if empty:
             torch._foreach_zero_(empty)                              # one multi-tensor launch, not one per parameter
             b.flags.index_fill_(0, self._missing_index(b, tuple(b.filled)), 0.0)
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b.ready = True
 
     @torch.no_grad()
     def _on_grad_ready(self, p: torch.nn.Parameter) -> None:
@@ -182,27 +197,45 @@ class BucketedGradientAverager:
         if not b.filled[pi]:
             b.filled[pi] = True
             b.pending -= 1
-        if b.pending == 0 and b.work is None:
+        if b.pending == 0 and b.work is None and not b.ready:
             self._launch(b)
 
     @torch.no_grad()
-    def finalize(self) -> None:
-        """Join the collectives.  Buckets with a parameter that got no gradient on this rank (e.g. the zero-weighted
-        lowest deep-supervision head) are launched here with zeros in its place.
+    def fill_missing(self) -> None:
+        """After backward: fill the buckets whose last gradient never came (a parameter without a gradient on this rank, e.g. the
+        zero-weighted lowest deep-supervision head, gets zeros in its place)."""
+        for b in self.buckets:
+            if not b.ready:
+                self._fill(b)
 
-        No host synchronisation after the first step of a given pattern, so a whole averaged step can be captured into one
-        hipGraph (``harness.GraphedTrainStep``; RCCL collectives are capturable): which parameters NO rank produced a
-        gradient for — those keep ``grad = None`` — is read back once per distinct local pattern and remembered.  That is
-        sound only while the pattern is STRUCTURAL, i.e. the same on every rank and every step (the zero-weighted head).
-        The summed flags show a violation on the device (0 < flag < world: some ranks produced the gradient, others did
-        not); every step adds those to a device counter, and :meth:`check_consistency` — one host read, called by the
-        caller wherever it synchronises anyway — raises if the contract was ever broken."""
+    @torch.no_grad()
+    def reduce_all(self) -> None:
+        """Launch the collective of every bucket that has none in flight (all of them under ``defer_collectives``).  Stateless with respect
+        to the hooks' bookkeeping: a step replayed from hipGraphs never runs the hooks again, and calls this between the two graphs."""
         for b in self.buckets:
             if b.work is None:
-                self._launch(b)
+                self._reduce(b)
+
+    @torch.no_grad()
+    def wait_all(self) -> None:
+        """The current stream waits for the collectives (no host synchronisation with RCCL)."""
+        for b in self.buckets:
+            if b.work is not None:
+                b.work.wait()
+                b.work = None
+
+    @torch.no_grad()
+    def finish_local(self) -> None:
+        """What follows the collectives, device-side only (capturable): the rank-consistency count, the 1 / world scale, ``p.grad`` pointed
+        at the reduced bucket views (``None`` for parameters NO rank produced a gradient for), the hooks' bookkeeping reset.
+
+        No host synchronisation after the first step of a given pattern: which parameters no rank produced a gradient for is read back once
+        per distinct local pattern and remembered.  That is sound only while the pattern is STRUCTURAL, i.e. the same on every rank and every
+        step (the zero-weighted head).  The summed flags show a violation on the device (0 < flag < world: some ranks produced the gradient,
+        others did not); every step adds those to a device counter, and :meth:`check_consistency` — one host read, called by the caller
+        wherever it synchronises anyway — raises if the contract was ever broken."""
         inv = 1.0 / self.world
         for bi, b in enumerate(self.buckets):
-            b.work.wait()
             if self.world > 1:
                 self._mismatch.add_(((b.flags > 0) & (b.flags < self.world)).sum())
             b.flat[:b.n_grad].mul_(inv)
@@ -219,9 +252,19 @@ class BucketedGradientAverager:
                 produced = self._produced_cache[key]
             for pi, p in enumerate(b.params):
                 p.grad = b.views[pi] if (produced is None or produced[pi]) else None
-            b.work = None
             b.pending = len(b.params)
             b.filled = [False] * len(b.params)
+            b.ready = False
+
+    @torch.no_grad()
+    def finalize(self) -> None:
+        """Join the collectives: ``fill_missing`` -> ``reduce_all`` -> ``wait_all`` -> ``finish_local``.  With the default
+        (``defer_collectives = False``) most buckets are already in flight — launched from the hooks during backward — and only the
+        stragglers start here."""
+        self.fill_missing()
+        self.reduce_all()
+        self.wait_all()
+        self.finish_local()
 
     def check_consistency(self) -> None:
         """Host read of the device-side mismatch counter (see :meth:`finalize`); raises if, on any step so far, some ranks

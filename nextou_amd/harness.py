@@ -224,6 +224,68 @@ class GraphedTrainStep:
             m.check_targets()
 
 
+class SplitGraphedTrainStep:
+    """The averaged (N > 1) training step as TWO hipGraphs around eager collectives (round 6): graph 1 = zero_grad -> forward -> loss ->
+    backward with the gradient hooks only FILLING the flat buckets (``BucketedGradientAverager.defer_collectives``); then the bucket
+    all-reduces, launched eagerly on RCCL's stream and joined by stream waits; graph 2 = 1 / world scale -> clip -> SGD.  No collective is ever
+    captured, so PyTorch's RCCL watchdog thread never meets an event "last recorded in a capturing stream" (the abort that a captured averaged
+    step can end in), and ~1 400 kernel launches per step still become two.  The price against :class:`GraphedTrainStep`
+    with captured collectives is the overlap of the all-reduces with backward: ~1.4-3 ms of ring time for cfg 2's 122.7 MB of gradients,
+    against the 6-8 ms the eager step loses to launch gaps (profiles/r06_cfg2_step_kernel_trace.md: 174.5 ms wall for 168.3 ms of kernels).
+
+    ``part1()`` returns the loss tensor; ``between()`` launches and joins the collectives; ``part2()`` finishes the step.  All three must be
+    free of host synchronisation (the averager's warm-up steps have cached its one host read).  Works with any backend: between the graphs
+    the collectives are ordinary eager calls (gloo's host-side reductions included)."""
+
+    def __init__(self, part1, between, part2, warmup: int = 2, network: Optional[torch.nn.Module] = None, loss: Optional[torch.nn.Module] = None):
+        from . import _lib
+        from .loss.bti_loss import BTI_Loss
+        import torch.distributed as dist
+        if network is not None:
+            assert_capturable(network)
+        self._deferred = [m for m in (loss.modules() if loss is not None else ()) if isinstance(m, BTI_Loss) and m.validate_targets is True]
+        for m in self._deferred:
+            m.validate_targets = "deferred"
+        _lib.lib().nextou_profile_enable(0)
+        self.between = between
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(int(warmup), 1)):
+                    part1()
+                    between()
+                    part2()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            # thread_local: the watchdog thread may query the events of the (finished) eager collectives whenever it likes; only this thread's
+            # calls are checked against the capture
+            mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+            self.graph1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph1, capture_error_mode=mode):
+                self.loss = part1()
+            between()                      # real collectives on whatever the buckets hold: keeps the averager's bookkeeping in step order
+            self.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph2, pool=self.graph1.pool(), capture_error_mode=mode):
+                part2()
+            torch.cuda.synchronize()
+        except BaseException:
+            for m in self._deferred:
+                m.validate_targets = True
+            self._deferred = []
+            raise
+
+    def __call__(self):
+        self.graph1.replay()
+        self.between()
+        self.graph2.replay()
+        return self.loss
+
+    def check(self) -> None:
+        for m in self._deferred:
+            m.check_targets()
+
+
 def assert_capturable(network: torch.nn.Module) -> None:
     """Raise unless ``network``'s forward is the same computation on every replay of a captured step: a graph block whose
     kNN dilation is > 1 with ``stochastic`` set draws ``torch.rand`` on the host per call (reference torch_edge.py:126-136)

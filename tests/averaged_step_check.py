@@ -30,7 +30,7 @@ import torch.distributed as dist  # noqa: E402
 import bench  # noqa: E402
 from nextou_amd import _lib  # noqa: E402
 from nextou_amd.ddp import BucketedGradientAverager, init_single_process_group  # noqa: E402
-from nextou_amd.harness import GraphedTrainStep, downsample_targets, synthetic_batch  # noqa: E402
+from nextou_amd.harness import GraphedTrainStep, SplitGraphedTrainStep, downsample_targets, synthetic_batch  # noqa: E402
 
 DEV = torch.device("cuda:0")
 
@@ -86,12 +86,18 @@ def main():
     init_single_process_group(args.backend)
 
     runs = {}
-    modes = [("plain_a", False, False), ("plain_b", False, False), ("avg_eager", True, False), ("plain_graph", False, True)]
+    modes = [("plain_a", False, False), ("plain_b", False, False), ("avg_eager", True, False), ("avg_split", True, "split"),
+             ("plain_graph", False, True)]
     if args.captured_collectives:
         modes.insert(3, ("avg_graph", True, True))
     for name, averaged, graphed in modes:
         t, step, averager = make(args.workload, averaged)
-        if graphed:
+        if graphed == "split":
+            # the default of every N > 1 bench run: two graphs around eager collectives (no collective captured)
+            averager.defer_collectives = True
+            run = SplitGraphedTrainStep(step.part1, step.between, step.part2, warmup=1, network=t.network, loss=t.loss)
+            done = 1
+        elif graphed:
             # step 1 eager, then capture (executes nothing); the replays are steps 2..  — with the default 2 steps the comparison is
             # "second step replayed" against "second step eager": one update after identical first steps, before the tiny random-label
             # network's chaos (discrete neighbour choices, train-mode BN on 2 patches) has amplified the run-to-run noise
@@ -136,6 +142,9 @@ def main():
         "grad_plain_vs_plain": dist_max(runs["plain_a"]["last"], runs["plain_b"]["last"]),
         "grad_avg_eager_vs_plain": min(dist_max(runs["avg_eager"]["last"], runs[k]["last"]) for k in ("plain_a", "plain_b")),
         "grad_avg_graph_vs_plain": vs_plain("avg_graph", "last"),
+        "grad_avg_split_vs_plain": vs_plain("avg_split", "last"),
+        "momentum_avg_split_vs_plain": vs_plain("avg_split", "m"),
+        "grad_is_none_avg_split": runs["avg_split"]["none"],
         "grad_plain_graph_vs_plain": min(dist_max(runs["plain_graph"]["last"], runs[k]["last"]) for k in ("plain_a", "plain_b")),
         "momentum_scale": float(runs["plain_a"]["m"].abs().max()),
         "momentum_plain_vs_plain": dist_max(runs["plain_a"]["m"], runs["plain_b"]["m"]),

@@ -46,17 +46,19 @@ def _check_averaged_record(r, modes):
 @pytest.mark.timeout(1800)
 def test_averaged_step_over_rccl_matches_plain_step():
     """World-size-1 RCCL group, learning rate 0 (tests/averaged_step_check.py says why), the DEFAULT modes of every N (round 6: the averaged
-    step runs eagerly unless `--graph on` is typed; the plain step is captured): after three steps the averaged step's gradients and the
-    optimizer's momentum buffers (what it was handed through `p.grad`, i.e. the bucket views) equal the plain step's: bit for bit when two
-    plain runs agree bit for bit, else within 4x their distance; the zero-weighted head's parameters keep grad = None; the weights did not
-    move.  No collective is captured here, so nothing of PyTorch's watchdog can end the process: no XFAIL clause."""
+    step replayed as TWO hipGraphs around eager collectives — harness.SplitGraphedTrainStep — and its eager form; the plain step captured):
+    after three steps the averaged step's gradients and the optimizer's momentum buffers (what it was handed through `p.grad`, i.e. the
+    bucket views) equal the plain step's: bit for bit when two plain runs agree bit for bit, else within 4x their distance; the
+    zero-weighted head's parameters keep grad = None; the weights did not move.  No collective is captured here, so nothing of PyTorch's
+    watchdog can end the process: no XFAIL clause."""
     proc = subprocess.run([sys.executable, os.path.join(REPO, "tests", "averaged_step_check.py"), "--backend", "nccl"],
                           capture_output=True, text=True, timeout=1500)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
     r = _json_line(proc.stdout)
     print(r)
     assert r["captured_collectives"] is False and r["grad_avg_graph_vs_plain"] is None
-    _check_averaged_record(r, ("avg_eager", "plain_graph"))
+    assert r["grad_is_none_plain"] == r["grad_is_none_avg_split"]
+    _check_averaged_record(r, ("avg_eager", "avg_split", "plain_graph"))
 
 
 @pytest.mark.timeout(1800)
@@ -71,15 +73,15 @@ def test_explicitly_captured_rccl_step_matches_plain_step():
     r = _json_line(proc.stdout)
     print(r)
     assert r["captured_collectives"] is True and r["grad_is_none_plain"] == r["grad_is_none_avg_graph"]
-    _check_averaged_record(r, ("avg_eager", "avg_graph", "plain_graph"))
+    _check_averaged_record(r, ("avg_eager", "avg_split", "avg_graph", "plain_graph"))
 
 
 @pytest.mark.timeout(1800)
 @pytest.mark.parametrize("graph", ["auto", "off", "on"])
 def test_bench_averaged_step_on_one_gpu(graph):
     """bench.py --force-averager: the N > 1 step (hooks, buckets, RCCL collectives, finalize, ClipSGD) on a world-size-1 RCCL group.
-    `auto` (the default of every N > 1 run) and `off` are the eager step — `off` is the mode that died with a GPU memory fault in
-    round 4 — and must simply pass; `on` is the explicit capture and the only mode with the watchdog XFAIL clause."""
+    `auto` (the default of every N > 1 run: two graphs around eager collectives) and `off` (the eager step — the mode that died with a GPU
+    memory fault in round 4) must simply pass; `on` captures the collectives too and is the only mode with the watchdog XFAIL clause."""
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "2", "--workload", "tiny", "--force-averager",
            "--graph", graph, "--no-miopen-find", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
@@ -87,8 +89,10 @@ def test_bench_averaged_step_on_one_gpu(graph):
         _xfail_on_watchdog_capture_error(out)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = _json_line(out.stdout)
-    assert rec["config"]["gradient_averager"] is True and rec["config"]["step_replayed_as_hipgraph"] is (graph == "on")
-    assert ("eager" in rec["config"]["graph_mode"]) is (graph != "on")
+    assert rec["config"]["gradient_averager"] is True and rec["config"]["step_replayed_as_hipgraph"] is (graph != "off")
+    assert rec["config"]["graph_capture_error"] is None
+    mode = rec["config"]["graph_mode"]
+    assert {"auto": "two graphs around eager collectives" in mode, "off": mode.startswith("eager"), "on": "collectives captured" in mode}[graph], mode
     assert rec["dist"]["initialized"] and rec["dist"]["backend"] == "nccl" and rec["dist"]["world_size"] == 1
     assert rec["value"] > 0 and rec["roofline"]["launches"] > 0
     assert rec["roofline_graph"]["K8_head_backward"]["launches"] > 0       # the heads' backward ran on this library's kernels
@@ -126,5 +130,6 @@ def test_bench_gpus_2_typed_without_a_launcher():
     assert out.returncode == 0, out.stderr[-3000:]
     rec = _json_line(out.stdout)
     assert rec["n_gpus"] == 2 and rec["dist"]["world_size"] == 2 and rec["dist"]["backend"] == "gloo"
-    assert rec["config"]["step_replayed_as_hipgraph"] is False and rec["config"]["global_batch"] == 4 and rec["value"] > 0
+    assert rec["config"]["step_replayed_as_hipgraph"] is True and "two graphs" in rec["config"]["graph_mode"]       # (gloo's collectives run between the graphs)
+    assert rec["config"]["graph_capture_error"] is None and rec["config"]["global_batch"] == 4 and rec["value"] > 0
     assert "without a launcher" in out.stderr

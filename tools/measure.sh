@@ -232,13 +232,15 @@ t_ab6() {            # round 6: same-box A/B of the round's step changes — def
   NEXTOU_SKIP_FORK=0 python bench.py --no-cpu-baseline --steps 20 > $OUT/ab6_nofork.json 2>/dev/null; field $OUT/ab6_nofork.json
   NEXTOU_STEM_BLOCK=0 python bench.py --no-cpu-baseline --steps 20 > $OUT/ab6_nostem.json 2>/dev/null; field $OUT/ab6_nostem.json
 }
-t_ngt1loop() {       # round 6: the DEFAULT mode of every N > 1 run — eager averaged step — twenty times over on a world-size-1 RCCL group
+t_ngt1loop() {       # round 6: the DEFAULT mode of every N > 1 run — two hipGraphs around eager collectives — twenty times over on a world-size-1 RCCL group
   ok=0; for i in $(seq 1 20); do
     timeout 600 python bench.py --steps 3 --warmup 2 --workload tiny --force-averager --no-miopen-find --no-cpu-baseline > $OUT/ngt1_$i.json 2> $OUT/ngt1_$i.log
-    rc=$?; if [ $rc -eq 0 ] && python -c "import json;d=json.load(open('$OUT/ngt1_$i.json'));assert d['config']['gradient_averager'] and not d['config']['step_replayed_as_hipgraph'] and d['dist']['backend']=='nccl'"; then ok=$((ok+1)); rm -f $OUT/ngt1_$i.log; else echo "run $i rc $rc"; tail -3 $OUT/ngt1_$i.log; fi
+    rc=$?; if [ $rc -eq 0 ] && python -c "import json;d=json.load(open('$OUT/ngt1_$i.json'));assert d['config']['gradient_averager'] and d['config']['step_replayed_as_hipgraph'] and 'two graphs' in d['config']['graph_mode'] and d['config']['graph_capture_error'] is None and d['dist']['backend']=='nccl'"; then ok=$((ok+1)); rm -f $OUT/ngt1_$i.log; else echo "run $i rc $rc"; tail -3 $OUT/ngt1_$i.log; fi
   done
-  echo "default N > 1 mode (eager averaged step, RCCL world size 1): $ok / 20 clean" | tee $OUT/ngt1_loop.txt
-  python bench.py --no-cpu-baseline --force-averager --steps 20 > $OUT/bench_cfg2_averaged_eager.json 2> $OUT/bench_cfg2_averaged_eager.log; field $OUT/bench_cfg2_averaged_eager.json
+  echo "default N > 1 mode (two graphs around eager collectives, RCCL world size 1): $ok / 20 clean" | tee $OUT/ngt1_loop.txt
+  python bench.py --no-cpu-baseline --force-averager --steps 20 > $OUT/bench_cfg2_averaged_split.json 2> $OUT/bench_cfg2_averaged_split.log; field $OUT/bench_cfg2_averaged_split.json
+  python bench.py --no-cpu-baseline --force-averager --graph off --steps 20 > $OUT/bench_cfg2_averaged_eager.json 2> $OUT/bench_cfg2_averaged_eager.log; field $OUT/bench_cfg2_averaged_eager.json
+  python bench.py --no-cpu-baseline --steps 20 > $OUT/bench_cfg2_plain_samebox.json 2> /dev/null; field $OUT/bench_cfg2_plain_samebox.json
 }
 t_guard() {
   python -m pytest tests/test_gpu_guard.py tests/test_gpu_head.py -q -m gpu -p no:cacheprovider 2>&1 | grep -v "MIOpen\|GridwiseOp\|amdgpu.ids" > $OUT/guard_pages_pytest.txt; tail -3 $OUT/guard_pages_pytest.txt
