@@ -10,7 +10,8 @@ Workload (BASELINE.json configs[1], SURVEY.md §8d cfg 2): 3-D NexToU, patch 64x
 max 324 features, 6 stages, 14 classes, batch 2 per GPU, fp32, BatchNorm in train mode,
 deep-supervision-weighted cross-entropy; synthetic N(0,1) volumes and random-init (He) weights.
 One step = zero_grad -> forward (5 heads) -> loss -> backward -> (N > 1: bucketed RCCL gradient
-average, overlapped with backward) -> clip_grad_norm_(12) -> SGD(nesterov).  `value` = all ranks'
+average; default: two hipGraphs around the eager all-reduces, `--graph off | on` overlap them with backward)
+-> clip_grad_norm_(12) -> SGD(nesterov).  `value` = all ranks'
 voxels / max-over-ranks time of exactly K steps between barrier + synchronize pairs.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
