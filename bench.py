@@ -606,11 +606,12 @@ def main():
             # sweep's best thread count — the faster of the two protocols, i.e. the fairer yardstick); `cpu_baseline_survey` is SURVEY.md
             # 8(d) to the letter (batch 2, 1 warm-up + 3 timed, all physical cores), ~10 min of host time and therefore a COMMITTED run
             # (`bench.py --cpu-protocol survey` reproduces it), not re-measured here
-            spath = os.path.join(REPO, "profiles", "r04_bench_cfg2_cpu_survey.json")
-            if os.path.exists(spath):
+            spath = next((p for p in (os.path.join(REPO, "profiles", n) for n in ("r06_bench_cfg2_cpu_survey.json", "r04_bench_cfg2_cpu_survey.json"))
+                          if os.path.exists(p)), None)
+            if spath is not None:
                 try:
                     sv = json.load(open(spath))["cpu_baseline"]
-                    line["cpu_baseline_survey"] = dict(sv, source="committed run profiles/r04_bench_cfg2_cpu_survey.json (not measured in this run)",
+                    line["cpu_baseline_survey"] = dict(sv, source="committed run profiles/%s (not measured in this run)" % os.path.basename(spath),
                                                        batch=2, timed_steps=3)
                 except (OSError, ValueError, KeyError):
                     line["cpu_baseline_survey"] = None
