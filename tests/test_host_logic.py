@@ -319,13 +319,14 @@ def test_rows_gemm_view_algebra_and_cpu_fallbacks():
 
 
 def test_gradient_bucket_views_carry_the_parameter_strides(monkeypatch):
-    """ddp._Bucket with NEXTOU_DDP_STRIDED_VIEWS=1 (opt-in): a bucket view of a channels-last (or otherwise permuted-dense) parameter has
-    the parameter's strides, aliases the flat buffer at its offset, and round-trips values; contiguous and non-dense parameters — and
-    every parameter by default — take the plain reshaped slice."""
+    """ddp._Bucket (default since round 6; NEXTOU_DDP_STRIDED_VIEWS=0 restores rounds 2-5): a bucket view of a channels-last (or otherwise
+    permuted-dense) parameter has the parameter's strides, aliases the flat buffer at its offset, and round-trips values; contiguous and
+    non-dense parameters — and every parameter with the switch at 0 — take the plain reshaped slice."""
     from nextou_amd.ddp import _Bucket, _dense_strides
+    monkeypatch.setenv("NEXTOU_DDP_STRIDED_VIEWS", "0")
     plain = _Bucket([torch.nn.Parameter(torch.randn(6, 4, 3, 3, 3).contiguous(memory_format=torch.channels_last_3d))])
     assert plain.views[0].is_contiguous() and plain.views[0].shape == (6, 4, 3, 3, 3)
-    monkeypatch.setenv("NEXTOU_DDP_STRIDED_VIEWS", "1")
+    monkeypatch.delenv("NEXTOU_DDP_STRIDED_VIEWS")
     a = torch.nn.Parameter(torch.randn(6, 4, 3, 3, 3).contiguous(memory_format=torch.channels_last_3d))
     b = torch.nn.Parameter(torch.randn(5, 7))
     c = torch.nn.Parameter(torch.randn(4, 2, 3, 3).contiguous(memory_format=torch.channels_last))
