@@ -82,6 +82,23 @@ def _worker(rank, world, port, tmp):
             grads = {n: p.grad.clone() for n, p in named if p.grad is not None}
         else:
             assert all(torch.equal(grads[n], p.grad) for n, p in named if p.grad is not None)
+    # round 6: the collectives deferred to after backward — the form harness.SplitGraphedTrainStep replays as graph / eager all-reduces / graph —
+    # gives the same reduced gradients, and the hooks launch nothing
+    averager.defer_collectives = True
+    for step in range(2):
+        averager.zero_grad()
+        out = trainer.network(data)
+        trainer.loss(out, downsample_targets(target, out)).backward()
+        assert all(b.work is None for b in averager.buckets)
+        averager.fill_missing()
+        averager.reduce_all()
+        assert all(b.work is not None for b in averager.buckets)
+        averager.wait_all()
+        averager.finish_local()
+        assert [n for n, p in named if p.grad is None] == ["decoder.seg_layers.0.weight", "decoder.seg_layers.0.bias"]
+        assert all(torch.equal(grads[n], p.grad) for n, p in named if p.grad is not None)
+    averager.defer_collectives = False
+    averager.check_consistency()
     state = {k: v.clone() for k, v in trainer.network.state_dict().items()}
     torch.save({"grads": grads}, os.path.join(tmp, "rank%d.pt" % rank))
     # all ranks hold the same parameters and the same reduced gradients
