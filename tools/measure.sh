@@ -17,6 +17,12 @@
 #   reprobf16  the guard-page reproducer with bf16 operands (tiny and cfg-2 head shapes) + two bf16 bench lines: the reduced-precision fault
 #              of round 5's closing tree
 #   bf16       round 6: bench.py --autocast-bf16 at cfg 2 / tiny / cfg 5 in find mode, twice each; on a fault a serialized rerun with MIOpen's log
+#   bf16ab     round 6: round 5's faulting bf16 configuration (NEXTOU_REDUCED_PRECISION_FILTERS=stored) three times; on a fault once more with synchronous
+#              launches and MIOpen's command log (profiles/r06_bf16/README.md)
+#   stem       round 6: K9 / DDP tests + the headline line with and without the stem block on one box
+#   k1small    round 6: small-graph kNN tests, tools/stem_bench.py, the K1 rows of the kernel bench with and without knn_small_kernel
+#   ab6        round 6: same-box A/B of the step changes (K9, small kNN, skip fork) against the round-5 routing (profiles/r06_step_ab.md)
+#   ngt1loop   round 6: the default N > 1 mode (two graphs around eager collectives) twenty times on a world-size-1 RCCL group + plain / split / eager lines
 #   guard      tests/test_gpu_guard.py + tests/test_gpu_head.py verbose (every own kernel on guard-page operands, outputs and workspaces)
 #   glue       the step's small ATen launches by op, shape and enclosing op (tools/aten_glue_profile.py --parents) + bench A/B of the round-5
 #              glue changes, hipGraph replay and eager (profiles/r05_aten_glue.md)
