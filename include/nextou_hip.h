@@ -566,16 +566,16 @@ int nextou_norm_act_fwd_partials(const float* x, const float* weight, const floa
  *            statistics, as in nextou_norm_act_fwd); gamma / beta (C,) or NULL = the norm's affine
  *   y        (B, D, H, W, Cpad) channels-last rows, Cpad >= C a multiple of 4, <= 48; channels C .. Cpad-1 are written as zeros (the
  *            padding channels of channel_pad.py)
- *   act_mask NULL or (ceil(B D H / 4), W, Cpad / 4) uint32 out: bit 4 i + j of word (row block, column, q) = pre-activation of channel
- *            4q + j at image row 4 block + i > 0 — the LeakyReLU mask the backward applies (recomputing it there cost 40 fma and 36
- *            registers per thread; this is one byte per voxel and quad, moved as dwords)
+ *   act_mask NULL or (ceil(B D H / 8), W, Cpad / 4) uint32 out: bit 4 i + j of word (row block, column, q) = pre-activation of channel
+ *            4q + j at image row 8 block + i > 0 — the LeakyReLU mask the backward applies (recomputing it there cost 40 fma and 36
+ *            registers per thread; this is half a byte per voxel and quad, moved as dwords)
  *   save_mean / save_invstd (C,) out; moments (54 doubles) out: the tap sums X1[9] and the packed upper triangle of the 9 x 9 tap
  *            autocorrelation — what the backward needs besides (S1, S2); running_mean / running_var updated as F.batch_norm does
  *   training = 0: running statistics, no moments pass (forward only: the backward below is the batch-statistics one)
  * nextou_stem_bwd: gweight (C, 9), ggamma (C,), gbeta (C,) — any may be NULL — from gy (B, D, H, W, Cpad) and act_mask in one pass.  The image gets no
  * gradient (the caller routes an image that requires one through the library convolution); d/d pre_bias is exactly zero.
  * workspace: nextou_stem_workspace_bytes() bytes, contents irrelevant.  Float64 sums in a fixed order: bit-reproducible.
- * HBM-bound: V (4 + 4 Cpad + Cpad / 4) bytes each way for V = B D H W voxels. */
+ * HBM-bound: V (4 + 4 Cpad + Cpad / 8) bytes each way for V = B D H W voxels. */
 size_t nextou_stem_workspace_bytes(int B, int D, int H, int W, int Cpad);
 int nextou_stem_fwd(const float* x, const float* weight, const float* pre_bias, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float* y, uint32_t* act_mask, float* save_mean, float* save_invstd,

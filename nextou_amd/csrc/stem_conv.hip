@@ -18,7 +18,7 @@
 //                 gbeta = S1, ggamma = sum dy' zhat = invstd (sum_t w_ct S2[c][t] - mean S1),
 //                 gw[c][t] = scale ( S2[c][t] - (S1/n) X1[t] - (ggamma/n) invstd (sum_t' w_ct' A[t'][t] - mean X1[t]) ).
 //                 The image needs no gradient (the caller checks), the folded conv bias gets exactly zero under batch statistics.
-// HBM-bound: V (4 + 4 Cpad + Cpad / 4) bytes each way for V voxels.  Sums: fp32 over a thread's own voxels (<= a few
+// HBM-bound: V (4 + 4 Cpad + Cpad / 8) bytes each way for V voxels.  Sums: fp32 over a thread's own voxels (<= a few
 // hundred terms), float64 across threads and workgroups in a fixed order: bit-reproducible.
 #include "common.h"
 #include <cstdlib>
@@ -30,6 +30,7 @@ constexpr int kTaps = 9;
 constexpr int kMom = kTaps + kTaps * (kTaps + 1) / 2;      // X1[9] + upper triangle of A (45)
 constexpr int kVox = 32;                                   // voxels of a row chunk per workgroup iteration
 constexpr int kMomThreads = 256;
+constexpr int kRB = 8;                                     // image rows per batch of the apply / backward kernels = rows per mask dword (4 bits each)
 
 __host__ __device__ constexpr int tri(int a, int b) {      // packed index of A[a][b], a <= b
     return kTaps + a * kTaps - a * (a - 1) / 2 + (b - a);
@@ -41,7 +42,7 @@ __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? 
 // ATen).  Every streaming kernel below walks DOWN the image rows at a fixed column, so the 3 x 3 window slides: per voxel three new values
 // (row r + 2, one iteration ahead of their use) instead of nine.  All loads are UNCONDITIONAL on clamped coordinates (the image is dense, a
 // clamped neighbour is always inside it) and the zero padding is a select at the use: written as `cond ? p[i] : 0` the compiler turned
-// every load into a branch with a wait — nine dependent round trips per voxel (the first version: 314 / 446 / 129 us where HBM allows 150).
+// every load into a branch with a wait — nine dependent round trips per voxel (the first version: 314 / 446 / 129 us where HBM allows 150; batches of 8 rows: apply 236 -> 210 us against batches of 4).
 struct Cols { int l, c, r; };                                       // clamped column indices of (w - 1, w, w + 1)
 __device__ __forceinline__ Cols clamp_cols(int w, int W) {
     const int wc = min(w, W - 1);
@@ -197,14 +198,14 @@ __global__ __launch_bounds__(kVox * 12) void stem_apply_kernel(const float* __re
     const bool active = w < W;
     const Cols k = clamp_cols(w, W);
     const int r0 = seg * rows_per_seg, r1 = min(R, r0 + rows_per_seg);
-    constexpr int RB = 4;                                   // image rows per iteration: RB + 2 window rows loaded as ONE batch of 18 loads,
+    constexpr int RB = kRB;                                 // image rows per iteration: RB + 2 window rows loaded as ONE batch,
     int h = r0 % H;                                         // so the memory latency is paid once per RB voxels (no cross-iteration register copies)
     float* yp = y + ((long long)r0 * W + k.c) * Cp + 4 * q;
     const long long ystep = (long long)W * Cp;
-    // the LeakyReLU mask for the backward: one dword per (block of RB = 4 image rows, column, quad), bit 4 i + j = pre-activation of channel 4q + j
+    // the LeakyReLU mask for the backward: one dword per (block of RB = 8 image rows, column, quad), bit 4 i + j = pre-activation of channel 4q + j
     // at row 4 block + i > 0 — ONE dword store per batch (a byte per voxel cost 70 us, 2-byte words were no better: sub-dword accesses are the slow kind); segments start at
-    // multiples of 4 rows (seg_plan), so blocks never straddle workgroups
-    uint32_t* mp = act ? act + ((long long)(r0 / 4) * W + k.c) * Q + q : nullptr;
+    // multiples of 8 rows (seg_plan), so blocks never straddle workgroups
+    uint32_t* mp = act ? act + ((long long)(r0 / kRB) * W + k.c) * Q + q : nullptr;
     for (int r = r0; r < r1; r += RB) {
         float rows[RB + 2][3];
         unsigned bits = 0;
@@ -248,10 +249,10 @@ __global__ __launch_bounds__(kVox * 12) void stem_bwd_kernel(const float* __rest
     const bool active = w < W;
     const Cols k = clamp_cols(w, W);
     const int r0 = seg * rows_per_seg, r1 = min(R, r0 + rows_per_seg);
-    constexpr int RB = 4;                                   // as in stem_apply_kernel: RB + 2 window rows, RB gradient pieces and RB mask bytes per batch
+    constexpr int RB = kRB;                                 // as in stem_apply_kernel: RB + 2 window rows, RB gradient pieces and one mask dword per batch
     const long long gstep = (long long)W * Cp;
     const float* gp = gy + ((long long)r0 * W + k.c) * Cp + 4 * q;
-    const uint32_t* mp = act + ((long long)(r0 / 4) * W + k.c) * Q + q;
+    const uint32_t* mp = act + ((long long)(r0 / kRB) * W + k.c) * Q + q;
     int h = r0 % H;
     for (int r = r0; r < r1; r += RB) {
         float rows[RB + 2][3];
@@ -351,7 +352,7 @@ SegPlan seg_plan(int R, int W, int cols_per_wg, int target) {
     int segs = target / p.blocks_w;
     if (segs > (R + 7) / 8) segs = (R + 7) / 8;
     if (segs < 1) segs = 1;
-    p.rows_per_seg = ((R + segs - 1) / segs + 3) & ~3;      // multiples of 4: the kernels' row blocks (and the mask's 4-row words) never straddle segments
+    p.rows_per_seg = ((R + segs - 1) / segs + kRB - 1) / kRB * kRB;      // multiples of kRB: the kernels' row blocks (and the mask's 8-row words) never straddle segments
     p.segs = (R + p.rows_per_seg - 1) / p.rows_per_seg;
     p.grid = p.segs * p.blocks_w;
     return p;
@@ -410,7 +411,7 @@ extern "C" int nextou_stem_fwd(const float* x, const float* weight, const float*
     }
     const int Q = Cpad / 4;
     const SegPlan ap = apply_plan(R, W);
-    ProfScope prof(s, kBoundHbm, (double)V * (4.0 + 4.0 * Cpad + (act_mask ? 1.0 * Q : 0.0)), "stem_apply_kernel[B%d C%d S%lld]", B, Cpad, V / B);
+    ProfScope prof(s, kBoundHbm, (double)V * (4.0 + 4.0 * Cpad + (act_mask ? 0.5 * Q : 0.0)), "stem_apply_kernel[B%d C%d S%lld]", B, Cpad, V / B);
     hipLaunchKernelGGL(stem_apply_kernel, dim3(ap.grid), dim3(kVox * Q), 0, s, x, weight, gamma, beta, save_mean, save_invstd, y, act_mask, R, H, W,
                        C, Q, ap.rows_per_seg, ap.blocks_w, slope);
     return check_launch("stem_apply_kernel");
@@ -433,7 +434,7 @@ extern "C" int nextou_stem_bwd(const float* x, const float* gy, const uint32_t* 
     const int G = bp.grid;
     double* partial = static_cast<double*>(workspace);
     {
-        ProfScope prof(s, kBoundHbm, (double)V * (4.0 + 4.0 * Cpad + 1.0 * Q), "stem_bwd_kernel[B%d C%d S%lld]", B, Cpad, V / B);
+        ProfScope prof(s, kBoundHbm, (double)V * (4.0 + 4.0 * Cpad + 0.5 * Q), "stem_bwd_kernel[B%d C%d S%lld]", B, Cpad, V / B);
         hipLaunchKernelGGL(stem_bwd_kernel, dim3(G), dim3(kVox * Q), 0, s, x, gy, act_mask, partial, R, H, W, Q, bp.rows_per_seg, bp.blocks_w, slope);
     }
     int rc = check_launch("stem_bwd_kernel");

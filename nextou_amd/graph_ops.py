@@ -761,7 +761,7 @@ class _HipBackend:
     @staticmethod
     def stem_fwd(x, w2, pre_bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope, c_pad, want_mask=True):
         """x: dense (B, 1, *sp) float32 image; w2 (C, 9) contiguous -> (y channels-last (B, c_pad, *sp), mean (C,), invstd (C,), moments (54,) f64 | None,
-        act (ceil(B D H / 4), W, c_pad / 4) int32 | None: the LeakyReLU mask bits the backward reads)"""
+        act (ceil(B D H / 8), W, c_pad / 4) int32 | None: the LeakyReLU mask bits the backward reads)"""
         L_ = _lib.lib()
         B, sp = x.shape[0], tuple(x.shape[2:])
         D, H, W = (1,) * (3 - len(sp)) + sp
@@ -770,7 +770,7 @@ class _HipBackend:
         mean = torch.empty((C,), dtype=torch.float32, device=x.device)
         invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
         moments = torch.empty((54,), dtype=torch.float64, device=x.device) if training else None
-        act = torch.empty(((B * D * H + 3) // 4, W, c_pad // 4), dtype=torch.int32, device=x.device) if (training and want_mask) else None
+        act = torch.empty(((B * D * H + 7) // 8, W, c_pad // 4), dtype=torch.int32, device=x.device) if (training and want_mask) else None
         need = int(L_.nextou_stem_workspace_bytes(B, D, H, W, c_pad))
         ws = torch.empty((max(need, 8) // 8,), dtype=torch.float64, device=x.device)
         with torch.cuda.device(x.device):
@@ -1644,7 +1644,7 @@ class _StemBlock(torch.autograd.Function):
     """The network's first ConvDropoutNormReLU — conv(1 -> C, [1,]3x3) -> BatchNorm -> LeakyReLU (reference
     NexToU_Encoder_Decoder.py:125-141, encoder.stages[0]) — on K9 (csrc/stem_conv.hip): the batch statistics come from the nine-tap
     moments of the image, the output rows are written once, and the backward is one pass over the incoming gradient; the convolution's
-    881-MB output (cfg 2) is never stored.  Saves the image, 2C + 54 numbers and one mask byte per voxel and channel quad (55 MB at cfg 2, moved as dwords)."""
+    881-MB output (cfg 2) is never stored.  Saves the image, 2C + 54 numbers and half a mask byte per voxel and channel quad (28 MB at cfg 2, dwords of 8 rows x 4 channels)."""
 
     @staticmethod
     def forward(ctx, x, weight, conv_bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope, c_pad):
