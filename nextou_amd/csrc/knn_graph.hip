@@ -1127,6 +1127,20 @@ __device__ __forceinline__ void small_load(const float* __restrict__ xb, int c0,
     }
 }
 
+// One point's strictly c-ordered chain of squares over a whole slab: all kSmKS values out of LDS first, then the dependent fmas (rows past C
+// are zero: fma(0, 0, s) = s)
+__device__ __forceinline__ float small_chain(const float* __restrict__ col, float s) {
+#pragma unroll
+    for (int k0 = 0; k0 < kSmKS; k0 += 32) {
+        float t[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t[k] = col[(k0 + k) * kSmW];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s = fmaf(t[k], t[k], s);
+    }
+    return s;
+}
+
 template <bool DIVIDE>
 __device__ __forceinline__ void small_store(float* __restrict__ slab, const float* __restrict__ den_s, const float4 (&v)[kSmPieces]) {
 #pragma unroll
@@ -1143,7 +1157,7 @@ __device__ __forceinline__ void small_store(float* __restrict__ slab, const floa
 }
 
 __global__ __launch_bounds__(kSmThreads) void knn_small_kernel(const float* __restrict__ x, const float* __restrict__ relpos,
-                                                               int32_t* __restrict__ out, int C, int N, int K) {
+                                                               int32_t* __restrict__ out, int C, int N, int K, int ablate) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* slab = lds;                           // [64][192]
     float* den_s = slab + kSmKS * kSmW;          // [192]
@@ -1158,25 +1172,7 @@ __global__ __launch_bounds__(kSmThreads) void knn_small_kernel(const float* __re
     const int chain_pt = tid - (kSmThreads - kSmW);      // the last three waves own the per-point chains
     const bool chain = chain_pt >= 0;
 
-    // ---- pass A: den
-    float4 v[kSmPieces];
-    small_load(xb, 0, C, N, v);
-    float ssum = 0.f;
-    for (int s = 0; s < n_slabs; ++s) {
-        __syncthreads();
-        small_store<false>(slab, den_s, v);
-        if (s + 1 < n_slabs) small_load(xb, (s + 1) * kSmKS, C, N, v);
-        else small_load(xb, 0, C, N, v);         // pass B's first slab
-        __syncthreads();
-        if (chain) {
-            const int kmax = min(kSmKS, C - s * kSmKS);
-#pragma unroll 8
-            for (int k = 0; k < kmax; ++k) { const float t = slab[k * kSmW + chain_pt]; ssum = fmaf(t, t, ssum); }
-        }
-    }
-    if (chain) den_s[chain_pt] = fmaxf(sqrtf(ssum), kNormEps);
-
-    // relative-position bias of this lane's four (query, candidate) pairs: in flight during pass B
+    // relative-position bias of this lane's four (query, candidate) pairs: in flight during both passes
     float rp[4] = {0.f, 0.f, 0.f, 0.f};
     if (relpos != nullptr && wave < n_tiles) {
 #pragma unroll
@@ -1186,25 +1182,51 @@ __global__ __launch_bounds__(kSmThreads) void knn_small_kernel(const float* __re
         }
     }
 
-    // ---- pass B: normalise on the way in, chain of squares, one distance tile per wave
+    // ---- 2 n_slabs stages: pass A (den) over the slabs, then pass B (normalise on the way in, chain of squares, one distance tile per wave)
+    // over the same slabs.  The loads of stage t + 2 are issued while stage t is stored and consumed (two register sets, stages in pairs so
+    // that the sets are indexed statically).
+    // Clocked with s_memtime inside workgroup (0, 0) at C = 384, N = 168 (round 6): pass A 0.93 us per slab, pass B 2.3 us per slab (of which
+    // ~1.4 us are the 12 IEEE divisions per lane, VALU work of all sixteen waves), distances 0.5 us, selection 2.9 us for the first wave and
+    // 7.8 us for the last (VALU-bound: 3 N compare-and-count per lane and query): 29.6 us inside the kernel, 41.6 us per launch from outside.
+    // Tried without gain: slabs of 128 channels; two slab buffers with one barrier per slab and half of the waves consuming before storing
+    // (43.4 us); the selection's compares as v_cmp + v_addc in inline assembly (43.3 us)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float qsum = 0.f;
-    for (int s = 0; s < n_slabs; ++s) {
-        __syncthreads();                         // den_s complete (s = 0) / the previous slab consumed
-        small_store<true>(slab, den_s, v);
-        if (s + 1 < n_slabs) small_load(xb, (s + 1) * kSmKS, C, N, v);
+    float ssum = 0.f, qsum = 0.f;
+    const int n_stages = 2 * n_slabs;
+    auto slab_of = [&](int t) { return (t >= n_slabs ? t - n_slabs : t) * kSmKS; };
+    auto stage = [&](int t, float4 (&v)[kSmPieces]) __attribute__((always_inline)) {
+        const bool pass_b = t >= n_slabs;
+        const int sl = pass_b ? t - n_slabs : t;
+        __syncthreads();                         // the previous slab consumed (and, entering pass B, den_s complete)
+        if (pass_b && !(ablate & 2)) small_store<true>(slab, den_s, v);
+        else small_store<false>(slab, den_s, v);
+        if (t + 2 < n_stages) small_load(xb, slab_of(t + 2), C, N, v);
         __syncthreads();
-        const int kmax = min(kSmKS, C - s * kSmKS);
-        if (chain) {
-#pragma unroll 8
-            for (int k = 0; k < kmax; ++k) { const float t = slab[k * kSmW + chain_pt]; qsum = fmaf(t, t, qsum); }
+        if (!pass_b) {
+            if (chain && !(ablate & 1)) ssum = small_chain(slab + chain_pt, ssum);
+            if (chain && sl == n_slabs - 1) den_s[chain_pt] = fmaxf(sqrtf(ssum), kNormEps);
+            return;
         }
-        if (wave < n_tiles) {
-            const int k4 = (kmax + 3) & ~3;      // (rows past C are zero: fma(0, 0, acc) = acc)
+        if (chain) qsum = small_chain(slab + chain_pt, qsum);
+        if (wave < n_tiles && !(ablate & 4)) {
+            // the slab's sixteen k-steps: all 32 operands out of LDS first, then the dependent MFMA chain (rows past C are zero: fma(0, 0, acc)
+            // = acc)
             const float* pa = slab + g * kSmW + qt * 16 + q;
             const float* pb = slab + g * kSmW + wave * 16 + q;
-#pragma unroll 4
-            for (int k0 = 0; k0 < k4; k0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[k0 * kSmW], pb[k0 * kSmW], acc, 0, 0, 0);
+            float av[kSmKS / 4], bv[kSmKS / 4];
+#pragma unroll
+            for (int i = 0; i < kSmKS / 4; ++i) { av[i] = pa[4 * i * kSmW]; bv[i] = pb[4 * i * kSmW]; }
+#pragma unroll
+            for (int i = 0; i < kSmKS / 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+        }
+    };
+    {
+        float4 va[kSmPieces], vb[kSmPieces];
+        small_load(xb, slab_of(0), C, N, va);
+        small_load(xb, slab_of(1), C, N, vb);    // (n_stages >= 2 always)
+        for (int t = 0; t < n_stages; t += 2) {
+            stage(t, va);
+            stage(t + 1, vb);
         }
     }
     if (chain) sq_s[chain_pt] = qsum;
@@ -1233,17 +1255,22 @@ __global__ __launch_bounds__(kSmThreads) void knn_small_kernel(const float* __re
     const int m0 = lane, m1 = lane + 64, m2 = lane + 128;
     const float d0 = row[m0], d1 = row[m1], d2 = row[m2];
     int r0 = 0, r1 = 0, r2 = 0;
-    const int n4 = (N + 3) & ~3;                 // (entries past N are +inf: never below a finite distance)
-    for (int mp = 0; mp < n4; mp += 4) {
-        const float4 o = *reinterpret_cast<const float4*>(row + mp);
-        r0 += (o.x < d0) + (o.y < d0) + (o.z < d0) + (o.w < d0);
-        r1 += (o.x < d1) + (o.y < d1) + (o.z < d1) + (o.w < d1);
-        r2 += (o.x < d2) + (o.y < d2) + (o.z < d2) + (o.w < d2);
+    const int n16 = (ablate & 8) ? 16 : (N + 15) & ~15;      // rows are 192 wide and +inf past N: whole groups of 16 are safe to read
+    for (int mp = 0; mp < n16; mp += 16) {                   // four 16-byte reads in flight per step
+        float4 o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = *reinterpret_cast<const float4*>(row + mp + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            r0 += (o[u].x < d0) + (o[u].y < d0) + (o[u].z < d0) + (o[u].w < d0);
+            r1 += (o[u].x < d1) + (o[u].y < d1) + (o[u].z < d1) + (o[u].w < d1);
+            r2 += (o[u].x < d2) + (o[u].y < d2) + (o[u].z < d2) + (o[u].w < d2);
+        }
     }
     int total = (m0 < N ? r0 : 0) + (m1 < N ? r1 : 0) + (m2 < N ? r2 : 0);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
-    if (total != N * (N - 1) / 2) {              // exact ties somewhere in this row: the full (dist, index) order
+    if (total != N * (N - 1) / 2 && !ablate) {              // exact ties somewhere in this row: the full (dist, index) order
         r0 = r1 = r2 = 0;
         for (int mp = 0; mp < N; ++mp) {
             const float o = row[mp];
@@ -1275,7 +1302,9 @@ static SmallPlan plan_small(int B, int N, int M, int K, bool has_y, const float*
 
 static int launch_small(const float* x, const float* relpos, int32_t* out, int B, int C, int N, int K, const SmallPlan& p, hipStream_t s) {
     ProfScope prof(s, kBoundMfma, 2.0 * B * (double)N * N * C, "knn_small_kernel[B%d C%d N%d K%d]", B, C, N, K);
-    hipLaunchKernelGGL(knn_small_kernel, dim3(cdiv(N, 16), B), dim3(kSmThreads), p.lds, s, x, relpos, out, C, N, K);
+    // experiments (NEXTOU_KNN_SMALL_ABLATE; wrong results with any bit set): 1 no pass-A chains, 2 no divisions, 4 no MFMAs, 8 no counting
+    static const int ablate = [] { const char* e = getenv("NEXTOU_KNN_SMALL_ABLATE"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL(knn_small_kernel, dim3(cdiv(N, 16), B), dim3(kSmThreads), p.lds, s, x, relpos, out, C, N, K, ablate);
     return check_launch("knn_small_kernel");
 }
 
