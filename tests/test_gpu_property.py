@@ -257,3 +257,72 @@ def test_pointwise_chain_any_shape(B, sp, g, a, b, c, two, with_res, training, m
             os.environ.pop("NEXTOU_PW_FUSE", None)
         else:
             os.environ["NEXTOU_PW_FUSE"] = old
+
+
+@settings(max_examples=24, deadline=None, derandomize=True)
+@given(B=st.integers(1, 24), C=st.integers(1, 140), n4=st.integers(1, 48), k=st.integers(1, 192), relpos=st.booleans(),
+       levels=st.sampled_from([0, 0, 2, 5]), seed=st.integers(0, 10 ** 6))
+def test_knn_small_kernel_any_shape_bit_exact(B, C, n4, k, relpos, levels, seed):
+    """knn_small_kernel (round 6: <= 192-point self graphs, N a multiple of 4, a handful of windows) on ragged tiles, one ... three channel slabs
+    and — `levels` > 0: features quantised to a few values, so that whole groups of candidates are at EXACTLY the same distance — the tie path of
+    the counting selection (reference torch_edge.py:58-90: topk's order on equal distances is the lower index, as restated by the oracle)."""
+    ops, ora = _ops_ora()
+    N = 4 * n4
+    if B * ((N + 15) // 16) > 384:
+        B = max(1, 384 // ((N + 15) // 16))
+    k = min(k, N)
+    x = _rand((B, C, N), seed)
+    if levels:
+        x = torch.round(x * levels) / levels
+        x[:, 0] += 0.5                                    # no all-zero point: 0 / eps stays what it is, but keep the norms apart from eps
+    rp = _rand((N, N), seed + 2, 0.05) if relpos else None
+    want = ora.knn_graph(x, None, rp, k)
+    got = ops.knn_graph(x.to(DEV), None, None if rp is None else rp.to(DEV), k)
+    assert torch.equal(got.cpu(), want)
+
+
+@settings(max_examples=16, deadline=None, derandomize=True)
+@given(B=st.integers(1, 3), D=st.integers(1, 5), H=st.integers(1, 21), W=st.integers(1, 70), C=st.integers(1, 48), two_d=st.booleans(),
+       training=st.booleans(), offset=st.sampled_from([0.0, 3.0]), seed=st.integers(0, 10 ** 6))
+def test_stem_block_any_shape(B, D, H, W, C, two_d, training, offset, seed):
+    """K9 (round 6; reference NexToU_Encoder_Decoder.py:125-136: Conv(1 -> C, [1,]3,3) -> BatchNorm -> LeakyReLU on the image) against float64 autograd:
+    ragged rows and row batches, every channel count up to the 48 the kernels take, 2-D and 3-D, batch and running statistics."""
+    import torch.nn.functional as F
+    from nextou_amd import graph_ops
+    g = torch.Generator().manual_seed(seed)
+    shape = (B, 1, H, W) if two_d else (B, 1, D, H, W)
+    x = (torch.randn(shape, generator=g) + offset).to(DEV)
+    st_ = list(x.stride()); st_[1] = 1
+    x = x.as_strided(x.shape, st_)
+    c_pad = (C + 3) // 4 * 4
+    w = (torch.randn((C, 1, 3, 3) if two_d else (C, 1, 1, 3, 3), generator=g) * 0.4).to(DEV).requires_grad_(True)
+    cb = torch.randn(C, generator=g).to(DEV).requires_grad_(True)
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).to(DEV).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g)).to(DEV).requires_grad_(True)
+    rm, rv = torch.randn(C, generator=g).to(DEV), (0.5 + torch.rand(C, generator=g)).to(DEV)
+    cl = torch.channels_last if two_d else torch.channels_last_3d
+    gy = torch.randn((B, c_pad) + tuple(shape[2:]), generator=g).to(DEV).contiguous(memory_format=cl)
+    rmd, rvd = rm.double().clone(), rv.double().clone()
+    if training:
+        y = graph_ops._StemBlock.apply(x, w, cb, gamma, beta, rm, rv, True, 0.1, 1e-5, 0.01, c_pad)
+        y.backward(gy)
+    else:                                                 # running statistics: forward only (stem_block_eligible declines eval-mode training)
+        with torch.no_grad():
+            y = graph_ops._StemBlock.apply(x, w, cb, gamma, beta, rm, rv, False, 0.1, 1e-5, 0.01, c_pad)
+    wd, cbd, gd, bd = (t.detach().double().clone().requires_grad_(True) for t in (w, cb, gamma, beta))
+    z = (F.conv2d if two_d else F.conv3d)(x.double().contiguous(), wd, cbd, 1, (1, 1) if two_d else (0, 1, 1))
+    count = z.numel() // C
+    if training and count == 1:
+        return                                            # torch refuses batch statistics over one value per channel
+    ry = F.leaky_relu(F.batch_norm(z, rmd, rvd, gd, bd, training, 0.1, 1e-5), 0.01)
+    scale = float(ry.abs().max()) + 1e-30
+    assert float((y[:, :C].double() - ry).abs().max()) <= 5e-5 * scale
+    if c_pad > C:
+        assert float(y[:, C:].abs().max()) == 0.0
+    assert torch.allclose(rm.double(), rmd, rtol=1e-5, atol=1e-6) and torch.allclose(rv.double(), rvd, rtol=1e-4, atol=1e-6)
+    if not training or count < 16:                        # (a handful of values per channel: the gradient through the batch statistics is all cancellation)
+        return
+    ry.backward(gy[:, :C].double())
+    tol = 2e-4
+    for name, a, e in (("weight", w.grad, wd.grad), ("gamma", gamma.grad, gd.grad), ("beta", beta.grad, bd.grad)):
+        assert float((a.double() - e).abs().max()) <= tol * (float(e.abs().max()) + 1e-30) + 1e-6, name
