@@ -124,24 +124,37 @@ __global__ __launch_bounds__(kMomThreads) void stem_moments_kernel(const float* 
 }
 
 // (2) moments -> per-channel (sum z, sum z^2): nextou_norm_finalize's `partial` with tiles = 1
-__global__ __launch_bounds__(256) void stem_stats_kernel(const double* __restrict__ partial, int G, const float* __restrict__ weight, int C,
-                                                         double* __restrict__ moments, double2* __restrict__ stats) {
-    __shared__ double part[4][kMom];
+constexpr int kStatsParts = 16;                            // waves of stem_stats_kernel, each summing every 16th workgroup's partial moments
+__global__ __launch_bounds__(64 * kStatsParts) void stem_stats_kernel(const double* __restrict__ partial, int G, const float* __restrict__ weight, int C,
+                                                                      double* __restrict__ moments, double2* __restrict__ stats) {
+    __shared__ double part[kStatsParts][kMom];
     __shared__ double M[kMom];
-    const int t = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+    const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (t < kMom) {
+        // eight loads in flight per lane (four waves walking G / 4 partials one dependent load at a time took 58 us for ~1 000 workgroups);
+        // the order of the sum is fixed by (wave, position): bit-reproducible
         double s = 0.0;
-        for (int g = quarter; g < G; g += 4) s += partial[(size_t)g * kMom + t];
-        part[quarter][t] = s;
+        int g = wave;
+        for (; g + 7 * kStatsParts < G; g += 8 * kStatsParts) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(g + u * kStatsParts) * kMom + t];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; g < G; g += kStatsParts) s += partial[(size_t)g * kMom + t];
+        part[wave][t] = s;
     }
     __syncthreads();
     if (threadIdx.x < kMom) {
-        const double s = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < kStatsParts; ++u) s += part[u][threadIdx.x];
         M[threadIdx.x] = s;
         moments[threadIdx.x] = s;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += 64 * kStatsParts) {
         double w[kTaps];
 #pragma unroll
         for (int a = 0; a < kTaps; ++a) w[a] = (double)weight[c * kTaps + a];
@@ -398,7 +411,7 @@ extern "C" int nextou_stem_fwd(const float* x, const float* weight, const float*
             ProfScope prof(s, kBoundHbm, 4.0 * (double)V, "stem_moments_kernel[B%d S%lld]", B, V / B);
             hipLaunchKernelGGL(stem_moments_kernel, dim3(G), dim3(kMomThreads), 0, s, x, partial, R, H, W, mp.rows_per_seg, mp.blocks_w);
         }
-        hipLaunchKernelGGL(stem_stats_kernel, dim3(1), dim3(256), 0, s, partial, G, weight, C, moments, stats);
+        hipLaunchKernelGGL(stem_stats_kernel, dim3(1), dim3(64 * kStatsParts), 0, s, partial, G, weight, C, moments, stats);
         int rc = check_launch("stem_moments_kernel");
         if (rc) return rc;
         rc = nextou_norm_finalize(reinterpret_cast<const double*>(stats), 1, (double)V, pre_bias, running_mean, running_var, save_mean,
