@@ -68,6 +68,10 @@ int nextou_profile_dropped(void);
  *   xs   = fma-chain_c xn^2 ;  inner = fma-chain_c xn*yn  (c ascending, one rounding per step)
  *   dist = ((xs + (-2*inner)) + ys) [+ relpos]
  *   neighbours = K smallest by (dist, index) lexicographic, emitted in that order.
+ *   Non-finite input: a distance that comes out NaN or +inf is ordered as FLT_MAX (after every finite distance, by
+ *   index among themselves), so every output id lies in [0, M) whatever the features hold — the reference's topk
+ *   puts NaN first instead; neither order means anything, but an id outside the candidates would be an out-of-bounds
+ *   gather in the aggregation (tests/test_gpu_knn_small.py::test_non_finite_features_still_give_valid_neighbour_ids).
  * y == NULL selects the self graph (M must equal N).  K here is k*dilation of the reference.
  * normalize = 1: the F.normalize step is part of the call (DenseDilatedKnnGraph.forward);
  * normalize = 0: inputs are taken as they are (dense_knn_matrix / xy_dense_knn_matrix called

@@ -32,6 +32,14 @@ namespace nextou {
 constexpr float kNormEps = 1e-12f;  // F.normalize eps (torch_edge.py:154-155,160)
 constexpr int kSentinelIdx = 0x7fffffff;
 
+// A distance that is NaN or +inf (a feature overflowed: fp16 autocast does that, and GradScaler expects to survive it) becomes the largest
+// finite float: it still sorts after every finite distance, ties among such candidates go by index, and — the point — it still ENTERS a list
+// whose empty slots are (+inf, sentinel), so every output slot holds a candidate id.  Left as NaN it would never compare below anything, the
+// row would keep its sentinels (or, in the counting kernel, leave slots unwritten) and the aggregation after it would gather out of bounds.
+// The reference's topk puts NaN first instead; both are garbage in, valid ids out.  One v_min_f32 (IEEE minNum: the non-NaN operand);
+// finite distances pass unchanged, so the bit-exactness tests are not affected.
+__device__ __forceinline__ float finite_or_last(float dist) { return fminf(dist, 3.402823466e+38f); }
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // --------------------------------------------------------------------------------------------
@@ -445,6 +453,7 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
                     if (valid) {
                         dist = (xsv + (-2.0f * v[4 * g + r])) + yv[r];
                         if (rp_row != nullptr) dist = dist + rv[r];
+                        dist = finite_or_last(dist);
                     }
                     if (BITONIC) {
                         fresh[4 * g + r] = valid ? make_key(dist, m) : kKeyMax;
@@ -716,6 +725,7 @@ __global__ __launch_bounds__(G == 2 ? 768 : 384) void knn_window_kernel(const fl
                 if (nvalid && m < m_end) {
                     dist = (xsv + (-2.0f * v[4 * g + r])) + yv[r];
                     if (rp_row != nullptr) dist = dist + rv[r];
+                    dist = finite_or_last(dist);
                 }
                 if (__any(dist < top.d[KB - 1]) && !(ablate & 4)) top.push_ascending(dist, m);
             }
@@ -974,7 +984,7 @@ __global__ __launch_bounds__(256) void knn_select_naive_kernel(const float* __re
     for (int j = 0; j < K; ++j) {
         unsigned long long best = ~0ull;
         for (int m = lane; m < M; m += 64) {
-            const unsigned long long key = knn_key(drow[m], m);
+            const unsigned long long key = knn_key(finite_or_last(drow[m]), m);      // (the distance matrix itself keeps its NaNs: nextou_pairwise_distance shares the kernel)
             if ((j == 0 || key > prev) && key < best) best = key;
         }
 #pragma unroll
@@ -1242,6 +1252,7 @@ __global__ __launch_bounds__(kSmThreads) void knn_small_kernel(const float* __re
             if (wave < n_tiles && n < N && m < N) {
                 dist = (sq_s[n] + (-2.0f * acc[r])) + sq_s[m];
                 if (relpos != nullptr) dist = dist + rp[r];
+                dist = finite_or_last(dist);
             }
             dist_s[i * kSmW + m] = dist;
         }

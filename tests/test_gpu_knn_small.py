@@ -150,3 +150,35 @@ print(json.dumps({"labels": labels, "ids": int(ids.sum()), "ids_hash": int((ids.
     assert not any(l.startswith("knn_small_kernel") or l.startswith("bn_one") for l in off["labels"]), off["labels"]
     assert (on["ids"], on["ids_hash"]) == (off["ids"], off["ids_hash"])                      # neighbour ids: the same bits
     assert abs(on["out"] - off["out"]) <= 1e-6 * on["out_abs"] + 1e-9                        # K6: the same sums in another order
+
+
+@pytest.mark.parametrize("name,shape,y_shape,k", [
+    ("small", (2, 70, 168), None, 9),              # knn_small_kernel (counting selection)
+    ("window", (600, 12, 168), None, 7),           # knn_window_kernel (whole windows per workgroup)
+    ("fused self", (2, 40, 1344), None, 32),       # prep + fused + merge of partial lists
+    ("fused xy", (2, 64, 2048), (2, 64, 512), 28),  # pooled graph
+    ("naive", (1, 16, 300), None, 40),             # K > 32: materialised distances + selection
+])
+def test_non_finite_features_still_give_valid_neighbour_ids(ops, name, shape, y_shape, k):
+    """A feature that overflowed (fp16 autocast: GradScaler expects to skip such a step, not to lose the process) makes distances NaN / inf.
+    The reference's topk still returns ids inside the candidate set (torch_edge.py:58-110); so must every kernel here — an id outside
+    [0, M) is an out-of-bounds gather in the aggregation that follows.  Non-finite distances sort last, by index."""
+    x = _rand(shape, 31)
+    y = None if y_shape is None else _rand(y_shape, 32)
+    src = x if y is None else y
+    M = src.shape[2]
+    bad = [5, 77, M - 1]
+    src[:, :, bad[0]] = float("nan")               # a whole candidate is NaN
+    src[0, 3, bad[1]] = float("inf")               # one channel of one candidate overflowed: inf / inf = NaN after the normalisation
+    src[-1, 0, bad[2]] = float("-inf")
+    got = ops.knn_graph(x.to(DEV), None if y is None else y.to(DEV), None, k)
+    torch.cuda.synchronize()
+    got = got.cpu()
+    assert got.shape == (shape[0], shape[2], k)
+    assert int(got.min()) >= 0 and int(got.max()) < M, (name, int(got.min()), int(got.max()))
+    srt = got.sort(-1).values
+    assert bool((srt[..., 1:] != srt[..., :-1]).all()), "%s: an id twice in one row" % name
+    finite_query = torch.isfinite(x).all(1)                                # (B, N)
+    bad_cand = ~torch.isfinite(src).all(1)                                 # (B, M)
+    hits = torch.gather(bad_cand.unsqueeze(1).expand(-1, shape[2], -1), 2, got.long())     # (B, N, k): neighbour is a non-finite candidate
+    assert not bool((hits & finite_query.unsqueeze(-1)).any()), "%s: a non-finite candidate ahead of finite ones" % name
