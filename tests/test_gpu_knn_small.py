@@ -155,6 +155,7 @@ print(json.dumps({"labels": labels, "ids": int(ids.sum()), "ids_hash": int((ids.
 @pytest.mark.parametrize("name,shape,y_shape,k", [
     ("small", (2, 70, 168), None, 9),              # knn_small_kernel (counting selection)
     ("window", (600, 12, 168), None, 7),           # knn_window_kernel (whole windows per workgroup)
+    ("window split", (40, 12, 168), None, 7),      # knn_window_kernel over 64-wide candidate splits + merge
     ("fused self", (2, 40, 1344), None, 32),       # prep + fused + merge of partial lists
     ("fused xy", (2, 64, 2048), (2, 64, 512), 28),  # pooled graph
     ("naive", (1, 16, 300), None, 40),             # K > 32: materialised distances + selection
