@@ -164,6 +164,7 @@ t_pmcjson() {
   probe head python $R/tools/head_bench.py --iters 3 --own-only --only "full res"
   probe stem python $R/tools/stem_bench.py --iters 3 --two          # round 6: K9 and K6's two-gradient backward at the stage-0 tensor
   probe s5pool python $R/tools/kernel_bench.py --cfg 2 --iters 3 --only "s5 Pool"      # knn_small_kernel
+  probe s5swin python $R/tools/kernel_bench.py --cfg 2 --iters 3 --only "s5 Swin"      # knn_small_kernel at K = 28: the bench line's K1 worst shape
   cd $R
 }
 t_convtable() {
