@@ -344,8 +344,10 @@ __device__ __forceinline__ void stage_slab(float* __restrict__ dst, const float*
 // grid = (query tiles, B, S): split s handles candidates [s*m_per_split, (s+1)*m_per_split).
 // S == 1: the final indices go to `out`; S > 1: every split writes its K best (dist, index) pairs
 // to part_d / part_i [(b*N + n)*S + s][K] and knn_merge_kernel picks the overall K best.
-template <int KB, int TILES, bool BITONIC>
-__global__ __launch_bounds__(512) void knn_fused_kernel(
+__device__ float glds_zero[4] = {0.f, 0.f, 0.f, 0.f};           // what an out-of-range piece of a direct-to-LDS slab reads
+
+template <int KB, int TILES, bool BITONIC, bool GLDS = false>
+__global__ __launch_bounds__(512, (TILES == 4 ? 3 : 1)) void knn_fused_kernel(
     const float* __restrict__ xn, const float* __restrict__ yn,
     const float* __restrict__ xs, const float* __restrict__ ys,
     const float* __restrict__ relpos, int32_t* __restrict__ out,
@@ -389,39 +391,8 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
     // pre-filter with per-lane compaction of the pushes: 460 vs 327 us on Pool s3 at 4 splits, break-even
     // at 2-3 splits where the lost parallelism costs more, profiles/r01_knn_compaction_ab.txt.)
     const bool share_ab = (yn == xn) && (QW == TM) && (n0 == 0) && (m_begin == 0) && (M <= TM);
-    if (share_ab) ldsB = ldsA;
-    for (int mc0 = m_begin; mc0 < m_end; mc0 += TM) {
-        f32x16 acc[TILES];
-#pragma unroll
-        for (int t = 0; t < TILES; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-        for (int c0 = 0; c0 < C; c0 += KS) {
-            __syncthreads();  // previous slab fully consumed
-            if (!(NEXTOU_ABLATE & 2) || c0 == 0) {
-                stage_slab(ldsA, yb, M, c0, C, mc0, m_end, TM, vec, KS);
-                if (!share_ab) stage_slab(ldsB, xb, N, c0, C, n0, N, QW, vec, KS);
-            }
-            __syncthreads();
-            int kmax = C - c0;
-            if (kmax > KS) kmax = KS;
-            kmax = (kmax + 1) & ~1;
-            for (int kp = 0; kp < kmax; kp += 2) {
-                const float bq = ldsB[(kp + h) * QW + wave * 32 + lq];
-#pragma unroll
-                for (int t = 0; t < TILES; ++t) {
-                    const float a = ldsA[(kp + h) * TM + t * 32 + lq];
-                    if (NEXTOU_ABLATE & 4) {
-                        acc[t][0] += a * bq;  // keeps the LDS reads alive
-                        continue;
-                    }
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc[t], 0, 0, 0);
-                }
-            }
-        }
-
-        // epilogue: distances of this chunk -> running top-K (ascending m per lane)
+    // epilogue: distances of a chunk -> running top-K (ascending m per lane)
+    auto epilogue = [&](const int mc0, f32x16 (&acc)[TILES]) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
             f32x16 v = acc[t];
@@ -467,6 +438,116 @@ __global__ __launch_bounds__(512) void knn_fused_kernel(
                 }
             }
             if (BITONIC) keys.absorb16(fresh);
+        }
+    };
+    if (share_ab) ldsB = ldsA;
+    if constexpr (GLDS) {
+        // Round 6: 16-channel slabs in THREE LDS buffers, filled by global_load_lds_dwordx4 (global -> LDS without registers: the register-prefetch
+        // pipeline of round 1 cost 50 VGPRs and an occupancy step).  (chunk, slab) pairs are ONE sequence: the loads of pair it + 2 are issued
+        // right behind the barrier that hands pair it to the MFMAs — into the buffer pair it - 1 has just left — and have two pairs' MFMAs (and,
+        // at a chunk's end, its whole selection epilogue) to arrive; one barrier per slab, in front of it a counted s_waitcnt: every wave issues
+        // the same four loads per pair, vmcnt returns in order, so "all but four" means pair it has landed while pair it + 1 stays in flight.
+        // An LDS row is 128 floats, a wave instruction writes lane x 16 B = two consecutive rows; pieces outside the matrix read a zero line
+        // instead (the destination is lane-linear, so the zero fill has to come through the source address).  Same MFMA order per accumulator:
+        // bit-identical distances.  Pool s3 287 -> 258 us with two buffers (one pair ahead), same box.
+        constexpr int KSG = 16;
+        static_assert(TM == 128 && !BITONIC, "two LDS rows per wave instruction");
+        const int spc = (C + KSG - 1) / KSG;                          // slabs per chunk
+        const int n_it = spc * ((m_end - m_begin + TM - 1) / TM);
+        constexpr int NBUF = 3;                                        // LDS buffers: the loads run TWO slabs ahead of the MFMAs
+        auto buffer = [&](int i) __attribute__((always_inline)) { return lds + i * (KSG * (TM + QW)); };
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // (scalar loop counters for the issue loops)
+        static_assert((KSG * TM / 256) % 4 == 0, "every wave issues the same number of loads per slab");
+        constexpr int kLoadsPerSlab = 2 * (KSG * TM / 256) / 4;         // per wave (nw == 4, QW == TM): what s_waitcnt leaves in flight
+        auto issue = [&](int ch, int sl, int bi) __attribute__((always_inline)) {
+            float* dA = buffer(bi);
+            float* dB = dA + KSG * TM;
+            const int c0 = sl * KSG, mc = m_begin + ch * TM;
+            const int rows = min(KSG, C - c0);
+            for (int j = wave_u; j < KSG * TM / 256; j += 4) {          // candidates: wave instruction j = LDS rows 2j, 2j + 1
+                const int r = 2 * j + (lane >> 5), c = (lane & 31) << 2;
+                const float* src = (r < rows && mc + c < m_end) ? yb + (size_t)(c0 + r) * M + mc + c : glds_zero;
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(dA + j * 256), 16, 0, 0);
+            }
+            for (int j = wave_u; j < KSG * QW / 256; j += 4) {          // queries (QW == 128 as well)
+                const int r = 2 * j + (lane >> 5), c = (lane & 31) << 2;
+                const float* src = (r < rows && n0 + c < N) ? xb + (size_t)(c0 + r) * N + n0 + c : glds_zero;
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(dB + j * 256), 16, 0, 0);
+            }
+        };
+        f32x16 acc[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        // (chunk, slab) of the pair two ahead of the one being multiplied
+        int ch = 0, sl = 0, pch = 0, psl = 0;
+        auto advance = [&](int& c_, int& s_) __attribute__((always_inline)) { if (++s_ == spc) { s_ = 0; ++c_; } };
+        if (n_it > 0) { issue(pch, psl, 0); advance(pch, psl); }
+        if (n_it > 1) { issue(pch, psl, 1); advance(pch, psl); }
+        int bi = 0;                                                     // buffer of pair `it`
+        for (int it = 0; it < n_it; ++it) {
+            // this wave's share of pair `it` is in LDS: every load but the kLoadsPerSlab of pair it + 1 has returned (vmcnt counts in order)
+            if (it + 1 < n_it) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerSlab) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                               // ... everybody's; and everybody is done with pair it - 1's buffer
+            asm volatile("" ::: "memory");
+            if (it + 2 < n_it) { issue(pch, psl, bi == 0 ? 2 : bi - 1); advance(pch, psl); }
+            const float* A = buffer(bi);
+            const float* Bq = A + KSG * TM;
+            int kmax = min(KSG, C - sl * KSG);
+            kmax = (kmax + 1) & ~1;
+            for (int kp = 0; kp < kmax; kp += 2) {
+                const float bq = Bq[(kp + h) * QW + wave * 32 + lq];
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    const float a = A[(kp + h) * TM + t * 32 + lq];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc[t], 0, 0, 0);
+                }
+            }
+            if (sl + 1 == spc) {
+                epilogue(m_begin + ch * TM, acc);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            }
+            advance(ch, sl);
+            bi = bi == NBUF - 1 ? 0 : bi + 1;
+        }
+    } else {
+        for (int mc0 = m_begin; mc0 < m_end; mc0 += TM) {
+            f32x16 acc[TILES];
+    #pragma unroll
+            for (int t = 0; t < TILES; ++t)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+            for (int c0 = 0; c0 < C; c0 += KS) {
+                __syncthreads();  // previous slab fully consumed
+                if (!(NEXTOU_ABLATE & 2) || c0 == 0) {
+                    stage_slab(ldsA, yb, M, c0, C, mc0, m_end, TM, vec, KS);
+                    if (!share_ab) stage_slab(ldsB, xb, N, c0, C, n0, N, QW, vec, KS);
+                }
+                __syncthreads();
+                int kmax = C - c0;
+                if (kmax > KS) kmax = KS;
+                kmax = (kmax + 1) & ~1;
+                for (int kp = 0; kp < kmax; kp += 2) {
+                    const float bq = ldsB[(kp + h) * QW + wave * 32 + lq];
+    #pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+                        const float a = ldsA[(kp + h) * TM + t * 32 + lq];
+                        if (NEXTOU_ABLATE & 4) {
+                            acc[t][0] += a * bq;  // keeps the LDS reads alive
+                            continue;
+                        }
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+
+            epilogue(mc0, acc);
         }
     }
 
@@ -1475,12 +1556,13 @@ static int launch_window(const FusedArgs& a, const float* x, const WindowPlan& w
     return w.splits > 1 ? launch_merge(a, w.splits, s) : 0;
 }
 
-template <int KB, int TILES, bool BITONIC>
+template <int KB, int TILES, bool BITONIC, bool GLDS = false>
 static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
     const int QW = 32 * p.nw;
     // (the kernel's share_ab condition: queries == candidates, one query tile, one chunk)
     const bool one_slab = a.yn == a.xn && QW == 32 * TILES && a.N <= QW && p.splits == 1 && a.M <= 32 * TILES;
-    const size_t lds = (size_t)p.ks * (one_slab ? 32 * TILES : 32 * TILES + QW) * sizeof(float);
+    const size_t lds = GLDS ? (size_t)3 * 16 * (32 * TILES + QW) * sizeof(float)        // three buffers of 16-channel slabs
+                            : (size_t)p.ks * (one_slab ? 32 * TILES : 32 * TILES + QW) * sizeof(float);
     dim3 grid(cdiv(a.N, QW), a.B, p.splits);
     // 16-B staging needs row strides and bases that keep every 4-float piece aligned
     const int vec_ok = (a.N % 4 == 0) && (a.M % 4 == 0) &&
@@ -1491,9 +1573,9 @@ static int launch_fused(const FusedArgs& a, const FusedPlan& p, hipStream_t s) {
         ProfScope prof(s, kBoundMfma, 2.0 * a.B * (double)a.N * a.M * a.C,
                        "knn_fused_kernel<%d,%d>[B%d C%d N%d M%d K%d]", KB, TILES, a.B, a.C, a.N, a.M, a.K);
         if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_fused_kernel<KB, TILES, BITONIC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_fused_kernel<KB, TILES, BITONIC, GLDS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds);
-        hipLaunchKernelGGL((knn_fused_kernel<KB, TILES, BITONIC>), grid, dim3(64 * p.nw), lds, s, a.xn, a.yn, a.xs, a.ys,
+        hipLaunchKernelGGL((knn_fused_kernel<KB, TILES, BITONIC, GLDS>), grid, dim3(64 * p.nw), lds, s, a.xn, a.yn, a.xs, a.ys,
                            a.relpos, a.out, a.part_d, a.part_i, a.C, a.N, a.M, a.K, p.m_per_split, vec_ok, p.ks);
     }
     if (int e = check_launch("knn_fused_kernel")) return e;
@@ -1506,7 +1588,15 @@ static int launch_fused_tiles(const FusedArgs& a, const FusedPlan& p, hipStream_
     // K = 32), so the network path is taken with 64-wide chunks only
     if (p.tiles == 1) return launch_fused<KB, 1, false>(a, p, s);
     if (p.tiles == 2) return use_networks(KB) ? launch_fused<KB, 2, true>(a, p, s) : launch_fused<KB, 2, false>(a, p, s);
-    if (p.tiles == 4) return launch_fused<KB, 4, false>(a, p, s);
+    if (p.tiles == 4) {
+        // direct-to-LDS double-buffered slabs (round 6) for the long-list pooled graphs: 4 waves x 128 candidates, 16-byte pieces throughout
+        if constexpr (KB >= 28) {
+            static const bool glds = [] { const char* e = getenv("NEXTOU_KNN_GLDS"); return !(e && e[0] == '0'); }();
+            const bool aligned = (a.N % 4 == 0) && (a.M % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.xn) | reinterpret_cast<uintptr_t>(a.yn)) & 15u) == 0;
+            if (glds && p.nw == 4 && aligned && p.m_per_split % 128 == 0) return launch_fused<KB, 4, false, true>(a, p, s);
+        }
+        return launch_fused<KB, 4, false>(a, p, s);
+    }
     return launch_fused<KB, 6, false>(a, p, s);
 }
 
