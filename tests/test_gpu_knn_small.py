@@ -111,7 +111,7 @@ def test_small_kernel_on_guard_pages(ops):
 
 
 def test_static_switches_turn_the_round_6_small_kernels_off():
-    """NEXTOU_KNN_SMALL=0 and NEXTOU_K6_ONE=0 are read once per process (no getenv on the launch path), so the off position needs its own process:
+    """NEXTOU_KNN_SMALL=0, NEXTOU_K6_ONE=0 and NEXTOU_KNN_GLDS=0 are read once per process (no getenv on the launch path), so the off position needs its own process:
     the same calls must take the multi-launch kernels and return the same bits."""
     import os
     import subprocess
@@ -127,19 +127,23 @@ y = torch.randn((2, 8, 4, 7, 6), generator=g).to(dev).contiguous(memory_format=t
 w, b = torch.rand(8, generator=g).to(dev) + 0.5, torch.randn(8, generator=g).to(dev)
 L.nextou_profile_enable(64)
 ids = graph_ops.knn_graph(x, None, None, 9, algo="fused")
+xq, yc = torch.randn((2, 40, 1024), generator=g).to(dev), torch.randn((2, 40, 640), generator=g).to(dev)
+rp = (torch.randn((1024, 640), generator=g) * 0.05).to(dev)
+long_ids = graph_ops.knn_graph(xq, yc, rp, 28, algo="fused")          # K > 16, M >= 512: the 128-wide kernel (direct-to-LDS slabs unless NEXTOU_KNN_GLDS=0)
 out = graph_ops.norm_act(y, w, b, None, None, True, 0.1, 1e-5, 0.01)
 torch.cuda.synchronize()
 buf = ctypes.create_string_buffer(1 << 16)
 n = L.nextou_profile_report(buf, len(buf))
 labels = [r["kernel"] for r in json.loads(buf.value.decode())] if n else []
-print(json.dumps({"labels": labels, "ids": int(ids.sum()), "ids_hash": int((ids.long() * torch.arange(ids.numel(), device=dev).view_as(ids) % 1000003).sum()),
+pos = torch.arange(long_ids.numel(), device=dev).view_as(long_ids)
+print(json.dumps({"labels": labels, "long": [int(long_ids.sum()), int((long_ids.long() * pos % 1000003).sum())], "ids": int(ids.sum()), "ids_hash": int((ids.long() * torch.arange(ids.numel(), device=dev).view_as(ids) % 1000003).sum()),
                   "out": out.double().sum().item(), "out_abs": out.double().abs().sum().item()}))
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     runs = {}
-    for name, extra in (("on", {}), ("off", {"NEXTOU_KNN_SMALL": "0", "NEXTOU_K6_ONE": "0"})):
+    for name, extra in (("on", {}), ("off", {"NEXTOU_KNN_SMALL": "0", "NEXTOU_K6_ONE": "0", "NEXTOU_KNN_GLDS": "0"})):
         env = dict(os.environ, PYTHONPATH=root, **extra)
-        for k in ("NEXTOU_KNN_SMALL", "NEXTOU_K6_ONE"):
+        for k in ("NEXTOU_KNN_SMALL", "NEXTOU_K6_ONE", "NEXTOU_KNN_GLDS"):
             if k not in extra:
                 env.pop(k, None)
         p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
@@ -149,6 +153,7 @@ print(json.dumps({"labels": labels, "ids": int(ids.sum()), "ids_hash": int((ids.
     assert any(l.startswith("knn_small_kernel") for l in on["labels"]) and any(l.startswith("bn_one") for l in on["labels"]), on["labels"]
     assert not any(l.startswith("knn_small_kernel") or l.startswith("bn_one") for l in off["labels"]), off["labels"]
     assert (on["ids"], on["ids_hash"]) == (off["ids"], off["ids_hash"])                      # neighbour ids: the same bits
+    assert any(l.startswith("knn_fused_kernel<28,4>") for l in on["labels"]) and on["long"] == off["long"]      # register-staged and direct-to-LDS slabs: the same ids
     assert abs(on["out"] - off["out"]) <= 1e-6 * on["out_abs"] + 1e-9                        # K6: the same sums in another order
 
 
