@@ -32,6 +32,7 @@ def test_cfg5_bf16_train_step_with_knn_checked_inside_the_run(monkeypatch):
     # MIOpen immediate mode: the find step over the bf16 96 x 256 x 256 convolutions costs minutes and this test is about one correct step
     monkeypatch.setattr(torch.backends.cudnn, "benchmark", False)
 
+    torch.cuda.empty_cache()       # (the step needs most of the GPU: blocks cached by earlier tests would be freed one failed allocation at a time)
     t0 = time.time()
     trainer, cfg, batch, classes = bench.build_trainer("cfg5", DEV, False)
     bench.move_to(trainer, DEV)
