@@ -6,6 +6,9 @@
 //   knn_fused_kernel  : f32 MFMA (32x32x2) distance tiles, LDS-staged channel slabs, and a
 //                       streaming per-query top-K kept entirely in registers; the (B,N,M)
 //                       distance matrix never exists in HBM
+//                       (128-wide chunks, K > 16: the slabs go global -> LDS directly, global_load_lds_dwordx4 into
+//                       three buffers, two slabs ahead of the MFMAs — round 6, NEXTOU_KNN_GLDS=0 for the register-staged loop)
+//   knn_window_kernel / knn_small_kernel : self graphs of <= 192 points in ONE launch, normalisation inside (rounds 4 / 6)
 //   knn_dist_naive / knn_select_naive : the materialising fallback (any K), also the on-GPU
 //                       cross-check of the "MFMA == fmaf chain" claim.
 //
